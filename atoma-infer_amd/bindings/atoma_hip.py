@@ -1,0 +1,245 @@
+"""ctypes binding of libatoma_hip.so + a minimal HIP-runtime device-buffer helper.
+
+This is plumbing for tests/, bench.py and __graft_entry__.py -- the product is the C ABI
+(include/atoma_hip.h).  No torch: device memory, events and streams come straight from
+libamdhip64.  Importing this module fails loudly if the HIP extension is not built.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "lib", "libatoma_hip.so")
+
+F16, BF16 = 0, 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `make -C atoma-infer_amd` (or python -c "
+        "'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
+lib = C.CDLL(os.path.abspath(LIB_PATH))
+
+_vp, _i32p, _i64p = C.c_void_p, C.c_void_p, C.c_void_p
+_u32, _i64, _f32, _int, _bool = C.c_uint32, C.c_int64, C.c_float, C.c_int, C.c_bool
+
+# ---- section 1: reference FFI (csrc/src/ffi.rs) ---------------------------------------------
+_RUN_MHA_ARGS = [
+    _vp, _vp, _vp, _vp, _vp, _vp,          # q k v o softmax_lse alibi_slopes
+    _i32p, _i32p,                          # cu_seqlens_q, cu_seqlens_k
+    _bool,                                 # is_seqlens_k_cumulative
+    _u32, _u32, _u32, _u32, _u32,          # q/k/v/o/alibi batch strides
+    _u32, _u32, _u32, _u32,                # row strides
+    _u32, _u32, _u32, _u32,                # head strides
+    _u32,                                  # num_splits
+    _u32, _u32, _u32, _u32, _u32,          # b h h_k d d_rounded
+    _f32, _f32,                            # softmax_scale, scale_softmax_log2
+    _i32p, _u32, _int,                     # block_table, stride, page_block_size
+    _i32p,                                 # seqused_k
+    _u32, _u32, _u32, _u32,                # seqlen_q, seqlen_k, rounded x2
+    _int, _int,                            # is_bf16, is_causal
+    _int, _int,                            # window left/right
+    _f32, _bool, _bool,                    # softcap, unpadded_lse, force_split_kernel
+    _vp, _vp,                              # lseaccum, oaccum
+]
+lib.run_mha.argtypes = _RUN_MHA_ARGS
+lib.run_mha.restype = None
+lib.run_mha_stream.argtypes = _RUN_MHA_ARGS + [_vp]
+lib.run_mha_stream.restype = None
+for _n in ("copy_blocks_f16", "copy_blocks_bf16"):
+    getattr(lib, _n).argtypes = [_vp, _vp, _vp, _i64, _i64, _i64, _vp]
+    getattr(lib, _n).restype = None
+lib.reshape_and_cache_flash.argtypes = [_vp, _vp, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _u32, _vp]
+lib.reshape_and_cache_flash.restype = None
+
+# ---- section 2 ---------------------------------------------------------------------------------
+lib.atoma_last_error.restype = C.c_char_p
+lib.atoma_last_error.argtypes = []
+lib.atoma_clear_error.restype = None
+lib.atoma_num_splits_heuristic.argtypes = [_i64, _i64, _i64, _i64]
+lib.atoma_num_splits_heuristic.restype = _int
+lib.atoma_compute_num_splits.argtypes = [_i64, _i64, _i64, _i64, _i64, _int]
+lib.atoma_compute_num_splits.restype = _int
+lib.atoma_swap_blocks.argtypes = [_vp, _vp, _i64p, _i64, _i64, _int, _vp]
+lib.atoma_swap_blocks.restype = _int
+lib.atoma_swap_blocks_multi.argtypes = [_vp, _vp, _i64, _i64p, _i64, _i64, _int, _vp]
+lib.atoma_swap_blocks_multi.restype = _int
+lib.atoma_host_alloc.argtypes = [C.c_size_t]
+lib.atoma_host_alloc.restype = _vp
+lib.atoma_host_free.argtypes = [_vp]
+lib.atoma_host_free.restype = None
+lib.atoma_device_count.restype = _int
+lib.atoma_num_cus.argtypes = [_int]
+lib.atoma_num_cus.restype = _int
+
+
+def _opt(name, argtypes, restype=_int):
+    """Entry points added later in the round: bind when present."""
+    if hasattr(lib, name):
+        f = getattr(lib, name)
+        f.argtypes, f.restype = argtypes, restype
+        return f
+    return None
+
+
+_opt("atoma_rms_norm", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _int, _vp])
+_opt("atoma_rope", [_vp, _vp, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp])
+_opt("atoma_rope_qk", [_vp, _vp, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp])
+_opt("atoma_rope_table", [_vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _int])
+_opt("atoma_comm_unique_id", [_vp])
+_opt("atoma_comm_init", [C.POINTER(_vp), _int, _int, _vp, _int])
+_opt("atoma_allreduce_sum", [_vp, _vp, _vp, _i64, _int, _vp])
+_opt("atoma_comm_destroy", [_vp])
+
+
+def last_error():
+    return lib.atoma_last_error().decode()
+
+
+def check():
+    e = last_error()
+    if e:
+        raise RuntimeError(e)
+
+
+# ---- HIP runtime (device memory / events) ------------------------------------------------------
+hip = C.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+hip.hipFree.argtypes = [_vp]
+hip.hipMemcpy.argtypes = [_vp, _vp, C.c_size_t, _int]
+hip.hipMemset.argtypes = [_vp, _int, C.c_size_t]
+hip.hipMemcpyAsync.argtypes = [_vp, _vp, C.c_size_t, _int, _vp]
+hip.hipEventCreate.argtypes = [C.POINTER(_vp)]
+hip.hipEventRecord.argtypes = [_vp, _vp]
+hip.hipEventSynchronize.argtypes = [_vp]
+hip.hipEventElapsedTime.argtypes = [C.POINTER(_f32), _vp, _vp]
+hip.hipEventDestroy.argtypes = [_vp]
+hip.hipStreamCreate.argtypes = [C.POINTER(_vp)]
+hip.hipStreamSynchronize.argtypes = [_vp]
+hip.hipStreamDestroy.argtypes = [_vp]
+hip.hipSetDevice.argtypes = [_int]
+hip.hipGetErrorString.restype = C.c_char_p
+hip.hipGetErrorString.argtypes = [_int]
+H2D, D2H, D2D = 1, 2, 3
+
+
+def hip_check(code, what="hip"):
+    if code != 0:
+        raise RuntimeError(f"{what}: {hip.hipGetErrorString(code).decode()} ({code})")
+
+
+def set_device(i):
+    hip_check(hip.hipSetDevice(i), "hipSetDevice")
+
+
+def synchronize():
+    hip_check(hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed region; `.ptr` is the raw device address."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = _vp()
+        hip_check(hip.hipMalloc(C.byref(p), max(self.nbytes, 16)), f"hipMalloc({self.nbytes})")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes)
+        if a.nbytes:
+            hip_check(hip.hipMemcpy(buf.ptr, a.ctypes.data, a.nbytes, H2D), "hipMemcpy H2D")
+        buf.shape, buf.dtype = a.shape, a.dtype
+        return buf
+
+    @classmethod
+    def zeros(cls, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        buf = cls(n)
+        if n:
+            hip_check(hip.hipMemset(buf.ptr, 0, n), "hipMemset")
+        buf.shape, buf.dtype = tuple(shape), np.dtype(dtype)
+        return buf
+
+    def fill_bytes(self, value):
+        hip_check(hip.hipMemset(self.ptr, value, self.nbytes), "hipMemset")
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        hip_check(hip.hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, H2D), "hipMemcpy H2D")
+
+    def numpy(self, dtype=None, shape=None):
+        dtype = np.dtype(dtype if dtype is not None else self.dtype)
+        shape = tuple(shape if shape is not None else self.shape)
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            hip_check(hip.hipMemcpy(out.ctypes.data, self.ptr, out.nbytes, D2H), "hipMemcpy D2H")
+        return out
+
+    def free(self):
+        if self.ptr:
+            hip.hipFree(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        e = _vp()
+        hip_check(hip.hipEventCreate(C.byref(e)), "hipEventCreate")
+        self.e = e.value
+
+    def record(self, stream=None):
+        hip_check(hip.hipEventRecord(self.e, stream), "hipEventRecord")
+
+    def synchronize(self):
+        hip_check(hip.hipEventSynchronize(self.e), "hipEventSynchronize")
+
+    def elapsed_ms(self, end):
+        ms = _f32()
+        hip_check(hip.hipEventElapsedTime(C.byref(ms), self.e, end.e), "hipEventElapsedTime")
+        return ms.value
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    return x.ptr if isinstance(x, DeviceBuffer) else x
+
+
+LOG2E = 1.4426950408889634
+
+
+def run_mha(q, k, v, o, *, b, h, h_k, d, seqlen_q, seqlen_k, softmax_scale, is_bf16,
+            q_strides, k_strides, v_strides, o_strides, is_causal=0, cu_seqlens_q=None,
+            cu_seqlens_k=None, is_seqlens_k_cumulative=True, block_table=None,
+            block_table_batch_stride=0, page_block_size=0, seqused_k=None, alibi_slopes=None,
+            alibi_slopes_batch_stride=0, softmax_lse=None, num_splits=0, force_split_kernel=False,
+            unpadded_lse=True, window=(-1, -1), softcap=0.0, lseaccum=None, oaccum=None, stream=None,
+            use_stream_entry=False):
+    """Thin keyword wrapper over the 47-argument reference entry point.  *_strides are
+    (batch, row, head) in elements."""
+    rnd = lambda x, m: (x + m - 1) // m * m
+    args = [_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(softmax_lse), _ptr(alibi_slopes),
+            _ptr(cu_seqlens_q), _ptr(cu_seqlens_k), bool(is_seqlens_k_cumulative),
+            q_strides[0], k_strides[0], v_strides[0], o_strides[0], alibi_slopes_batch_stride,
+            q_strides[1], k_strides[1], v_strides[1], o_strides[1],
+            q_strides[2], k_strides[2], v_strides[2], o_strides[2],
+            num_splits, b, h, h_k, d, rnd(d, 32), float(softmax_scale), float(softmax_scale * LOG2E),
+            _ptr(block_table), block_table_batch_stride, page_block_size, _ptr(seqused_k),
+            seqlen_q, seqlen_k, rnd(seqlen_q, 128), rnd(seqlen_k, 128), int(is_bf16), int(is_causal),
+            window[0], window[1], float(softcap), bool(unpadded_lse), bool(force_split_kernel),
+            _ptr(lseaccum), _ptr(oaccum)]
+    if use_stream_entry or stream is not None:
+        lib.run_mha_stream(*args, stream)
+    else:
+        lib.run_mha(*args)
+    check()

@@ -1,0 +1,563 @@
+// Paged-KV decode attention for gfx950 ("paged_attention v1/v2"): seqlen_q == 1.
+//
+// Replaces the reference's split-KV FlashAttention kernel when it is used for decode
+//   /root/reference/csrc/kernels/flash_fwd_kernel.h:504-1092 (compute_attn_1rowblock_splitkv, paged K/V)
+//   /root/reference/csrc/kernels/flash_fwd_kernel.h:1131-1313 (combine_attn_seqk_parallel)
+// reached through csrc::flash_attn_kv_cache_full (csrc/src/lib.rs:1521-1855).
+//
+// The reference runs a 64-row MMA tile for ONE query row and gives every q head of a GQA
+// group its own CTA (K/V re-read h/h_k times).  Decode is HBM-bound (h/h_k FLOP per byte),
+// so this kernel is organised around the byte stream instead:
+//
+//  * one 64-lane wavefront per (sequence, kv head, KV split); all q heads of the GQA group
+//    are processed together, so every K/V byte is fetched exactly once;
+//  * a 16-token tile of one kv head is 16 rows of D*2 bytes; a row is read by D/8 adjacent
+//    lanes with one 16-byte load each (full 128-byte lines, 1 KiB per wave instruction);
+//    P tiles (8 KiB each for D=128) are kept in flight per wave in registers;
+//  * block-table entries travel through the scalar cache (wave-uniform s_load, 64-byte lines =
+//    16 page ids per memory access), fetched 2P tiles ahead of use, so the table is never on
+//    the critical path and is never read beyond the pages the sequence owns (the reference
+//    does, SURVEY B/Q6);
+//  * q.k: v_dot2c_f32_{bf16,f16} on the lane's 8 elements, then an all-reduce over the
+//    D/8 lanes of the row with DPP adds (no LDS);
+//  * each group of D/8 lanes keeps its own online-softmax state (running max, sum, O) for
+//    the rows it owns, so there is no cross-lane traffic in the loop; the groups are
+//    merged once at the end with the usual LSE rescale;
+//  * P is rounded to the storage dtype before P.V (as the reference: softmax.h + the
+//    bf16 MMA) and P.V is again v_dot2c on token pairs;
+//  * KV splits write fp32 partial O / LSE to a workspace and a small combine kernel merges
+//    them (same math as the reference's combine kernel).
+//
+// Algorithmic HBM bytes per call: 2*B*S*h_k*D*2 (K,V once) + 2*B*h*D*2 + 4*B*ceil(S/page) + 4*B.
+#include "attn_params.h"
+
+#include <mutex>
+
+namespace atoma {
+
+struct DecodeParams {
+    const uint16_t *q, *k, *v;
+    uint16_t *o;
+    float *lse;            // [b][h] or nullptr
+    float *o_accum;        // [splits][b][h][D] fp32
+    float *lse_accum;      // [splits][b][h]
+    const int *block_table;
+    const int *cu_seqlens_k;
+    const int *seqused_k;
+    const float *alibi_slopes;
+    int64_t q_batch_stride, q_head_stride, o_batch_stride, o_head_stride;
+    int64_t k_batch_stride, k_row_stride, k_head_stride;
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    int64_t block_table_batch_stride;
+    int alibi_batch_stride;
+    int page_size;         // tokens per page (multiple of 16); 0 = contiguous cache
+    int b, h, h_k, g, gchunks;
+    int seqlen_k;
+    int is_seqlens_k_cumulative;
+    int num_splits;
+    float scale, scale_log2;
+};
+
+// all-reduce over the LPR adjacent lanes that hold one row (DPP, no LDS)
+template <int LPR> __device__ __forceinline__ float row_allreduce(float x) {
+    if constexpr (LPR >= 2) x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    if constexpr (LPR >= 4) x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    if constexpr (LPR >= 8) x += __builtin_amdgcn_update_dpp(0.f, x, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    if constexpr (LPR >= 16) x += __builtin_amdgcn_update_dpp(0.f, x, 0x140, 0xf, 0xf, true); // row_mirror
+    if constexpr (LPR >= 32) x += __shfl_xor(x, 16, 64);
+    return x;
+}
+
+template <typename T> __device__ __forceinline__ uint32_t pack_pair(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack_pair<bf16_t>(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_v));  // v_cvt_pk_bf16_f32
+}
+template <> __device__ __forceinline__ uint32_t pack_pair<f16_t>(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_v));   // v_cvt_pk_f16_f32 (RNE)
+}
+
+template <typename T, int D, int G, int P, int MINW>
+__global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodeParams p) {
+    constexpr int LPR = D / 8;     // lanes per row
+    constexpr int RPI = 64 / LPR;  // rows per load instruction
+    constexpr int IPP = 16 / RPI;  // load instructions per 16-token tile
+    static_assert(IPP >= 2 && IPP % 2 == 0, "token pairs for the P.V dot2");
+    const int lane = threadIdx.x;
+    const int sub = lane / LPR, dc = lane % LPR;
+
+    int id = blockIdx.x;
+    const int hk_chunks = p.h_k * p.gchunks;
+    const int hkc = id % hk_chunks;
+    id /= hk_chunks;
+    const int split = id % p.num_splits;
+    const int b = id / p.num_splits;
+    const int hk = hkc / p.gchunks, gc = hkc % p.gchunks;
+    const int hq0 = hk * p.g + gc * G;
+    const int nq = min(G, p.g - gc * G);
+
+    // sequence length: /root/reference/csrc/kernels/block_info.h:16-23
+    int L;
+    int64_t kv_row0 = 0;  // first row of this sequence in a varlen (cumulative) K/V tensor
+    if (p.cu_seqlens_k == nullptr) L = p.seqlen_k;
+    else if (p.is_seqlens_k_cumulative) {
+        kv_row0 = p.cu_seqlens_k[b];
+        L = p.cu_seqlens_k[b + 1] - (int)kv_row0;
+    } else L = p.cu_seqlens_k[b];
+    if (p.seqused_k) L = p.seqused_k[b];
+
+    const int n_tiles = (L + 15) >> 4;
+    const int per = (n_tiles + p.num_splits - 1) / p.num_splits;
+    const int t0 = split * per;
+    const int t1 = min(t0 + per, n_tiles);
+
+    const float sl2 = p.scale_log2;
+    float m[G], l[G], o[G][8];
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+        m[gq] = -INFINITY;
+        l[gq] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[gq][e] = 0.f;
+    }
+
+    if (t0 < t1) {
+        // ---- q: 8 elements per lane per head, replicated over the RPI row groups ----
+        uint4 qv[G];
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) {
+            qv[gq] = make_uint4(0, 0, 0, 0);
+            if (gq < nq)
+                qv[gq] = *reinterpret_cast<const uint4 *>(p.q + (int64_t)b * p.q_batch_stride +
+                                                          (int64_t)(hq0 + gq) * p.q_head_stride + dc * 8);
+        }
+        float alibi[G];
+        const bool has_alibi = p.alibi_slopes != nullptr;
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq)
+            alibi[gq] = (has_alibi && gq < nq) ? p.alibi_slopes[b * p.alibi_batch_stride + hq0 + gq] * 1.4426950408889634f : 0.f;
+
+        // ---- loader ----
+        // Page ids come through the scalar cache (s_load_dword on a wave-uniform address), one
+        // per tile, fetched 2P tiles ahead of use: they ride lgkmcnt, so the K/V stream's vmcnt
+        // accounting stays exact, and the 64-byte scalar-cache line makes the table read coalesced
+        // (16 ids per HBM/L2 access).  The index is clamped to the pages the sequence owns.
+        const bool paged = p.block_table != nullptr;
+        const uint32_t tpp = paged ? (uint32_t)(p.page_size >> 4) : 1u;  // tiles per page
+        const uint32_t tpp_magic = tpp > 1 ? (uint32_t)((0x100000000ull + tpp - 1) / tpp) : 0u;
+        const int last_pg = paged ? (L + p.page_size - 1) / p.page_size - 1 : 0;
+        const int *bt_row = paged ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+        const char *kbase = reinterpret_cast<const char *>(p.k + (int64_t)hk * p.k_head_stride);
+        const char *vbase = reinterpret_cast<const char *>(p.v + (int64_t)hk * p.v_head_stride);
+        if (!paged) {
+            const bool cum = p.cu_seqlens_k && p.is_seqlens_k_cumulative;
+            kbase += (cum ? kv_row0 * p.k_row_stride : (int64_t)b * p.k_batch_stride) * 2;
+            vbase += (cum ? kv_row0 * p.v_row_stride : (int64_t)b * p.v_batch_stride) * 2;
+        }
+        const int64_t k_row_bytes = p.k_row_stride * 2, v_row_bytes = p.v_row_stride * 2;
+        const int64_t k_page_bytes = p.k_batch_stride * 2, v_page_bytes = p.v_batch_stride * 2;
+        // per-lane byte offset inside a tile (row `sub` of each RPI-row slab, 16-byte chunk `dc`)
+        const uint32_t k_lane_off = (uint32_t)(sub * k_row_bytes + dc * 16);
+        const uint32_t v_lane_off = (uint32_t)(sub * v_row_bytes + dc * 16);
+
+        auto page_of = [&](int tile, uint32_t &tip) -> int {  // wave-uniform
+            if (tpp == 1) { tip = 0; return tile; }
+            const uint32_t pg = __umulhi((uint32_t)tile, tpp_magic);
+            tip = (uint32_t)tile - pg * tpp;
+            return (int)pg;
+        };
+        auto fetch_pid = [&](int tile) -> int {  // scalar load, always in bounds
+            if (!paged) return 0;
+            uint32_t tip;
+            const int pg = min(page_of(tile, tip), last_pg);
+            return bt_row[pg];
+        };
+        auto tile_bases = [&](int tile, int pid, const char *&kt, const char *&vt) {
+            if (paged) {
+                uint32_t tip;
+                (void)page_of(tile, tip);
+                kt = kbase + (int64_t)pid * k_page_bytes + (int64_t)(tip << 4) * k_row_bytes;
+                vt = vbase + (int64_t)pid * v_page_bytes + (int64_t)(tip << 4) * v_row_bytes;
+            } else {
+                kt = kbase + (int64_t)(tile << 4) * k_row_bytes;
+                vt = vbase + (int64_t)(tile << 4) * v_row_bytes;
+            }
+        };
+        // full tile: uniform base + fixed lane offset (saddr form, no per-lane address math)
+        auto issue_fast = [&](uint4 (&kb)[IPP], uint4 (&vb)[IPP], int tile, int pid) {
+            const char *kt, *vt;
+            tile_bases(tile, pid, kt, vt);
+#pragma unroll
+            for (int r = 0; r < IPP; ++r)
+                kb[r] = *reinterpret_cast<const uint4 *>(kt + (int64_t)(r * RPI) * k_row_bytes + k_lane_off);
+#pragma unroll
+            for (int r = 0; r < IPP; ++r)
+                vb[r] = *reinterpret_cast<const uint4 *>(vt + (int64_t)(r * RPI) * v_row_bytes + v_lane_off);
+        };
+        // any tile: rows clamped to the last row of the sequence, so a contiguous (non-paged)
+        // cache is never read past its end; paged tiles always have their 16 rows
+        auto issue_tail = [&](uint4 (&kb)[IPP], uint4 (&vb)[IPP], int tile, int pid) {
+            const char *kt, *vt;
+            tile_bases(tile, pid, kt, vt);
+            const int lastrow = paged ? 15 : min(15, L - 1 - (tile << 4));
+#pragma unroll
+            for (int r = 0; r < IPP; ++r) {
+                const int row = min(r * RPI + sub, lastrow);
+                kb[r] = *reinterpret_cast<const uint4 *>(kt + (int64_t)row * k_row_bytes + dc * 16);
+            }
+#pragma unroll
+            for (int r = 0; r < IPP; ++r) {
+                const int row = min(r * RPI + sub, lastrow);
+                vb[r] = *reinterpret_cast<const uint4 *>(vt + (int64_t)row * v_row_bytes + dc * 16);
+            }
+        };
+
+        auto compute = [&](const uint4 (&kb)[IPP], const uint4 (&vb)[IPP], int tile) {
+            float s[IPP][G];
+#pragma unroll
+            for (int r = 0; r < IPP; ++r)
+#pragma unroll
+                for (int gq = 0; gq < G; ++gq) {
+                    float a = dot2<T>(kb[r].x, qv[gq].x, 0.f);
+                    a = dot2<T>(kb[r].y, qv[gq].y, a);
+                    a = dot2<T>(kb[r].z, qv[gq].z, a);
+                    a = dot2<T>(kb[r].w, qv[gq].w, a);
+                    s[r][gq] = row_allreduce<LPR>(a) * sl2;  // log2 domain
+                }
+            const int tok0 = (tile << 4) + sub;
+            if (has_alibi) {  // wave-uniform
+#pragma unroll
+                for (int r = 0; r < IPP; ++r)
+#pragma unroll
+                    for (int gq = 0; gq < G; ++gq)
+                        s[r][gq] -= alibi[gq] * (float)(L - 1 - (tok0 + r * RPI));  // mask.h:183, row 0 of 1
+            }
+            if ((tile << 4) + 16 > L) {  // wave-uniform: ragged last tile
+#pragma unroll
+                for (int r = 0; r < IPP; ++r)
+                    if (tok0 + r * RPI >= L) {
+#pragma unroll
+                        for (int gq = 0; gq < G; ++gq) s[r][gq] = -INFINITY;
+                    }
+            }
+            float mnew[G];
+            bool changed = false;
+#pragma unroll
+            for (int gq = 0; gq < G; ++gq) {
+                float mx = s[0][gq];
+#pragma unroll
+                for (int r = 1; r < IPP; ++r) mx = fmaxf(mx, s[r][gq]);
+                mnew[gq] = fmaxf(m[gq], mx);
+                changed |= mnew[gq] > m[gq];
+            }
+            if (__any(changed)) {  // rescale only when some running max moved
+#pragma unroll
+                for (int gq = 0; gq < G; ++gq) {
+                    const float ms = mnew[gq] == -INFINITY ? 0.f : mnew[gq];
+                    const float alpha = __builtin_amdgcn_exp2f(m[gq] - ms);
+                    l[gq] *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[gq][e] *= alpha;
+                    m[gq] = mnew[gq];
+                }
+            }
+            uint32_t pp[IPP / 2][G];
+#pragma unroll
+            for (int gq = 0; gq < G; ++gq) {
+                const float ms = m[gq] == -INFINITY ? 0.f : m[gq];
+                float pr[IPP];
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < IPP; ++r) {
+                    pr[r] = __builtin_amdgcn_exp2f(s[r][gq] - ms);
+                    sum += pr[r];
+                }
+                l[gq] += sum;
+#pragma unroll
+                for (int c = 0; c < IPP / 2; ++c) pp[c][gq] = pack_pair<T>(pr[2 * c], pr[2 * c + 1]);
+            }
+            // P.V on token pairs: (V[r0][e], V[r1][e]) . (p[r0], p[r1])
+#pragma unroll
+            for (int c = 0; c < IPP / 2; ++c) {
+                const uint32_t a[4] = {vb[2 * c].x, vb[2 * c].y, vb[2 * c].z, vb[2 * c].w};
+                const uint32_t bb[4] = {vb[2 * c + 1].x, vb[2 * c + 1].y, vb[2 * c + 1].z, vb[2 * c + 1].w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t lo = __builtin_amdgcn_perm(bb[w], a[w], 0x05040100u);  // (a.lo, b.lo)
+                    const uint32_t hi = __builtin_amdgcn_perm(bb[w], a[w], 0x07060302u);  // (a.hi, b.hi)
+#pragma unroll
+                    for (int gq = 0; gq < G; ++gq) {
+                        o[gq][2 * w] = dot2<T>(lo, pp[c][gq], o[gq][2 * w]);
+                        o[gq][2 * w + 1] = dot2<T>(hi, pp[c][gq], o[gq][2 * w + 1]);
+                    }
+                }
+            }
+        };
+
+        // ---- software pipeline: P tiles in flight per wave ----
+        // The steady-state loop has no conditional loads, so the compiler's vmcnt waits are exact
+        // (tile t is consumed while tiles t+1 .. t+P-1 and the just-issued t+P stay in flight);
+        // the last < 2P tiles go through the conditional tail.
+        uint4 kb[P][IPP], vb[P][IPP];
+        int pid[P];
+        int t = t0;
+        const int steady_end = min(t1, paged ? n_tiles : (L >> 4));  // tiles below this load without clamping
+        if (t0 + 2 * P <= steady_end) {
+            // long sequence: unconditional prologue, so the loop header sees ONE load history
+#pragma unroll
+            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                issue_fast(kb[s], vb[s], t0 + s, pid[s]);
+                pid[s] = fetch_pid(t0 + s + P);
+            }
+            for (; t + 2 * P <= steady_end; t += P) {
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    compute(kb[s], vb[s], t + s);
+                    issue_fast(kb[s], vb[s], t + s + P, pid[s]);
+                    pid[s] = fetch_pid(t + s + 2 * P);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
+#pragma unroll
+            for (int s = 0; s < P; ++s)
+                if (t0 + s < t1) {
+                    issue_tail(kb[s], vb[s], t0 + s, pid[s]);
+                    pid[s] = fetch_pid(t0 + s + P);
+                }
+        }
+        for (; t < t1; t += P) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                if (t + s < t1) {
+                    compute(kb[s], vb[s], t + s);
+                    if (t + s + P < t1) {
+                        issue_tail(kb[s], vb[s], t + s + P, pid[s]);
+                        pid[s] = fetch_pid(t + s + 2 * P);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- merge the RPI row groups (each has its own m, l, o) ----
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+        float mt = m[gq];
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) mt = fmaxf(mt, __shfl_xor(mt, off, 64));
+        const float ms = mt == -INFINITY ? 0.f : mt;
+        const float w = __builtin_amdgcn_exp2f(m[gq] - ms);
+        float lt = l[gq] * w;
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) lt += __shfl_xor(lt, off, 64);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = o[gq][e] * w;
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) x += __shfl_xor(x, off, 64);
+            o[gq][e] = x;
+        }
+        m[gq] = mt;
+        l[gq] = lt;
+    }
+
+    if (sub != 0) return;
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+        if (gq >= nq) continue;
+        const int hq = hq0 + gq;
+        const bool empty = !(l[gq] > 0.f);  // no visible key (L == 0 or empty split)
+        const float inv = empty ? 0.f : 1.f / l[gq];
+        // natural-log LSE: m*scale + ln(l); m is already scaled by scale*log2e
+        const float lse = empty ? INFINITY : (m[gq] + __builtin_amdgcn_logf(l[gq])) * 0.6931471805599453f;
+        if (p.num_splits == 1) {
+            uint4 w4;
+            w4.x = pack2<T>(o[gq][0] * inv, o[gq][1] * inv);
+            w4.y = pack2<T>(o[gq][2] * inv, o[gq][3] * inv);
+            w4.z = pack2<T>(o[gq][4] * inv, o[gq][5] * inv);
+            w4.w = pack2<T>(o[gq][6] * inv, o[gq][7] * inv);
+            *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + dc * 8) = w4;
+            if (p.lse && dc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
+        } else {
+            const int64_t row = ((int64_t)split * p.b + b) * p.h + hq;
+            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + dc * 8);
+            dst[0] = make_float4(o[gq][0] * inv, o[gq][1] * inv, o[gq][2] * inv, o[gq][3] * inv);
+            dst[1] = make_float4(o[gq][4] * inv, o[gq][5] * inv, o[gq][6] * inv, o[gq][7] * inv);
+            if (dc == 0) p.lse_accum[row] = empty ? -INFINITY : lse;  // flash_fwd_kernel.h:543-582
+        }
+    }
+}
+
+// LSE-weighted merge of the split partials: /root/reference/csrc/kernels/flash_fwd_kernel.h:1204-1236.
+// One wavefront per (b, q head); lane i owns D/64 output pairs.
+template <typename T, int D>
+__global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p) {
+    const int lane = threadIdx.x;
+    const int64_t bh = blockIdx.x;  // b * h + hq
+    const int b = (int)(bh / p.h), hq = (int)(bh % p.h);
+    const int64_t stride = (int64_t)p.b * p.h;
+    float mx = -INFINITY;
+    for (int s = lane; s < p.num_splits; s += 64) mx = fmaxf(mx, p.lse_accum[s * stride + bh]);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float ms = mx == -INFINITY ? 0.f : mx;
+    float tot = 0.f;
+    for (int s = lane; s < p.num_splits; s += 64) tot += __expf(p.lse_accum[s * stride + bh] - ms);
+#pragma unroll
+    for (int off = 32; off; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    const bool empty = !(tot > 0.f);
+    const float lse = empty ? INFINITY : __logf(tot) + ms;
+    constexpr int EPL = D / 64;  // elements per lane
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int s = 0; s < p.num_splits; ++s) {
+        const float ls = p.lse_accum[s * stride + bh];
+        const float w = empty ? 0.f : __expf(ls - lse);
+        const float *src = p.o_accum + (s * stride + bh) * D + lane * EPL;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] += w * src[e];
+    }
+    uint16_t *dst = p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + lane * EPL;
+    if constexpr (EPL % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; e += 2) *reinterpret_cast<uint32_t *>(dst + e) = pack2<T>(acc[e], acc[e + 1]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) dst[e] = (uint16_t)f32_to_bits<T>(acc[e]);
+    }
+    if (p.lse && lane == 0) p.lse[bh] = lse;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+// Grow-only fp32 workspace for split partials, one per (device, stream).  The reference hands
+// caller scratch to the kernel and may drop it right after the async launch
+// (/root/reference/csrc/src/lib.rs:1023-1042,1100); owning the scratch here removes that race.
+struct Workspace {
+    int device;
+    hipStream_t stream;
+    void *ptr;
+    size_t bytes;
+};
+static std::vector<Workspace> g_ws;
+static std::mutex *g_ws_mu = new std::mutex;
+
+void *workspace(hipStream_t stream, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(*g_ws_mu);
+    for (auto &w : g_ws)
+        if (w.device == dev && w.stream == stream) {
+            if (w.bytes >= bytes) return w.ptr;
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(w.ptr);
+            w.ptr = nullptr;
+            w.bytes = 0;
+            if (!check_hip(hipMalloc(&w.ptr, bytes), "workspace hipMalloc")) return nullptr;
+            w.bytes = bytes;
+            return w.ptr;
+        }
+    Workspace w{dev, stream, nullptr, 0};
+    if (!check_hip(hipMalloc(&w.ptr, bytes), "workspace hipMalloc")) return nullptr;
+    w.bytes = bytes;
+    g_ws.push_back(w);
+    return w.ptr;
+}
+
+// Split count for THIS kernel: enough wavefronts to put ~8 on every CU (2 per SIMD), never
+// fewer than 8 tiles (128 tokens) per split.  (The reference's heuristic, lib.rs:2122-2199,
+// is tuned for 128-thread CTAs of a 64-row tile; it is restated as atoma_compute_num_splits.)
+int decode_num_splits(int64_t waves_per_split, int max_seqlen_k) {
+    const int64_t target = (int64_t)device_num_cus() * 8;
+    if (waves_per_split * 2 > target) return 1;
+    int64_t s = cdiv(target, waves_per_split);
+    const int64_t n_tiles = cdiv(max_seqlen_k, 16);
+    const int64_t max_s = n_tiles / 8 > 0 ? n_tiles / 8 : 1;
+    if (s > max_s) s = max_s;
+    if (s > 128) s = 128;
+    return (int)(s < 1 ? 1 : s);
+}
+
+template <typename T, int D, int G>
+static void launch_decode_tdg(const DecodeParams &p, hipStream_t stream) {
+    // tiles in flight per wave / waves per SIMD the register budget is capped for: G = 8 at
+    // D = 128 needs more than 256 VGPRs (64 for O, 32 for q, 64 per K+V pair in flight).
+    constexpr int P = (G >= 8) ? 2 : 3;
+    constexpr int MINW = (G >= 8 && D >= 128) ? 1 : 2;
+    const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
+    hipLaunchKernelGGL((paged_decode_kernel<T, D, G, P, MINW>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    if (!ATOMA_CHECK_LAUNCH("paged_decode_kernel")) return;
+    if (p.num_splits > 1) {
+        hipLaunchKernelGGL((decode_combine_kernel<T, D>), dim3((unsigned)((int64_t)p.b * p.h)), dim3(64), 0, stream, p);
+        ATOMA_CHECK_LAUNCH("decode_combine_kernel");
+    }
+}
+
+template <typename T, int D>
+static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
+    const int g = p.g;
+    const int G = g >= 8 ? 8 : (g > 2 ? 4 : (g == 2 ? 2 : 1));
+    p.gchunks = (int)cdiv(g, G);
+    if (p.num_splits <= 0) p.num_splits = decode_num_splits((int64_t)p.b * p.h_k * p.gchunks, p.seqlen_k);
+    if (p.num_splits > 1) {
+        const size_t rows = (size_t)p.num_splits * p.b * p.h;
+        float *ws = static_cast<float *>(workspace(stream, rows * (D + 1) * sizeof(float)));
+        if (!ws) return;
+        p.o_accum = ws;
+        p.lse_accum = ws + rows * D;
+    }
+    switch (G) {
+        case 1: launch_decode_tdg<T, D, 1>(p, stream); break;
+        case 2: launch_decode_tdg<T, D, 2>(p, stream); break;
+        case 4: launch_decode_tdg<T, D, 4>(p, stream); break;
+        default: launch_decode_tdg<T, D, 8>(p, stream); break;
+    }
+}
+
+bool decode_supported(int d) { return d == 64 || d == 128; }
+
+void launch_paged_decode(DecodeParams &p, int d, bool is_bf16, hipStream_t stream) {
+    if (is_bf16) {
+        if (d == 64) launch_decode_td<bf16_t, 64>(p, stream);
+        else launch_decode_td<bf16_t, 128>(p, stream);
+    } else {
+        if (d == 64) launch_decode_td<f16_t, 64>(p, stream);
+        else launch_decode_td<f16_t, 128>(p, stream);
+    }
+}
+
+// AttnParams (run_mha's view) -> DecodeParams.  seqlen_q == 1, so q/o row strides drop out.
+void launch_paged_decode_from_attn(const AttnParams &a, bool is_bf16, int num_splits_hint, hipStream_t stream) {
+    (void)num_splits_hint;  // the caller's split count is tuned for the reference's CTA shape; see decode_num_splits
+    DecodeParams p{};
+    p.q = a.q; p.k = a.k; p.v = a.v; p.o = a.o;
+    p.lse = a.lse;
+    p.block_table = a.block_table;
+    p.cu_seqlens_k = a.cu_seqlens_k;
+    p.seqused_k = a.seqused_k;
+    p.alibi_slopes = a.alibi_slopes;
+    p.q_batch_stride = a.q_batch_stride; p.q_head_stride = a.q_head_stride;
+    p.o_batch_stride = a.o_batch_stride; p.o_head_stride = a.o_head_stride;
+    p.k_batch_stride = a.k_batch_stride; p.k_row_stride = a.k_row_stride; p.k_head_stride = a.k_head_stride;
+    p.v_batch_stride = a.v_batch_stride; p.v_row_stride = a.v_row_stride; p.v_head_stride = a.v_head_stride;
+    p.block_table_batch_stride = a.block_table_batch_stride;
+    p.alibi_batch_stride = a.alibi_batch_stride;
+    p.page_size = a.page_size;
+    p.b = a.b; p.h = a.h; p.h_k = a.h_k; p.g = a.h / a.h_k;
+    p.seqlen_k = a.seqlen_k;
+    p.is_seqlens_k_cumulative = a.is_seqlens_k_cumulative;
+    p.num_splits = 0;  // 0 = let decode_num_splits choose
+    p.scale = a.scale; p.scale_log2 = a.scale_log2;
+    launch_paged_decode(p, a.d, is_bf16, stream);
+}
+
+}  // namespace atoma

@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline micro-benchmark on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY 8d "C2a"): paged-attention decode, B=256 sequences,
+32 q heads / 8 kv heads (Llama-3.1-8B, TP=1), d=128, seq=4096 for every sequence, block_size=16,
+bf16, q/K/V ~ N(0,1), block table = seeded random permutation over 73 728 physical pages,
+scale 1/sqrt(128).  One "step" = one pass of the hot path over the batch = one
+`run_mha` decode call (csrc/src/ffi.rs:4-64) producing 256 new-token attention outputs.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 shards kv heads over ranks (tensor parallel, worker.rs:584-591) -- total work fixed
+("strong" scaling) -- and each step ends with the path's one exchange step, the sum all-reduce
+of the [B, h*d] activations over RCCL/xGMI (multi_gpu.rs:141-179).
+
+Prints ONE JSON line on rank 0.  `value` = algorithmic HBM GB/s of the whole job with inputs
+resident in HBM; `roofline` prices the dominant kernel against 8 TB/s; `cpu_baseline` is the
+oracle's C restatement (oracle/c/oracle.c, OpenMP) timed on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "atoma-infer_amd", "bindings"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(B, S, h, hk, d, page, e=2):
+    """K and V once + q in + o out + block table + seqlens."""
+    return 2 * B * S * hk * d * e + 2 * B * h * d * e + 4 * B * ((S + page - 1) // page) + 4 * B
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seq", type=int, default=4096)
+    ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=8)
+    ap.add_argument("--head-dim", type=int, default=128)
+    ap.add_argument("--block-size", type=int, default=16)
+    ap.add_argument("--identity-table", action="store_true", help="physical page i = logical page i")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-seqs", type=int, default=64)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch  # only for the rendezvous / barrier / max-over-ranks (gloo, CPU tensors)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import atoma_hip as ah
+    from oracle.halfs import BF16, from_f32
+
+    ah.set_device(local_rank)
+    B, S, h, hk, d, page = args.batch, args.seq, args.heads, args.kv_heads, args.head_dim, args.block_size
+    assert hk % world == 0 and h % world == 0, "kv heads must divide over the ranks"
+    h_l, hk_l = h // world, hk // world                       # this rank's head shard
+    pages_per_seq = (S + page - 1) // page
+    n_pages = int(B * pages_per_seq * 1.125)                   # 73 728 for C2a
+    rng = np.random.default_rng(0)
+    bt = (np.arange(B * pages_per_seq) if args.identity_table else rng.permutation(n_pages)[: B * pages_per_seq])
+    bt = bt.astype(np.int32).reshape(B, pages_per_seq)
+    lens = np.full(B, S, np.int32)
+
+    # K/V caches [n_pages, page, hk_l, d] bf16 ~ N(0,1): a 64 MiB random slab tiled over the cache
+    page_elems = page * hk_l * d
+    slab_pages = max(1, min(n_pages, (64 << 20) // (page_elems * 2)))
+    slab_k = from_f32(rng.standard_normal((slab_pages, page_elems), dtype=np.float32), BF16)
+    slab_v = from_f32(rng.standard_normal((slab_pages, page_elems), dtype=np.float32), BF16)
+    cache_bytes = n_pages * page_elems * 2
+    dkc, dvc = ah.DeviceBuffer(cache_bytes), ah.DeviceBuffer(cache_bytes)
+    for dst, slab in ((dkc, slab_k), (dvc, slab_v)):
+        off = 0
+        while off < cache_bytes:
+            n = min(slab.nbytes, cache_bytes - off)
+            ah.hip_check(ah.hip.hipMemcpy(dst.ptr + off, slab.ctypes.data, n, ah.H2D), "upload cache")
+            off += n
+    q = from_f32(rng.standard_normal((B, 1, h_l, d), dtype=np.float32), BF16)
+    dq, dbt, dl = ah.DeviceBuffer.from_numpy(q), ah.DeviceBuffer.from_numpy(bt), ah.DeviceBuffer.from_numpy(lens)
+    do = ah.DeviceBuffer(q.nbytes)
+    scale = float(d ** -0.5)
+
+    comm = None
+    if world > 1:
+        import torch
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (C.c_uint8 * 128)()
+            assert ah.lib.atoma_comm_unique_id(raw) == 0, ah.last_error()
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        dist.broadcast(idbuf, 0)
+        raw = (C.c_uint8 * 128)(*idbuf.tolist())
+        comm = C.c_void_p()
+        assert ah.lib.atoma_comm_init(C.byref(comm), rank, world, raw, local_rank) == 0, ah.last_error()
+        act = ah.DeviceBuffer.zeros((B, h * d), np.uint16)    # [B, hidden] activations to all-reduce
+        act_out = ah.DeviceBuffer.zeros((B, h * d), np.uint16)
+
+    def step():
+        ah.run_mha(dq, dkc, dvc, do, b=B, h=h_l, h_k=hk_l, d=d, seqlen_q=1, seqlen_k=pages_per_seq * page,
+                   softmax_scale=scale, is_bf16=1, q_strides=(h_l * d, h_l * d, d), o_strides=(h_l * d, h_l * d, d),
+                   k_strides=(page * hk_l * d, hk_l * d, d), v_strides=(page * hk_l * d, hk_l * d, d),
+                   cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt,
+                   block_table_batch_stride=pages_per_seq, page_block_size=page, force_split_kernel=True,
+                   unpadded_lse=False)
+        if comm is not None:
+            assert ah.lib.atoma_allreduce_sum(comm, act.ptr, act_out.ptr, B * h * d, BF16, None) == 0, ah.last_error()
+
+    def barrier():
+        ah.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ah.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # per-launch duration of the attention kernel: HIP events on the stream it is launched on (NULL)
+    ev = [(ah.Event(), ah.Event()) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(None)
+        step()
+        ev[i][1].record(None)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    launch_ms = [a.elapsed_ms(b_) for a, b_ in ev]
+    kern_ms = float(np.mean(launch_ms))
+
+    ms_per_step = wall * 1e3 / args.steps
+    total_bytes = algorithmic_bytes(B, S, h, hk, d, page)           # whole job (all ranks)
+    rank_bytes = algorithmic_bytes(B, S, h_l, hk_l, d, page)
+    value = total_bytes / (ms_per_step * 1e-3) / 1e9
+    achieved = rank_bytes / (kern_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "paged-attn decode HBM GB/s (decode tokens/s/GPU alongside), Llama-3.1-8B shape, TP=%d" % world,
+        "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "decode_tokens_per_s": round(B / (ms_per_step * 1e-3), 1),
+        "decode_tokens_per_s_per_gpu": round(B / (ms_per_step * 1e-3) / world, 1),
+        "config": {"workload": "paged_attention_v2 micro-bench (BASELINE.json configs[1]): bs=%d, %d heads (%d kv), "
+                               "d=%d, seq=%d, block_size=%d, bf16, %s block table over %d pages"
+                               % (B, h, hk, d, S, page, "identity" if args.identity_table else "random-permutation",
+                                  n_pages),
+                   "parallelism": "tp%d (kv-head shards)" % world, "step": "one run_mha decode call over the batch"
+                   + (" + all-reduce of [B, h*d] bf16" if world > 1 else "")},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "paged_decode_kernel<bf16,128,G=4>", "kernel_ms": round(kern_ms, 4),
+                     "algorithmic_bytes_per_launch": rank_bytes},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk_l, h_l)
+    if rank == 0:
+        print(json.dumps(out))
+    if comm is not None:
+        ah.lib.atoma_comm_destroy(comm)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
+    """The oracle's C restatement (fa_acausal over the gathered pages, f32, OpenMP) on the first
+    `--cpu-sample-seqs` sequences of the same workload; throughput is per byte, so the sample
+    scales linearly to the batch."""
+    from util import oracle_c
+    lib = oracle_c()
+    Bs = min(args.cpu_sample_seqs, args.batch)
+    d, page, S = args.head_dim, args.block_size, args.seq
+    # host copy of the cache: the same slab tiling as on the device
+    reps = -(-n_pages // slab_k.shape[0])
+    kc = np.tile(slab_k, (reps, 1))[:n_pages].reshape(n_pages, page, hk, d)
+    vc = np.tile(slab_v, (reps, 1))[:n_pages].reshape(n_pages, page, hk, d)
+    qs = np.ascontiguousarray(q[:Bs])
+    o = np.zeros_like(qs)
+    bts = np.ascontiguousarray(bt[:Bs])
+    ls = np.ascontiguousarray(lens[:Bs])
+    i64 = C.c_int64
+    lib.oracle_attention.argtypes = [C.c_void_p] * 6 + [C.c_int] + [i64] * 12 + [C.c_int] * 4 + [
+        C.c_float, C.c_void_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.oracle_max_threads.restype = C.c_int
+    cores = os.cpu_count() or 1
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def run():
+        lib.oracle_attention(vp(qs), vp(kc), vp(vc), vp(o), None, vp(ls), 0,
+                             h * d, page * hk * d, page * hk * d, h * d,
+                             h * d, hk * d, hk * d, h * d, d, d, d, d,
+                             Bs, h, hk, d, float(d ** -0.5), vp(bts), bts.shape[1], page, 1, bts.shape[1] * page,
+                             1, 0, cores)
+    run()                                                           # warm the page cache / threads
+    t0 = time.perf_counter()
+    reps_done = 0
+    while reps_done < 3 or (time.perf_counter() - t0 < 10.0 and reps_done < 50):
+        run()
+        reps_done += 1
+    dt = (time.perf_counter() - t0) / reps_done
+    nbytes = algorithmic_bytes(Bs, S, h, hk, d, page)
+    return {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "threads": int(lib.oracle_max_threads()),
+            "sample": "first %d of %d sequences of the same workload (same tensors), %d repetitions, %.3f s each; "
+                      "fa_acausal f32 restatement (oracle/c/oracle.c, gcc -O3 -fopenmp)" % (Bs, args.batch, reps_done, dt),
+            "decode_tokens_per_s": round(Bs / dt, 1)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,265 @@
+/*
+ * atoma_hip.h -- C ABI of libatoma_hip.so, the MI355X (gfx950) drop-in for atoma-infer's
+ * paged-attention hot path.
+ *
+ * SECTION 1 is the reference's own FFI boundary, symbol for symbol and argument for
+ * argument: /root/reference/csrc/src/ffi.rs:3-102 (definitions: csrc/kernels/flash_api.cu:22-159,
+ * csrc/kernels/cache_manager.cu:43-81,215-242).  A Rust build of the reference links this
+ * library instead of `libflashattention.a` + `cudart` (csrc/build.rs:105-113) and needs no
+ * source change in csrc/src/ffi.rs.  All strides are in ELEMENTS, all pointers are device
+ * pointers unless stated, `void *stream` is a `hipStream_t`.
+ *
+ * SECTION 2 holds what the reference does NOT route through its C ABI (it delegates to
+ * cudarc / Candle / NCCL) but which sits on the same hot path: swap_blocks, RMSNorm, RoPE,
+ * the tensor-parallel all-reduce, and the error channel.  Each entry names the reference
+ * interface it replaces.
+ *
+ * SECTION 3 is the host-side mirror of the reference's Candle operator layer
+ * (csrc/src/lib.rs, csrc/src/cache_manager.rs, models/src/flash_attention.rs): same
+ * function names, argument meaning and error strings, over a plain tensor descriptor.
+ *
+ * Error convention: the reference's entry points return void and call exit() on a launch
+ * failure (csrc/kernels/flash_fwd_launch_template.h:25-31).  Here every entry point records
+ * failures in a thread-local slot readable through atoma_last_error(); void signatures are
+ * kept so the ABI stays identical.  int-returning extension functions return 0 on success.
+ */
+#ifndef ATOMA_HIP_H
+#define ATOMA_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* dtype codes: 0/1 are the reference's (csrc/src/cache_manager.rs:384-390) */
+enum { ATOMA_F16 = 0, ATOMA_BF16 = 1, ATOMA_F32 = 2, ATOMA_U32 = 3, ATOMA_I64 = 4, ATOMA_U8 = 5, ATOMA_I32 = 6 };
+
+/* ------------------------------------------------------------------------------------------
+ * SECTION 1 -- the reference FFI (csrc/src/ffi.rs)
+ * ------------------------------------------------------------------------------------------ */
+
+/* csrc/src/ffi.rs:4-64 == csrc/kernels/flash_api.cu:22-159.  FlashAttention-2 forward:
+ * dense / varlen prefill, paged split-KV decode ("paged_attention v1/v2") and split combine.
+ * Launches on the NULL stream like the reference (flash_api.cu:157).
+ *   num_splits <= 1 && !force_split_kernel -> prefill kernel, else split-KV kernel (+combine)
+ *   block_table != NULL: k/v are paged caches [nb, page, h_k, d]; k_batch_stride is the page
+ *   stride; cu_seqlens_k holds per-sequence lengths when !is_seqlens_k_cumulative.
+ *   softmax_lseaccum_ptr / oaccum_ptr: caller scratch, fp32 [num_splits,b,h,seqlen_q] and
+ *   [num_splits,b,h,seqlen_q,d_rounded]; only read/written when num_splits > 1. */
+void run_mha(void *q_ptr, void *k_ptr, void *v_ptr, void *o_ptr, void *softmax_lse_ptr,
+             void *alibi_slopes_ptr, int32_t *cu_seqlens_q_ptr, int32_t *cu_seqlens_k_ptr,
+             bool is_seqlens_k_cumulative, uint32_t q_batch_stride, uint32_t k_batch_stride,
+             uint32_t v_batch_stride, uint32_t o_batch_stride, uint32_t alibi_slopes_batch_stride,
+             uint32_t q_row_stride, uint32_t k_row_stride, uint32_t v_row_stride,
+             uint32_t o_row_stride, uint32_t q_head_stride, uint32_t k_head_stride,
+             uint32_t v_head_stride, uint32_t o_head_stride, uint32_t num_splits, uint32_t b,
+             uint32_t h, uint32_t h_k, uint32_t d, uint32_t d_rounded, float softmax_scale,
+             float scale_softmax_log2, int *block_table, uint32_t block_table_batch_stride,
+             int page_block_size, int *seqused_k, uint32_t seqlen_q, uint32_t seqlen_k,
+             uint32_t seqlen_q_rounded, uint32_t seqlen_k_rounded, int is_bf16, int is_causal,
+             int window_size_left, int window_size_right, float softcap, bool unpadded_lse,
+             bool force_split_kernel, void *softmax_lseaccum_ptr, void *oaccum_ptr);
+
+/* csrc/src/ffi.rs:66-84 == csrc/kernels/cache_manager.cu:43-81.  Copy-on-write page copies
+ * for all layers in one launch: key/value_cache_ptrs are DEVICE arrays of int64 per-layer
+ * base pointers, block_mapping a DEVICE int64 [num_pairs][2] of (src,dst) page numbers. */
+void copy_blocks_f16(void *key_cache_ptrs, void *value_cache_ptrs, const void *block_mapping,
+                     int64_t num_layers, int64_t num_pairs, int64_t numel_per_block, void *stream);
+void copy_blocks_bf16(void *key_cache_ptrs, void *value_cache_ptrs, const void *block_mapping,
+                      int64_t num_layers, int64_t num_pairs, int64_t numel_per_block, void *stream);
+
+/* csrc/src/ffi.rs:86-101 == csrc/kernels/cache_manager.cu:215-242.  Scatter new K,V tokens
+ * [num_tokens, num_heads, head_size] (row strides key_stride/value_stride) into the paged
+ * caches [nb, block_size, num_heads, head_size] at slot_mapping[t] (< 0 = padding, skipped).
+ * dtype: 0 = f16, 1 = bf16. */
+void reshape_and_cache_flash(void *key, void *value, void *key_cache, void *value_cache,
+                             int64_t *slot_mapping, int64_t block_stride, int64_t num_tokens,
+                             int64_t num_heads, int64_t head_size, int64_t block_size,
+                             int64_t key_stride, int64_t value_stride, uint32_t dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SECTION 2 -- same hot path, not behind the reference's C ABI
+ * ------------------------------------------------------------------------------------------ */
+
+/* Error channel (replaces exit() in csrc/kernels/flash_fwd_launch_template.h:25-31).
+ * Returns "" when the calling thread's last library call succeeded. */
+const char *atoma_last_error(void);
+void atoma_clear_error(void);
+
+/* run_mha with an explicit stream (the reference hard-codes stream 0, flash_api.cu:157). */
+void run_mha_stream(void *q_ptr, void *k_ptr, void *v_ptr, void *o_ptr, void *softmax_lse_ptr,
+                    void *alibi_slopes_ptr, int32_t *cu_seqlens_q_ptr, int32_t *cu_seqlens_k_ptr,
+                    bool is_seqlens_k_cumulative, uint32_t q_batch_stride, uint32_t k_batch_stride,
+                    uint32_t v_batch_stride, uint32_t o_batch_stride,
+                    uint32_t alibi_slopes_batch_stride, uint32_t q_row_stride,
+                    uint32_t k_row_stride, uint32_t v_row_stride, uint32_t o_row_stride,
+                    uint32_t q_head_stride, uint32_t k_head_stride, uint32_t v_head_stride,
+                    uint32_t o_head_stride, uint32_t num_splits, uint32_t b, uint32_t h,
+                    uint32_t h_k, uint32_t d, uint32_t d_rounded, float softmax_scale,
+                    float scale_softmax_log2, int *block_table, uint32_t block_table_batch_stride,
+                    int page_block_size, int *seqused_k, uint32_t seqlen_q, uint32_t seqlen_k,
+                    uint32_t seqlen_q_rounded, uint32_t seqlen_k_rounded, int is_bf16,
+                    int is_causal, int window_size_left, int window_size_right, float softcap,
+                    bool unpadded_lse, bool force_split_kernel, void *softmax_lseaccum_ptr,
+                    void *oaccum_ptr, void *stream);
+
+/* Split count the library would pick (csrc/src/lib.rs:2122-2199, `num_splits_heuristic` and
+ * `compute_num_splits`, with the CU count in place of the SM count).  num_cus <= 0: query
+ * the current device. */
+int atoma_num_splits_heuristic(int64_t batch_nheads_mblocks, int64_t num_sms, int64_t num_n_blocks,
+                               int64_t max_splits);
+int atoma_compute_num_splits(int64_t batch_size, int64_t num_heads, int64_t head_size,
+                             int64_t max_seqlen_k, int64_t max_seqlen_q, int num_cus);
+
+/* swap_blocks (csrc/src/cache_manager.rs:18-128 + csrc/src/ops.rs:14-220: one async memcpy per
+ * page there).  dst[page d] = src[page s] for every (s,d) in `mapping` (HOST int64 [n][2]),
+ * whole pages of block_size_in_bytes.  kind: 0 = gpu->gpu (same device), 1 = cpu->gpu,
+ * 2 = gpu->cpu.  Host pointers that the device can address (atoma_host_alloc or
+ * hipHostRegister'ed) are moved by one gather/scatter kernel over PCIe; pageable host memory
+ * falls back to per-page hipMemcpyAsync.  Stream-ordered; the caller syncs the stream. */
+enum { ATOMA_SWAP_GPU_TO_GPU = 0, ATOMA_SWAP_CPU_TO_GPU = 1, ATOMA_SWAP_GPU_TO_CPU = 2 };
+int atoma_swap_blocks(const void *src, void *dst, const int64_t *mapping, int64_t num_pairs,
+                      int64_t block_size_in_bytes, int kind, void *stream);
+/* Same for many tensors at once (every layer's K and V: worker.rs:602-632 loops them). */
+int atoma_swap_blocks_multi(const void *const *srcs, void *const *dsts, int64_t num_tensors,
+                            const int64_t *mapping, int64_t num_pairs, int64_t block_size_in_bytes,
+                            int kind, void *stream);
+/* Pinned, device-addressable host memory for the CPU KV cache (the reference uses pageable
+ * Candle CPU tensors, backends/vllm/src/worker.rs:570-598). */
+void *atoma_host_alloc(size_t bytes);
+void atoma_host_free(void *p);
+
+/* RMSNorm (models/src/llama.rs:402,408,474 -> candle_nn::ops::rms_norm): per row
+ * y = T(rsqrt(mean(x^2) + eps) * x * w), f32 arithmetic, one rounding. */
+int atoma_rms_norm(const void *x, const void *weight, void *y, int64_t rows, int64_t hidden,
+                   int64_t x_row_stride, int64_t y_row_stride, float eps, int dtype, void *stream);
+
+/* RoPE, rotate-half (models/src/llama.rs:218-251 -> candle_nn::rotary_emb::rope), with the
+ * reference's index_select of the cos/sin rows fused in: x,y [T, heads, d] (token / head
+ * strides in elements, d contiguous), tables [max_pos, d/2] in the tensor dtype, positions
+ * int64 [T].  per_op_rounding != 0 reproduces Candle's arithmetic in the tensor dtype
+ * (every product and the sum rounded); 0 = f32 round-once.  y may alias x. */
+int atoma_rope(const void *x, void *y, const void *cos_table, const void *sin_table,
+               const int64_t *positions, int64_t num_tokens, int64_t num_heads, int64_t head_dim,
+               int64_t x_token_stride, int64_t x_head_stride, int64_t y_token_stride,
+               int64_t y_head_stride, int dtype, int per_op_rounding, void *stream);
+/* q and k in one launch (the reference calls rope twice per layer, llama.rs:296-297). */
+int atoma_rope_qk(void *q, void *k, const void *cos_table, const void *sin_table,
+                  const int64_t *positions, int64_t num_tokens, int64_t num_q_heads,
+                  int64_t num_kv_heads, int64_t head_dim, int64_t q_token_stride,
+                  int64_t k_token_stride, int dtype, int per_op_rounding, void *stream);
+/* cos/sin table of `Cache::new` (models/src/llama.rs:154-200) built on the HOST into
+ * cos_out/sin_out [max_pos, head_dim/2] (storage dtype).  rope_factor <= 0: no Llama-3 scaling. */
+int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head_dim,
+                     float rope_theta, float rope_factor, float low_freq_factor,
+                     float high_freq_factor, int64_t original_max_position_embeddings, int dtype);
+
+/* Tensor-parallel sum all-reduce (models/src/multi_gpu.rs:141-179 `AllReduce::cuda_fwd`,
+ * bootstrap backends/vllm/src/model_executor.rs:413,436-439 `Id::new` / `Comm::from_rank`).
+ * One process (or thread) per GPU over RCCL/xGMI.  id128: 128-byte ncclUniqueId. */
+int atoma_comm_unique_id(void *id128_out);
+int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128, int device);
+int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, int dtype, void *stream);
+int atoma_comm_destroy(void *comm);
+
+/* Device helpers used by the host layer, tests and bench (plain HIP runtime, no torch). */
+int atoma_device_count(void);
+int atoma_num_cus(int device);
+
+/* ------------------------------------------------------------------------------------------
+ * SECTION 3 -- host mirror of the reference's Candle operator layer
+ * ------------------------------------------------------------------------------------------ */
+
+/* A Candle `Tensor` as the ops see it (storage pointer already advanced by start_offset,
+ * shape, strides in elements): candle_core::Layout.  device: -1 = host, >= 0 HIP ordinal. */
+typedef struct atoma_tensor {
+    void *data;
+    int32_t dtype;
+    int32_t device;
+    int32_t rank;
+    int32_t _pad;
+    int64_t shape[5];
+    int64_t stride[5];
+} atoma_tensor;
+
+/* csrc::flash_attn (csrc/src/lib.rs:392-411): q [b,sq,h,d], k,v [b,sk,hk,d] -> out [b,sq,h,d]
+ * (contiguous, caller-allocated).  Returns 0 or -1 with the reference's error text in
+ * atoma_last_error(). */
+int atoma_flash_attn(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
+                     float softmax_scale, int causal, atoma_tensor *out);
+/* csrc::flash_attn_varlen (lib.rs:1160-1188). q [total_q,h,d], k,v [total_k,hk,d],
+ * seqlens_q/k u32 cumulative [B+1]. */
+int atoma_flash_attn_varlen(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
+                            const atoma_tensor *seqlens_q, const atoma_tensor *seqlens_k,
+                            int64_t max_seqlen_q, int64_t max_seqlen_k, float softmax_scale,
+                            int causal, atoma_tensor *out);
+/* csrc::flash_attn_varlen_with_block_table (lib.rs:1392-1420). k,v = paged caches
+ * [nb,page,hk,d]; window_* < 0 = None; alibi_slopes / block_table may be NULL. */
+int atoma_flash_attn_varlen_with_block_table(const atoma_tensor *q, const atoma_tensor *k,
+                                             const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                             const atoma_tensor *seqlens_q, const atoma_tensor *seqlens_k,
+                                             int64_t max_seqlen_q, int64_t max_seqlen_k,
+                                             float softmax_scale, int64_t window_size_left,
+                                             int64_t window_size_right, const atoma_tensor *block_table,
+                                             atoma_tensor *out);
+/* csrc::flash_attn_kv_cache_full (lib.rs:2083-2105). q [B,sq,h,d]; caches [B_c,sk,hk,d] or
+ * paged [nb,page,hk,d] with block_table [B,max_blocks] u32; seqlens_k u32 [B] or NULL. */
+int atoma_flash_attn_kv_cache_full(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
+                                   const atoma_tensor *alibi_slopes, float softmax_scale,
+                                   const atoma_tensor *block_table, const atoma_tensor *seqlens_k,
+                                   int causal, atoma_tensor *out);
+/* csrc::reshape_and_cache_flash (csrc/src/cache_manager.rs:319-535). */
+int atoma_reshape_and_cache_flash(const atoma_tensor *key, const atoma_tensor *value,
+                                  const atoma_tensor *key_cache, const atoma_tensor *value_cache,
+                                  const atoma_tensor *slot_mapping);
+/* csrc::copy_blocks (cache_manager.rs:148-307): block_mapping i64 [num_pairs,2] on the device. */
+int atoma_copy_blocks(const atoma_tensor *const *key_caches, int64_t num_key_caches,
+                      const atoma_tensor *const *value_caches, int64_t num_value_caches,
+                      const atoma_tensor *block_mapping);
+/* csrc::swap_blocks (cache_manager.rs:18-128): mapping = HOST u32 pairs [(src,dst)...]. */
+int atoma_swap_blocks_tensor(const atoma_tensor *src, atoma_tensor *dst, const uint32_t *mapping_pairs,
+                             int64_t num_pairs);
+
+/* models::FlashAttentionMetadata + FlashAttention::forward (models/src/flash_attention.rs:
+ * 11-146,322-469).  NULL tensor pointers = None. */
+typedef struct atoma_attn_metadata {
+    const atoma_tensor *slot_mapping;               /* i64 [T] */
+    int64_t num_prefill_tokens, num_decoding_tokens;
+    /* prefill_metadata */
+    int has_prefill;
+    const atoma_tensor *prefill_block_tables;       /* u32 [Bp,max_blocks] or NULL */
+    int64_t max_prefill_sequence_length;
+    const atoma_tensor *query_start_locations;      /* u32 [Bp+1] */
+    const atoma_tensor *sequence_start_locations;   /* u32 [Bp+1] */
+    int64_t max_sequence_length_k;                  /* max(sequence_lengths) (flash_attention.rs:419) */
+    /* decoding_metadata */
+    int has_decoding;
+    const atoma_tensor *decoding_block_tables;      /* u32 [Bd,max_blocks] */
+    const atoma_tensor *decoding_sequence_lengths;  /* u32 [Bd] */
+} atoma_attn_metadata;
+
+typedef struct atoma_flash_attention {
+    int64_t num_heads, num_kv_heads, head_dim;
+    float softmax_scale;
+    const atoma_tensor *alibi_slopes;               /* f32 [h] or NULL */
+    int64_t sliding_window;                         /* < 0 = None */
+    int32_t kv_cache_dtype, device;
+} atoma_flash_attention;
+
+/* FlashAttention::new checks (flash_attention.rs:198-230). */
+int atoma_flash_attention_new(atoma_flash_attention *self, int64_t num_heads, int64_t num_kv_heads,
+                              int64_t head_dim, float softmax_scale, const atoma_tensor *alibi_slopes,
+                              int64_t sliding_window, int32_t kv_cache_dtype, int32_t device);
+/* FlashAttention::forward: q [T,h,d], k,v [T,hk,d], kv_cache [2,nb,page,hk,d] -> out [T,h*d]. */
+int atoma_flash_attention_forward(const atoma_flash_attention *self, const atoma_tensor *q,
+                                  const atoma_tensor *k, const atoma_tensor *v,
+                                  const atoma_tensor *kv_cache, const atoma_attn_metadata *meta,
+                                  atoma_tensor *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATOMA_HIP_H */

@@ -1,0 +1,48 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/atoma_hip.h
+declares (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "atoma_hip.h")
+LIB = os.path.join(ROOT, "atoma-infer_amd", "lib", "libatoma_hip.so")
+
+# the reference's own FFI (csrc/src/ffi.rs:3-102): these four must exist under these names
+REFERENCE_SYMBOLS = ["run_mha", "copy_blocks_f16", "copy_blocks_bf16", "reshape_and_cache_flash"]
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b([A-Za-z_]\w*)\s*\(", text, flags=re.M)
+    return sorted({n for n in names if n.startswith("atoma_") or n in REFERENCE_SYMBOLS or n == "run_mha_stream"})
+
+
+def test_library_is_built():
+    assert os.path.exists(LIB), "libatoma_hip.so missing: run __graft_entry__.build()"
+
+
+def test_every_declared_symbol_is_exported():
+    lib = C.CDLL(LIB)
+    names = declared_functions()
+    assert len(names) >= 20, names
+    for n in REFERENCE_SYMBOLS:
+        assert n in names
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/atoma_hip.h but not exported: {missing}"
+
+
+def test_error_channel_and_host_heuristics_without_gpu():
+    lib = C.CDLL(LIB)
+    lib.atoma_last_error.restype = C.c_char_p
+    assert lib.atoma_last_error() == b""
+    lib.atoma_num_splits_heuristic.argtypes = [C.c_int64] * 4
+    assert lib.atoma_num_splits_heuristic(48, 108, 64, 128) == 2     # csrc/src/lib.rs:2116-2121 doc example
+    lib.atoma_compute_num_splits.argtypes = [C.c_int64] * 5 + [C.c_int]
+    assert lib.atoma_compute_num_splits(256, 32, 128, 4096, 1, 256) == 1
+    assert lib.atoma_compute_num_splits(1, 32, 128, 4096, 1, 256) > 1
+    # swap_blocks with an invalid src/dst device combination: the reference's error string
+    lib.atoma_swap_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+    assert lib.atoma_swap_blocks(None, None, None, 0, 0, 7, None) != 0
+    assert lib.atoma_last_error().startswith(b"swap_blocks: Either src and dst are on the same cuda device")

@@ -1,0 +1,176 @@
+"""Paged decode attention (run_mha with seqlen_q = 1) against the oracle, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import attn_oracle as A
+from oracle.halfs import F16, BF16, to_f32
+from util import rand_half, make_paged_cache, assert_close, c_attention
+
+pytestmark = pytest.mark.gpu
+CASES = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_cases.npz"))
+
+
+def gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, causal=1, alibi=None, seqlens_cumulative=False):
+    """q [B,1,h,d]; paged caches [nb,page,hk,d] (bt given) or contiguous [B,S,hk,d] (bt None)."""
+    B, _, h, d = q.shape
+    hk = kc.shape[2]
+    dq, dk, dv = (gpu.DeviceBuffer.from_numpy(a) for a in (q, kc, vc))
+    do = gpu.DeviceBuffer(q.nbytes)
+    do.fill_bytes(0xFF)                                          # poison: every element must be written
+    dlse = gpu.DeviceBuffer.zeros((B, h), np.float32)
+    dbt = gpu.DeviceBuffer.from_numpy(np.ascontiguousarray(bt, np.int32)) if bt is not None else None
+    dl = gpu.DeviceBuffer.from_numpy(np.ascontiguousarray(lens, np.int32)) if lens is not None else None
+    da = gpu.DeviceBuffer.from_numpy(np.asarray(alibi, np.float32)) if alibi is not None else None
+    page = kc.shape[1] if bt is not None else 0
+    seqlen_k = bt.shape[1] * page if bt is not None else kc.shape[1]
+    gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=seqlen_k, softmax_scale=float(scale),
+                is_bf16=dtype, q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d),
+                k_strides=(kc.shape[1] * hk * d, hk * d, d), v_strides=(vc.shape[1] * hk * d, hk * d, d),
+                is_causal=0 if alibi is None else causal,      # lib.rs:1629-1631: causal off for seqlen_q == 1
+                cu_seqlens_k=dl, is_seqlens_k_cumulative=seqlens_cumulative, block_table=dbt,
+                block_table_batch_stride=0 if bt is None else bt.shape[1], page_block_size=page,
+                alibi_slopes=da, softmax_lse=dlse, force_split_kernel=bt is not None, unpadded_lse=False)
+    gpu.synchronize()
+    return do.numpy(np.uint16, q.shape), dlse.numpy()
+
+
+@pytest.mark.parametrize("tag,dtype", [("d1", BF16), ("d2", F16)])
+def test_decode_golden_fixtures(gpu, tag, dtype):
+    c = CASES
+    out, _ = gpu_decode(gpu, c[f"{tag}_q"], c[f"{tag}_kc"], c[f"{tag}_vc"], c[f"{tag}_bt"], c[f"{tag}_lens"],
+                        c[f"{tag}_scale"], dtype)
+    assert_close(out, c[f"{tag}_out_f32"], dtype, what=f"{tag} vs fa_acausal oracle")
+    assert_close(out, c[f"{tag}_out_kernel"], dtype, what=f"{tag} vs kernel-faithful oracle")
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("d,h,hk,page", [(128, 32, 8, 16), (128, 8, 8, 16), (128, 16, 2, 16), (128, 6, 2, 32),
+                                         (64, 32, 8, 16), (64, 4, 4, 64), (128, 32, 2, 16), (64, 16, 8, 16)])
+def test_decode_matches_oracle_ragged(gpu, dtype, d, h, hk, page):
+    """GQA group sizes 1,2,3,4,8,16, both head sizes, pages of 16/32/64 tokens, ragged lengths
+    around every tile/page boundary, including the empty sequence."""
+    rng = np.random.default_rng(d + h * 7 + hk + page)
+    lens = np.array([0, 1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 200, 333], np.int32)
+    nb = int(sum((L + page - 1) // page for L in lens)) + 3
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+    q = rand_half(rng, (len(lens), 1, h, d), dtype)
+    scale = np.float32(d ** -0.5)
+    out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype)
+    ref = A.flash_attn_kv_cache(q, kc, vc, scale, dtype, bt, lens, mode="f32")
+    assert_close(out, ref, dtype, what="decode vs oracle")
+    assert not out[0].any(), "empty sequence must produce exact zeros (flash_fwd_kernel.h:97-133)"
+    assert np.isposinf(lse[0]).all() and np.isfinite(lse[1:]).all()
+
+
+def test_decode_lse_values(gpu):
+    rng = np.random.default_rng(77)
+    lens = np.array([40, 129], np.int32)
+    kc, vc, bt = make_paged_cache(rng, 16, 16, 2, 128, BF16, lens)
+    q = rand_half(rng, (2, 1, 8, 128), BF16)
+    sc = np.float32(128 ** -0.5)
+    _, lse = gpu_decode(gpu, q, kc, vc, bt, lens, sc, BF16)
+    for b in range(2):
+        kb = A.gather_paged(to_f32(kc, BF16), bt[b], lens[b], 16)
+        _, want = A.attend_rows(to_f32(q, BF16)[b], kb, kb, sc)
+        assert np.allclose(lse[b], want[:, 0], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,L", [(1, 4096), (2, 1500), (3, 257)])
+def test_decode_split_kv_small_batch(gpu, B, L):
+    """Few sequences, long context: the library splits KV across wavefronts and merges with the
+    combine kernel ('paged_attention v2'); result must still match the unsplit oracle."""
+    rng = np.random.default_rng(B * 1000 + L)
+    lens = np.array([L - 7 * i for i in range(B)], np.int32)
+    h, hk, d, page = 32, 8, 128, 16
+    nb = int(sum((x + page - 1) // page for x in lens)) + 2
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    scale = np.float32(d ** -0.5)
+    out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, scale, BF16)
+    ref = c_attention(q, kc, vc, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bt.shape[1] * page,
+                      scale=float(scale), is_bf16=1, q_strides=(h * d, h * d, d),
+                      k_strides=(page * hk * d, hk * d, d), v_strides=(page * hk * d, hk * d, d),
+                      o_shape=q.shape, o_strides=(h * d, h * d, d), cu_k=lens, k_cumulative=False,
+                      block_table=bt, page=page)
+    assert_close(out, ref, BF16, what="split-KV decode vs C oracle")
+    assert np.isfinite(lse).all()
+
+
+def test_decode_contiguous_cache_without_block_table(gpu):
+    """flash_attn_kv_cache_full with block_table = None: caches [B, S, hk, d], per-sequence
+    lengths; the ragged last tile must not read past the cache (rows are clamped)."""
+    rng = np.random.default_rng(8)
+    B, S, h, hk, d = 5, 100, 8, 2, 128
+    kc, vc = rand_half(rng, (B, S, hk, d), BF16), rand_half(rng, (B, S, hk, d), BF16)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    lens = np.array([100, 1, 50, 99, 16], np.int32)
+    out, _ = gpu_decode(gpu, q, kc, vc, None, lens, 0.09, BF16)
+    ref = A.flash_attn_kv_cache(q, kc, vc, 0.09, BF16, None, lens)
+    assert_close(out, ref, BF16, what="contiguous kv cache")
+    out, _ = gpu_decode(gpu, q, kc, vc, None, None, 0.09, BF16)      # seqlens_k = None -> full S
+    assert_close(out, A.flash_attn_kv_cache(q, kc, vc, 0.09, BF16), BF16, what="contiguous kv cache, full length")
+
+
+def test_decode_alibi(gpu):
+    rng = np.random.default_rng(9)
+    lens = np.array([70, 33], np.int32)
+    kc, vc, bt = make_paged_cache(rng, 10, 16, 2, 128, BF16, lens)
+    q = rand_half(rng, (2, 1, 8, 128), BF16)
+    slopes = (2.0 ** -np.arange(1, 9)).astype(np.float32)
+    out, _ = gpu_decode(gpu, q, kc, vc, bt, lens, 0.088, BF16, alibi=slopes)
+    ref = A.flash_attn_kv_cache(q, kc, vc, 0.088, BF16, bt, lens, causal=True, alibi_slopes=slopes)
+    assert_close(out, ref, BF16, what="decode + ALiBi")
+
+
+def test_decode_block_table_permutation_invariance_bit_exact(gpu):
+    """Size-independent property: where the pages physically live must not change a single
+    bit of the result (same rows, same order of arithmetic)."""
+    rng = np.random.default_rng(10)
+    lens = np.array([513, 1000, 64], np.int32)
+    h, hk, d, page = 16, 4, 128, 16
+    need = [(int(L) + page - 1) // page for L in lens]
+    nb = sum(need)
+    kc0, vc0, bt0 = make_paged_cache(rng, nb, page, hk, d, BF16, lens, shuffle=False)
+    q = rand_half(rng, (3, 1, h, d), BF16)
+    perm = rng.permutation(nb)                               # new physical home of each page
+    kc1, vc1 = np.empty_like(kc0), np.empty_like(vc0)
+    kc1[perm], vc1[perm] = kc0, vc0
+    bt1 = np.where(np.arange(bt0.shape[1])[None] < np.array(need)[:, None], perm[bt0], 0).astype(np.int32)
+    a, _ = gpu_decode(gpu, q, kc0, vc0, bt0, lens, 0.088, BF16)
+    b, _ = gpu_decode(gpu, q, kc1, vc1, bt1, lens, 0.088, BF16)
+    assert np.array_equal(a, b)
+
+
+def test_decode_full_size_properties_c2a(gpu):
+    """BASELINE.json configs[1] at full size (B=256, h=32, h_k=8, d=128, seq=4096, page 16, bf16):
+    too big for the oracle, so check properties: (1) V = per-(page,row) constant makes the
+    output a convex combination -> bounded by V's range and equal across d; (2) a sequence whose
+    keys are all identical gets the exact mean of its V rows; (3) a sampled subset of sequences
+    matches the C oracle."""
+    rng = np.random.default_rng(12)
+    B, h, hk, d, S, page = 256, 32, 8, 128, 4096, 16
+    nb = B * (S // page)
+    bt = rng.permutation(nb).astype(np.int32).reshape(B, S // page)
+    kc = rand_half(rng, (nb, page, hk, d), BF16)
+    vrow = rand_half(rng, (nb, page, hk, 1), BF16)
+    vc = np.broadcast_to(vrow, (nb, page, hk, d)).copy()
+    kc[bt[0]] = kc[bt[0][0], 0, 0, 0]                          # sequence 0: all keys identical
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    lens = np.full(B, S, np.int32)
+    out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
+    o = to_f32(out, BF16)
+    assert np.isfinite(o).all() and np.isfinite(lse).all()
+    assert np.ptp(o, axis=-1).max() == 0, "V constant along d -> output constant along d"
+    v = to_f32(vrow, BF16)
+    assert o.max() <= v.max() + 1e-6 and o.min() >= v.min() - 1e-6
+    mean_v = to_f32(vc, BF16)[bt[0]].reshape(S, hk, d).mean(0)               # [hk, d]
+    got0 = o[0, 0].reshape(hk, h // hk, d)
+    assert np.abs(got0 - mean_v[:, None]).max() < 2e-3
+    pick = [1, 100, 255]
+    ref = c_attention(q[pick], kc, vc, b=len(pick), h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=S, scale=d ** -0.5,
+                      is_bf16=1, q_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                      v_strides=(page * hk * d, hk * d, d), o_shape=(len(pick), 1, h, d), o_strides=(h * d, h * d, d),
+                      cu_k=lens[pick], k_cumulative=False, block_table=bt[pick], page=page)
+    assert_close(out[pick], ref, BF16, what="C2a sampled sequences vs C oracle")

@@ -1,0 +1,90 @@
+"""Shared helpers for the parity tests (numpy side)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from oracle.halfs import F16, BF16, from_f32, to_f32  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rand_half(rng, shape, dtype, scale=1.0):
+    """N(0, scale) rounded to the storage dtype, as uint16 bit patterns."""
+    return from_f32((rng.standard_normal(shape) * scale).astype(np.float32), dtype)
+
+
+def ulp_tol(ref_f32, dtype, atol=1e-3):
+    """|got - ref| <= atol + eps*|ref|, eps = one unit in the last place of the storage dtype
+    (2^-7 bf16, 2^-10 f16): the '1e-3 bf16 tolerance' of BASELINE.json made scale-aware
+    (SURVEY 8c)."""
+    eps = 2.0 ** -7 if dtype == BF16 else 2.0 ** -10
+    return atol + eps * np.abs(ref_f32)
+
+
+def assert_close(got_bits, ref_bits, dtype, atol=1e-3, what=""):
+    got, ref = to_f32(got_bits, dtype), to_f32(ref_bits, dtype)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.isfinite(got).all(), f"{what}: non-finite output"
+    err = np.abs(got - ref)
+    tol = ulp_tol(ref, dtype, atol)
+    bad = err > tol
+    assert not bad.any(), (f"{what}: {bad.sum()} of {bad.size} beyond tolerance; max err {err.max():.3e} "
+                           f"at {np.unravel_index(err.argmax(), err.shape)} (ref {ref.flat[err.argmax()]:.5f})")
+
+
+_oracle_lib = None
+
+
+def oracle_c():
+    """ctypes handle of oracle/_build/liboracle.so (built on demand with gcc)."""
+    global _oracle_lib
+    if _oracle_lib is None:
+        so = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+        src = os.path.join(ROOT, "oracle", "c", "oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        _oracle_lib = C.CDLL(so)
+    return _oracle_lib
+
+
+def c_attention(q, k, v, *, b, h, h_k, d, seqlen_q, seqlen_k, scale, is_bf16, q_strides, k_strides, v_strides,
+                o_shape, o_strides, causal=0, cu_q=None, cu_k=None, k_cumulative=True, block_table=None,
+                page=0, threads=0):
+    """oracle_attention() of oracle/c/oracle.c on numpy uint16 arrays; strides = (batch,row,head)."""
+    lib = oracle_c()
+    o = np.zeros(o_shape, np.uint16)
+    P = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    cu_q = None if cu_q is None else np.ascontiguousarray(cu_q, np.int32)
+    cu_k = None if cu_k is None else np.ascontiguousarray(cu_k, np.int32)
+    bt = None if block_table is None else np.ascontiguousarray(block_table, np.int32)
+    i64 = C.c_int64
+    lib.oracle_attention.argtypes = [C.c_void_p] * 6 + [C.c_int] + [i64] * 12 + [C.c_int] * 4 + [C.c_float,
+                                     C.c_void_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.oracle_attention(P(q), P(k), P(v), P(o), P(cu_q), P(cu_k), int(k_cumulative),
+                         q_strides[0], k_strides[0], v_strides[0], o_strides[0],
+                         q_strides[1], k_strides[1], v_strides[1], o_strides[1],
+                         q_strides[2], k_strides[2], v_strides[2], o_strides[2],
+                         b, h, h_k, d, scale, P(bt), 0 if bt is None else bt.shape[1], page,
+                         seqlen_q, seqlen_k, int(is_bf16), int(causal), threads)
+    return o
+
+
+def make_paged_cache(rng, num_blocks, page, h_k, d, dtype, lens, shuffle=True):
+    """K,V caches [nb,page,hk,d] filled with N(0,1) and a block table [B,max_blocks] whose rows
+    own disjoint, randomly placed physical pages (unused entries = 0, as the worker pads them:
+    backends/vllm/src/worker.rs:410-412)."""
+    B = len(lens)
+    need = [(int(L) + page - 1) // page for L in lens]
+    max_blocks = max(1, max(need))
+    assert sum(need) <= num_blocks
+    perm = rng.permutation(num_blocks) if shuffle else np.arange(num_blocks)
+    bt = np.zeros((B, max_blocks), np.int32)
+    pos = 0
+    for i, n in enumerate(need):
+        bt[i, :n] = perm[pos:pos + n]
+        pos += n
+    kc = rand_half(rng, (num_blocks, page, h_k, d), dtype)
+    vc = rand_half(rng, (num_blocks, page, h_k, d), dtype)
+    return kc, vc, bt
