@@ -1,0 +1,292 @@
+// RMSNorm and RoPE for gfx950 -- the two small per-layer ops next to attention.
+//
+// The reference does not own these kernels: it calls Candle
+//   RMSNorm  /root/reference/models/src/llama.rs:402,408,474  -> candle_nn::ops::rms_norm
+//   RoPE     /root/reference/models/src/llama.rs:218-251      -> candle_nn::rotary_emb::rope
+// (candle 0.9.2-alpha.1, not vendored; semantics restated in oracle/norm_rope_oracle.py).
+// Both are HBM-bound streaming ops: 16-byte vector access, one pass over the data.
+//   RMSNorm bytes = 2*T*hidden*2 + hidden*2 ;  RoPE bytes = 2*T*(h+h_k)*d*2 + 2*T*(d/2)*2
+// The reference wraps RoPE in 4 transposes + contiguous() copies per layer
+// (llama.rs:273-303) because Candle's kernel wants [1, h, T, d]; this kernel works on the
+// [T, h, d] layout the projections produce and fuses the cos/sin index_select.
+#include "common.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace atoma {
+
+template <typename T> __device__ __forceinline__ void unpack8(const uint4 &v, float (&f)[8]) {
+    f[0] = lo_to_f32<T>(v.x); f[1] = hi_to_f32<T>(v.x);
+    f[2] = lo_to_f32<T>(v.y); f[3] = hi_to_f32<T>(v.y);
+    f[4] = lo_to_f32<T>(v.z); f[5] = hi_to_f32<T>(v.z);
+    f[6] = lo_to_f32<T>(v.w); f[7] = hi_to_f32<T>(v.w);
+}
+template <typename T> __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = pack2<T>(f[0], f[1]); v.y = pack2<T>(f[2], f[3]);
+    v.z = pack2<T>(f[4], f[5]); v.w = pack2<T>(f[6], f[7]);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm: one 256-thread workgroup per row; the row stays in registers between the
+// sum-of-squares pass and the scale pass (ITERS x 8 elements per thread).
+// ------------------------------------------------------------------------------------------
+constexpr int NORM_THREADS = 256;
+
+template <typename T, int ITERS>
+__global__ void __launch_bounds__(NORM_THREADS)
+rms_norm_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w, uint16_t *__restrict__ y,
+                int hidden, int64_t x_row_stride, int64_t y_row_stride, float eps) {
+    __shared__ float red[NORM_THREADS / 64];
+    const int64_t row = blockIdx.x;
+    const uint16_t *xr = x + row * x_row_stride;
+    uint16_t *yr = y + row * y_row_stride;
+    const int nvec = hidden >> 3;
+    uint4 xv[ITERS];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = it * NORM_THREADS + threadIdx.x;
+        xv[it] = make_uint4(0, 0, 0, 0);
+        if (i < nvec) xv[it] = reinterpret_cast<const uint4 *>(xr)[i];
+        float f[8];
+        unpack8<T>(xv[it], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_THREADS / 64; ++i) tot += red[i];
+    const float scale = 1.0f / sqrtf(tot / (float)hidden + eps);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = it * NORM_THREADS + threadIdx.x;
+        if (i < nvec) {
+            float f[8], g[8];
+            unpack8<T>(xv[it], f);
+            unpack8<T>(reinterpret_cast<const uint4 *>(w)[i], g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (scale * f[e]) * g[e];  // candle-kernels rmsnorm order
+            reinterpret_cast<uint4 *>(yr)[i] = pack8<T>(f);
+        }
+    }
+}
+
+// any hidden size / alignment: two passes over the row through L2
+template <typename T>
+__global__ void __launch_bounds__(NORM_THREADS)
+rms_norm_generic_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w, uint16_t *__restrict__ y,
+                        int hidden, int64_t x_row_stride, int64_t y_row_stride, float eps) {
+    __shared__ float red[NORM_THREADS / 64];
+    const int64_t row = blockIdx.x;
+    const uint16_t *xr = x + row * x_row_stride;
+    uint16_t *yr = y + row * y_row_stride;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < hidden; i += NORM_THREADS) {
+        const float f = lo_to_f32<T>(xr[i]);
+        ss += f * f;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_THREADS / 64; ++i) tot += red[i];
+    const float scale = 1.0f / sqrtf(tot / (float)hidden + eps);
+    for (int i = threadIdx.x; i < hidden; i += NORM_THREADS)
+        yr[i] = (uint16_t)f32_to_bits<T>((scale * lo_to_f32<T>(xr[i])) * lo_to_f32<T>(w[i]));
+}
+
+template <typename T>
+static void launch_rms_norm(const void *x, const void *w, void *y, int64_t rows, int64_t hidden, int64_t xs,
+                            int64_t ys, float eps, hipStream_t stream) {
+    auto x16 = static_cast<const uint16_t *>(x);
+    auto w16 = static_cast<const uint16_t *>(w);
+    auto y16 = static_cast<uint16_t *>(y);
+    const bool vec = hidden % 8 == 0 && xs % 8 == 0 && ys % 8 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0;
+    const int64_t iters = cdiv(hidden / 8, NORM_THREADS);
+    dim3 grid((unsigned)rows), block(NORM_THREADS);
+    if (vec && iters <= 1)
+        hipLaunchKernelGGL((rms_norm_kernel<T, 1>), grid, block, 0, stream, x16, w16, y16, (int)hidden, xs, ys, eps);
+    else if (vec && iters <= 2)
+        hipLaunchKernelGGL((rms_norm_kernel<T, 2>), grid, block, 0, stream, x16, w16, y16, (int)hidden, xs, ys, eps);
+    else if (vec && iters <= 4)
+        hipLaunchKernelGGL((rms_norm_kernel<T, 4>), grid, block, 0, stream, x16, w16, y16, (int)hidden, xs, ys, eps);
+    else if (vec && iters <= 8)
+        hipLaunchKernelGGL((rms_norm_kernel<T, 8>), grid, block, 0, stream, x16, w16, y16, (int)hidden, xs, ys, eps);
+    else
+        hipLaunchKernelGGL((rms_norm_generic_kernel<T>), grid, block, 0, stream, x16, w16, y16, (int)hidden, xs, ys, eps);
+    ATOMA_CHECK_LAUNCH("rms_norm");
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE (rotate-half): thread = (token, head, 8-element chunk of the first half).
+// PER_OP = Candle's arithmetic in the tensor dtype: every product and the sum are rounded.
+// ------------------------------------------------------------------------------------------
+template <typename T, bool PER_OP>
+__device__ __forceinline__ void rope_chunk(const uint16_t *x, uint16_t *y, const uint16_t *cosr, const uint16_t *sinr,
+                                           int half, int c) {
+    float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
+    unpack8<T>(*reinterpret_cast<const uint4 *>(x + c * 8), x1);
+    unpack8<T>(*reinterpret_cast<const uint4 *>(x + half + c * 8), x2);
+    unpack8<T>(*reinterpret_cast<const uint4 *>(cosr + c * 8), cs);
+    unpack8<T>(*reinterpret_cast<const uint4 *>(sinr + c * 8), sn);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if constexpr (PER_OP) {
+            y1[e] = round_through<T>(x1[e] * cs[e]) - round_through<T>(x2[e] * sn[e]);
+            y2[e] = round_through<T>(x1[e] * sn[e]) + round_through<T>(x2[e] * cs[e]);
+        } else {
+            y1[e] = x1[e] * cs[e] - x2[e] * sn[e];
+            y2[e] = x1[e] * sn[e] + x2[e] * cs[e];
+        }
+    }
+    *reinterpret_cast<uint4 *>(y + c * 8) = pack8<T>(y1);
+    *reinterpret_cast<uint4 *>(y + half + c * 8) = pack8<T>(y2);
+}
+
+// Two tensors (q and k) in one launch; nb heads == 0 disables the second.
+template <typename T, bool PER_OP>
+__global__ void __launch_bounds__(256)
+rope_kernel(const uint16_t *__restrict__ xa, uint16_t *__restrict__ ya, int heads_a, int64_t xa_ts, int64_t xa_hs,
+            int64_t ya_ts, int64_t ya_hs, const uint16_t *__restrict__ xb, uint16_t *__restrict__ yb, int heads_b,
+            int64_t xb_ts, int64_t xb_hs, int64_t yb_ts, int64_t yb_hs, const uint16_t *__restrict__ cos_t,
+            const uint16_t *__restrict__ sin_t, const int64_t *__restrict__ positions, int head_dim) {
+    const int64_t t = blockIdx.x;
+    const int half = head_dim >> 1;
+    const int cpr = half >> 3;  // chunks per (token, head)
+    const int64_t pos = positions[t];
+    const uint16_t *cosr = cos_t + pos * half, *sinr = sin_t + pos * half;
+    const int total = (heads_a + heads_b) * cpr;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int head = i / cpr, c = i - head * cpr;
+        if (head < heads_a)
+            rope_chunk<T, PER_OP>(xa + t * xa_ts + head * xa_hs, ya + t * ya_ts + head * ya_hs, cosr, sinr, half, c);
+        else
+            rope_chunk<T, PER_OP>(xb + t * xb_ts + (head - heads_a) * xb_hs, yb + t * yb_ts + (head - heads_a) * yb_hs,
+                                  cosr, sinr, half, c);
+    }
+}
+
+static int launch_rope(const void *xa, void *ya, int64_t ha, int64_t xa_ts, int64_t xa_hs, int64_t ya_ts, int64_t ya_hs,
+                       const void *xb, void *yb, int64_t hb, int64_t xb_ts, int64_t xb_hs, int64_t yb_ts, int64_t yb_hs,
+                       const void *cos_t, const void *sin_t, const int64_t *positions, int64_t T, int64_t d, int dtype,
+                       int per_op, hipStream_t stream) {
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("rope: dtype must be f16 or bf16"); return -1; }
+    if (d % 16 != 0) { set_error("rope: head_dim must be a multiple of 16"); return -1; }
+    const int64_t strides[] = {xa_ts, xa_hs, ya_ts, ya_hs, xb_ts, xb_hs, yb_ts, yb_hs};
+    for (int64_t s : strides)
+        if (s % 8 != 0) { set_error("rope: strides must be multiples of 8 elements"); return -1; }
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(xa) | reinterpret_cast<uintptr_t>(ya) | reinterpret_cast<uintptr_t>(xb) |
+                           reinterpret_cast<uintptr_t>(yb) | reinterpret_cast<uintptr_t>(cos_t) | reinterpret_cast<uintptr_t>(sin_t);
+    if (ptrs & 15u) { set_error("rope: tensors must be 16-byte aligned"); return -1; }
+    if (T <= 0 || ha + hb <= 0) return 0;
+    const int64_t work = (ha + hb) * (d / 16);
+    int threads = (int)(cdiv(work, 64) * 64);
+    threads = threads > 256 ? 256 : threads;
+#define ATOMA_ROPE_LAUNCH(TT, PO)                                                                                     \
+    hipLaunchKernelGGL((rope_kernel<TT, PO>), dim3((unsigned)T), dim3(threads), 0, stream,                            \
+                       static_cast<const uint16_t *>(xa), static_cast<uint16_t *>(ya), (int)ha, xa_ts, xa_hs, ya_ts,  \
+                       ya_hs, static_cast<const uint16_t *>(xb), static_cast<uint16_t *>(yb), (int)hb, xb_ts, xb_hs,  \
+                       yb_ts, yb_hs, static_cast<const uint16_t *>(cos_t), static_cast<const uint16_t *>(sin_t),      \
+                       positions, (int)d)
+    if (dtype == ATOMA_BF16) { if (per_op) ATOMA_ROPE_LAUNCH(bf16_t, true); else ATOMA_ROPE_LAUNCH(bf16_t, false); }
+    else { if (per_op) ATOMA_ROPE_LAUNCH(f16_t, true); else ATOMA_ROPE_LAUNCH(f16_t, false); }
+#undef ATOMA_ROPE_LAUNCH
+    return ATOMA_CHECK_LAUNCH("rope") ? 0 : -1;
+}
+
+// host-side f32 -> storage rounding for the table builder
+static uint16_t host_f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static uint16_t host_f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+
+}  // namespace atoma
+
+extern "C" {
+
+int atoma_rms_norm(const void *x, const void *weight, void *y, int64_t rows, int64_t hidden, int64_t x_row_stride,
+                   int64_t y_row_stride, float eps, int dtype, void *stream) {
+    atoma::clear_error();
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { atoma::set_error("rms_norm: dtype must be f16 or bf16"); return -1; }
+    if (rows <= 0 || hidden <= 0) return 0;
+    auto s = static_cast<hipStream_t>(stream);
+    if (dtype == ATOMA_BF16) atoma::launch_rms_norm<atoma::bf16_t>(x, weight, y, rows, hidden, x_row_stride, y_row_stride, eps, s);
+    else atoma::launch_rms_norm<atoma::f16_t>(x, weight, y, rows, hidden, x_row_stride, y_row_stride, eps, s);
+    return atoma::has_error() ? -1 : 0;
+}
+
+int atoma_rope(const void *x, void *y, const void *cos_table, const void *sin_table, const int64_t *positions,
+               int64_t num_tokens, int64_t num_heads, int64_t head_dim, int64_t x_token_stride, int64_t x_head_stride,
+               int64_t y_token_stride, int64_t y_head_stride, int dtype, int per_op_rounding, void *stream) {
+    atoma::clear_error();
+    return atoma::launch_rope(x, y, num_heads, x_token_stride, x_head_stride, y_token_stride, y_head_stride, nullptr,
+                              nullptr, 0, 0, 0, 0, 0, cos_table, sin_table, positions, num_tokens, head_dim, dtype,
+                              per_op_rounding, static_cast<hipStream_t>(stream));
+}
+
+int atoma_rope_qk(void *q, void *k, const void *cos_table, const void *sin_table, const int64_t *positions,
+                  int64_t num_tokens, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                  int64_t q_token_stride, int64_t k_token_stride, int dtype, int per_op_rounding, void *stream) {
+    atoma::clear_error();
+    return atoma::launch_rope(q, q, num_q_heads, q_token_stride, head_dim, q_token_stride, head_dim, k, k, num_kv_heads,
+                              k_token_stride, head_dim, k_token_stride, head_dim, cos_table, sin_table, positions,
+                              num_tokens, head_dim, dtype, per_op_rounding, static_cast<hipStream_t>(stream));
+}
+
+// models/src/llama.rs:146-200 (Cache::new): f32 arithmetic throughout, table rounded to the model dtype.
+int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head_dim, float rope_theta,
+                     float rope_factor, float low_freq_factor, float high_freq_factor,
+                     int64_t original_max_position_embeddings, int dtype) {
+    atoma::clear_error();
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { atoma::set_error("rope_table: dtype must be f16 or bf16"); return -1; }
+    if (head_dim <= 0 || head_dim % 2) { atoma::set_error("rope_table: head_dim must be even"); return -1; }
+    const int64_t half = head_dim / 2;
+    std::vector<float> inv((size_t)half);
+    for (int64_t j = 0; j < half; ++j) {
+        float f = 1.0f / powf(rope_theta, (float)(2 * j) / (float)head_dim);
+        if (rope_factor > 0.f) {  // Llama-3 wavelength-dependent scaling (llama.rs:163-186)
+            const float orig = (float)original_max_position_embeddings;
+            const float low_wl = orig / low_freq_factor, high_wl = orig / high_freq_factor;
+            const float wavelen = 2.0f * 3.14159265358979323846f / f;
+            if (wavelen < high_wl) {
+            } else if (wavelen > low_wl) {
+                f = f / rope_factor;
+            } else {
+                const float smooth = (orig / wavelen - low_freq_factor) / (high_freq_factor - low_freq_factor);
+                f = (1.0f - smooth) * f / rope_factor + smooth * f;
+            }
+        }
+        inv[(size_t)j] = f;
+    }
+    auto *c16 = static_cast<uint16_t *>(cos_out);
+    auto *s16 = static_cast<uint16_t *>(sin_out);
+    for (int64_t p = 0; p < max_pos; ++p)
+        for (int64_t j = 0; j < half; ++j) {
+            const float ang = (float)p * inv[(size_t)j];
+            const float c = cosf(ang), s = sinf(ang);
+            c16[p * half + j] = dtype == ATOMA_BF16 ? atoma::host_f32_to_bf16(c) : atoma::host_f32_to_f16(c);
+            s16[p * half + j] = dtype == ATOMA_BF16 ? atoma::host_f32_to_bf16(s) : atoma::host_f32_to_f16(s);
+        }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,6 +1,349 @@
-// placeholder until the MFMA prefill kernel lands (next commit): nothing is routed here yet.
+// FlashAttention-2 style prefill for gfx950 on the MFMA matrix cores: dense / varlen / paged
+// K-V, causal or not, GQA, head_dim 64 or 128, bf16 or f16.
+//
+// Replaces /root/reference/csrc/kernels/flash_fwd_kernel.h:56-500 (compute_attn_1rowblock, the
+// CUTLASS sm80 kernel behind csrc::flash_attn_varlen, csrc/src/lib.rs:606-1103) and the
+// seqlen_q > 1 use of the paged split-KV kernel (flash_fwd_kernel.h:504-1092, prefix / chunked
+// prefill: csrc/src/lib.rs:1392-1420).  Same numerics contract: exp2-domain online softmax,
+// fp32 accumulation, P rounded to the storage dtype before P.V (softmax.h:65-185).
+//
+// Shape of the computation (wave64, v_mfma_f32_32x32x16_{bf16,f16}):
+//  * workgroup = 4 waves = 128 query rows of one (sequence, q head); wave w owns 32 rows;
+//  * "swapped" products: S^T = K.Q^T and O^T = V^T.P^T, so a lane's accumulator registers all
+//    belong to ONE query row (column l&31): the online softmax (row max / sum / rescale of O)
+//    is lane-local, with a single lane <-> lane+32 exchange per K/V tile for the row max;
+//  * the C layout of S^T (keys (r&3)+8(r>>2)+4(l>>5)) is used directly as the k-slot order of
+//    the P^T operand, and the V^T operand is fetched with ds_read_b64_tr_b16 in that same key
+//    order -- P never leaves registers and needs no lane permutation;
+//  * K/V tiles of 64 keys are staged through LDS (shared by the 4 waves), double buffered, by
+//    direct global->LDS DMA (global_load_lds_dwordx4): the DMA for tile t+1 is issued before
+//    the MFMAs of tile t, one barrier per tile; 16-byte chunks are XOR-swizzled per row (on the
+//    DMA's source address) so that the K reads (ds_read_b128, one key row per lane) and the V
+//    transpose reads are bank-conflict free;
+//  * causal: K/V tiles above the diagonal are never loaded; a wave skips tiles that are
+//    entirely masked for its own 32 rows; masking code runs only on diagonal / tail tiles;
+//  * workgroups are issued longest-first (last query block first) for causal balance.
+// MFMA-bound: 4*Lq*Lk*d flops per (sequence, head) (half of it when causal).
 #include "attn_params.h"
+
 namespace atoma {
-bool prefill_mfma_supported(const AttnParams &) { return false; }
-void launch_prefill_mfma(const AttnParams &, bool, hipStream_t) {}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_v;
+typedef __attribute__((ext_vector_type(4))) short short4_v;
+typedef __attribute__((ext_vector_type(16))) float f32x16_v;
+typedef __attribute__((ext_vector_type(2))) float f32x2_v;
+
+template <typename T> __device__ __forceinline__ f32x16_v mfma32(const uint4 &a, const uint4 &b, f32x16_v c);
+template <> __device__ __forceinline__ f32x16_v mfma32<bf16_t>(const uint4 &a, const uint4 &b, f32x16_v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x16_v mfma32<f16_t>(const uint4 &a, const uint4 &b, f32x16_v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a), __builtin_bit_cast(f16x8_v, b), c, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t cvt_pk<bf16_t>(float lo, float hi) {
+    f32x2_v v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_v));
+}
+template <> __device__ __forceinline__ uint32_t cvt_pk<f16_t>(float lo, float hi) {
+    f32x2_v v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_v));
+}
+
+constexpr int PF_BM = 128;      // query rows per workgroup (4 waves x 32)
+constexpr int PF_BN = 64;       // keys per K/V tile
+constexpr int PF_THREADS = 256;
+
+template <int D> struct PfSwz {
+    static constexpr int CPR = D / 8;  // 16-byte chunks per row
+    // K tile, read one key row per lane with ds_read_b128: 16 consecutive rows must hit 16
+    // different 16-byte slots of the 256-byte bank row.
+    __device__ static __forceinline__ int k(int row, int chunk) {
+        return D == 128 ? (chunk ^ (row & 15)) : (chunk ^ ((row >> 1) & 7));
+    }
+    // V tile, read with ds_read_b64_tr_b16: a 32-lane group touches 4 consecutive key rows x 64 bytes.
+    __device__ static __forceinline__ int v(int row, int chunk) {
+        return D == 128 ? (chunk ^ ((row & 3) << 2)) : (chunk ^ (((row >> 1) & 1) << 2));
+    }
+};
+
+// One 1 KiB global->LDS DMA (global_load_lds_dwordx4): LDS destination = wave-uniform byte
+// address in M0 + lane*16, per-lane global source.  Issued from inline asm so that hipcc does
+// not treat every later ds_read as dependent on it (it would drain the DMA with vmcnt(0) before
+// the first LDS read of the tile being computed); the consumer side waits explicitly with
+// dma_wait_all() ahead of the workgroup barrier.
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_uniform)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// K/V tile loader: direct global -> LDS DMA (global_load_lds_dwordx4, 1 KiB per wave
+// instruction, no staging registers).  The DMA writes LDS linearly (wave-uniform base + lane*16),
+// so the XOR swizzle is applied on the SOURCE side: lane -> (row, slot) of the LDS image,
+// chunk = slot ^ f(row) of the global row.
+template <int D> struct PfLoader {
+    static constexpr int CPR = D / 8;
+    static constexpr int ROWB = D * 2;
+    static constexpr int TILEB = PF_BN * ROWB;
+    static constexpr int NDMA = TILEB / 1024 / (PF_THREADS / 64);  // DMA instructions per wave per tile (K or V)
+    const uint16_t *kbase, *vbase;
+    const int *bt;
+    int64_t k_page, k_row, v_page, v_row;
+    int page_size, last_key, wave, lane;
+
+    __device__ __forceinline__ void issue(int tile, char *kt) const {
+        char *vt = kt + TILEB;
+        const uint16_t *ksrc[NDMA], *vsrc[NDMA];
+        // all block-table lookups first, then the DMAs back to back (a lookup's vmcnt wait
+        // would otherwise drain the DMA issued just before it)
+#pragma unroll
+        for (int u = 0; u < NDMA; ++u) {
+            const int q = wave * NDMA + u;          // 1 KiB piece of the tile
+            const int L = q * 64 + lane;             // 16-byte unit in the LDS image
+            const int row = L / CPR, slot = L % CPR;
+            const int key = min(tile * PF_BN + row, last_key);  // never read past the sequence
+            int64_t koff, voff;
+            if (bt) {
+                const int pg = bt[key / page_size], r = key % page_size;
+                koff = (int64_t)pg * k_page + (int64_t)r * k_row;
+                voff = (int64_t)pg * v_page + (int64_t)r * v_row;
+            } else {
+                koff = (int64_t)key * k_row;
+                voff = (int64_t)key * v_row;
+            }
+            ksrc[u] = kbase + koff + PfSwz<D>::k(row, slot) * 8;   // XOR is its own inverse
+            vsrc[u] = vbase + voff + PfSwz<D>::v(row, slot) * 8;
+        }
+        const uint32_t k_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)kt;
+        const uint32_t v_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)vt;
+#pragma unroll
+        for (int u = 0; u < NDMA; ++u) {
+            const uint32_t off = (uint32_t)((wave * NDMA + u) * 1024);
+            glds16(ksrc[u], __builtin_amdgcn_readfirstlane(k_lds + off));
+            glds16(vsrc[u], __builtin_amdgcn_readfirstlane(v_lds + off));
+        }
+    }
+};
+
+template <typename T, int D, bool CAUSAL>
+__global__ void __launch_bounds__(PF_THREADS, 2) prefill_mfma_kernel(const AttnParams p) {
+    constexpr int CPR = D / 8;
+    constexpr int ROWB = D * 2;                     // bytes per tile row
+    constexpr int TILEB = PF_BN * ROWB;             // bytes per K (or V) tile
+    constexpr int NJ = D / 16;                      // MFMA k-steps over d for S^T = K.Q^T
+    constexpr int NDB = D / 32;                     // 32-row blocks of O^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
+
+    const int tid = threadIdx.x, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (scalar branches below)
+    const int mblk = (int)gridDim.x - 1 - (int)blockIdx.x;  // longest (most keys) first
+    const int hq = blockIdx.y, b = blockIdx.z;
+    const SeqInfo si(p, b);
+    const int m0 = mblk * PF_BM;
+    if (m0 >= si.len_q) return;
+    const int hk = hq / (p.h / p.h_k);
+    const int shift = si.len_k - si.len_q;          // mask.h:170: key <= row + seqlen_k - seqlen_q
+    const int mw0 = m0 + wave * 32;                 // first query row of this wave
+    const int my_q = mw0 + lq;                      // this lane's query row
+
+    // keys the workgroup / this wave can see at all
+    int n_end = si.len_k;
+    if (CAUSAL) n_end = min(n_end, m0 + PF_BM + shift);
+    int n_end_w = si.len_k;
+    if (CAUSAL) n_end_w = min(n_end_w, mw0 + 32 + shift);
+    const int n_tiles = n_end > 0 ? (n_end + PF_BN - 1) / PF_BN : 0;
+
+    // ---- Q^T fragments: lane = (query lq, d half hi); B operand of S^T = K.Q^T ----
+    uint4 qf[NJ];
+    {
+        const int qrow = min(my_q, si.len_q - 1);
+        const uint16_t *qp = p.q + si.q_offset(p.q_batch_stride, p.q_row_stride, b) + (int64_t)qrow * p.q_row_stride +
+                             (int64_t)hq * p.q_head_stride + hi * 8;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) qf[j] = *reinterpret_cast<const uint4 *>(qp + j * 16);
+        // Make hipcc retire these loads HERE: its vmcnt bookkeeping does not see the asm DMAs below,
+        // and a counted wait for q inside the tile loop would drain the DMA queue every iteration.
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(qf[j].x), "+v"(qf[j].y), "+v"(qf[j].z), "+v"(qf[j].w));
+    }
+
+    const bool paged = p.block_table != nullptr;
+    const int *bt = paged ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+    const uint16_t *kbase = p.k + (int64_t)hk * p.k_head_stride + (paged ? 0 : si.k_offset(p.k_batch_stride, p.k_row_stride, b));
+    const uint16_t *vbase = p.v + (int64_t)hk * p.v_head_stride + (paged ? 0 : si.k_offset(p.v_batch_stride, p.v_row_stride, b));
+    PfLoader<D> ld;
+    ld.kbase = kbase; ld.vbase = vbase; ld.bt = bt;
+    ld.k_page = p.k_batch_stride; ld.k_row = p.k_row_stride; ld.v_page = p.v_batch_stride; ld.v_row = p.v_row_stride;
+    ld.page_size = p.page_size; ld.last_key = si.len_k - 1; ld.wave = wave; ld.lane = lane;
+    f32x16_v oacc[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    float m_run = -INFINITY, l_part = 0.f;   // running max (both halves agree), this lane's part of the row sum
+    const float sl2 = p.scale_log2;
+    const float slope_l2 = 0.f;              // ALiBi is routed to the generic kernel
+    (void)slope_l2;
+
+    if (n_tiles > 0) {
+        ld.issue(0, smem);
+        dma_wait_all();
+        __syncthreads();
+    }
+    for (int t = 0; t < n_tiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < n_tiles) ld.issue(t + 1, smem + (buf ^ 1) * 2 * TILEB);  // DMA in flight during the MFMAs below
+        const int kv0 = t * PF_BN;
+        if (kv0 < n_end_w) {  // wave-uniform: tile not entirely masked for this wave's rows
+            const char *kt = smem + buf * 2 * TILEB, *vt = kt + TILEB;
+            // ---- S^T[key][query] for the two 32-key halves ----
+            f32x16_v s[2];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+                const int row = blk * 32 + lq;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(kt + row * ROWB + PfSwz<D>::k(row, 2 * j + hi) * 16);
+                    s[blk] = mfma32<T>(a, qf[j], s[blk]);
+                }
+            }
+            // ---- scale, mask (diagonal / tail tiles only), online softmax ----
+            const bool need_mask = (kv0 + PF_BN > si.len_k) || (CAUSAL && kv0 + PF_BN > mw0 + shift + 1);
+            if (need_mask) {  // wave-uniform: diagonal / tail tiles only
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kv0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const bool ok = key < si.len_k && (!CAUSAL || key <= my_q + shift);
+                        s[blk][r] = ok ? s[blk][r] : -INFINITY;
+                    }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[blk][r] *= sl2;   // scale > 0: -inf stays -inf
+                    mx = fmaxf(mx, s[blk][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float ms = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
+            m_run = m_new;
+            uint4 pp[2][2];  // P^T operands: [32-key half][16-key k-step]
+            float psum = 0.f;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                float e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    e[r] = __builtin_amdgcn_exp2f(s[blk][r] - ms);
+                    psum += e[r];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    pp[blk][kk].x = cvt_pk<T>(e[8 * kk + 0], e[8 * kk + 1]);
+                    pp[blk][kk].y = cvt_pk<T>(e[8 * kk + 2], e[8 * kk + 3]);
+                    pp[blk][kk].z = cvt_pk<T>(e[8 * kk + 4], e[8 * kk + 5]);
+                    pp[blk][kk].w = cvt_pk<T>(e[8 * kk + 6], e[8 * kk + 7]);
+                }
+            }
+            l_part = l_part * alpha + psum;
+            if (__any(alpha != 1.f)) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+            }
+            // ---- O^T[d][query] += V^T . P^T ----
+            // 16-lane group g = lane>>4 reads a [4 keys][16 d] block transposed: lanes 4j+c of the
+            // group supply the address of V[key j][16-col block, 4c..4c+3]; the group's lanes then
+            // hold, for d column 16*(g&1) + (lane&15), the 4 keys.
+            const int g = lane >> 4, jrow = (lane & 15) >> 2, cc = lane & 3;
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        uint4 a;
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            const int row = blk * 32 + kk * 16 + 4 * hi + jrow + 8 * half;
+                            const int dcol = db * 32 + 16 * (g & 1) + 4 * cc;  // element index, 4 contiguous
+                            const char *addr = vt + row * ROWB + PfSwz<D>::v(row, dcol >> 3) * 16 + (dcol & 7) * 2;
+                            const short4_v r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (__attribute__((address_space(3))) short4_v *)(addr));
+                            const uint2 r2 = __builtin_bit_cast(uint2, r4);
+                            if (half == 0) { a.x = r2.x; a.y = r2.y; } else { a.z = r2.x; a.w = r2.y; }
+                        }
+                        oacc[db] = mfma32<T>(a, pp[blk][kk], oacc[db]);
+                    }
+        }
+        dma_wait_all();   // this wave's DMA pieces of tile t+1 have landed ...
+        __syncthreads();  // ... and so have everybody else's; tile t's buffer is free again
+    }
+
+    // ---- epilogue: total row sum = own part + partner lane's part (same running max) ----
+    const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+    if (my_q >= si.len_q) return;
+    const bool empty = !(l_tot > 0.f);
+    const float inv = empty ? 0.f : 1.f / l_tot;
+    uint16_t *op = p.o + si.q_offset(p.o_batch_stride, p.o_row_stride, b) + (int64_t)my_q * p.o_row_stride +
+                   (int64_t)hq * p.o_head_stride;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            uint2 w;
+            w.x = pack2<T>(oacc[db][4 * r4 + 0] * inv, oacc[db][4 * r4 + 1] * inv);
+            w.y = pack2<T>(oacc[db][4 * r4 + 2] * inv, oacc[db][4 * r4 + 3] * inv);
+            *reinterpret_cast<uint2 *>(op + db * 32 + 8 * r4 + 4 * hi) = w;  // d = 32db + (r&3) + 8(r>>2) + 4hi
+        }
+    if (p.lse && hi == 0) {
+        const float lse = empty ? INFINITY : (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+        if (p.unpadded_lse && p.cu_seqlens_q) p.lse[(int64_t)hq * p.cu_seqlens_q[p.b] + si.sum_q + my_q] = lse;
+        else p.lse[((int64_t)b * p.h + hq) * p.seqlen_q + my_q] = lse;
+    }
+}
+
+bool prefill_mfma_supported(const AttnParams &p) {
+    return (p.d == 64 || p.d == 128) && p.alibi_slopes == nullptr && p.seqlen_q > 1;
+}
+
+template <typename T, int D, bool CAUSAL>
+static void launch_pf(const AttnParams &p, hipStream_t stream) {
+    constexpr int smem = 2 * 2 * PF_BN * D * 2;
+    static bool attr_set = false;  // 64 KiB for D = 128: above the default dynamic-LDS limit
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)cdiv(p.seqlen_q, PF_BM), (unsigned)p.h, (unsigned)p.b);
+    hipLaunchKernelGGL((prefill_mfma_kernel<T, D, CAUSAL>), grid, dim3(PF_THREADS), smem, stream, p);
+    ATOMA_CHECK_LAUNCH("prefill_mfma_kernel");
+}
+
+void launch_prefill_mfma(const AttnParams &p, bool is_bf16, hipStream_t stream) {
+    if (p.b <= 0 || p.h <= 0 || p.seqlen_q <= 0) return;
+#define ATOMA_PF(TT, DD)                                         \
+    do {                                                         \
+        if (p.is_causal) launch_pf<TT, DD, true>(p, stream);     \
+        else launch_pf<TT, DD, false>(p, stream);                \
+    } while (0)
+    if (is_bf16) { if (p.d == 128) ATOMA_PF(bf16_t, 128); else ATOMA_PF(bf16_t, 64); }
+    else { if (p.d == 128) ATOMA_PF(f16_t, 128); else ATOMA_PF(f16_t, 64); }
+#undef ATOMA_PF
+}
+
 }  // namespace atoma

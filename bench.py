@@ -207,7 +207,7 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     lib.oracle_attention.argtypes = [C.c_void_p] * 6 + [C.c_int] + [i64] * 12 + [C.c_int] * 4 + [
         C.c_float, C.c_void_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.oracle_max_threads.restype = C.c_int
-    cores = os.cpu_count() or 1
+    cores = int(os.environ.get("ATOMA_BENCH_CPU_THREADS", 0)) or len(os.sched_getaffinity(0)) or 1
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
 
     def run():

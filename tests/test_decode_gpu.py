@@ -6,7 +6,7 @@ import pytest
 
 from oracle import attn_oracle as A
 from oracle.halfs import F16, BF16, to_f32
-from util import rand_half, make_paged_cache, assert_close, c_attention
+from util import rand_half, make_paged_cache, assert_close, c_attention, ATOL_VS_F32, attn_atol
 
 pytestmark = pytest.mark.gpu
 CASES = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_cases.npz"))
@@ -41,8 +41,10 @@ def test_decode_golden_fixtures(gpu, tag, dtype):
     c = CASES
     out, _ = gpu_decode(gpu, c[f"{tag}_q"], c[f"{tag}_kc"], c[f"{tag}_vc"], c[f"{tag}_bt"], c[f"{tag}_lens"],
                         c[f"{tag}_scale"], dtype)
-    assert_close(out, c[f"{tag}_out_f32"], dtype, what=f"{tag} vs fa_acausal oracle")
-    assert_close(out, c[f"{tag}_out_kernel"], dtype, what=f"{tag} vs kernel-faithful oracle")
+    for i, L in enumerate(c[f"{tag}_lens"]):
+        for mode in ("f32", "kernel"):
+            assert_close(out[i], c[f"{tag}_out_{mode}"][i], dtype, atol=attn_atol(dtype, L),
+                         what=f"{tag} seq {i} (L={L}) vs {mode} oracle")
 
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
@@ -58,8 +60,10 @@ def test_decode_matches_oracle_ragged(gpu, dtype, d, h, hk, page):
     q = rand_half(rng, (len(lens), 1, h, d), dtype)
     scale = np.float32(d ** -0.5)
     out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype)
-    ref = A.flash_attn_kv_cache(q, kc, vc, scale, dtype, bt, lens, mode="f32")
-    assert_close(out, ref, dtype, what="decode vs oracle")
+    for mode in ("f32", "kernel"):
+        ref = A.flash_attn_kv_cache(q, kc, vc, scale, dtype, bt, lens, mode=mode)
+        for i, L in enumerate(lens):
+            assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"decode L={L} vs {mode} oracle")
     assert not out[0].any(), "empty sequence must produce exact zeros (flash_fwd_kernel.h:97-133)"
     assert np.isposinf(lse[0]).all() and np.isfinite(lse[1:]).all()
 
@@ -94,7 +98,7 @@ def test_decode_split_kv_small_batch(gpu, B, L):
                       k_strides=(page * hk * d, hk * d, d), v_strides=(page * hk * d, hk * d, d),
                       o_shape=q.shape, o_strides=(h * d, h * d, d), cu_k=lens, k_cumulative=False,
                       block_table=bt, page=page)
-    assert_close(out, ref, BF16, what="split-KV decode vs C oracle")
+    assert_close(out, ref, BF16, atol=1e-3, what="split-KV decode vs C oracle (f32)")
     assert np.isfinite(lse).all()
 
 
@@ -108,9 +112,9 @@ def test_decode_contiguous_cache_without_block_table(gpu):
     lens = np.array([100, 1, 50, 99, 16], np.int32)
     out, _ = gpu_decode(gpu, q, kc, vc, None, lens, 0.09, BF16)
     ref = A.flash_attn_kv_cache(q, kc, vc, 0.09, BF16, None, lens)
-    assert_close(out, ref, BF16, what="contiguous kv cache")
+    assert_close(out, ref, BF16, atol=ATOL_VS_F32[BF16], what="contiguous kv cache")
     out, _ = gpu_decode(gpu, q, kc, vc, None, None, 0.09, BF16)      # seqlens_k = None -> full S
-    assert_close(out, A.flash_attn_kv_cache(q, kc, vc, 0.09, BF16), BF16, what="contiguous kv cache, full length")
+    assert_close(out, A.flash_attn_kv_cache(q, kc, vc, 0.09, BF16), BF16, atol=ATOL_VS_F32[BF16], what="contiguous kv cache, full length")
 
 
 def test_decode_alibi(gpu):
@@ -121,7 +125,7 @@ def test_decode_alibi(gpu):
     slopes = (2.0 ** -np.arange(1, 9)).astype(np.float32)
     out, _ = gpu_decode(gpu, q, kc, vc, bt, lens, 0.088, BF16, alibi=slopes)
     ref = A.flash_attn_kv_cache(q, kc, vc, 0.088, BF16, bt, lens, causal=True, alibi_slopes=slopes)
-    assert_close(out, ref, BF16, what="decode + ALiBi")
+    assert_close(out, ref, BF16, atol=ATOL_VS_F32[BF16], what="decode + ALiBi")
 
 
 def test_decode_block_table_permutation_invariance_bit_exact(gpu):
@@ -173,4 +177,4 @@ def test_decode_full_size_properties_c2a(gpu):
                       is_bf16=1, q_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
                       v_strides=(page * hk * d, hk * d, d), o_shape=(len(pick), 1, h, d), o_strides=(h * d, h * d, d),
                       cu_k=lens[pick], k_cumulative=False, block_table=bt[pick], page=page)
-    assert_close(out[pick], ref, BF16, what="C2a sampled sequences vs C oracle")
+    assert_close(out[pick], ref, BF16, atol=1e-3, what="C2a sampled sequences vs C oracle (f32)")

@@ -1,0 +1,49 @@
+"""Host-side logic of the library that needs no GPU: rope table builder, split heuristic."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import attn_oracle as A, norm_rope_oracle as NR
+from oracle.halfs import F16, BF16, to_f32
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = C.CDLL(os.path.join(ROOT, "atoma-infer_amd", "lib", "libatoma_hip.so"))
+lib.atoma_rope_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_int64, C.c_int]
+lib.atoma_num_splits_heuristic.argtypes = [C.c_int64] * 4
+lib.atoma_compute_num_splits.argtypes = [C.c_int64] * 5 + [C.c_int]
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_rope_table_matches_oracle(dtype, scaled):
+    """models/src/llama.rs:146-200.  libm powf/cosf/sinf vs numpy's float32 routines can differ in
+    the last f32 bit: a one-ulp difference in inv_freq moves the angle pos*inv_freq by up to
+    pos * 2^-23 (relative to inv_freq = 1), i.e. the table entry by ~2.5e-4 at pos = 2047 -- the
+    same uncertainty separates either implementation from the reference's own (Rust powf + CUDA
+    cosf).  Entries therefore agree to that absolute bound plus one storage rounding unit."""
+    max_pos, d = 2048, 128
+    cos, sin = np.zeros((max_pos, d // 2), np.uint16), np.zeros((max_pos, d // 2), np.uint16)
+    sc = dict(factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192)
+    rc = lib.atoma_rope_table(cos.ctypes.data, sin.ctypes.data, max_pos, d, 500000.0, 8.0 if scaled else 0.0, 1.0, 4.0,
+                              8192, dtype)
+    assert rc == 0
+    rc_, rs_ = NR.rope_table(max_pos, d, 500000.0, dtype, sc if scaled else None)
+    for got, ref in ((cos, rc_), (sin, rs_)):
+        g, r = to_f32(got, dtype), to_f32(ref, dtype)
+        eps = 2.0 ** -7 if dtype == BF16 else 2.0 ** -10   # one unit in the last place
+        assert (np.abs(g - r) <= max_pos * 2.0 ** -22 + eps * np.abs(r)).all()
+        assert (got != ref).mean() < 0.02
+
+
+def test_split_heuristic_matches_oracle_exhaustively():
+    """csrc/src/lib.rs:2122-2199 restated twice (C++ in the library, numpy in the oracle)."""
+    rng = np.random.default_rng(0)
+    for _ in range(400):
+        bnm, sms, nb, mx = int(rng.integers(1, 3000)), int(rng.integers(1, 1024)), int(rng.integers(1, 300)), 128
+        assert lib.atoma_num_splits_heuristic(bnm, sms, nb, mx) == A.num_splits_heuristic(bnm, sms, nb, mx)
+    for b, h, d, sk, sq in [(1, 32, 128, 4096, 1), (64, 8, 128, 4096, 1), (256, 32, 128, 4096, 1), (4, 32, 64, 8192, 1),
+                            (2, 16, 256, 1000, 7)]:
+        assert lib.atoma_compute_num_splits(b, h, d, sk, sq, 256) == A.compute_num_splits(b, h, d, sk, sq, 256)

@@ -1,0 +1,132 @@
+"""MFMA prefill kernel (run_mha with seqlen_q > 1, head_dim 64/128) against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import attn_oracle as A
+from oracle.halfs import F16, BF16, to_f32
+from util import rand_half, make_paged_cache, assert_close, c_attention, ATOL_VS_F32
+from test_attention_golden_gpu import gpu_varlen
+
+pytestmark = pytest.mark.gpu
+
+
+def c_varlen(q, k, v, cu_q, cu_k, scale, causal, dtype, bt=None):
+    Tq, h, d = q.shape
+    hk = k.shape[-2]
+    page = k.shape[1] if bt is not None else 0
+    kstr = (page * hk * d, hk * d, d) if bt is not None else (0, hk * d, d)
+    return c_attention(q, k, v, b=len(cu_q) - 1, h=h, h_k=hk, d=d, seqlen_q=0, seqlen_k=0, scale=float(scale),
+                       is_bf16=dtype, q_strides=(0, h * d, d), k_strides=kstr, v_strides=kstr, o_shape=q.shape,
+                       o_strides=(0, h * d, d), causal=int(causal), cu_q=cu_q, cu_k=cu_k, block_table=bt, page=page)
+
+
+def check_rows(out, ref, cu_q, cu_k, causal, dtype, what):
+    """1e-3 for rows that see >= 128 keys, the P-rounding bound for the first rows of a causal
+    sequence (util.ATOL_FEW_KEYS explains)."""
+    for b in range(len(cu_q) - 1):
+        q0, q1 = int(cu_q[b]), int(cu_q[b + 1])
+        Lq, Lk = q1 - q0, int(cu_k[b + 1] - cu_k[b])
+        if Lq == 0:
+            continue
+        seen = np.minimum(Lk, np.arange(Lq) + Lk - Lq + 1) if causal else np.full(Lq, Lk)
+        many = seen >= 128
+        if many.any():
+            assert_close(out[q0:q1][many], ref[q0:q1][many], dtype, atol=1e-3, what=f"{what} seq {b} rows with >=128 keys")
+        if (~many).any():
+            assert_close(out[q0:q1][~many], ref[q0:q1][~many], dtype, atol=ATOL_VS_F32[dtype],
+                         what=f"{what} seq {b} rows with <128 keys")
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("d,h,hk", [(128, 8, 2), (64, 8, 8), (128, 4, 1), (64, 6, 2)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_prefill_varlen_matches_oracle(gpu, dtype, d, h, hk, causal):
+    """Ragged batch: lengths around every tile boundary (1, 31..33, 63..65, 127..129, 300),
+    GQA groups 1/3/4, both head sizes."""
+    rng = np.random.default_rng(d + h + hk + causal)
+    lens = np.array([1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 300], np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    q, k, v = rand_half(rng, (T, h, d), dtype), rand_half(rng, (T, hk, d), dtype), rand_half(rng, (T, hk, d), dtype)
+    out, lse = gpu_varlen(gpu, q, k, v, cu, cu, d ** -0.5, causal, dtype)
+    ref = A.flash_attn_varlen(q, k, v, cu, cu, d ** -0.5, causal, dtype)
+    check_rows(out, ref, cu, cu, causal, dtype, "prefill")
+    assert np.isfinite(lse).all()
+
+
+def test_prefill_lse_values(gpu):
+    rng = np.random.default_rng(2)
+    cu = np.array([0, 70, 200], np.int32)
+    q, k, v = rand_half(rng, (200, 4, 128), BF16), rand_half(rng, (200, 2, 128), BF16), rand_half(rng, (200, 2, 128), BF16)
+    _, lse = gpu_varlen(gpu, q, k, v, cu, cu, 0.088, True, BF16)
+    _, want = A.flash_attn_varlen(q, k, v, cu, cu, 0.088, True, BF16, return_lse=True)
+    for b in range(2):
+        assert np.allclose(lse[:, cu[b]:cu[b + 1]], want[b], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_prefill_llama_shape_2048_vs_c_oracle(gpu, d):
+    """One 2048-token prompt + a 500-token one, Llama GQA (4 q heads per kv head), causal."""
+    rng = np.random.default_rng(d)
+    cu = np.array([0, 2048, 2548], np.int32)
+    h, hk = 8, 2
+    q, k, v = rand_half(rng, (2548, h, d), BF16), rand_half(rng, (2548, hk, d), BF16), rand_half(rng, (2548, hk, d), BF16)
+    out, _ = gpu_varlen(gpu, q, k, v, cu, cu, d ** -0.5, True, BF16)
+    ref = c_varlen(q, k, v, cu, cu, d ** -0.5, True, BF16)
+    check_rows(out, ref, cu, cu, True, BF16, "prefill 2048")
+
+
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("page", [16, 64])
+def test_prefill_paged_prefix_chunked(gpu, causal, page):
+    """flash_attn_varlen_with_block_table (lib.rs:1392-1420): new query tokens attend over the
+    paged cache holding prefix + themselves (Lq < Lk; causal offset Lk - Lq, mask.h:170)."""
+    rng = np.random.default_rng(page + causal)
+    d, h, hk = 128, 8, 2
+    lens_k = np.array([500, 129, 64, 1000], np.int32)
+    lens_q = np.array([100, 129, 1, 300], np.int32)
+    nb = int(sum((x + page - 1) // page for x in lens_k)) + 2
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens_k)
+    cu_q = np.concatenate([[0], np.cumsum(lens_q)]).astype(np.int32)
+    cu_k = np.concatenate([[0], np.cumsum(lens_k)]).astype(np.int32)
+    q = rand_half(rng, (int(cu_q[-1]), h, d), BF16)
+    out, _ = gpu_varlen(gpu, q, kc, vc, cu_q, cu_k, d ** -0.5, causal, BF16, bt=bt)
+    ref = A.flash_attn_varlen(q, kc, vc, cu_q, cu_k, d ** -0.5, causal, BF16, block_table=bt)
+    check_rows(out, ref, cu_q, cu_k, causal, BF16, f"paged prefix page={page}")
+
+
+def test_prefill_dense_entry_and_strided_heads(gpu):
+    """csrc::flash_attn layout [b, s, h, d] with batch strides (no cu_seqlens) and q taken as a
+    slice of a fused qkv projection (row stride 3*h*d)."""
+    rng = np.random.default_rng(4)
+    b, s, h, d = 3, 160, 4, 64
+    qkv = rand_half(rng, (b, s, 3, h, d), F16)
+    dqkv = gpu.DeviceBuffer.from_numpy(qkv)
+    do = gpu.DeviceBuffer(b * s * h * d * 2)
+    row = 3 * h * d
+    gpu.run_mha(dqkv.ptr, dqkv.ptr + h * d * 2, dqkv.ptr + 2 * h * d * 2, do, b=b, h=h, h_k=h, d=d, seqlen_q=s,
+                seqlen_k=s, softmax_scale=0.125, is_bf16=0, q_strides=(s * row, row, d), k_strides=(s * row, row, d),
+                v_strides=(s * row, row, d), o_strides=(s * h * d, h * d, d), is_causal=1)
+    gpu.synchronize()
+    out = do.numpy(np.uint16, (b, s, h, d))
+    ref = A.flash_attn(np.ascontiguousarray(qkv[:, :, 0]), np.ascontiguousarray(qkv[:, :, 1]),
+                       np.ascontiguousarray(qkv[:, :, 2]), 0.125, True, F16)
+    assert_close(out, ref, F16, atol=ATOL_VS_F32[F16], what="dense entry, fused-qkv strides")
+
+
+def test_prefill_linearity_in_v_full_size(gpu):
+    """Size-independent property at the prefill config (S = 2048, 8B head shape, one kv group):
+    attention is linear in V: attn(q,k,v1+v2) = attn(q,k,v1) + attn(q,k,v2) up to rounding."""
+    rng = np.random.default_rng(6)
+    S, h, hk, d = 2048, 4, 1, 128
+    cu = np.array([0, S], np.int32)
+    q, k = rand_half(rng, (S, h, d), BF16), rand_half(rng, (S, hk, d), BF16)
+    v1 = rand_half(rng, (S, hk, d), BF16)
+    v2 = rand_half(rng, (S, hk, d), BF16)
+    from oracle.halfs import from_f32
+    v12 = from_f32(to_f32(v1, BF16) + to_f32(v2, BF16), BF16)
+    o1, _ = gpu_varlen(gpu, q, k, v1, cu, cu, d ** -0.5, True, BF16)
+    o2, _ = gpu_varlen(gpu, q, k, v2, cu, cu, d ** -0.5, True, BF16)
+    o12, _ = gpu_varlen(gpu, q, k, v12, cu, cu, d ** -0.5, True, BF16)
+    err = np.abs(to_f32(o12, BF16) - (to_f32(o1, BF16) + to_f32(o2, BF16)))
+    assert err.max() < 0.06 and err.mean() < 2e-3, (err.max(), err.mean())   # bf16 roundings of v12, o1, o2, o12
