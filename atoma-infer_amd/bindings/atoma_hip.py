@@ -243,3 +243,70 @@ def run_mha(q, k, v, o, *, b, h, h_k, d, seqlen_q, seqlen_k, softmax_scale, is_b
     else:
         lib.run_mha(*args)
     check()
+
+
+# ---- section 3: host mirror of the reference's Candle operator layer ---------------------------
+F32, U32, I64, U8, I32 = 2, 3, 4, 5, 6
+_DT_SIZE = {F16: 2, BF16: 2, F32: 4, U32: 4, I64: 8, U8: 1, I32: 4}
+
+
+class Tensor(C.Structure):
+    """include/atoma_hip.h `atoma_tensor`: a Candle tensor as the ops see it."""
+    _fields_ = [("data", _vp), ("dtype", C.c_int32), ("device", C.c_int32), ("rank", C.c_int32), ("_pad", C.c_int32),
+                ("shape", _i64 * 5), ("stride", _i64 * 5)]
+
+
+def tensor(data, shape, dtype, device=0, strides=None, offset_elems=0):
+    """Descriptor over a DeviceBuffer / raw pointer / numpy array (device=-1)."""
+    t = Tensor()
+    if isinstance(data, np.ndarray):
+        ptr, device = data.ctypes.data, -1
+    else:
+        ptr = _ptr(data)
+    t.data = (ptr or 0) + offset_elems * _DT_SIZE[dtype] if ptr is not None else None
+    t.dtype, t.device, t.rank = dtype, device, len(shape)
+    if strides is None:
+        strides, acc = [], 1
+        for s in reversed(shape):
+            strides.insert(0, acc)
+            acc *= s
+    for i, (s, st) in enumerate(zip(shape, strides)):
+        t.shape[i], t.stride[i] = s, st
+    return t
+
+
+class AttnMetadata(C.Structure):
+    _fields_ = [("slot_mapping", C.POINTER(Tensor)), ("num_prefill_tokens", _i64), ("num_decoding_tokens", _i64),
+                ("has_prefill", _int), ("prefill_block_tables", C.POINTER(Tensor)),
+                ("max_prefill_sequence_length", _i64), ("query_start_locations", C.POINTER(Tensor)),
+                ("sequence_start_locations", C.POINTER(Tensor)), ("max_sequence_length_k", _i64),
+                ("has_decoding", _int), ("decoding_block_tables", C.POINTER(Tensor)),
+                ("decoding_sequence_lengths", C.POINTER(Tensor))]
+
+
+class FlashAttention(C.Structure):
+    _fields_ = [("num_heads", _i64), ("num_kv_heads", _i64), ("head_dim", _i64), ("softmax_scale", _f32),
+                ("alibi_slopes", C.POINTER(Tensor)), ("sliding_window", _i64), ("kv_cache_dtype", C.c_int32),
+                ("device", C.c_int32)]
+
+
+_TP = C.POINTER(Tensor)
+_opt("atoma_flash_attn", [_TP, _TP, _TP, _f32, _int, _TP])
+_opt("atoma_flash_attn_varlen", [_TP, _TP, _TP, _TP, _TP, _i64, _i64, _f32, _int, _TP])
+_opt("atoma_flash_attn_varlen_with_block_table", [_TP, _TP, _TP, _TP, _TP, _TP, _i64, _i64, _f32, _i64, _i64, _TP, _TP])
+_opt("atoma_flash_attn_kv_cache_full", [_TP, _TP, _TP, _TP, _f32, _TP, _TP, _int, _TP])
+_opt("atoma_reshape_and_cache_flash", [_TP, _TP, _TP, _TP, _TP])
+_opt("atoma_copy_blocks", [C.POINTER(_TP), _i64, C.POINTER(_TP), _i64, _TP])
+_opt("atoma_swap_blocks_tensor", [_TP, _TP, C.POINTER(C.c_uint32), _i64])
+_opt("atoma_flash_attention_new", [C.POINTER(FlashAttention), _i64, _i64, _i64, _f32, _TP, _i64, C.c_int32, C.c_int32])
+_opt("atoma_flash_attention_forward", [C.POINTER(FlashAttention), _TP, _TP, _TP, _TP, C.POINTER(AttnMetadata), _TP])
+
+
+def ref(t):
+    """byref() for an optional Tensor."""
+    return None if t is None else C.byref(t)
+
+
+def tensor_array(ts):
+    arr = (_TP * len(ts))(*[C.pointer(t) for t in ts])
+    return arr

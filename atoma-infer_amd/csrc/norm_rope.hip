@@ -134,6 +134,10 @@ static void launch_rms_norm(const void *x, const void *w, void *y, int64_t rows,
 template <typename T, bool PER_OP>
 __device__ __forceinline__ void rope_chunk(const uint16_t *x, uint16_t *y, const uint16_t *cosr, const uint16_t *sinr,
                                            int half, int c) {
+    // No contraction here: for f16 the compiler narrows the f32 expressions below to half
+    // arithmetic (legitimately -- f32 carries 2p+2 bits) and would then fuse mul+sub into one
+    // v_fma_f16, i.e. drop exactly the intermediate rounding PER_OP exists to reproduce.
+#pragma clang fp contract(off)
     float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
     unpack8<T>(*reinterpret_cast<const uint4 *>(x + c * 8), x1);
     unpack8<T>(*reinterpret_cast<const uint4 *>(x + half + c * 8), x2);

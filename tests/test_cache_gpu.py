@@ -116,7 +116,7 @@ def test_copy_blocks_reference_case(gpu, fn, dtype):
         assert np.array_equal(gk[l][2], gk[l][0]) and np.array_equal(gk[l][3], gk[l][1])
 
 
-@pytest.mark.parametrize("L,P,shape", [(32, 64, (96, 16, 8, 128)), (3, 1, (5, 16, 8, 128)), (2, 7, (16, 16, 1, 12))])
+@pytest.mark.parametrize("L,P,shape", [(32, 64, (160, 16, 8, 128)), (3, 1, (5, 16, 8, 128)), (2, 7, (16, 16, 1, 12))])
 def test_copy_blocks_llama_pages_and_odd_sizes(gpu, L, P, shape):
     rng = np.random.default_rng(L * 100 + P)
     ks = [rand_half(rng, shape, BF16) for _ in range(L)]

@@ -36,8 +36,9 @@ ATOL_VS_F32 = ATOL_FEW_KEYS            # name used by tests that mix short and l
 
 
 def attn_atol(dtype, visible_keys):
-    """1e-3 once a row attends over >= 128 keys, the P-rounding bound below that."""
-    return 1e-3 if visible_keys >= 128 else ATOL_FEW_KEYS[dtype]
+    """1e-3 once a row attends over >= 512 keys (the BASELINE configs use 2048-4096), the
+    P-rounding bound below that."""
+    return 1e-3 if visible_keys >= 512 else ATOL_FEW_KEYS[dtype]
 
 
 def assert_close(got_bits, ref_bits, dtype, atol=1e-3, what=""):

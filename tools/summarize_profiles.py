@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs under gpurun_out/ into the small, committed summaries under profiles/.
+
+usage: python tools/summarize_profiles.py r01
+  gpurun_out/prof_<tag>/*_kernel_stats.csv           -> profiles/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats)
+  gpurun_out/pmc_fetch_<tag>, pmc_write_<tag> (CSV)  -> profiles/<tag>_pmc.json            (separate --pmc passes)
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in
+KiB, and on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced stream, so
+traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+for src in glob.glob(os.path.join(root, "gpurun_out", f"prof_{tag}*", "*_kernel_stats.csv")):
+    name = os.path.basename(os.path.dirname(src)).replace("prof_", "")
+    shutil.copy(src, os.path.join(out, f"{name}_kernel_stats.csv"))
+    print("copied", src)
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for kind in ("fetch", "write"):
+    for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{kind}_{tag}*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {}
+for kern, ctrs in pmc.items():
+    if "rocclr" in kern:
+        continue
+    e = {c: {"launches": len(v), "mean_KiB": sum(v) / len(v)} for c, v in ctrs.items()}
+    f = e.get("FETCH_SIZE", {}).get("mean_KiB")
+    w = e.get("WRITE_SIZE", {}).get("mean_KiB")
+    if f is not None and w is not None:
+        e["hbm_traffic_bytes_per_launch"] = (2 * f + w) * 1024
+        e["correction"] = "2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE, KiB -> bytes"
+    summary[kern] = e
+json.dump(summary, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1))
