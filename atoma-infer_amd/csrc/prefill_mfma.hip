@@ -132,7 +132,6 @@ template <int D> struct PfLoader {
 
 template <typename T, int D, bool CAUSAL>
 __global__ void __launch_bounds__(PF_THREADS, 2) prefill_mfma_kernel(const AttnParams p) {
-    constexpr int CPR = D / 8;
     constexpr int ROWB = D * 2;                     // bytes per tile row
     constexpr int TILEB = PF_BN * ROWB;             // bytes per K (or V) tile
     constexpr int NJ = D / 16;                      // MFMA k-steps over d for S^T = K.Q^T

@@ -74,8 +74,9 @@ def main():
 
     ah.set_device(local_rank)
     B, S, h, hk, d, page = args.batch, args.seq, args.heads, args.kv_heads, args.head_dim, args.block_size
-    assert hk % world == 0 and h % world == 0, "kv heads must divide over the ranks"
-    h_l, hk_l = h // world, hk // world                       # this rank's head shard
+    import tp
+    qs_, ks_ = tp.head_shard(h, hk, rank, world)               # this rank's head shard (kv-head TP)
+    h_l, hk_l = qs_.stop - qs_.start, ks_.stop - ks_.start
     pages_per_seq = (S + page - 1) // page
     n_pages = int(B * pages_per_seq * 1.125)                   # 73 728 for C2a
     rng = np.random.default_rng(0)
@@ -103,16 +104,8 @@ def main():
 
     comm = None
     if world > 1:
-        import torch
-        idbuf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            raw = (C.c_uint8 * 128)()
-            assert ah.lib.atoma_comm_unique_id(raw) == 0, ah.last_error()
-            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
-        dist.broadcast(idbuf, 0)
-        raw = (C.c_uint8 * 128)(*idbuf.tolist())
-        comm = C.c_void_p()
-        assert ah.lib.atoma_comm_init(C.byref(comm), rank, world, raw, local_rank) == 0, ah.last_error()
+        import tp
+        comm = tp.rccl_comm(ah, dist, rank, world, local_rank)      # unique id from rank 0, one comm per GPU
         act = ah.DeviceBuffer.zeros((B, h * d), np.uint16)    # [B, hidden] activations to all-reduce
         act_out = ah.DeviceBuffer.zeros((B, h * d), np.uint16)
 

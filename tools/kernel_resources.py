@@ -2,7 +2,7 @@
 """usage: tools/kernel_resources.py <csrc/file.hip> -- per-kernel VGPR / spill / scratch / occupancy (gfx950)."""
 import re, subprocess, sys, os
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "atoma-infer_amd")
-cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-honor-nans", "-fno-signed-zeros",
+cmd = ["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast-honor-pragmas", "-fno-honor-nans", "-fno-signed-zeros",
        "-Rpass-analysis=kernel-resource-usage", "-c", sys.argv[1], "-o", "/tmp/_kr.o"]
 out = subprocess.run(cmd, cwd=root, capture_output=True, text=True).stderr
 rows, cur = [], None
