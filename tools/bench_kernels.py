@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Per-kernel measurements of the hot path on one MI355X (BASELINE.md section 2 workloads).
+
+Prints one JSON line per workload: achieved GB/s (HBM-bound kernels) or TFLOP/s (prefill), the
+algorithmic bytes / flops it is computed from, and the fraction of the chip peak.  Timing = HIP events
+on the NULL stream around `iters` back-to-back launches after warm-up.
+
+  python tools/bench_kernels.py [decode prefill cache norm swap]   (default: all)
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "atoma-infer_amd", "bindings"))
+import atoma_hip as ah  # noqa: E402
+from oracle.halfs import BF16, from_f32  # noqa: E402
+
+HBM, MFMA_BF16 = 8000.0, 2500.0  # GB/s, TFLOP/s dense (MI355X_MICROARCH.md)
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    ah.synchronize()
+    a, b = ah.Event(), ah.Event()
+    a.record(None)
+    for _ in range(iters):
+        fn()
+    b.record(None)
+    b.synchronize()
+    return a.elapsed_ms(b) / iters
+
+
+def rand_dev(rng, nbytes):
+    """nbytes of bf16 N(0,1) on the device: a 64 MiB random slab tiled."""
+    slab = from_f32(rng.standard_normal(min(nbytes // 2, 32 << 20), dtype=np.float32), BF16)
+    buf = ah.DeviceBuffer(nbytes)
+    off = 0
+    while off < nbytes:
+        n = min(slab.nbytes, nbytes - off)
+        ah.hip_check(ah.hip.hipMemcpy(buf.ptr + off, slab.ctypes.data, n, ah.H2D), "upload")
+        off += n
+    return buf
+
+
+def emit(name, ms, nbytes=None, flops=None, **extra):
+    rec = {"workload": name, "ms": round(ms, 4)}
+    if nbytes is not None:
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        rec.update(algorithmic_bytes=int(nbytes), GBps=round(gbs, 1), frac_hbm=round(gbs / HBM, 4))
+    if flops is not None:
+        tf = flops / (ms * 1e-3) / 1e12
+        rec.update(flops=int(flops), TFLOPs=round(tf, 1), frac_mfma=round(tf / MFMA_BF16, 4))
+    rec.update(extra)
+    print(json.dumps(rec), flush=True)
+
+
+def decode_case(name, B, S, h, hk, d=128, page=16, identity=False, ragged=False, seed=0):
+    rng = np.random.default_rng(seed)
+    pps = (S + page - 1) // page
+    n_pages = int(B * pps * 1.125)
+    bt = (np.arange(B * pps) if identity else rng.permutation(n_pages)[: B * pps]).astype(np.int32).reshape(B, pps)
+    lens = (rng.integers(S // 2, S + 1, B) if ragged else np.full(B, S)).astype(np.int32)
+    kc, vc = rand_dev(rng, n_pages * page * hk * d * 2), rand_dev(rng, n_pages * page * hk * d * 2)
+    q = rand_dev(rng, B * h * d * 2)
+    o = ah.DeviceBuffer(B * h * d * 2)
+    dbt, dl = ah.DeviceBuffer.from_numpy(bt), ah.DeviceBuffer.from_numpy(lens)
+
+    def run():
+        ah.run_mha(q, kc, vc, o, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=pps * page, softmax_scale=d ** -0.5,
+                   is_bf16=1, q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                   v_strides=(page * hk * d, hk * d, d), cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt,
+                   block_table_batch_stride=pps, page_block_size=page, force_split_kernel=True, unpadded_lse=False)
+    ms = timeit(run)
+    tot = int(lens.astype(np.int64).sum())
+    nbytes = 2 * tot * hk * d * 2 + 2 * B * h * d * 2 + 4 * int(((lens + page - 1) // page).sum()) + 4 * B
+    emit(name, ms, nbytes=nbytes, tokens_per_s=round(B / (ms * 1e-3)))
+    for b_ in (kc, vc, q, o, dbt, dl):
+        b_.free()
+
+
+def bench_decode():
+    decode_case("C2a decode B=256 h=32 hk=8 S=4096 random table", 256, 4096, 32, 8)
+    decode_case("C2c decode identity table", 256, 4096, 32, 8, identity=True)
+    decode_case("C2c decode ragged U[2048,4096]", 256, 4096, 32, 8, ragged=True)
+    decode_case("C2b decode MHA hk=32", 256, 4096, 32, 32)
+    decode_case("decode 70B TP=8 shard: B=64 h=8 hk=1 S=4096 (split-KV)", 64, 4096, 8, 1)
+    decode_case("decode B=1 S=4096 (split-KV)", 1, 4096, 32, 8)
+    decode_case("decode B=16 S=8192", 16, 8192, 32, 8)
+    decode_case("decode B=256 S=1024", 256, 1024, 32, 8)
+    decode_case("decode Llama-3.2-1B shape d=64 B=256 S=4096", 256, 4096, 32, 8, d=64)
+
+
+def bench_prefill():
+    rng = np.random.default_rng(1)
+    h, hk, d = 32, 8, 128
+    for S, nseq in ((2048, 4), (4096, 2), (512, 16)):
+        T = S * nseq
+        q, k, v = rand_dev(rng, T * h * d * 2), rand_dev(rng, T * hk * d * 2), rand_dev(rng, T * hk * d * 2)
+        o = ah.DeviceBuffer(T * h * d * 2)
+        cu = ah.DeviceBuffer.from_numpy((np.arange(nseq + 1) * S).astype(np.int32))
+
+        def run():
+            ah.run_mha(q, k, v, o, b=nseq, h=h, h_k=hk, d=d, seqlen_q=S, seqlen_k=S, softmax_scale=d ** -0.5, is_bf16=1,
+                       q_strides=(0, h * d, d), o_strides=(0, h * d, d), k_strides=(0, hk * d, d), v_strides=(0, hk * d, d),
+                       is_causal=1, cu_seqlens_q=cu, cu_seqlens_k=cu)
+        ms = timeit(run, iters=10)
+        flops = 4 * S * S * h * d / 2 * nseq
+        emit(f"P1 prefill causal varlen S={S} x{nseq} (8B heads)", ms, flops=flops, tokens_per_s=round(T / (ms * 1e-3)))
+        for b_ in (q, k, v, o, cu):
+            b_.free()
+
+
+def bench_cache():
+    rng = np.random.default_rng(2)
+    hk, d, page, nb = 8, 128, 16, 4096
+    kc, vc = rand_dev(rng, nb * page * hk * d * 2), rand_dev(rng, nb * page * hk * d * 2)
+    for T in (256, 2048, 8192):
+        k, v = rand_dev(rng, T * hk * d * 2), rand_dev(rng, T * hk * d * 2)
+        slots = ah.DeviceBuffer.from_numpy(rng.permutation(nb * page)[:T].astype(np.int64))
+        ms = timeit(lambda: ah.lib.reshape_and_cache_flash(k.ptr, v.ptr, kc.ptr, vc.ptr, slots.ptr, page * hk * d, T, hk, d,
+                                                           page, hk * d, hk * d, 1, None))
+        emit(f"K4 reshape_and_cache_flash T={T}", ms, nbytes=4 * T * hk * d * 2 + 8 * T)
+    L = 32
+    caches = [(rand_dev(rng, 1024 * page * hk * d * 2), rand_dev(rng, 1024 * page * hk * d * 2)) for _ in range(L)]
+    kp = ah.DeviceBuffer.from_numpy(np.array([c[0].ptr for c in caches], np.int64))
+    vp = ah.DeviceBuffer.from_numpy(np.array([c[1].ptr for c in caches], np.int64))
+    for P in (1, 64, 500):
+        perm = rng.permutation(1024)
+        mp = ah.DeviceBuffer.from_numpy(np.stack([perm[:P], perm[P:2 * P]], 1).astype(np.int64))
+        ms = timeit(lambda: ah.lib.copy_blocks_bf16(kp.ptr, vp.ptr, mp.ptr, L, P, page * hk * d, None))
+        emit(f"K5 copy_blocks L=32 pairs={P}", ms, nbytes=4 * P * L * page * hk * d * 2)
+
+
+def bench_norm():
+    rng = np.random.default_rng(3)
+    for T in (256, 2048):
+        hidden = 4096
+        x, w, y = rand_dev(rng, T * hidden * 2), rand_dev(rng, hidden * 2), ah.DeviceBuffer(T * hidden * 2)
+        ms = timeit(lambda: ah.lib.atoma_rms_norm(x.ptr, w.ptr, y.ptr, T, hidden, hidden, hidden, 1e-5, 1, None))
+        emit(f"N1 rms_norm T={T} hidden=4096", ms, nbytes=2 * T * hidden * 2 + hidden * 2)
+        h, hk, d = 32, 8, 128
+        q, k = rand_dev(rng, T * h * d * 2), rand_dev(rng, T * hk * d * 2)
+        cos, sin = rand_dev(rng, 8192 * 64 * 2), rand_dev(rng, 8192 * 64 * 2)
+        pos = ah.DeviceBuffer.from_numpy(rng.integers(0, 8192, T).astype(np.int64))
+        ms = timeit(lambda: ah.lib.atoma_rope_qk(q.ptr, k.ptr, cos.ptr, sin.ptr, pos.ptr, T, h, hk, d, h * d, hk * d, 1, 1, None))
+        emit(f"N1 rope q+k T={T}", ms, nbytes=2 * T * (h + hk) * d * 2 + 2 * T * (d // 2) * 2)
+
+
+def bench_swap():
+    rng = np.random.default_rng(4)
+    L, page_bytes, nb = 32, 16 * 8 * 128 * 2, 2048
+    gpu = [rand_dev(rng, nb * page_bytes) for _ in range(2 * L)]
+    for pinned in (True, False):
+        if pinned:
+            host_ptrs = [ah.lib.atoma_host_alloc(nb * page_bytes) for _ in range(2 * L)]
+        else:
+            keep = [np.zeros(nb * page_bytes, np.uint8) for _ in range(2 * L)]
+            host_ptrs = [a.ctypes.data for a in keep]
+        gp = (C.c_void_p * (2 * L))(*[b.ptr for b in gpu])
+        hp = (C.c_void_p * (2 * L))(*host_ptrs)
+        for n in (16, 256, 2048):
+            m = np.stack([rng.permutation(nb)[:n], rng.permutation(nb)[:n]], 1).astype(np.int64)
+            for kind, s, d_, label in ((2, gp, hp, "gpu->cpu"), (1, hp, gp, "cpu->gpu")):
+                def run():
+                    rc = ah.lib.atoma_swap_blocks_multi(s, d_, 2 * L, m.ctypes.data, n, page_bytes, kind, None)
+                    assert rc == 0, ah.last_error()
+                ms = timeit(run, iters=3, warmup=1)
+                emit(f"C5 swap {label} {'pinned' if pinned else 'pageable'} pages={n} (x{2 * L} tensors)", ms,
+                     nbytes=2 * L * page_bytes * n, note="bytes moved one way over PCIe; frac_hbm is not meaningful here")
+        if pinned:
+            for p in host_ptrs:
+                ah.lib.atoma_host_free(p)
+
+
+if __name__ == "__main__":
+    ah.set_device(0)
+    which = sys.argv[1:] or ["decode", "prefill", "cache", "norm", "swap"]
+    for w in which:
+        globals()["bench_" + w]()
