@@ -69,6 +69,8 @@ lib.atoma_host_alloc.restype = _vp
 lib.atoma_host_free.argtypes = [_vp]
 lib.atoma_host_free.restype = None
 lib.atoma_device_count.restype = _int
+lib.atoma_set_option.argtypes = [C.c_char_p, _int]
+lib.atoma_set_option.restype = _int
 lib.atoma_num_cus.argtypes = [_int]
 lib.atoma_num_cus.restype = _int
 

@@ -564,11 +564,32 @@ int decode_num_splits(int64_t waves_per_split, int max_seqlen_k) {
     return (int)(s < 1 ? 1 : s);
 }
 
-// Tuning knobs, overridable for A/B runs: ATOMA_DECODE_P = tiles in flight per wave (2..4),
-// ATOMA_DECODE_NT = 0/1 non-temporal K/V loads.
+// Tuning knobs (atoma_set_option / environment, for A/B runs and tests):
+//   decode_p            ATOMA_DECODE_P            tiles in flight per wave (2..4)
+//   decode_nt           ATOMA_DECODE_NT           0/1 non-temporal K/V loads
+//   decode_chunk_tiles  ATOMA_DECODE_CHUNK_TILES  > 0: cut ragged batches into chunks of that many tiles
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
+}
+struct DecodeOptions {
+    int p = env_int("ATOMA_DECODE_P", DECODE_DEFAULT_P);
+    int nt = env_int("ATOMA_DECODE_NT", DECODE_DEFAULT_NT);
+    int chunk_tiles = env_int("ATOMA_DECODE_CHUNK_TILES", DECODE_CHUNK_TILES);
+};
+static DecodeOptions &decode_options() {
+    static DecodeOptions o;
+    return o;
+}
+extern int prefill_cfg;  // prefill_mfma.hip
+bool set_decode_option(const std::string &name, int value) {
+    DecodeOptions &o = decode_options();
+    if (name == "prefill_cfg") { prefill_cfg = value; return true; }
+    if (name == "decode_p") o.p = value;
+    else if (name == "decode_nt") o.nt = value;
+    else if (name == "decode_chunk_tiles") o.chunk_tiles = value;
+    else return false;
+    return true;
 }
 
 template <typename T, int D, int G, int P, int MINW, bool NT>
@@ -582,8 +603,7 @@ static void launch_decode_tdg(const DecodeParams &p, hipStream_t stream) {
     // tiles in flight per wave / waves per SIMD the register budget is capped for: G = 8 at
     // D = 128 needs more than 256 VGPRs (64 for O, 32 for q, 64 per K+V pair in flight).
     constexpr int MINW = (G >= 8 && D >= 128) ? 1 : 2;
-    static const int cfg_p = env_int("ATOMA_DECODE_P", DECODE_DEFAULT_P);
-    static const int cfg_nt = env_int("ATOMA_DECODE_NT", DECODE_DEFAULT_NT);
+    const int cfg_p = decode_options().p, cfg_nt = decode_options().nt;
     const int P = (G >= 8 && cfg_p > 2) ? 2 : cfg_p;
     if (cfg_nt) {
         if (P >= 4) launch_decode_cfg<T, D, G, 4, MINW, true>(p, stream);
@@ -610,7 +630,7 @@ static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
         const int64_t waves = (int64_t)p.b * p.h_k * p.gchunks;
         p.num_splits = decode_num_splits(waves, p.seqlen_k);
         p.chunk_tiles = 0;
-        static const int chunk_cfg = env_int("ATOMA_DECODE_CHUNK_TILES", DECODE_CHUNK_TILES);
+        const int chunk_cfg = decode_options().chunk_tiles;
         const int64_t max_tiles = cdiv(p.seqlen_k, 16);
         if (p.num_splits == 1 && chunk_cfg > 0 && max_tiles >= 2 * chunk_cfg && (p.cu_seqlens_k || p.seqused_k)) {
             // enough wavefronts without splitting: split only if the kernel finds the batch ragged

@@ -8,21 +8,23 @@
 // fp32 accumulation, P rounded to the storage dtype before P.V (softmax.h:65-185).
 //
 // Shape of the computation (wave64, v_mfma_f32_32x32x16_{bf16,f16}):
-//  * workgroup = 4 waves = 128 query rows of one (sequence, q head); wave w owns 32 rows;
+//  * workgroup = W waves (4: 128 query rows, two workgroups per CU; or 8: 256 rows, one per CU) of one
+//    (sequence, q head); wave w owns 32 rows;
 //  * "swapped" products: S^T = K.Q^T and O^T = V^T.P^T, so a lane's accumulator registers all
 //    belong to ONE query row (column l&31): the online softmax (row max / sum / rescale of O)
 //    is lane-local, with a single lane <-> lane+32 exchange per K/V tile for the row max;
 //  * the C layout of S^T (keys (r&3)+8(r>>2)+4(l>>5)) is used directly as the k-slot order of
 //    the P^T operand, and the V^T operand is fetched with ds_read_b64_tr_b16 in that same key
 //    order -- P never leaves registers and needs no lane permutation;
-//  * K/V tiles of 64 keys are staged through LDS (shared by the 4 waves), double buffered, by
-//    direct global->LDS DMA (global_load_lds_dwordx4): the DMA for tile t+1 is issued before
-//    the MFMAs of tile t, one barrier per tile; 16-byte chunks are XOR-swizzled per row (on the
+//  * K/V tiles of 64 keys are staged through LDS (shared by the waves) in a 2- or 3-deep ring by
+//    direct global->LDS DMA (global_load_lds_dwordx4): later tiles are in flight during the MFMAs
+//    of tile t, counted vmcnt wait, one barrier per tile; 16-byte chunks are XOR-swizzled per row (on the
 //    DMA's source address) so that the K reads (ds_read_b128, one key row per lane) and the V
 //    transpose reads are bank-conflict free;
 //  * causal: K/V tiles above the diagonal are never loaded; a wave skips tiles that are
 //    entirely masked for its own 32 rows; masking code runs only on diagonal / tail tiles;
-//  * workgroups are issued longest-first (last query block first) for causal balance.
+//  * workgroups are issued longest-first (last query block first) for causal balance, and all
+//    workgroups that share a kv head's K/V are steered to the same XCD (L2 reuse).
 // MFMA-bound: 4*Lq*Lk*d flops per (sequence, head) (half of it when causal).
 #include "attn_params.h"
 
@@ -33,6 +35,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_v;
 typedef __attribute__((ext_vector_type(4))) short short4_v;
 typedef __attribute__((ext_vector_type(16))) float f32x16_v;
 typedef __attribute__((ext_vector_type(2))) float f32x2_v;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_v;
 
 template <typename T> __device__ __forceinline__ f32x16_v mfma32(const uint4 &a, const uint4 &b, f32x16_v c);
 template <> __device__ __forceinline__ f32x16_v mfma32<bf16_t>(const uint4 &a, const uint4 &b, f32x16_v c) {
@@ -51,9 +54,8 @@ template <> __device__ __forceinline__ uint32_t cvt_pk<f16_t>(float lo, float hi
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_v));
 }
 
-constexpr int PF_BM = 128;      // query rows per workgroup (4 waves x 32)
-constexpr int PF_BN = 64;       // keys per K/V tile
-constexpr int PF_THREADS = 256;
+constexpr int PF_BN = 64;              // keys per K/V tile
+constexpr int PF_SGU = 8;              // (sequence, q head) units scheduled together on an XCD (2 kv groups at g = 4)
 
 template <int D> struct PfSwz {
     static constexpr int CPR = D / 8;  // 16-byte chunks per row
@@ -80,72 +82,148 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst_unifor
                  : "v"(gsrc), "s"(lds_dst_uniform)
                  : "memory");
 }
+// same with a wave-uniform 64-bit base in SGPRs + a 32-bit per-lane byte offset (no per-lane 64-bit math)
+__device__ __forceinline__ void glds16_saddr(uint64_t base_uniform, uint32_t voff, uint32_t lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base_uniform), "s"(lds_dst_uniform)
+                 : "memory");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's DMAs are still in flight (they complete in issue order)
+template <int N> __device__ __forceinline__ void dma_wait_keep() {
+    static_assert(N == 2 || N == 4 || N == 8, "extend the switch");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+__device__ __forceinline__ uint64_t uniform64(uint64_t x) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 
-// K/V tile loader: direct global -> LDS DMA (global_load_lds_dwordx4, 1 KiB per wave
-// instruction, no staging registers).  The DMA writes LDS linearly (wave-uniform base + lane*16),
-// so the XOR swizzle is applied on the SOURCE side: lane -> (row, slot) of the LDS image,
-// chunk = slot ^ f(row) of the global row.
-template <int D> struct PfLoader {
+// K/V tile loader: direct global -> LDS DMA (1 KiB per wave instruction, no staging registers).
+// The DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle is applied on the
+// SOURCE side: lane -> (row, slot) of the LDS image, chunk = slot ^ f(row) of the global row.
+// Everything that depends only on the lane is computed once (init); a tile of a contiguous K/V
+// tensor that lies fully inside the sequence costs no vector ALU at all (uniform base in SGPRs).
+template <int D, int W> struct PfLoader {
     static constexpr int CPR = D / 8;
     static constexpr int ROWB = D * 2;
     static constexpr int TILEB = PF_BN * ROWB;
-    static constexpr int NDMA = TILEB / 1024 / (PF_THREADS / 64);  // DMA instructions per wave per tile (K or V)
+    static constexpr int NDMA = TILEB / 1024 / W;  // DMA instructions per wave per tile (K or V)
     const uint16_t *kbase, *vbase;
     const int *bt;
     int64_t k_page, k_row, v_page, v_row;
-    int page_size, last_key, wave, lane;
+    int page_size, page_shift, last_key, wave;
+    int row[NDMA];                    // tile row this lane fetches in DMA piece u
+    uint32_t kchunk[NDMA], vchunk[NDMA];   // element offset of the (de-swizzled) 16-byte chunk inside the row
+    uint32_t kfast[NDMA], vfast[NDMA];     // byte offset from the tile base, contiguous layout
+
+    __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+        for (int u = 0; u < NDMA; ++u) {
+            const int L = (wave * NDMA + u) * 64 + lane;   // 16-byte unit in the LDS image
+            row[u] = L / CPR;
+            const int slot = L % CPR;
+            kchunk[u] = PfSwz<D>::k(row[u], slot) * 8;      // XOR is its own inverse
+            vchunk[u] = PfSwz<D>::v(row[u], slot) * 8;
+            kfast[u] = (uint32_t)(row[u] * k_row * 2) + kchunk[u] * 2;
+            vfast[u] = (uint32_t)(row[u] * v_row * 2) + vchunk[u] * 2;
+        }
+    }
 
     __device__ __forceinline__ void issue(int tile, char *kt) const {
         char *vt = kt + TILEB;
+        const uint32_t k_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)kt;
+        const uint32_t v_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)vt;
+        const int key0 = tile * PF_BN;
+        if (!bt && key0 + PF_BN - 1 <= last_key) {  // workgroup-uniform: contiguous tensor, full tile
+            const uint64_t kb = uniform64((uint64_t)(kbase + (int64_t)key0 * k_row));
+            const uint64_t vb = uniform64((uint64_t)(vbase + (int64_t)key0 * v_row));
+#pragma unroll
+            for (int u = 0; u < NDMA; ++u) {
+                const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * NDMA + u) * 1024));
+                glds16_saddr(kb, kfast[u], k_lds + off);
+                glds16_saddr(vb, vfast[u], v_lds + off);
+            }
+            return;
+        }
         const uint16_t *ksrc[NDMA], *vsrc[NDMA];
         // all block-table lookups first, then the DMAs back to back (a lookup's vmcnt wait
         // would otherwise drain the DMA issued just before it)
 #pragma unroll
         for (int u = 0; u < NDMA; ++u) {
-            const int q = wave * NDMA + u;          // 1 KiB piece of the tile
-            const int L = q * 64 + lane;             // 16-byte unit in the LDS image
-            const int row = L / CPR, slot = L % CPR;
-            const int key = min(tile * PF_BN + row, last_key);  // never read past the sequence
+            const int key = min(key0 + row[u], last_key);  // never read past the sequence
             int64_t koff, voff;
             if (bt) {
-                const int pg = bt[key / page_size], r = key % page_size;
+                const int pi = page_shift >= 0 ? key >> page_shift : key / page_size;
+                const int r = key - pi * page_size;
+                const int pg = bt[pi];
                 koff = (int64_t)pg * k_page + (int64_t)r * k_row;
                 voff = (int64_t)pg * v_page + (int64_t)r * v_row;
             } else {
                 koff = (int64_t)key * k_row;
                 voff = (int64_t)key * v_row;
             }
-            ksrc[u] = kbase + koff + PfSwz<D>::k(row, slot) * 8;   // XOR is its own inverse
-            vsrc[u] = vbase + voff + PfSwz<D>::v(row, slot) * 8;
+            ksrc[u] = kbase + koff + kchunk[u];
+            vsrc[u] = vbase + voff + vchunk[u];
         }
-        const uint32_t k_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)kt;
-        const uint32_t v_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)vt;
 #pragma unroll
         for (int u = 0; u < NDMA; ++u) {
-            const uint32_t off = (uint32_t)((wave * NDMA + u) * 1024);
-            glds16(ksrc[u], __builtin_amdgcn_readfirstlane(k_lds + off));
-            glds16(vsrc[u], __builtin_amdgcn_readfirstlane(v_lds + off));
+            const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * NDMA + u) * 1024));
+            glds16(ksrc[u], k_lds + off);
+            glds16(vsrc[u], v_lds + off);
         }
     }
 };
 
-template <typename T, int D, bool CAUSAL>
-__global__ void __launch_bounds__(PF_THREADS, 2) prefill_mfma_kernel(const AttnParams p) {
+// W waves per workgroup (32 query rows each), NB LDS tile buffers (prefetch distance NB - 1).
+template <typename T, int D, bool CAUSAL, int W, int NB>
+__global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParams p) {
+    constexpr int PF_BM = 32 * W;
+    constexpr int NDMA2 = 2 * PfLoader<D, W>::NDMA;   // DMA instructions per wave per tile (K and V)
     constexpr int ROWB = D * 2;                     // bytes per tile row
     constexpr int TILEB = PF_BN * ROWB;             // bytes per K (or V) tile
     constexpr int NJ = D / 16;                      // MFMA k-steps over d for S^T = K.Q^T
     constexpr int NDB = D / 32;                     // 32-row blocks of O^T
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NB][K tile | V tile]
 
     const int tid = threadIdx.x, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (scalar branches below)
-    const int mblk = (int)gridDim.x - 1 - (int)blockIdx.x;  // longest (most keys) first
-    const int hq = blockIdx.y, b = blockIdx.z;
+    // Workgroup -> (sequence, q head, query block).  Measured dispatch policy of the chip
+    // (tools/probes/dispatch_probe.hip): workgroup L runs on XCD L % 8 and shader engine (L / 8) % 4 --
+    // both fixed by the index -- and on the first free CU of that engine, in index order.  So:
+    //  * units (sequence, q head) are dealt to XCDs in contiguous slices: all query blocks of all q heads
+    //    of a kv head read the same K/V (1 MiB at S = 2048) and stay behind one 4 MiB L2;
+    //  * inside an XCD, PF_SGU units at a time, blocks are ordered longest-first (causal: last block
+    //    first) across those units, and dealt to the 4 shader engines in snake order, so every engine
+    //    gets the same amount of work and its CUs take it in LPT order.
+    // The grid is padded to 8 * (largest slice) * m_blocks; surplus workgroups exit here.
+    const int L = (int)blockIdx.x, xcd = L & 7, i = L >> 3;
+    const int m_blocks = (p.seqlen_q + PF_BM - 1) / PF_BM;
+    const int n_units = p.b * p.h, uq = n_units >> 3, ur = n_units & 7;
+    const int nu_x = uq + (xcd < ur ? 1 : 0);                                  // units of this XCD
+    const int u0_x = xcd < ur ? xcd * (uq + 1) : ur * (uq + 1) + (xcd - ur) * uq;
+    const int count_x = nu_x * m_blocks;
+    if (i >= count_x) return;
+    int rank = i;
+    {
+        const int q4 = i >> 2, s4 = i & 3;
+        if (q4 * 4 + 4 <= count_x) rank = q4 * 4 + ((q4 & 1) ? 3 - s4 : s4);     // snake over the 4 shader engines
+    }
+    const int sg_items = PF_SGU * m_blocks, sg = rank / sg_items, rr = rank - sg * sg_items;
+    const int units_in_sg = min(PF_SGU, nu_x - sg * PF_SGU);
+    const int mpos = rr / units_in_sg, uu = rr - mpos * units_in_sg;
+    const int unit = u0_x + sg * PF_SGU + uu;
+    const int b = unit / p.h, hq = unit - b * p.h;                               // q heads of a kv group are adjacent
+    const int mblk = m_blocks - 1 - mpos;                                        // longest (most keys) first
+    const int hk_ = hq / (p.h / p.h_k);
     const SeqInfo si(p, b);
     const int m0 = mblk * PF_BM;
     if (m0 >= si.len_q) return;
-    const int hk = hq / (p.h / p.h_k);
+    const int hk = hk_;
     const int shift = si.len_k - si.len_q;          // mask.h:170: key <= row + seqlen_k - seqlen_q
     const int mw0 = m0 + wave * 32;                 // first query row of this wave
     const int my_q = mw0 + lq;                      // this lane's query row
@@ -175,47 +253,75 @@ __global__ void __launch_bounds__(PF_THREADS, 2) prefill_mfma_kernel(const AttnP
     const int *bt = paged ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
     const uint16_t *kbase = p.k + (int64_t)hk * p.k_head_stride + (paged ? 0 : si.k_offset(p.k_batch_stride, p.k_row_stride, b));
     const uint16_t *vbase = p.v + (int64_t)hk * p.v_head_stride + (paged ? 0 : si.k_offset(p.v_batch_stride, p.v_row_stride, b));
-    PfLoader<D> ld;
+    PfLoader<D, W> ld;
     ld.kbase = kbase; ld.vbase = vbase; ld.bt = bt;
     ld.k_page = p.k_batch_stride; ld.k_row = p.k_row_stride; ld.v_page = p.v_batch_stride; ld.v_row = p.v_row_stride;
-    ld.page_size = p.page_size; ld.last_key = si.len_k - 1; ld.wave = wave; ld.lane = lane;
+    ld.page_size = p.page_size; ld.last_key = si.len_k - 1; ld.wave = wave;
+    ld.page_shift = (p.page_size > 0 && (p.page_size & (p.page_size - 1)) == 0) ? __builtin_ctz(p.page_size) : -1;
+    ld.init(lane);
+    // ---- per-lane LDS read offsets (tile-relative), computed once ----
+    // K: lane reads key row lq (+32 per 32-key half) at chunk 2j+hi, swizzled by the row.
+    uint32_t koff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) koff[j] = (uint32_t)(lq * ROWB + PfSwz<D>::k(lq, 2 * j + hi) * 16);
+    // V^T via ds_read_b64_tr_b16: 16-lane group g2 = lane>>4 reads a [4 keys][16 d] block transposed;
+    // lanes 4j+c of the group supply the address of V[key j][16-col block, 4c..4c+3]; afterwards the
+    // group's lanes hold, for d column 16*(g2&1) + (lane&15), the 4 keys.  Row part 4hi+jrow and the
+    // swizzle depend only on the lane; 32-key half, 16-key k-step and +8 rows are immediates.
+    const int g2 = lane >> 4, jrow = (lane & 15) >> 2, cc = lane & 3;
+    uint32_t voff[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        const int vrow = 4 * hi + jrow;
+        const int dcol = db * 32 + 16 * (g2 & 1) + 4 * cc;  // element index, 4 contiguous
+        voff[db] = (uint32_t)(vrow * ROWB + PfSwz<D>::v(vrow, dcol >> 3) * 16 + (dcol & 7) * 2);
+    }
+
     f32x16_v oacc[NDB];
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-    float m_run = -INFINITY, l_part = 0.f;   // running max (both halves agree), this lane's part of the row sum
+    float m_run = -INFINITY, l_part = 0.f;   // running max in the scaled log2 domain (both halves agree); this lane's part of the row sum
     const float sl2 = p.scale_log2;
-    const float slope_l2 = 0.f;              // ALiBi is routed to the generic kernel
-    (void)slope_l2;
 
-    if (n_tiles > 0) {
-        ld.issue(0, smem);
-        dma_wait_all();
-        __syncthreads();
-    }
+    // LDS ring of NB tiles, prefetch distance NB - 1, ONE barrier per tile:
+    //   wait for this wave's pieces of tile t (later tiles may stay in flight) -> barrier (everyone's
+    //   pieces of tile t are in LDS, and everyone is done reading tile t-1) -> issue tile t+NB-1 into the
+    //   buffer tile t-1 used -> MFMAs of tile t.
+#pragma unroll
+    for (int s0 = 0; s0 < NB - 1; ++s0)
+        if (s0 < n_tiles) ld.issue(s0, smem + s0 * 2 * TILEB);
+    int buf = 0;
     for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < n_tiles) ld.issue(t + 1, smem + (buf ^ 1) * 2 * TILEB);  // DMA in flight during the MFMAs below
+        if (NB > 2 && t + 1 < n_tiles) dma_wait_keep<NDMA2>();   // NB == 3: tile t+1 stays in flight
+        else dma_wait_all();
+        __syncthreads();
+        if (t + NB - 1 < n_tiles) {
+            const int nb = buf + NB - 1 >= NB ? buf - 1 : buf + NB - 1;
+            ld.issue(t + NB - 1, smem + nb * 2 * TILEB);
+        }
         const int kv0 = t * PF_BN;
         if (kv0 < n_end_w) {  // wave-uniform: tile not entirely masked for this wave's rows
-            const char *kt = smem + buf * 2 * TILEB, *vt = kt + TILEB;
+            const uint32_t kt = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(smem + buf * 2 * TILEB);
+            const uint32_t vt = kt + TILEB;
             // ---- S^T[key][query] for the two 32-key halves ----
             f32x16_v s[2];
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
-                const int row = blk * 32 + lq;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const uint4 a = *reinterpret_cast<const uint4 *>(kt + row * ROWB + PfSwz<D>::k(row, 2 * j + hi) * 16);
+                    const u32x4_v av = *(const __attribute__((address_space(3))) u32x4_v *)(uintptr_t)(kt + koff[j] + blk * 32 * ROWB);
+                    uint4 a;
+                    a.x = av[0]; a.y = av[1]; a.z = av[2]; a.w = av[3];
                     s[blk] = mfma32<T>(a, qf[j], s[blk]);
                 }
             }
-            // ---- scale, mask (diagonal / tail tiles only), online softmax ----
+            // ---- mask (diagonal / tail tiles only), online softmax in the exp2 domain ----
             const bool need_mask = (kv0 + PF_BN > si.len_k) || (CAUSAL && kv0 + PF_BN > mw0 + shift + 1);
-            if (need_mask) {  // wave-uniform: diagonal / tail tiles only
+            if (need_mask) {  // wave-uniform
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -225,16 +331,13 @@ __global__ void __launch_bounds__(PF_THREADS, 2) prefill_mfma_kernel(const AttnP
                         s[blk][r] = ok ? s[blk][r] : -INFINITY;
                     }
             }
-            float mx = -INFINITY;
+            float mx = -INFINITY;   // raw-domain max (scale > 0 commutes with max)
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[blk][r] *= sl2;   // scale > 0: -inf stays -inf
-                    mx = fmaxf(mx, s[blk][r]);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
+            const float m_new = fmaxf(m_run, mx * sl2);
             const float ms = m_new == -INFINITY ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
             m_run = m_new;
@@ -245,7 +348,7 @@ __global__ void __launch_bounds__(PF_THREADS, 2) prefill_mfma_kernel(const AttnP
                 float e[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    e[r] = __builtin_amdgcn_exp2f(s[blk][r] - ms);
+                    e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[blk][r], sl2, -ms));  // one fma: s*scale*log2e - max
                     psum += e[r];
                 }
 #pragma unroll
@@ -264,10 +367,6 @@ __global__ void __launch_bounds__(PF_THREADS, 2) prefill_mfma_kernel(const AttnP
                     for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
             }
             // ---- O^T[d][query] += V^T . P^T ----
-            // 16-lane group g = lane>>4 reads a [4 keys][16 d] block transposed: lanes 4j+c of the
-            // group supply the address of V[key j][16-col block, 4c..4c+3]; the group's lanes then
-            // hold, for d column 16*(g&1) + (lane&15), the 4 keys.
-            const int g = lane >> 4, jrow = (lane & 15) >> 2, cc = lane & 3;
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -277,19 +376,16 @@ __global__ void __launch_bounds__(PF_THREADS, 2) prefill_mfma_kernel(const AttnP
                         uint4 a;
 #pragma unroll
                         for (int half = 0; half < 2; ++half) {
-                            const int row = blk * 32 + kk * 16 + 4 * hi + jrow + 8 * half;
-                            const int dcol = db * 32 + 16 * (g & 1) + 4 * cc;  // element index, 4 contiguous
-                            const char *addr = vt + row * ROWB + PfSwz<D>::v(row, dcol >> 3) * 16 + (dcol & 7) * 2;
+                            const uint32_t addr = vt + voff[db] + (blk * 32 + kk * 16 + 8 * half) * ROWB;
                             const short4_v r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) short4_v *)(addr));
+                                (__attribute__((address_space(3))) short4_v *)(uintptr_t)addr);
                             const uint2 r2 = __builtin_bit_cast(uint2, r4);
                             if (half == 0) { a.x = r2.x; a.y = r2.y; } else { a.z = r2.x; a.w = r2.y; }
                         }
                         oacc[db] = mfma32<T>(a, pp[blk][kk], oacc[db]);
                     }
         }
-        dma_wait_all();   // this wave's DMA pieces of tile t+1 have landed ...
-        __syncthreads();  // ... and so have everybody else's; tile t's buffer is free again
+        buf = buf + 1 == NB ? 0 : buf + 1;
     }
 
     // ---- epilogue: total row sum = own part + partner lane's part (same running max) ----
@@ -319,18 +415,28 @@ bool prefill_mfma_supported(const AttnParams &p) {
     return (p.d == 64 || p.d == 128) && p.alibi_slopes == nullptr && p.seqlen_q > 1;
 }
 
-template <typename T, int D, bool CAUSAL>
-static void launch_pf(const AttnParams &p, hipStream_t stream) {
-    constexpr int smem = 2 * 2 * PF_BN * D * 2;
-    static bool attr_set = false;  // 64 KiB for D = 128: above the default dynamic-LDS limit
+template <typename T, int D, bool CAUSAL, int W, int NB>
+static void launch_pf_cfg(const AttnParams &p, hipStream_t stream) {
+    constexpr int smem = NB * 2 * PF_BN * D * 2;
+    static bool attr_set = false;  // up to 96 KiB: above the default dynamic-LDS limit
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL, W, NB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    dim3 grid((unsigned)cdiv(p.seqlen_q, PF_BM), (unsigned)p.h, (unsigned)p.b);
-    hipLaunchKernelGGL((prefill_mfma_kernel<T, D, CAUSAL>), grid, dim3(PF_THREADS), smem, stream, p);
+    const int64_t m_blocks = cdiv(p.seqlen_q, 32 * W), n_units = (int64_t)p.b * p.h;
+    const int64_t nu_max = n_units / 8 + (n_units % 8 ? 1 : 0);
+    dim3 grid((unsigned)(8 * nu_max * m_blocks));   // padded: see the mapping comment in the kernel
+    hipLaunchKernelGGL((prefill_mfma_kernel<T, D, CAUSAL, W, NB>), grid, dim3(64 * W), smem, stream, p);
     ATOMA_CHECK_LAUNCH("prefill_mfma_kernel");
+}
+
+int prefill_cfg = 0;   // atoma_set_option("prefill_cfg", 0|1): 0 = 4 waves x 2 buffers (2 workgroups per CU), 1 = 8 waves x 3 buffers
+
+template <typename T, int D, bool CAUSAL>
+static void launch_pf(const AttnParams &p, hipStream_t stream) {
+    if (prefill_cfg == 1) launch_pf_cfg<T, D, CAUSAL, 8, 3>(p, stream);
+    else launch_pf_cfg<T, D, CAUSAL, 4, 2>(p, stream);
 }
 
 void launch_prefill_mfma(const AttnParams &p, bool is_bf16, hipStream_t stream) {

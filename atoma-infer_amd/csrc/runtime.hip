@@ -12,6 +12,8 @@ void set_error(const std::string &msg) { g_error = msg; }
 void clear_error() { g_error.clear(); }
 bool has_error() { return !g_error.empty(); }
 
+bool set_decode_option(const std::string &name, int value);  // paged_decode.hip
+
 int device_num_cus() {
     // The reference queries cudaDeviceGetAttribute on EVERY attention call
     // (/root/reference/csrc/src/lib.rs:1545,2201-2233); cache it per device instead.
@@ -68,6 +70,13 @@ int atoma_compute_num_splits(int64_t batch_size, int64_t num_heads, int64_t head
     const int64_t m_blocks = atoma::cdiv(max_seqlen_q, 64);
     if (num_cus <= 0) num_cus = atoma::device_num_cus();
     return atoma::num_splits_heuristic(batch_size * num_heads * m_blocks, (int64_t)num_cus * 2, n_blocks, 128);
+}
+
+int atoma_set_option(const char *name, int value) {
+    atoma::clear_error();
+    if (name && atoma::set_decode_option(name, value)) return 0;
+    atoma::set_error(std::string("atoma_set_option: unknown option ") + (name ? name : "(null)"));
+    return -1;
 }
 
 int atoma_device_count(void) {

@@ -165,6 +165,11 @@ int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128
 int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, int dtype, void *stream);
 int atoma_comm_destroy(void *comm);
 
+/* Tuning knobs for A/B measurements and tests: "decode_p" (K/V tiles in flight per wavefront, 2..4),
+ * "decode_nt" (0/1 non-temporal K/V loads), "decode_chunk_tiles" (> 0: cut ragged decode batches into
+ * chunks of that many 16-token tiles).  Defaults also come from ATOMA_DECODE_{P,NT,CHUNK_TILES}. */
+int atoma_set_option(const char *name, int value);
+
 /* Device helpers used by the host layer, tests and bench (plain HIP runtime, no torch). */
 int atoma_device_count(void);
 int atoma_num_cus(int device);

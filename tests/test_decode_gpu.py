@@ -106,9 +106,7 @@ def test_decode_ragged_large_batch_chunk_mode(gpu):
     """A batch big enough to fill the chip without splitting (B*h_k >= 1024) but ragged: the kernel
     itself detects the imbalance and cuts sequences into 1024-token chunks merged by the combine
     kernel; sequences shorter than a chunk are written directly.  Same answer as the oracle."""
-    import os
-    if os.environ.get("ATOMA_DECODE_CHUNK_TILES") is None:
-        pass  # default build: chunk mode off -> this is then simply a large ragged-batch parity test
+    assert gpu.lib.atoma_set_option(b"decode_chunk_tiles", 64) == 0     # experimental mode, off by default
     rng = np.random.default_rng(99)
     B, h, hk, d, page = 272, 4, 4, 64, 16
     lens = rng.integers(16, 3000, B).astype(np.int32)
@@ -128,6 +126,10 @@ def test_decode_ragged_large_batch_chunk_mode(gpu):
     lens_u = np.full(B, 1500, np.int32)
     out_u, _ = gpu_decode(gpu, q, kc, vc, bt[:, :94].copy() % nb, lens_u, d ** -0.5, BF16)
     assert np.isfinite(to_f32(out_u, BF16)).all()
+    assert gpu.lib.atoma_set_option(b"decode_chunk_tiles", 0) == 0
+    out2, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)        # default route, same batch
+    for i, L in enumerate(lens):
+        assert_close(out2[i], ref[i], BF16, atol=attn_atol(BF16, L), what=f"ragged batch (unsplit) seq {i} (L={L})")
 
 
 def test_decode_contiguous_cache_without_block_table(gpu):
