@@ -54,7 +54,17 @@ template <> __device__ __forceinline__ uint32_t cvt_pk<f16_t>(float lo, float hi
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_v));
 }
 
+#ifndef PREFILL_DEFAULT_CFG
+#define PREFILL_DEFAULT_CFG 0
+#endif
 constexpr int PF_BN = 64;              // keys per K/V tile
+// -DPF_TIMING: per-phase cycle accounting (s_memtime) of wave 0 of every workgroup, written to p.lse as
+// [workgroup][8] floats (wait+barrier, dma issue, qk, softmax, pv, tiles, total, -) -- tools/probes/prefill_phases.py
+#ifdef PF_TIMING
+#define PF_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += (float)(now_ - tlast); tlast = now_; } while (0)
+#else
+#define PF_T(i) do {} while (0)
+#endif
 constexpr int PF_SGU = 8;              // (sequence, q head) units scheduled together on an XCD (2 kv groups at g = 4)
 
 template <int D> struct PfSwz {
@@ -180,7 +190,7 @@ template <int D, int W> struct PfLoader {
 };
 
 // W waves per workgroup (32 query rows each), NB LDS tile buffers (prefetch distance NB - 1).
-template <typename T, int D, bool CAUSAL, int W, int NB>
+template <typename T, int D, bool CAUSAL, int W, int NB, bool PRIO>
 __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParams p) {
     constexpr int PF_BM = 32 * W;
     constexpr int NDMA2 = 2 * PfLoader<D, W>::NDMA;   // DMA instructions per wave per tile (K and V)
@@ -292,33 +302,58 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
 #pragma unroll
     for (int s0 = 0; s0 < NB - 1; ++s0)
         if (s0 < n_tiles) ld.issue(s0, smem + s0 * 2 * TILEB);
+#ifdef PF_TIMING
+    float tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
     int buf = 0;
     for (int t = 0; t < n_tiles; ++t) {
         if (NB > 2 && t + 1 < n_tiles) dma_wait_keep<NDMA2>();   // NB == 3: tile t+1 stays in flight
         else dma_wait_all();
         __syncthreads();
+        PF_T(0);
         if (t + NB - 1 < n_tiles) {
             const int nb = buf + NB - 1 >= NB ? buf - 1 : buf + NB - 1;
             ld.issue(t + NB - 1, smem + nb * 2 * TILEB);
         }
+        PF_T(1);
         const int kv0 = t * PF_BN;
         if (kv0 < n_end_w) {  // wave-uniform: tile not entirely masked for this wave's rows
             const uint32_t kt = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(smem + buf * 2 * TILEB);
             const uint32_t vt = kt + TILEB;
+            // Per-tile read bases = buffer address + the lane's constant offset.  They are made opaque
+            // so that the remaining constants (32-key half, 16-key step, +8 rows) fold into the ds_read
+            // `offset:` immediates instead of costing one v_add per LDS read (the reassociator would
+            // otherwise pair the constant with the uniform buffer address).
+            uint32_t kb_[NJ], vb_[NDB];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { kb_[j] = kt + koff[j]; asm volatile("" : "+v"(kb_[j])); }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) { vb_[db] = vt + voff[db]; asm volatile("" : "+v"(vb_[db])); }
             // ---- S^T[key][query] for the two 32-key halves ----
             f32x16_v s[2];
+            if (PRIO) __builtin_amdgcn_s_setprio(1);   // MFMA clusters outrank the partner wave's softmax VALU
 #pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
+            for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+            // the two 32-key halves are independent accumulators: alternate them so that no MFMA
+            // waits for the previous one's result
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const u32x4_v av = *(const __attribute__((address_space(3))) u32x4_v *)(uintptr_t)(kt + koff[j] + blk * 32 * ROWB);
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const u32x4_v av = *(const __attribute__((address_space(3))) u32x4_v *)(uintptr_t)(kb_[j] + blk * 32 * ROWB);
                     uint4 a;
                     a.x = av[0]; a.y = av[1]; a.z = av[2]; a.w = av[3];
                     s[blk] = mfma32<T>(a, qf[j], s[blk]);
                 }
-            }
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+#ifdef PF_TIMING
+            asm volatile("" :: "v"(s[0][0]), "v"(s[1][15]));
+#endif
+            PF_T(2);
             // ---- mask (diagonal / tail tiles only), online softmax in the exp2 domain ----
             const bool need_mask = (kv0 + PF_BN > si.len_k) || (CAUSAL && kv0 + PF_BN > mw0 + shift + 1);
             if (need_mask) {  // wave-uniform
@@ -366,17 +401,23 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
             }
+#ifdef PF_TIMING
+            asm volatile("" :: "v"(pp[0][0].x), "v"(pp[1][1].w));
+#endif
+            PF_T(3);
             // ---- O^T[d][query] += V^T . P^T ----
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            // (32-key half, 16-key step) outer, the NDB independent accumulators inner
 #pragma unroll
-            for (int db = 0; db < NDB; ++db)
+            for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
+                for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
+                    for (int db = 0; db < NDB; ++db) {
                         uint4 a;
 #pragma unroll
                         for (int half = 0; half < 2; ++half) {
-                            const uint32_t addr = vt + voff[db] + (blk * 32 + kk * 16 + 8 * half) * ROWB;
+                            const uint32_t addr = vb_[db] + (blk * 32 + kk * 16 + 8 * half) * ROWB;
                             const short4_v r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                 (__attribute__((address_space(3))) short4_v *)(uintptr_t)addr);
                             const uint2 r2 = __builtin_bit_cast(uint2, r4);
@@ -384,10 +425,23 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
                         }
                         oacc[db] = mfma32<T>(a, pp[blk][kk], oacc[db]);
                     }
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+#ifdef PF_TIMING
+            asm volatile("" :: "v"(oacc[0][0]), "v"(oacc[NDB - 1][15]));
+#endif
+            PF_T(4);
         }
         buf = buf + 1 == NB ? 0 : buf + 1;
     }
 
+#ifdef PF_TIMING
+    if (p.lse && tid == 0) {
+        tacc[5] = (float)n_tiles;
+        tacc[6] = (float)(__builtin_readcyclecounter() - tstart);
+        for (int i2 = 0; i2 < 8; ++i2) p.lse[(int64_t)blockIdx.x * 8 + i2] = tacc[i2];
+    }
+    if (p.lse) return;
+#endif
     // ---- epilogue: total row sum = own part + partner lane's part (same running max) ----
     const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
     if (my_q >= si.len_q) return;
@@ -415,28 +469,34 @@ bool prefill_mfma_supported(const AttnParams &p) {
     return (p.d == 64 || p.d == 128) && p.alibi_slopes == nullptr && p.seqlen_q > 1;
 }
 
-template <typename T, int D, bool CAUSAL, int W, int NB>
+template <typename T, int D, bool CAUSAL, int W, int NB, bool PRIO>
 static void launch_pf_cfg(const AttnParams &p, hipStream_t stream) {
     constexpr int smem = NB * 2 * PF_BN * D * 2;
     static bool attr_set = false;  // up to 96 KiB: above the default dynamic-LDS limit
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL, W, NB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL, W, NB, PRIO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     const int64_t m_blocks = cdiv(p.seqlen_q, 32 * W), n_units = (int64_t)p.b * p.h;
     const int64_t nu_max = n_units / 8 + (n_units % 8 ? 1 : 0);
     dim3 grid((unsigned)(8 * nu_max * m_blocks));   // padded: see the mapping comment in the kernel
-    hipLaunchKernelGGL((prefill_mfma_kernel<T, D, CAUSAL, W, NB>), grid, dim3(64 * W), smem, stream, p);
+    hipLaunchKernelGGL((prefill_mfma_kernel<T, D, CAUSAL, W, NB, PRIO>), grid, dim3(64 * W), smem, stream, p);
     ATOMA_CHECK_LAUNCH("prefill_mfma_kernel");
 }
 
-int prefill_cfg = 0;   // atoma_set_option("prefill_cfg", 0|1): 0 = 4 waves x 2 buffers (2 workgroups per CU), 1 = 8 waves x 3 buffers
+// atoma_set_option("prefill_cfg", bits): bit 0 = 8 waves x 3 buffers (else 4 waves x 2 buffers, two
+// workgroups per CU), bit 1 = s_setprio around the MFMA clusters.
+int prefill_cfg = PREFILL_DEFAULT_CFG;
 
 template <typename T, int D, bool CAUSAL>
 static void launch_pf(const AttnParams &p, hipStream_t stream) {
-    if (prefill_cfg == 1) launch_pf_cfg<T, D, CAUSAL, 8, 3>(p, stream);
-    else launch_pf_cfg<T, D, CAUSAL, 4, 2>(p, stream);
+    switch (prefill_cfg & 3) {
+        case 0: launch_pf_cfg<T, D, CAUSAL, 4, 2, false>(p, stream); break;
+        case 1: launch_pf_cfg<T, D, CAUSAL, 8, 3, false>(p, stream); break;
+        case 2: launch_pf_cfg<T, D, CAUSAL, 4, 2, true>(p, stream); break;
+        default: launch_pf_cfg<T, D, CAUSAL, 8, 3, true>(p, stream); break;
+    }
 }
 
 void launch_prefill_mfma(const AttnParams &p, bool is_bf16, hipStream_t stream) {

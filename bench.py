@@ -62,11 +62,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # ATOMA_BENCH_FORCE_COMM=1: take the multi-rank code path (gloo rendezvous, RCCL communicator, per-step
+    # all-reduce) even with one rank -- lets a single-GPU box exercise what the 8-GPU run will execute.
+    force_comm = os.environ.get("ATOMA_BENCH_FORCE_COMM") == "1"
     dist = None
-    if world > 1:
+    if world > 1 or force_comm:
         import torch  # only for the rendezvous / barrier / max-over-ranks (gloo, CPU tensors)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import atoma_hip as ah
@@ -103,7 +107,7 @@ def main():
     scale = float(d ** -0.5)
 
     comm = None
-    if world > 1:
+    if world > 1 or force_comm:
         import tp
         comm = tp.rccl_comm(ah, dist, rank, world, local_rank)      # unique id from rank 0, one comm per GPU
         act = ah.DeviceBuffer.zeros((B, h * d), np.uint16)    # [B, hidden] activations to all-reduce
@@ -163,7 +167,7 @@ def main():
                                % (B, h, hk, d, S, page, "identity" if args.identity_table else "random-permutation",
                                   n_pages),
                    "parallelism": "tp%d (kv-head shards)" % world, "step": "one run_mha decode call over the batch"
-                   + (" + all-reduce of [B, h*d] bf16" if world > 1 else "")},
+                   + (" + all-reduce of [B, h*d] bf16" if comm is not None else "")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "paged_decode_kernel<bf16,128,G=4>", "kernel_ms": round(kern_ms, 4),
