@@ -377,14 +377,23 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
             const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
             m_run = m_new;
             uint4 pp[2][2];  // P^T operands: [32-key half][16-key k-step]
-            float psum = 0.f;
+            // packed f32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction) around
+            // the 32 v_exp_f32; four independent partial sums keep the add chain short
+            f32x2_v ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+            const f32x2_v sl2v = {sl2, sl2}, nmsv = {-ms, -ms};
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 float e[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[blk][r], sl2, -ms));  // one fma: s*scale*log2e - max
-                    psum += e[r];
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_v x = {s[blk][r], s[blk][r + 1]};
+                    const f32x2_v y = __builtin_elementwise_fma(x, sl2v, nmsv);   // s*scale*log2e - max
+                    f32x2_v ev;
+                    ev[0] = __builtin_amdgcn_exp2f(y[0]);
+                    ev[1] = __builtin_amdgcn_exp2f(y[1]);
+                    e[r] = ev[0];
+                    e[r + 1] = ev[1];
+                    ps2[(r >> 1) & 1] += ev;
                 }
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -394,6 +403,8 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
                     pp[blk][kk].w = cvt_pk<T>(e[8 * kk + 6], e[8 * kk + 7]);
                 }
             }
+            const f32x2_v pst = ps2[0] + ps2[1];
+            const float psum = pst[0] + pst[1];
             l_part = l_part * alpha + psum;
             if (__any(alpha != 1.f)) {
 #pragma unroll
