@@ -208,3 +208,44 @@ def test_decode_full_size_properties_c2a(gpu):
                       v_strides=(page * hk * d, hk * d, d), o_shape=(len(pick), 1, h, d), o_strides=(h * d, h * d, d),
                       cu_k=lens[pick], k_cumulative=False, block_table=bt[pick], page=page)
     assert_close(out[pick], ref, BF16, atol=1e-3, what="C2a sampled sequences vs C oracle (f32)")
+
+
+def test_decode_seqused_k_and_cumulative_lengths(gpu):
+    """block_info.h:16-23: seqused_k overrides the length; cumulative cu_seqlens_k addresses a varlen K/V."""
+    rng = np.random.default_rng(55)
+    B, h, hk, d = 4, 8, 2, 128
+    lens = np.array([30, 64, 1, 100], np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    k, v = rand_half(rng, (int(cu[-1]), hk, d), BF16), rand_half(rng, (int(cu[-1]), hk, d), BF16)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    used = np.array([10, 64, 1, 77], np.int32)
+    dq, dk, dv = (gpu.DeviceBuffer.from_numpy(a) for a in (q, k, v))
+    do = gpu.DeviceBuffer(q.nbytes)
+    dcu, dused = gpu.DeviceBuffer.from_numpy(cu), gpu.DeviceBuffer.from_numpy(used)
+    for su, want_lens in ((None, lens), (dused, used)):
+        gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=100, softmax_scale=0.088, is_bf16=1,
+                    q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(0, hk * d, d),
+                    v_strides=(0, hk * d, d), cu_seqlens_k=dcu, is_seqlens_k_cumulative=True, seqused_k=su,
+                    unpadded_lse=False)
+        gpu.synchronize()
+        out = do.numpy(np.uint16, q.shape)
+        for b in range(B):
+            kb, vb = k[cu[b]: cu[b] + want_lens[b]][None], v[cu[b]: cu[b] + want_lens[b]][None]
+            ref = A.flash_attn_kv_cache(q[b:b + 1], kb, vb, 0.088, BF16)
+            assert_close(out[b:b + 1], ref, BF16, atol=ATOL_VS_F32[BF16], what=f"cumulative lens seq {b}")
+
+
+@pytest.mark.parametrize("dtype", [F16])
+def test_decode_f16_long_sequences(gpu, dtype):
+    rng = np.random.default_rng(66)
+    lens = np.array([4096, 2500, 4095], np.int32)
+    h, hk, d, page = 32, 8, 128, 16
+    nb = int(sum((int(x) + page - 1) // page for x in lens)) + 1
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+    q = rand_half(rng, (3, 1, h, d), dtype)
+    out, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+    ref = c_attention(q, kc, vc, b=3, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bt.shape[1] * page, scale=d ** -0.5,
+                      is_bf16=0, q_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                      v_strides=(page * hk * d, hk * d, d), o_shape=q.shape, o_strides=(h * d, h * d, d), cu_k=lens,
+                      k_cumulative=False, block_table=bt, page=page)
+    assert_close(out, ref, dtype, atol=1e-3, what="f16 long decode vs C oracle")

@@ -130,3 +130,52 @@ def test_prefill_linearity_in_v_full_size(gpu):
     o12, _ = gpu_varlen(gpu, q, k, v12, cu, cu, d ** -0.5, True, BF16)
     err = np.abs(to_f32(o12, BF16) - (to_f32(o1, BF16) + to_f32(o2, BF16)))
     assert err.max() < 0.06 and err.mean() < 2e-3, (err.max(), err.mean())   # bf16 roundings of v12, o1, o2, o12
+
+
+def test_prefill_more_queries_than_keys_and_empty_sequences(gpu):
+    """Edge cases of mask.h:170 / flash_fwd_kernel.h:97-133: causal with Lq > Lk (the first Lq - Lk rows see
+    no key -> exact zeros), a sequence with no keys at all, and a zero-length query sequence in the batch."""
+    rng = np.random.default_rng(8)
+    d, h, hk, page = 128, 4, 2, 16
+    lens_q = np.array([40, 0, 7, 130], np.int32)
+    lens_k = np.array([25, 16, 0, 130], np.int32)
+    kc, vc, bt = make_paged_cache(rng, 14, page, hk, d, BF16, lens_k)
+    cu_q = np.concatenate([[0], np.cumsum(lens_q)]).astype(np.int32)
+    cu_k = np.concatenate([[0], np.cumsum(lens_k)]).astype(np.int32)
+    q = rand_half(rng, (int(cu_q[-1]), h, d), BF16)
+    for causal in (True, False):
+        out, lse = gpu_varlen(gpu, q, kc, vc, cu_q, cu_k, d ** -0.5, causal, BF16, bt=bt)
+        ref = A.flash_attn_varlen(q, kc, vc, cu_q, cu_k, d ** -0.5, causal, BF16, block_table=bt)
+        assert_close(out, ref, BF16, atol=ATOL_VS_F32[BF16], what=f"Lq>Lk / empty, causal={causal}")
+        if causal:
+            assert not out[:15].any()                 # rows 0..14 of sequence 0: key <= row + 25 - 40 < 0
+        assert not out[40:47].any()                   # sequence 2 has no keys
+        assert np.isposinf(lse[:, 40:47]).all()
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+def test_prefill_d64_paged_llama_1b_shape(gpu, dtype):
+    """Llama-3.2-1B head shape (d = 64, 32 q / 8 kv heads) through the paged path, causal."""
+    rng = np.random.default_rng(int(dtype) + 40)
+    d, h, hk, page = 64, 32, 8, 16
+    lens = np.array([200, 65], np.int32)
+    kc, vc, bt = make_paged_cache(rng, 20, page, hk, d, dtype, lens)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    q = rand_half(rng, (int(cu[-1]), h, d), dtype)
+    out, _ = gpu_varlen(gpu, q, kc, vc, cu, cu, d ** -0.5, True, dtype, bt=bt)
+    ref = A.flash_attn_varlen(q, kc, vc, cu, cu, d ** -0.5, True, dtype, block_table=bt)
+    assert_close(out, ref, dtype, atol=ATOL_VS_F32[dtype], what="d=64 paged causal")
+
+
+def test_prefill_both_workgroup_shapes_agree(gpu):
+    """The 8-wave / 3-buffer variant (option prefill_cfg) must give the same numbers as the default."""
+    rng = np.random.default_rng(9)
+    cu = np.array([0, 300, 1000], np.int32)
+    q, k, v = rand_half(rng, (1000, 8, 128), BF16), rand_half(rng, (1000, 2, 128), BF16), rand_half(rng, (1000, 2, 128), BF16)
+    outs = []
+    for cfg in (0, 1, 2, 3):
+        assert gpu.lib.atoma_set_option(b"prefill_cfg", cfg) == 0
+        outs.append(gpu_varlen(gpu, q, k, v, cu, cu, 0.088, True, BF16)[0])
+    gpu.lib.atoma_set_option(b"prefill_cfg", 0)
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
