@@ -550,15 +550,15 @@ void *workspace(hipStream_t stream, size_t bytes) {
     return w.ptr;
 }
 
-// Split count for THIS kernel: enough wavefronts to put ~8 on every CU (2 per SIMD), never
-// fewer than 8 tiles (128 tokens) per split.  (The reference's heuristic, lib.rs:2122-2199,
+// Split count for THIS kernel: enough wavefronts to fill the resident slots of every CU (8, or 4 for the
+// 512-register G = 8 / d = 128 variant), never fewer than `min_tiles` 16-token tiles per split.  (The reference's heuristic, lib.rs:2122-2199,
 // is tuned for 128-thread CTAs of a 64-row tile; it is restated as atoma_compute_num_splits.)
-int decode_num_splits(int64_t waves_per_split, int max_seqlen_k) {
-    const int64_t target = (int64_t)device_num_cus() * 8;
+int decode_num_splits(int64_t waves_per_split, int max_seqlen_k, int waves_per_cu, int min_tiles) {
+    const int64_t target = (int64_t)device_num_cus() * waves_per_cu;
     if (waves_per_split * 2 > target) return 1;
     int64_t s = cdiv(target, waves_per_split);
     const int64_t n_tiles = cdiv(max_seqlen_k, 16);
-    const int64_t max_s = n_tiles / 8 > 0 ? n_tiles / 8 : 1;
+    const int64_t max_s = n_tiles / min_tiles > 0 ? n_tiles / min_tiles : 1;
     if (s > max_s) s = max_s;
     if (s > 128) s = 128;
     return (int)(s < 1 ? 1 : s);
@@ -576,6 +576,8 @@ struct DecodeOptions {
     int p = env_int("ATOMA_DECODE_P", DECODE_DEFAULT_P);
     int nt = env_int("ATOMA_DECODE_NT", DECODE_DEFAULT_NT);
     int chunk_tiles = env_int("ATOMA_DECODE_CHUNK_TILES", DECODE_CHUNK_TILES);
+    int waves_per_cu = env_int("ATOMA_DECODE_WAVES_PER_CU", 0);   // 0 = resident capacity
+    int min_tiles = env_int("ATOMA_DECODE_MIN_TILES", 8);
 };
 static DecodeOptions &decode_options() {
     static DecodeOptions o;
@@ -588,6 +590,8 @@ bool set_decode_option(const std::string &name, int value) {
     if (name == "decode_p") o.p = value;
     else if (name == "decode_nt") o.nt = value;
     else if (name == "decode_chunk_tiles") o.chunk_tiles = value;
+    else if (name == "decode_waves_per_cu") o.waves_per_cu = value;
+    else if (name == "decode_min_tiles") o.min_tiles = value;
     else return false;
     return true;
 }
@@ -628,7 +632,9 @@ static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
     p.gchunks = (int)cdiv(g, G);
     if (p.num_splits <= 0) {
         const int64_t waves = (int64_t)p.b * p.h_k * p.gchunks;
-        p.num_splits = decode_num_splits(waves, p.seqlen_k);
+        const int cap = (G >= 8 && D >= 128) ? 4 : 8;   // resident wavefronts per CU of the variant that will run
+        const int wpc = decode_options().waves_per_cu > 0 ? decode_options().waves_per_cu : cap;
+        p.num_splits = decode_num_splits(waves, p.seqlen_k, wpc, std::max(1, decode_options().min_tiles));
         p.chunk_tiles = 0;
         const int chunk_cfg = decode_options().chunk_tiles;
         const int64_t max_tiles = cdiv(p.seqlen_k, 16);
