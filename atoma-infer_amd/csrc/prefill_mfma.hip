@@ -27,6 +27,8 @@
 //    workgroups that share a kv head's K/V are steered to the same XCD (L2 reuse).
 // MFMA-bound: 4*Lq*Lk*d flops per (sequence, head) (half of it when causal).
 #include "attn_params.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace atoma {
 
@@ -58,9 +60,16 @@ template <> __device__ __forceinline__ uint32_t cvt_pk<f16_t>(float lo, float hi
 #define PREFILL_DEFAULT_CFG 0
 #endif
 constexpr int PF_BN = 64;              // keys per K/V tile
+// The running row max is only raised when the new tile's max exceeds it by more than PF_DEFER (log2 units):
+// P = exp2(S - m) then stays <= 2^PF_DEFER (exact in the f32 sums, representable in f16 / bf16) and the
+// rescale of O and of the row sums becomes rare instead of per-tile.
+constexpr float PF_DEFER = 8.f;
 // -DPF_TIMING: per-phase cycle accounting (s_memtime) of wave 0 of every workgroup, written to p.lse as
 // [workgroup][8] floats (wait+barrier, dma issue, qk, softmax, pv, tiles, total, -) -- tools/probes/prefill_phases.py
 #ifdef PF_TIMING
+#ifndef PF_TIMING_TID
+#define PF_TIMING_TID 0
+#endif
 #define PF_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += (float)(now_ - tlast); tlast = now_; } while (0)
 #else
 #define PF_T(i) do {} while (0)
@@ -103,10 +112,8 @@ __device__ __forceinline__ void glds16_saddr(uint64_t base_uniform, uint32_t vof
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wait until at most N of this wave's DMAs are still in flight (they complete in issue order)
 template <int N> __device__ __forceinline__ void dma_wait_keep() {
-    static_assert(N == 2 || N == 4 || N == 8, "extend the switch");
-    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 __device__ __forceinline__ uint64_t uniform64(uint64_t x) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x), hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
@@ -144,19 +151,20 @@ template <int D, int W> struct PfLoader {
         }
     }
 
-    __device__ __forceinline__ void issue(int tile, char *kt) const {
-        char *vt = kt + TILEB;
-        const uint32_t k_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)kt;
-        const uint32_t v_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)vt;
-        const int key0 = tile * PF_BN;
-        if (!bt && key0 + PF_BN - 1 <= last_key) {  // workgroup-uniform: contiguous tensor, full tile
-            const uint64_t kb = uniform64((uint64_t)(kbase + (int64_t)key0 * k_row));
-            const uint64_t vb = uniform64((uint64_t)(vbase + (int64_t)key0 * v_row));
+    // Issue the DMAs of K tile `ktile` -> LDS byte address k_lds and of V tile `vtile` -> v_lds
+    // (either may be < 0: skipped; the conditions are workgroup-uniform).
+    __device__ __forceinline__ void issue2(int ktile, uint32_t k_lds, int vtile, uint32_t v_lds) const {
+        const bool do_k = ktile >= 0, do_v = vtile >= 0;
+        const int kkey0 = ktile * PF_BN, vkey0 = vtile * PF_BN;
+        if (!bt && (!do_k || kkey0 + PF_BN - 1 <= last_key) && (!do_v || vkey0 + PF_BN - 1 <= last_key)) {
+            // contiguous tensor, full tiles: uniform base in SGPRs + the lane's constant offset
+            const uint64_t kb = uniform64((uint64_t)(kbase + (int64_t)kkey0 * k_row));
+            const uint64_t vb = uniform64((uint64_t)(vbase + (int64_t)vkey0 * v_row));
 #pragma unroll
             for (int u = 0; u < NDMA; ++u) {
                 const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * NDMA + u) * 1024));
-                glds16_saddr(kb, kfast[u], k_lds + off);
-                glds16_saddr(vb, vfast[u], v_lds + off);
+                if (do_k) glds16_saddr(kb, kfast[u], k_lds + off);
+                if (do_v) glds16_saddr(vb, vfast[u], v_lds + off);
             }
             return;
         }
@@ -165,17 +173,18 @@ template <int D, int W> struct PfLoader {
         // would otherwise drain the DMA issued just before it)
 #pragma unroll
         for (int u = 0; u < NDMA; ++u) {
-            const int key = min(key0 + row[u], last_key);  // never read past the sequence
+            const int kkey = min(max(kkey0, 0) + row[u], last_key);  // never read past the sequence
+            const int vkey = min(max(vkey0, 0) + row[u], last_key);
             int64_t koff, voff;
             if (bt) {
-                const int pi = page_shift >= 0 ? key >> page_shift : key / page_size;
-                const int r = key - pi * page_size;
-                const int pg = bt[pi];
-                koff = (int64_t)pg * k_page + (int64_t)r * k_row;
-                voff = (int64_t)pg * v_page + (int64_t)r * v_row;
+                const int kpi = page_shift >= 0 ? kkey >> page_shift : kkey / page_size;
+                const int vpi = page_shift >= 0 ? vkey >> page_shift : vkey / page_size;
+                const int kpg = bt[kpi], vpg = bt[vpi];
+                koff = (int64_t)kpg * k_page + (int64_t)(kkey - kpi * page_size) * k_row;
+                voff = (int64_t)vpg * v_page + (int64_t)(vkey - vpi * page_size) * v_row;
             } else {
-                koff = (int64_t)key * k_row;
-                voff = (int64_t)key * v_row;
+                koff = (int64_t)kkey * k_row;
+                voff = (int64_t)vkey * v_row;
             }
             ksrc[u] = kbase + koff + kchunk[u];
             vsrc[u] = vbase + voff + vchunk[u];
@@ -183,9 +192,23 @@ template <int D, int W> struct PfLoader {
 #pragma unroll
         for (int u = 0; u < NDMA; ++u) {
             const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * NDMA + u) * 1024));
-            glds16(ksrc[u], k_lds + off);
-            glds16(vsrc[u], v_lds + off);
+            if (do_k) glds16(ksrc[u], k_lds + off);
+            if (do_v) glds16(vsrc[u], v_lds + off);
         }
+    }
+    // contiguous K / V tensor, tile fully inside the sequence: piece u of this wave's share, from a
+    // wave-uniform tile base (no per-lane address arithmetic)
+    __device__ __forceinline__ bool fast_tile(int tile) const { return !bt && tile * PF_BN + PF_BN - 1 <= last_key; }
+    __device__ __forceinline__ uint64_t k_tile_base(int tile) const { return uniform64((uint64_t)(kbase + (int64_t)tile * PF_BN * k_row)); }
+    __device__ __forceinline__ uint64_t v_tile_base(int tile) const { return uniform64((uint64_t)(vbase + (int64_t)tile * PF_BN * v_row)); }
+    template <int U> __device__ __forceinline__ void fast_piece(bool is_v, uint64_t tile_base, uint32_t lds) const {
+        const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * NDMA + U) * 1024));
+        glds16_saddr(tile_base, is_v ? vfast[U] : kfast[U], lds + off);
+    }
+    // K and V of the same tile into one [K tile | V tile] buffer
+    __device__ __forceinline__ void issue(int tile, char *kt) const {
+        const uint32_t k_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)kt;
+        issue2(tile, k_lds, tile, k_lds + TILEB);
     }
 };
 
@@ -295,6 +318,129 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
     float m_run = -INFINITY, l_part = 0.f;   // running max in the scaled log2 domain (both halves agree); this lane's part of the row sum
     const float sl2 = p.scale_log2;
 
+#ifdef PF_TIMING
+    float tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+
+    // ---- S^T[key][query] = K.Q^T of one tile, the two 32-key halves ----
+    auto qk_tile = [&](uint32_t kt, f32x16_v (&s)[2]) {
+        // Per-tile read bases = buffer address + the lane's constant offset.  They are made opaque
+        // so that the remaining constants (32-key half, 16-key step, +8 rows) fold into the ds_read
+        // `offset:` immediates instead of costing one v_add per LDS read (the reassociator would
+        // otherwise pair the constant with the uniform buffer address).
+        uint32_t kb_[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { kb_[j] = kt + koff[j]; asm volatile("" : "+v"(kb_[j])); }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);   // MFMA clusters outrank the partner wave's softmax VALU
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+        // the two 32-key halves are independent accumulators: alternate them so that no MFMA
+        // waits for the previous one's result
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const u32x4_v av = *(const __attribute__((address_space(3))) u32x4_v *)(uintptr_t)(kb_[j] + blk * 32 * ROWB);
+                uint4 a;
+                a.x = av[0]; a.y = av[1]; a.z = av[2]; a.w = av[3];
+                s[blk] = mfma32<T>(a, qf[j], s[blk]);
+            }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- mask (diagonal / tail tiles only), online softmax in the exp2 domain; rescales O ----
+    auto softmax_tile = [&](f32x16_v (&s)[2], int kv0, uint4 (&pp)[2][2]) {
+        const bool need_mask = (kv0 + PF_BN > si.len_k) || (CAUSAL && kv0 + PF_BN > mw0 + shift + 1);
+        if (need_mask) {  // wave-uniform
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < si.len_k && (!CAUSAL || key <= my_q + shift);
+                    s[blk][r] = ok ? s[blk][r] : -INFINITY;
+                }
+        }
+        float mx = -INFINITY;   // raw-domain max (scale > 0 commutes with max)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_cand = fmaxf(m_run, mx * sl2);
+        const float m_new = m_cand > m_run + PF_DEFER ? m_cand : m_run;   // deferred raise (PF_DEFER)
+        const float ms = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
+        m_run = m_new;
+        // packed f32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction) around
+        // the 32 v_exp_f32; four independent partial sums keep the add chain short
+        f32x2_v ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        const f32x2_v sl2v = {sl2, sl2}, nmsv = {-ms, -ms};
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_v x = {s[blk][r], s[blk][r + 1]};
+                const f32x2_v y = __builtin_elementwise_fma(x, sl2v, nmsv);   // s*scale*log2e - max
+                f32x2_v ev;
+                ev[0] = __builtin_amdgcn_exp2f(y[0]);
+                ev[1] = __builtin_amdgcn_exp2f(y[1]);
+                e[r] = ev[0];
+                e[r + 1] = ev[1];
+                ps2[(r >> 1) & 1] += ev;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                pp[blk][kk].x = cvt_pk<T>(e[8 * kk + 0], e[8 * kk + 1]);
+                pp[blk][kk].y = cvt_pk<T>(e[8 * kk + 2], e[8 * kk + 3]);
+                pp[blk][kk].z = cvt_pk<T>(e[8 * kk + 4], e[8 * kk + 5]);
+                pp[blk][kk].w = cvt_pk<T>(e[8 * kk + 6], e[8 * kk + 7]);
+            }
+        }
+        const f32x2_v pst = ps2[0] + ps2[1];
+        const float psum = pst[0] + pst[1];
+        l_part = l_part * alpha + psum;
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        }
+    };
+
+    // ---- O^T[d][query] += V^T . P^T of one tile ----
+    auto pv_tile = [&](uint32_t vt, const uint4 (&pp)[2][2]) {
+        uint32_t vb_[NDB];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) { vb_[db] = vt + voff[db]; asm volatile("" : "+v"(vb_[db])); }
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        // (32-key half, 16-key step) outer, the NDB independent accumulators inner
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    uint4 a;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const uint32_t addr = vb_[db] + (blk * 32 + kk * 16 + 8 * half) * ROWB;
+                        const short4_v r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) short4_v *)(uintptr_t)addr);
+                        const uint2 r2 = __builtin_bit_cast(uint2, r4);
+                        if (half == 0) { a.x = r2.x; a.y = r2.y; } else { a.z = r2.x; a.w = r2.y; }
+                    }
+                    oacc[db] = mfma32<T>(a, pp[blk][kk], oacc[db]);
+                }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
     // LDS ring of NB tiles, prefetch distance NB - 1, ONE barrier per tile:
     //   wait for this wave's pieces of tile t (later tiles may stay in flight) -> barrier (everyone's
     //   pieces of tile t are in LDS, and everyone is done reading tile t-1) -> issue tile t+NB-1 into the
@@ -302,11 +448,6 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
 #pragma unroll
     for (int s0 = 0; s0 < NB - 1; ++s0)
         if (s0 < n_tiles) ld.issue(s0, smem + s0 * 2 * TILEB);
-#ifdef PF_TIMING
-    float tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tlast = __builtin_readcyclecounter();
-    const unsigned long long tstart = tlast;
-#endif
     int buf = 0;
     for (int t = 0; t < n_tiles; ++t) {
         if (NB > 2 && t + 1 < n_tiles) dma_wait_keep<NDMA2>();   // NB == 3: tile t+1 stays in flight
@@ -320,123 +461,20 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
         PF_T(1);
         const int kv0 = t * PF_BN;
         if (kv0 < n_end_w) {  // wave-uniform: tile not entirely masked for this wave's rows
-            const uint32_t kt = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)(smem + buf * 2 * TILEB);
-            const uint32_t vt = kt + TILEB;
-            // Per-tile read bases = buffer address + the lane's constant offset.  They are made opaque
-            // so that the remaining constants (32-key half, 16-key step, +8 rows) fold into the ds_read
-            // `offset:` immediates instead of costing one v_add per LDS read (the reassociator would
-            // otherwise pair the constant with the uniform buffer address).
-            uint32_t kb_[NJ], vb_[NDB];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) { kb_[j] = kt + koff[j]; asm volatile("" : "+v"(kb_[j])); }
-#pragma unroll
-            for (int db = 0; db < NDB; ++db) { vb_[db] = vt + voff[db]; asm volatile("" : "+v"(vb_[db])); }
-            // ---- S^T[key][query] for the two 32-key halves ----
+            const uint32_t kt = smem_lds + buf * 2 * TILEB;
             f32x16_v s[2];
-            if (PRIO) __builtin_amdgcn_s_setprio(1);   // MFMA clusters outrank the partner wave's softmax VALU
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
-            // the two 32-key halves are independent accumulators: alternate them so that no MFMA
-            // waits for the previous one's result
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    const u32x4_v av = *(const __attribute__((address_space(3))) u32x4_v *)(uintptr_t)(kb_[j] + blk * 32 * ROWB);
-                    uint4 a;
-                    a.x = av[0]; a.y = av[1]; a.z = av[2]; a.w = av[3];
-                    s[blk] = mfma32<T>(a, qf[j], s[blk]);
-                }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            uint4 pp[2][2];  // P^T operands: [32-key half][16-key k-step]
+            qk_tile(kt, s);
 #ifdef PF_TIMING
             asm volatile("" :: "v"(s[0][0]), "v"(s[1][15]));
 #endif
             PF_T(2);
-            // ---- mask (diagonal / tail tiles only), online softmax in the exp2 domain ----
-            const bool need_mask = (kv0 + PF_BN > si.len_k) || (CAUSAL && kv0 + PF_BN > mw0 + shift + 1);
-            if (need_mask) {  // wave-uniform
-#pragma unroll
-                for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kv0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const bool ok = key < si.len_k && (!CAUSAL || key <= my_q + shift);
-                        s[blk][r] = ok ? s[blk][r] : -INFINITY;
-                    }
-            }
-            float mx = -INFINITY;   // raw-domain max (scale > 0 commutes with max)
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx * sl2);
-            const float ms = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
-            m_run = m_new;
-            uint4 pp[2][2];  // P^T operands: [32-key half][16-key k-step]
-            // packed f32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction) around
-            // the 32 v_exp_f32; four independent partial sums keep the add chain short
-            f32x2_v ps2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-            const f32x2_v sl2v = {sl2, sl2}, nmsv = {-ms, -ms};
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                float e[16];
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const f32x2_v x = {s[blk][r], s[blk][r + 1]};
-                    const f32x2_v y = __builtin_elementwise_fma(x, sl2v, nmsv);   // s*scale*log2e - max
-                    f32x2_v ev;
-                    ev[0] = __builtin_amdgcn_exp2f(y[0]);
-                    ev[1] = __builtin_amdgcn_exp2f(y[1]);
-                    e[r] = ev[0];
-                    e[r + 1] = ev[1];
-                    ps2[(r >> 1) & 1] += ev;
-                }
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    pp[blk][kk].x = cvt_pk<T>(e[8 * kk + 0], e[8 * kk + 1]);
-                    pp[blk][kk].y = cvt_pk<T>(e[8 * kk + 2], e[8 * kk + 3]);
-                    pp[blk][kk].z = cvt_pk<T>(e[8 * kk + 4], e[8 * kk + 5]);
-                    pp[blk][kk].w = cvt_pk<T>(e[8 * kk + 6], e[8 * kk + 7]);
-                }
-            }
-            const f32x2_v pst = ps2[0] + ps2[1];
-            const float psum = pst[0] + pst[1];
-            l_part = l_part * alpha + psum;
-            if (__any(alpha != 1.f)) {
-#pragma unroll
-                for (int db = 0; db < NDB; ++db)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-            }
+            softmax_tile(s, kv0, pp);
 #ifdef PF_TIMING
             asm volatile("" :: "v"(pp[0][0].x), "v"(pp[1][1].w));
 #endif
             PF_T(3);
-            // ---- O^T[d][query] += V^T . P^T ----
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
-            // (32-key half, 16-key step) outer, the NDB independent accumulators inner
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int db = 0; db < NDB; ++db) {
-                        uint4 a;
-#pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const uint32_t addr = vb_[db] + (blk * 32 + kk * 16 + 8 * half) * ROWB;
-                            const short4_v r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (__attribute__((address_space(3))) short4_v *)(uintptr_t)addr);
-                            const uint2 r2 = __builtin_bit_cast(uint2, r4);
-                            if (half == 0) { a.x = r2.x; a.y = r2.y; } else { a.z = r2.x; a.w = r2.y; }
-                        }
-                        oacc[db] = mfma32<T>(a, pp[blk][kk], oacc[db]);
-                    }
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            pv_tile(kt + TILEB, pp);
 #ifdef PF_TIMING
             asm volatile("" :: "v"(oacc[0][0]), "v"(oacc[NDB - 1][15]));
 #endif
@@ -476,6 +514,460 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Software-pipelined kernels: 4 waves per workgroup, RB 32-row query blocks per wave.
+//   RB = 1: 128-row workgroup, two workgroups per CU (two waves per SIMD, 256 registers each);
+//   RB = 2: 256-row workgroup, ONE wave per SIMD with the whole 512-register file; every K / V^T
+//           fragment read from LDS feeds two MFMAs.
+// The matrix pipe and the VALU are separate issue ports of a SIMD but a wave issues in order, so the two
+// instruction streams are interleaved in program order and pinned with sched_barrier(0):
+//   phase B(t):  S(t+1) = K(t+1).Q^T  (MFMA + K ds_read_b128)   ||  P(t) = exp2(S(t) - m), row sums, pack  (VALU)
+//   phase C(t):  O += V(t)^T.P(t)^T   (MFMA + V^T tr reads)     ||  row max of S(t+1), rescale decision  (VALU)
+// The running max is only raised when some row's new max exceeds it by more than PF_DEFER (log2 units;
+// P <= 2^PF_DEFER stays exact in the f32 sums and representable in f16 / bf16), so the rescale of O is
+// a rare, separate block and phases B and C are straight-line code.
+// LDS: rings of NS K tiles and NS V tiles (NS = 2 at RB = 1, 3 at RB = 2); tile t lives in slot t % NS.
+// Prefetch groups {K0}, {K1, V0}, .. {K(NS-1), V(NS-2)} before the loop, then {K(t+NS), V(t+NS-1)} at the
+// top of iteration t, into the slots of K(t) and V(t-1), which are free once the barrier is passed.
+//
+// Register files.  VALU instructions only see the arch VGPRs; hipcc's own MFMA selection puts every D/C
+// operand in the accumulator file once a kernel may exceed 256 registers and then shuffles tuples
+// between the files (v_accvgpr_* by the hundred per tile).  So the accumulator registers below PF_NACC
+// are owned by the asm statements, with literal register numbers:  O^T[rb][db] = a[16(rb.NDB+db) ..+15],
+// Q^T[rb][j] = a[PF_QA + 4(rb.NJ+j) ..+3]; S (read by the softmax VALU), P, and the K / V^T operands are
+// ordinary variables in arch VGPRs.  Every statement lists the owned registers as clobbered, so hipcc
+// keeps out of them (it spills to the accumulator registers above).  hipcc pads nothing inside an asm
+// string: `s_nop 1` covers a just-written VGPR (or v_accvgpr_write) -> MFMA operand read; readers of an
+// MFMA's D other than the next MFMA of its accumulation chain come after an `s_nop 11` (8-pass MFMA D
+// -> any other access: 12 wait states).
+#define PF_ACC_CLOBBERS_96 \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", \
+    "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+    "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", \
+    "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", \
+    "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", \
+    "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", \
+    "a92", "a93", "a94", "a95"
+#define PF_ACC_CLOBBERS_192 \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", \
+    "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+    "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", \
+    "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", \
+    "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", \
+    "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", \
+    "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", \
+    "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", \
+    "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", \
+    "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", \
+    "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", \
+    "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", \
+    "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", \
+    "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191"
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// NACC = number of asm-owned accumulator registers (96: RB = 1, 192: RB = 2)
+template <typename T, int NACC> struct PfAcc;
+#define ATOMA_PF_ACC(TT, MN, NACC, CLOB)                                                                                  \
+    template <> struct PfAcc<TT, NACC> {                                                                                  \
+        /* s (+)= k.Q^T[q]: D (tied: the tuple keeps its registers across the tile loop), A in VGPRs (K fragment     */    \
+        /* straight from LDS), B = a[q..q+3] */                                                                           \
+        template <bool FIRST, int Q>                                                                                      \
+        static __device__ __forceinline__ void qk(f32x16_v &s, const u32x4_v &k) {                                        \
+            if constexpr (FIRST)                                                                                          \
+                asm volatile(MN " %0, %1, a[%2:%3], 0" : "+v"(s) : "v"(k), "n"(Q), "n"(Q + 3) : CLOB);                     \
+            else                                                                                                          \
+                asm volatile(MN " %0, %1, a[%2:%3], %0" : "+v"(s) : "v"(k), "n"(Q), "n"(Q + 3) : CLOB);                    \
+        }                                                                                                                 \
+        /* a[o..o+15] += vt.p (p written by VALU: two wait states first) */                                                \
+        template <int O>                                                                                                  \
+        static __device__ __forceinline__ void pv(const u32x4_v &vt, const u32x4_v &p) {                                   \
+            asm volatile("s_nop 1\n\t" MN " a[%2:%3], %0, %1, a[%2:%3]" :: "v"(vt), "v"(p), "n"(O), "n"(O + 15) : CLOB);    \
+        }                                                                                                                 \
+        template <int A> static __device__ __forceinline__ void write4(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) { \
+            asm volatile("v_accvgpr_write_b32 a[%4], %0\n\tv_accvgpr_write_b32 a[%5], %1\n\t"                              \
+                         "v_accvgpr_write_b32 a[%6], %2\n\tv_accvgpr_write_b32 a[%7], %3"                                  \
+                         :: "v"(x0), "v"(x1), "v"(x2), "v"(x3), "n"(A), "n"(A + 1), "n"(A + 2), "n"(A + 3) : CLOB);        \
+        }                                                                                                                 \
+        template <int A> static __device__ __forceinline__ void read4(float &x0, float &x1, float &x2, float &x3) {        \
+            asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\t"                                \
+                         "v_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"                                    \
+                         : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3) : "n"(A), "n"(A + 1), "n"(A + 2), "n"(A + 3) : CLOB);    \
+        }                                                                                                                 \
+        template <int A> static __device__ __forceinline__ void scale4(float alpha) { /* a[A..A+3] *= alpha */             \
+            float t0, t1, t2, t3;                                                                                         \
+            asm volatile("v_accvgpr_read_b32 %0, a[%5]\n\tv_accvgpr_read_b32 %1, a[%6]\n\t"                                \
+                         "v_accvgpr_read_b32 %2, a[%7]\n\tv_accvgpr_read_b32 %3, a[%8]\n\t"                                \
+                         "v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_mul_f32 %2, %2, %4\n\tv_mul_f32 %3, %3, %4\n\t" \
+                         "v_accvgpr_write_b32 a[%5], %0\n\tv_accvgpr_write_b32 a[%6], %1\n\t"                              \
+                         "v_accvgpr_write_b32 a[%7], %2\n\tv_accvgpr_write_b32 a[%8], %3"                                  \
+                         : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)                                                     \
+                         : "v"(alpha), "n"(A), "n"(A + 1), "n"(A + 2), "n"(A + 3) : CLOB);                                 \
+        }                                                                                                                 \
+        /* MFMA D (accumulator file) -> v_accvgpr_read */                                                                 \
+        static __device__ __forceinline__ void fence() { asm volatile("s_nop 11" ::: CLOB); }                              \
+    }
+ATOMA_PF_ACC(bf16_t, "v_mfma_f32_32x32x16_bf16", 96, PF_ACC_CLOBBERS_96);
+ATOMA_PF_ACC(f16_t, "v_mfma_f32_32x32x16_f16", 96, PF_ACC_CLOBBERS_96);
+ATOMA_PF_ACC(bf16_t, "v_mfma_f32_32x32x16_bf16", 192, PF_ACC_CLOBBERS_192);
+ATOMA_PF_ACC(f16_t, "v_mfma_f32_32x32x16_f16", 192, PF_ACC_CLOBBERS_192);
+#undef ATOMA_PF_ACC
+
+template <typename T, int D, bool CAUSAL, int RB>
+__global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(const AttnParams p) {
+    constexpr int W = 4, PF_BM = 32 * RB * W;
+    constexpr int NDMA = PfLoader<D, W>::NDMA;
+    constexpr int ROWB = D * 2, TILEB = PF_BN * ROWB, NJ = D / 16, NDB = D / 32;
+    constexpr int NS = RB == 2 ? 3 : 2;              // LDS ring depth (tiles of K, and of V)
+    constexpr int PF_QA = RB * NDB * 16;             // first accumulator register of Q^T
+    constexpr int NACC = RB * 96;
+    static_assert(PF_QA + RB * NJ * 4 <= NACC, "accumulator map exceeds the clobber list");
+    using Acc = PfAcc<T, NACC>;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];  // K tiles [NS] | V tiles [NS]
+
+    const int tid = threadIdx.x, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (sequence, q head, query block): same XCD / shader-engine aware order as above
+    const int L = (int)blockIdx.x, xcd = L & 7, i = L >> 3;
+    const int m_blocks = (p.seqlen_q + PF_BM - 1) / PF_BM;
+    const int n_units = p.b * p.h, uq = n_units >> 3, ur = n_units & 7;
+    const int nu_x = uq + (xcd < ur ? 1 : 0);
+    const int u0_x = xcd < ur ? xcd * (uq + 1) : ur * (uq + 1) + (xcd - ur) * uq;
+    const int count_x = nu_x * m_blocks;
+    if (i >= count_x) return;
+    int rank = i;
+    {
+        const int q4 = i >> 2, s4 = i & 3;
+        if (q4 * 4 + 4 <= count_x) rank = q4 * 4 + ((q4 & 1) ? 3 - s4 : s4);
+    }
+    const int sg_items = PF_SGU * m_blocks, sg = rank / sg_items, rr = rank - sg * sg_items;
+    const int units_in_sg = min(PF_SGU, nu_x - sg * PF_SGU);
+    const int mpos = rr / units_in_sg, uu = rr - mpos * units_in_sg;
+    const int unit = u0_x + sg * PF_SGU + uu;
+    const int b = unit / p.h, hq = unit - b * p.h;
+    const int mblk = m_blocks - 1 - mpos;
+    const int hk = hq / (p.h / p.h_k);
+    const SeqInfo si(p, b);
+    const int m0 = mblk * PF_BM;
+    if (m0 >= si.len_q) return;
+    const int shift = si.len_k - si.len_q;
+    const int mw0 = m0 + wave * 32 * RB;             // first query row of this wave
+    const int my_q0 = mw0 + lq;                      // this lane's query row in row block 0 (+32 per block)
+
+    int n_end = si.len_k, n_end_w = si.len_k;
+    if (CAUSAL) {
+        n_end = min(n_end, m0 + PF_BM + shift);
+        n_end_w = min(n_end_w, mw0 + 32 * RB + shift);
+    }
+    const int n_tiles = n_end > 0 ? (n_end + PF_BN - 1) / PF_BN : 0;
+
+    // ---- Q^T fragments -> accumulator file; O^T = 0 ----
+    static_for<0, RB>([&](auto RBc) {
+        constexpr int rb = decltype(RBc)::value;
+        const int qrow = min(my_q0 + 32 * rb, si.len_q - 1);
+        const uint16_t *qp = p.q + si.q_offset(p.q_batch_stride, p.q_row_stride, b) + (int64_t)qrow * p.q_row_stride +
+                             (int64_t)hq * p.q_head_stride + hi * 8;
+        u32x4_v qv[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) qv[j] = *reinterpret_cast<const u32x4_v *>(qp + j * 16);
+        static_for<0, NJ>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            Acc::template write4<PF_QA + (rb * NJ + j) * 4>(qv[j][0], qv[j][1], qv[j][2], qv[j][3]);
+        });
+    });
+    static_for<0, RB * NDB * 4>([&](auto Ic) { Acc::template write4<decltype(Ic)::value * 4>(0u, 0u, 0u, 0u); });
+
+    const bool paged = p.block_table != nullptr;
+    PfLoader<D, W> ld;
+    ld.kbase = p.k + (int64_t)hk * p.k_head_stride + (paged ? 0 : si.k_offset(p.k_batch_stride, p.k_row_stride, b));
+    ld.vbase = p.v + (int64_t)hk * p.v_head_stride + (paged ? 0 : si.k_offset(p.v_batch_stride, p.v_row_stride, b));
+    ld.bt = paged ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+    ld.k_page = p.k_batch_stride; ld.k_row = p.k_row_stride; ld.v_page = p.v_batch_stride; ld.v_row = p.v_row_stride;
+    ld.page_size = p.page_size; ld.last_key = si.len_k - 1; ld.wave = wave;
+    ld.page_shift = (p.page_size > 0 && (p.page_size & (p.page_size - 1)) == 0) ? __builtin_ctz(p.page_size) : -1;
+    ld.init(lane);
+
+    uint32_t koff[NJ], voff[NDB];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) koff[j] = (uint32_t)(lq * ROWB + PfSwz<D>::k(lq, 2 * j + hi) * 16);
+    {
+        const int g2 = lane >> 4, jrow = (lane & 15) >> 2, cc = lane & 3, vrow = 4 * hi + jrow;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const int dcol = db * 32 + 16 * (g2 & 1) + 4 * cc;
+            voff[db] = (uint32_t)(vrow * ROWB + PfSwz<D>::v(vrow, dcol >> 3) * 16 + (dcol & 7) * 2);
+        }
+    }
+
+    float m_run[RB], l_part[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) { m_run[rb] = -INFINITY; l_part[rb] = 0.f; }
+    const float sl2 = p.scale_log2;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+
+#ifdef PF_TIMING
+    float tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+    const unsigned long long tstart = tlast;
+#endif
+    f32x16_v s_a[RB][2], s_b[RB][2];   // raw scores of two consecutive tiles (roles alternate)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_a[rb][blk][r] = s_b[rb][blk][r] = 0.f;
+    u32x4_v pp[RB][2][2];              // P^T operands of the current tile: [row block][32-key half][16-key k-step]
+
+    auto read_k = [&](uint32_t addr) { return *(const __attribute__((address_space(3))) u32x4_v *)(uintptr_t)addr; };
+    auto read_vt = [&](uint32_t addr) {   // two transposed 8-byte reads = one A operand (16 keys x this lane's d column)
+        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) short4_v *)(uintptr_t)addr));
+        const uint2 hi2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) short4_v *)(uintptr_t)(addr + 8 * ROWB)));
+        const u32x4_v a = {lo.x, lo.y, hi2.x, hi2.y};
+        return a;
+    };
+    auto fence_s = [&](f32x16_v (&s)[RB][2]) {   // S (MFMA D in VGPRs) is read by VALU code next
+        if constexpr (RB == 2) asm volatile("s_nop 11" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[RB - 1][0]), "+v"(s[RB - 1][1]));
+        else asm volatile("s_nop 11" : "+v"(s[0][0]), "+v"(s[0][1]));
+    };
+
+    // ---- phase B: [s_out = K.Q^T of the tile at kt]  ||  [P = exp2(s_in*scale - m), row sums, pack] ----
+    // The instruction stream is written in issue order and pinned with sched_barrier(0): one MFMA, then
+    // its share of the softmax VALU work (the matrix pipe is busy 32 cycles per MFMA; a wave issues in
+    // order), K fragments fetched from LDS one k-step ahead.
+    auto phase_b = [&](auto with_qk, auto with_sm, uint32_t kt, f32x16_v (&s_in)[RB][2], f32x16_v (&s_out)[RB][2]) {
+        constexpr bool QK = decltype(with_qk)::value, SM = decltype(with_sm)::value;
+        constexpr int NM = NJ * 2 * RB, EPM = RB * 32 / NM;   // MFMAs per phase, score elements handled beside each
+        uint32_t kb_[NJ];
+        u32x4_v kf[2][2];                                   // K fragments [k-step parity][32-key half]
+        if (QK) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { kb_[j] = kt + koff[j]; asm volatile("" : "+v"(kb_[j])); }
+            kf[0][0] = read_k(kb_[0]);
+            kf[0][1] = read_k(kb_[0] + 32 * ROWB);
+        }
+        float nms[RB], ps[RB][2];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            nms[rb] = m_run[rb] == -INFINITY ? 0.f : -m_run[rb];
+            ps[rb][0] = ps[rb][1] = 0.f;
+        }
+        static_for<0, NM>([&](auto Mc) {
+            constexpr int m = decltype(Mc)::value, j = m / (2 * RB), blk = (m / RB) & 1, rb = m % RB;
+            if constexpr (QK) {
+                if constexpr (m % (2 * RB) == 0 && j + 1 < NJ) {   // prefetch the next k-step's fragments
+                    kf[(j + 1) & 1][0] = read_k(kb_[j + 1]);
+                    kf[(j + 1) & 1][1] = read_k(kb_[j + 1] + 32 * ROWB);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                Acc::template qk<j == 0, PF_QA + (rb * NJ + j) * 4>(s_out[rb][blk], kf[j & 1][blk]);
+            }
+            if constexpr (SM) {
+#pragma unroll
+                for (int n = m * EPM; n < (m + 1) * EPM; ++n) {
+                    const int erb = n >> 5, eblk = (n >> 4) & 1, r = n & 15;
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s_in[erb][eblk][r], sl2, nms[erb]));
+                    s_in[erb][eblk][r] = e;
+                    ps[erb][r & 1] += e;
+                }
+                if constexpr (((m + 1) * EPM) % 8 == 0) {     // a group of 8 is complete: pack it
+                    constexpr int g = ((m + 1) * EPM) / 8 - 1, grb = g >> 2, gblk = (g >> 1) & 1, kk = g & 1;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        pp[grb][gblk][kk][c] = cvt_pk<T>(s_in[grb][gblk][8 * kk + 2 * c], s_in[grb][gblk][8 * kk + 2 * c + 1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (SM) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) l_part[rb] += ps[rb][0] + ps[rb][1];
+        }
+        if (QK) fence_s(s_out);
+    };
+
+    auto mask_tile = [&](f32x16_v (&s)[RB][2], int kv0) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < si.len_k && (!CAUSAL || key <= my_q0 + 32 * rb + shift);
+                    s[rb][blk][r] = ok ? s[rb][blk][r] : -INFINITY;
+                }
+    };
+    // deferred raise of the running max; placed after every P.V MFMA of the previous tile
+    auto raise_max = [&](const float (&mx)[RB]) {
+        bool need = false;
+        float m_new[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const float m = fmaxf(mx[rb], __shfl_xor(mx[rb], 32, 64)) * sl2;
+            m_new[rb] = m;
+            need = need || (m > m_run[rb] + PF_DEFER);
+        }
+        if (__any(need)) {   // rare after the first tiles: rescale O and the row sums to the new reference
+            Acc::fence();
+            static_for<0, RB>([&](auto RBc) {
+                constexpr int rb = decltype(RBc)::value;
+                const float mt = fmaxf(m_run[rb], m_new[rb]);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - (mt == -INFINITY ? 0.f : mt));
+                m_run[rb] = mt;
+                l_part[rb] *= alpha;
+                static_for<0, NDB * 4>([&](auto Ic) { Acc::template scale4<rb * NDB * 16 + decltype(Ic)::value * 4>(alpha); });
+            });
+        }
+    };
+
+    // ---- phase C: [O += V^T.P^T of the tile at vt]  ||  [row max of s_new] ----
+    auto phase_c = [&](auto with_max, uint32_t vt, f32x16_v (&s_new)[RB][2], float (&mx)[RB]) {
+        constexpr bool MX = decltype(with_max)::value;
+        constexpr int NA = 4 * NDB, EPM = 32 / NA;           // V^T operands per tile; score elements per MFMA
+        uint32_t vb_[NDB];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) { vb_[db] = vt + voff[db]; asm volatile("" : "+v"(vb_[db])); }
+        u32x4_v vf[2];
+        vf[0] = read_vt(vb_[0]);
+        if (MX) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) mx[rb] = s_new[rb][0][0];
+        }
+        static_for<0, NA>([&](auto Nc) {
+            constexpr int n = decltype(Nc)::value, q = n / NDB, db = n % NDB, blk = q >> 1, kk = q & 1;
+            if constexpr (n + 1 < NA) {
+                constexpr int q1 = (n + 1) / NDB, db1 = (n + 1) % NDB;
+                vf[(n + 1) & 1] = read_vt(vb_[db1] + ((q1 >> 1) * 32 + (q1 & 1) * 16) * ROWB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            static_for<0, RB>([&](auto Rc) {
+                constexpr int rb = decltype(Rc)::value;
+                Acc::template pv<(rb * NDB + db) * 16>(vf[n & 1], pp[rb][blk][kk]);
+                if constexpr (MX) {
+                    constexpr int e0 = (n * RB + rb) * EPM;   // 0 .. 32.RB: elements of the flattened [rb][blk][r]
+#pragma unroll
+                    for (int e = e0; e < e0 + EPM; ++e) mx[e >> 5] = fmaxf(mx[e >> 5], s_new[e >> 5][(e >> 4) & 1][e & 15]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+    auto tile_max = [&](f32x16_v (&s)[RB][2], float (&mx)[RB]) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, s[rb][blk][r]);
+            mx[rb] = m;
+        }
+    };
+    auto need_mask = [&](int kv0) { return (kv0 + PF_BN > si.len_k) || (CAUSAL && kv0 + PF_BN > mw0 + shift + 1); };
+    const std::true_type yes;
+    const std::false_type no;
+    auto k_slot = [&](int t) { return smem_lds + (uint32_t)(t % NS) * TILEB; };
+    auto v_slot = [&](int t) { return smem_lds + (uint32_t)(NS + t % NS) * TILEB; };
+
+    // one tile: s_c holds the raw scores of tile t (row max already folded into m_run), s_n receives tile t+1
+    auto iteration = [&](int t, f32x16_v (&s_c)[RB][2], f32x16_v (&s_n)[RB][2]) {
+        // K(t+1), V(t) must have landed; the NS - 2 younger groups may stay in flight (all of them are
+        // complete groups as long as K(t+NS-1) exists)
+        if (NS > 2 && t + NS - 1 < n_tiles) dma_wait_keep<(NS - 2) * 2 * NDMA>();
+        else dma_wait_all();
+        __syncthreads();
+        PF_T(0);
+        if (t + NS - 1 < n_tiles) ld.issue2(t + NS < n_tiles ? t + NS : -1, k_slot(t + NS), t + NS - 1, v_slot(t + NS - 1));
+        PF_T(1);
+        const int kv0 = t * PF_BN;
+        const bool cur = kv0 < n_end_w, nxt = t + 1 < n_tiles && kv0 + PF_BN < n_end_w;   // wave-uniform; nxt implies cur
+        float mx[RB];
+        if (nxt) {
+            phase_b(yes, yes, k_slot(t + 1), s_c, s_n);
+            PF_T(2);
+            if (need_mask(kv0 + PF_BN)) mask_tile(s_n, kv0 + PF_BN);
+            phase_c(yes, v_slot(t), s_n, mx);
+            PF_T(3);
+            raise_max(mx);
+            PF_T(4);
+        } else if (cur) {
+            phase_b(no, yes, 0, s_c, s_n);
+            phase_c(no, v_slot(t), s_n, mx);
+        }
+    };
+
+    if (n_tiles > 0) {
+        // prefetch groups {K0}, {K1, V0}, .. ; K(0) must have landed, everything issued after it may stay in flight
+        ld.issue2(0, k_slot(0), -1, 0);
+        int younger = 0;   // pieces issued after K(0)
+#pragma unroll
+        for (int g = 1; g < NS; ++g) {
+            if (g - 1 < n_tiles) {
+                ld.issue2(g < n_tiles ? g : -1, k_slot(g), g - 1, v_slot(g - 1));
+                younger += (g < n_tiles ? 2 : 1) * NDMA;
+            }
+        }
+        if (younger == (2 * NS - 2) * NDMA) dma_wait_keep<(2 * NS - 2) * NDMA>();
+        else if (younger == NDMA) dma_wait_keep<NDMA>();
+        else if (NS == 3 && younger == 3 * NDMA) dma_wait_keep<3 * NDMA>();
+        else dma_wait_all();
+        __syncthreads();
+        if (0 < n_end_w) {
+            float mx[RB];
+            phase_b(yes, no, k_slot(0), s_b, s_a);
+            if (need_mask(0)) mask_tile(s_a, 0);
+            tile_max(s_a, mx);
+            raise_max(mx);
+        }
+    }
+    for (int t = 0; t < n_tiles; t += 2) {
+        iteration(t, s_a, s_b);
+        if (t + 1 < n_tiles) iteration(t + 1, s_b, s_a);
+    }
+
+#ifdef PF_TIMING
+    if (p.lse && tid == PF_TIMING_TID) {
+        tacc[5] = (float)n_tiles;
+        tacc[6] = (float)(__builtin_readcyclecounter() - tstart);
+        for (int i2 = 0; i2 < 8; ++i2) p.lse[(int64_t)blockIdx.x * 8 + i2] = tacc[i2];
+    }
+    if (p.lse) return;
+#endif
+    // ---- epilogue ----
+    Acc::fence();
+    static_for<0, RB>([&](auto RBc) {
+        constexpr int rb = decltype(RBc)::value;
+        const int my_q = my_q0 + 32 * rb;
+        const float l_tot = l_part[rb] + __shfl_xor(l_part[rb], 32, 64);
+        const bool empty = !(l_tot > 0.f);
+        const float inv = empty ? 0.f : 1.f / l_tot;
+        uint16_t *op = p.o + si.q_offset(p.o_batch_stride, p.o_row_stride, b) + (int64_t)my_q * p.o_row_stride +
+                       (int64_t)hq * p.o_head_stride;
+        static_for<0, NDB * 4>([&](auto Ic) {
+            constexpr int db = decltype(Ic)::value >> 2, r4 = decltype(Ic)::value & 3;
+            float x0, x1, x2, x3;
+            Acc::template read4<(rb * NDB + db) * 16 + 4 * r4>(x0, x1, x2, x3);
+            uint2 w;
+            w.x = pack2<T>(x0 * inv, x1 * inv);
+            w.y = pack2<T>(x2 * inv, x3 * inv);
+            if (my_q < si.len_q) *reinterpret_cast<uint2 *>(op + db * 32 + 8 * r4 + 4 * hi) = w;
+        });
+        if (p.lse && hi == 0 && my_q < si.len_q) {
+            const float lse = empty ? INFINITY : (m_run[rb] + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+            if (p.unpadded_lse && p.cu_seqlens_q) p.lse[(int64_t)hq * p.cu_seqlens_q[p.b] + si.sum_q + my_q] = lse;
+            else p.lse[((int64_t)b * p.h + hq) * p.seqlen_q + my_q] = lse;
+        }
+    });
+}
+
 bool prefill_mfma_supported(const AttnParams &p) {
     return (p.d == 64 || p.d == 128) && p.alibi_slopes == nullptr && p.seqlen_q > 1;
 }
@@ -496,17 +988,38 @@ static void launch_pf_cfg(const AttnParams &p, hipStream_t stream) {
     ATOMA_CHECK_LAUNCH("prefill_mfma_kernel");
 }
 
-// atoma_set_option("prefill_cfg", bits): bit 0 = 8 waves x 3 buffers (else 4 waves x 2 buffers, two
-// workgroups per CU), bit 1 = s_setprio around the MFMA clusters.
+template <typename T, int D, bool CAUSAL, int RB>
+static void launch_pf_pipe(const AttnParams &p, hipStream_t stream) {
+    constexpr int smem = (RB == 2 ? 6 : 4) * PF_BN * D * 2;   // K and V rings of 3 (RB = 2) or 2 tiles
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_pipe_kernel<T, D, CAUSAL, RB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    const int64_t m_blocks = cdiv(p.seqlen_q, 128 * RB), n_units = (int64_t)p.b * p.h;
+    const int64_t nu_max = n_units / 8 + (n_units % 8 ? 1 : 0);
+    dim3 grid((unsigned)(8 * nu_max * m_blocks));
+    hipLaunchKernelGGL((prefill_pipe_kernel<T, D, CAUSAL, RB>), grid, dim3(256), smem, stream, p);
+    ATOMA_CHECK_LAUNCH("prefill_pipe_kernel");
+}
+
+// atoma_set_option("prefill_cfg", n): 0 = tile-sequential loop (4 waves x 32 rows, two workgroups per CU), the
+// default; 2 = software-pipelined loop, 4 waves x 64 rows, one wave per SIMD (experimental: correct, but its
+// un-overlapped barrier / LDS-DMA issue time makes it slower than 0 -- DESIGN.md).  RB = 1 of the pipelined
+// kernel is not instantiated: hipcc splits a 256-register budget 128 / 128 between the two register files
+// and the arch half spills.  The environment variable ATOMA_PREFILL_CFG overrides the option.
 int prefill_cfg = PREFILL_DEFAULT_CFG;
+static int prefill_cfg_effective() {
+    static const int env = [] { const char *e = getenv("ATOMA_PREFILL_CFG"); return e ? atoi(e) : -1; }();
+    return env >= 0 ? env : prefill_cfg;   // the environment wins (lets the test suite run against a variant)
+}
 
 template <typename T, int D, bool CAUSAL>
 static void launch_pf(const AttnParams &p, hipStream_t stream) {
-    switch (prefill_cfg & 3) {
-        case 0: launch_pf_cfg<T, D, CAUSAL, 4, 2, false>(p, stream); break;
-        case 1: launch_pf_cfg<T, D, CAUSAL, 8, 3, false>(p, stream); break;
-        case 2: launch_pf_cfg<T, D, CAUSAL, 4, 2, true>(p, stream); break;
-        default: launch_pf_cfg<T, D, CAUSAL, 8, 3, true>(p, stream); break;
+    switch (prefill_cfg_effective()) {
+        case 2: launch_pf_pipe<T, D, CAUSAL, 2>(p, stream); break;
+        default: launch_pf_cfg<T, D, CAUSAL, 4, 2, false>(p, stream); break;
     }
 }
 

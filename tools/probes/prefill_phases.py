@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "atoma-infer_amd", "bindings"))
 import atoma_hip as ah
-lib = C.CDLL(os.path.join(ROOT, "tools", "probes", "libatoma_hip_timing.so"))
+lib = C.CDLL(os.path.join(ROOT, "tools", "probes", os.environ.get("PF_TIMING_LIB", "libatoma_hip_timing.so")))
 lib.run_mha.argtypes = ah._RUN_MHA_ARGS
 lib.atoma_set_option.argtypes = [C.c_char_p, C.c_int]
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -33,6 +33,6 @@ for S, nseq in ((2048, 4), (2048, 16)):
     t = dbg.numpy()
     t = t[t[:, 5] > 0]
     per_tile = t[:, :5].sum(0) / t[:, 5].sum()
-    names = ["wait+barrier", "dma issue", "qk", "softmax", "pv"]
+    names = ["wait+barrier", "dma issue", "qk", "softmax", "pv"] if cfg != 2 else ["wait+barrier", "dma issue", "phase B", "phase C", "raise max"]
     print(f"S={S} x{nseq} cfg={cfg}: workgroups {len(t)}, tiles/wg {t[:,5].mean():.1f}, cycles per tile:",
-          {n: int(x) for n, x in zip(names, per_tile)}, "sum", int(per_tile.sum()), "total/tiles", int(t[:, 6].sum() / t[:, 5].sum()))
+          {n: int(x) for n, x in zip(names, per_tile)}, "sum", int(per_tile.sum()), "total/tiles", int(t[:, 6].sum() / t[:, 5].sum()), "vmcnt wait", int(t[:, 7].sum() / t[:, 5].sum()))
