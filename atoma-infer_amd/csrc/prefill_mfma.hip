@@ -213,7 +213,7 @@ template <int D, int W> struct PfLoader {
 };
 
 // W waves per workgroup (32 query rows each), NB LDS tile buffers (prefetch distance NB - 1).
-template <typename T, int D, bool CAUSAL, int W, int NB, bool PRIO>
+template <typename T, int D, bool CAUSAL, int W, int NB>
 __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParams p) {
     constexpr int PF_BM = 32 * W;
     constexpr int NDMA2 = 2 * PfLoader<D, W>::NDMA;   // DMA instructions per wave per tile (K and V)
@@ -326,6 +326,9 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
 
     // ---- S^T[key][query] = K.Q^T of one tile, the two 32-key halves ----
+    // LDS fragments are fetched one k-step ahead of the MFMAs that use them and the order is pinned with
+    // sched_barrier(0): left alone, hipcc issues each ds_read right in front of its MFMA and the LDS
+    // latency shows once per MFMA pair.
     auto qk_tile = [&](uint32_t kt, f32x16_v (&s)[2]) {
         // Per-tile read bases = buffer address + the lane's constant offset.  They are made opaque
         // so that the remaining constants (32-key half, 16-key step, +8 rows) fold into the ds_read
@@ -334,23 +337,36 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
         uint32_t kb_[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { kb_[j] = kt + koff[j]; asm volatile("" : "+v"(kb_[j])); }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);   // MFMA clusters outrank the partner wave's softmax VALU
+        auto read_k = [&](uint32_t addr) {
+            const u32x4_v av = *(const __attribute__((address_space(3))) u32x4_v *)(uintptr_t)addr;
+            uint4 a;
+            a.x = av[0]; a.y = av[1]; a.z = av[2]; a.w = av[3];
+            return a;
+        };
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[blk][r] = 0.f;
+        constexpr int KLA = 2;          // k-steps of lookahead (an LDS read takes 100+ cycles under load, a k-step 64)
+        uint4 kf[KLA + 1][2];           // [k-step % (KLA + 1)][32-key half]
+#pragma unroll
+        for (int j = 0; j < KLA && j < NJ; ++j) {
+            kf[j][0] = read_k(kb_[j]);
+            kf[j][1] = read_k(kb_[j] + 32 * ROWB);
+        }
         // the two 32-key halves are independent accumulators: alternate them so that no MFMA
         // waits for the previous one's result
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const u32x4_v av = *(const __attribute__((address_space(3))) u32x4_v *)(uintptr_t)(kb_[j] + blk * 32 * ROWB);
-                uint4 a;
-                a.x = av[0]; a.y = av[1]; a.z = av[2]; a.w = av[3];
-                s[blk] = mfma32<T>(a, qf[j], s[blk]);
+        for (int j = 0; j < NJ; ++j) {
+            if (j + KLA < NJ) {
+                kf[(j + KLA) % (KLA + 1)][0] = read_k(kb_[j + KLA]);
+                kf[(j + KLA) % (KLA + 1)][1] = read_k(kb_[j + KLA] + 32 * ROWB);
             }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) s[blk] = mfma32<T>(kf[j % (KLA + 1)][blk], qf[j], s[blk]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     // ---- mask (diagonal / tail tiles only), online softmax in the exp2 domain; rescales O ----
@@ -419,26 +435,29 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
         uint32_t vb_[NDB];
 #pragma unroll
         for (int db = 0; db < NDB; ++db) { vb_[db] = vt + voff[db]; asm volatile("" : "+v"(vb_[db])); }
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-        // (32-key half, 16-key step) outer, the NDB independent accumulators inner
+        auto read_vt = [&](uint32_t addr) {   // two transposed 8-byte reads = one A operand
+            const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4_v *)(uintptr_t)addr));
+            const uint2 hi2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) short4_v *)(uintptr_t)(addr + 8 * ROWB)));
+            uint4 a;
+            a.x = lo.x; a.y = lo.y; a.z = hi2.x; a.w = hi2.y;
+            return a;
+        };
+        // (32-key half, 16-key step) outer, the NDB independent accumulators inner; operands one step ahead
+        constexpr int NA = 4 * NDB, VLA = 4;   // operands per tile; operands (= MFMAs, 32 cycles each) of lookahead
+        auto vaddr = [&](int n) { const int q = n / NDB; return vb_[n % NDB] + ((q >> 1) * 32 + (q & 1) * 16) * ROWB; };
+        uint4 vf[VLA + 1];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int n = 0; n < VLA && n < NA; ++n) vf[n] = read_vt(vaddr(n));
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int db = 0; db < NDB; ++db) {
-                    uint4 a;
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const uint32_t addr = vb_[db] + (blk * 32 + kk * 16 + 8 * half) * ROWB;
-                        const short4_v r4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) short4_v *)(uintptr_t)addr);
-                        const uint2 r2 = __builtin_bit_cast(uint2, r4);
-                        if (half == 0) { a.x = r2.x; a.y = r2.y; } else { a.z = r2.x; a.w = r2.y; }
-                    }
-                    oacc[db] = mfma32<T>(a, pp[blk][kk], oacc[db]);
-                }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        for (int n = 0; n < NA; ++n) {
+            const int q = n / NDB, db = n % NDB, blk = q >> 1, kk = q & 1;
+            if (n + VLA < NA) vf[(n + VLA) % (VLA + 1)] = read_vt(vaddr(n + VLA));
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[db] = mfma32<T>(vf[n % (VLA + 1)], pp[blk][kk], oacc[db]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     // LDS ring of NB tiles, prefetch distance NB - 1, ONE barrier per tile:
@@ -656,20 +675,24 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
     const int m0 = mblk * PF_BM;
     if (m0 >= si.len_q) return;
     const int shift = si.len_k - si.len_q;
-    const int mw0 = m0 + wave * 32 * RB;             // first query row of this wave
-    const int my_q0 = mw0 + lq;                      // this lane's query row in row block 0 (+32 per block)
+    // Row block rb of wave w = rows m0 + rb.RSTEP + 32w ..+31: the waves' blocks are interleaved (not 64
+    // consecutive rows per wave), so that under a causal mask all four waves need (almost) the same
+    // number of K/V tiles and nobody idles at the per-tile barrier.
+    constexpr int RSTEP = PF_BM / RB;
+    const int mw0 = m0 + wave * 32;                  // first query row of this wave's block 0
+    const int my_q0 = mw0 + lq;                      // this lane's query row in row block 0 (+RSTEP per block)
 
     int n_end = si.len_k, n_end_w = si.len_k;
     if (CAUSAL) {
         n_end = min(n_end, m0 + PF_BM + shift);
-        n_end_w = min(n_end_w, mw0 + 32 * RB + shift);
+        n_end_w = min(n_end_w, mw0 + (RB - 1) * RSTEP + 32 + shift);   // the wave's last block decides
     }
     const int n_tiles = n_end > 0 ? (n_end + PF_BN - 1) / PF_BN : 0;
 
     // ---- Q^T fragments -> accumulator file; O^T = 0 ----
     static_for<0, RB>([&](auto RBc) {
         constexpr int rb = decltype(RBc)::value;
-        const int qrow = min(my_q0 + 32 * rb, si.len_q - 1);
+        const int qrow = min(my_q0 + RSTEP * rb, si.len_q - 1);
         const uint16_t *qp = p.q + si.q_offset(p.q_batch_stride, p.q_row_stride, b) + (int64_t)qrow * p.q_row_stride +
                              (int64_t)hq * p.q_head_stride + hi * 8;
         u32x4_v qv[NJ];
@@ -801,7 +824,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const bool ok = key < si.len_k && (!CAUSAL || key <= my_q0 + 32 * rb + shift);
+                    const bool ok = key < si.len_k && (!CAUSAL || key <= my_q0 + RSTEP * rb + shift);
                     s[rb][blk][r] = ok ? s[rb][blk][r] : -INFINITY;
                 }
     };
@@ -835,22 +858,24 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
         uint32_t vb_[NDB];
 #pragma unroll
         for (int db = 0; db < NDB; ++db) { vb_[db] = vt + voff[db]; asm volatile("" : "+v"(vb_[db])); }
-        u32x4_v vf[2];
-        vf[0] = read_vt(vb_[0]);
+        constexpr int VLA = 4 / RB;      // operands of lookahead = 4 MFMAs = 128 cycles (an LDS read takes 100+ under load)
+        auto vaddr = [&](int n) { const int q = n / NDB; return vb_[n % NDB] + ((q >> 1) * 32 + (q & 1) * 16) * ROWB; };
+        u32x4_v vf[VLA + 1];
+#pragma unroll
+        for (int n = 0; n < VLA; ++n) vf[n] = read_vt(vaddr(n));
         if (MX) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) mx[rb] = s_new[rb][0][0];
         }
         static_for<0, NA>([&](auto Nc) {
             constexpr int n = decltype(Nc)::value, q = n / NDB, db = n % NDB, blk = q >> 1, kk = q & 1;
-            if constexpr (n + 1 < NA) {
-                constexpr int q1 = (n + 1) / NDB, db1 = (n + 1) % NDB;
-                vf[(n + 1) & 1] = read_vt(vb_[db1] + ((q1 >> 1) * 32 + (q1 & 1) * 16) * ROWB);
+            if constexpr (n + VLA < NA) {
+                vf[(n + VLA) % (VLA + 1)] = read_vt(vaddr(n + VLA));
                 __builtin_amdgcn_sched_barrier(0);
             }
             static_for<0, RB>([&](auto Rc) {
                 constexpr int rb = decltype(Rc)::value;
-                Acc::template pv<(rb * NDB + db) * 16>(vf[n & 1], pp[rb][blk][kk]);
+                Acc::template pv<(rb * NDB + db) * 16>(vf[n % (VLA + 1)], pp[rb][blk][kk]);
                 if constexpr (MX) {
                     constexpr int e0 = (n * RB + rb) * EPM;   // 0 .. 32.RB: elements of the flattened [rb][blk][r]
 #pragma unroll
@@ -945,7 +970,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
     Acc::fence();
     static_for<0, RB>([&](auto RBc) {
         constexpr int rb = decltype(RBc)::value;
-        const int my_q = my_q0 + 32 * rb;
+        const int my_q = my_q0 + RSTEP * rb;
         const float l_tot = l_part[rb] + __shfl_xor(l_part[rb], 32, 64);
         const bool empty = !(l_tot > 0.f);
         const float inv = empty ? 0.f : 1.f / l_tot;
@@ -972,19 +997,24 @@ bool prefill_mfma_supported(const AttnParams &p) {
     return (p.d == 64 || p.d == 128) && p.alibi_slopes == nullptr && p.seqlen_q > 1;
 }
 
-template <typename T, int D, bool CAUSAL, int W, int NB, bool PRIO>
+template <typename T, int D, bool CAUSAL, int W, int NB>
 static void launch_pf_cfg(const AttnParams &p, hipStream_t stream) {
+#ifdef PF_TIMING   // ATOMA_PF_ONE_WG=1: pad the LDS request so that only one workgroup fits a CU (occupancy experiment)
+    static const int pad = getenv("ATOMA_PF_ONE_WG") ? 96 * 1024 - NB * 2 * PF_BN * D * 2 : 0;
+    const int smem = NB * 2 * PF_BN * D * 2 + pad;
+#else
     constexpr int smem = NB * 2 * PF_BN * D * 2;
+#endif
     static bool attr_set = false;  // up to 96 KiB: above the default dynamic-LDS limit
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL, W, NB, PRIO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL, W, NB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     const int64_t m_blocks = cdiv(p.seqlen_q, 32 * W), n_units = (int64_t)p.b * p.h;
     const int64_t nu_max = n_units / 8 + (n_units % 8 ? 1 : 0);
     dim3 grid((unsigned)(8 * nu_max * m_blocks));   // padded: see the mapping comment in the kernel
-    hipLaunchKernelGGL((prefill_mfma_kernel<T, D, CAUSAL, W, NB, PRIO>), grid, dim3(64 * W), smem, stream, p);
+    hipLaunchKernelGGL((prefill_mfma_kernel<T, D, CAUSAL, W, NB>), grid, dim3(64 * W), smem, stream, p);
     ATOMA_CHECK_LAUNCH("prefill_mfma_kernel");
 }
 
@@ -1019,7 +1049,7 @@ template <typename T, int D, bool CAUSAL>
 static void launch_pf(const AttnParams &p, hipStream_t stream) {
     switch (prefill_cfg_effective()) {
         case 2: launch_pf_pipe<T, D, CAUSAL, 2>(p, stream); break;
-        default: launch_pf_cfg<T, D, CAUSAL, 4, 2, false>(p, stream); break;
+        default: launch_pf_cfg<T, D, CAUSAL, 4, 2>(p, stream); break;
     }
 }
 
