@@ -133,7 +133,7 @@ static void launch_rms_norm(const void *x, const void *w, void *y, int64_t rows,
 // ------------------------------------------------------------------------------------------
 template <typename T, bool PER_OP>
 __device__ __forceinline__ void rope_chunk(const uint16_t *x, uint16_t *y, const uint16_t *cosr, const uint16_t *sinr,
-                                           int half, int c) {
+                                           int half, int c, uint16_t *y_copy = nullptr) {
     // No contraction here: for f16 the compiler narrows the f32 expressions below to half
     // arithmetic (legitimately -- f32 carries 2p+2 bits) and would then fuse mul+sub into one
     // v_fma_f16, i.e. drop exactly the intermediate rounding PER_OP exists to reproduce.
@@ -153,8 +153,13 @@ __device__ __forceinline__ void rope_chunk(const uint16_t *x, uint16_t *y, const
             y2[e] = x1[e] * sn[e] + x2[e] * cs[e];
         }
     }
-    *reinterpret_cast<uint4 *>(y + c * 8) = pack8<T>(y1);
-    *reinterpret_cast<uint4 *>(y + half + c * 8) = pack8<T>(y2);
+    const uint4 lo = pack8<T>(y1), hi = pack8<T>(y2);
+    *reinterpret_cast<uint4 *>(y + c * 8) = lo;
+    *reinterpret_cast<uint4 *>(y + half + c * 8) = hi;
+    if (y_copy) {   // second destination of the same rotated chunk (the KV cache page)
+        *reinterpret_cast<uint4 *>(y_copy + c * 8) = lo;
+        *reinterpret_cast<uint4 *>(y_copy + half + c * 8) = hi;
+    }
 }
 
 // Two tensors (q and k) in one launch; nb heads == 0 disables the second.
@@ -208,6 +213,45 @@ static int launch_rope(const void *xa, void *ya, int64_t ha, int64_t xa_ts, int6
     return ATOMA_CHECK_LAUNCH("rope") ? 0 : -1;
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused RoPE(q, k) + reshape_and_cache_flash(k, v): one pass over a step's q / k / v instead of two
+// launches.  q and k are rotated in place (the prefill attention reads them as
+// tensors, llama.rs:273-303), the rotated k and v also go to their cache slot; slot < 0 = padding token
+// (cache_kernels.cu:306-310).  Block = one token; a thread handles one 16-byte chunk pair (RoPE) or one
+// 16-byte chunk (v copy).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool PER_OP>
+__global__ void __launch_bounds__(256)
+rope_cache_kernel(uint16_t *__restrict__ q, uint16_t *__restrict__ k, const uint16_t *__restrict__ v,
+                  uint16_t *__restrict__ k_cache, uint16_t *__restrict__ v_cache, const int64_t *__restrict__ slot_mapping,
+                  const uint16_t *__restrict__ cos_t, const uint16_t *__restrict__ sin_t,
+                  const int64_t *__restrict__ positions, int heads_q, int heads_kv, int head_dim, int64_t q_ts, int64_t k_ts,
+                  int64_t v_ts, int64_t block_stride, int page_size) {
+    const int64_t t = blockIdx.x;
+    const int half = head_dim >> 1, cpr = half >> 3, vpr = head_dim >> 3;
+    const int64_t pos = positions[t], slot = slot_mapping[t];
+    const uint16_t *cosr = cos_t + pos * half, *sinr = sin_t + pos * half;
+    const int64_t row = slot >= 0 ? (slot / page_size) * block_stride + (slot % page_size) * (int64_t)heads_kv * head_dim : 0;
+    const int n_rope = (heads_q + heads_kv) * cpr, total = n_rope + (slot >= 0 ? heads_kv * vpr : 0);
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        if (i < n_rope) {
+            const int head = i / cpr, c = i - head * cpr;
+            if (head < heads_q) {
+                uint16_t *x = q + t * q_ts + (int64_t)head * head_dim;
+                rope_chunk<T, PER_OP>(x, x, cosr, sinr, half, c);
+            } else {
+                const int hk = head - heads_q;
+                uint16_t *x = k + t * k_ts + (int64_t)hk * head_dim;
+                rope_chunk<T, PER_OP>(x, x, cosr, sinr, half, c, slot >= 0 ? k_cache + row + (int64_t)hk * head_dim : nullptr);
+            }
+        } else {
+            const int j = i - n_rope, hk = j / vpr, c = j - hk * vpr;
+            *reinterpret_cast<uint4 *>(v_cache + row + (int64_t)hk * head_dim + c * 8) =
+                *reinterpret_cast<const uint4 *>(v + t * v_ts + (int64_t)hk * head_dim + c * 8);
+        }
+    }
+}
+
 // host-side f32 -> storage rounding for the table builder
 static uint16_t host_f32_to_bf16(float f) {
     uint32_t u;
@@ -254,6 +298,39 @@ int atoma_rope_qk(void *q, void *k, const void *cos_table, const void *sin_table
     return atoma::launch_rope(q, q, num_q_heads, q_token_stride, head_dim, q_token_stride, head_dim, k, k, num_kv_heads,
                               k_token_stride, head_dim, k_token_stride, head_dim, cos_table, sin_table, positions,
                               num_tokens, head_dim, dtype, per_op_rounding, static_cast<hipStream_t>(stream));
+}
+
+int atoma_rope_qk_cache(void *q, void *k, const void *v, void *k_cache, void *v_cache, const int64_t *slot_mapping,
+                        const void *cos_table, const void *sin_table, const int64_t *positions, int64_t num_tokens,
+                        int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t q_token_stride,
+                        int64_t k_token_stride, int64_t v_token_stride, int64_t block_stride, int64_t page_size, int dtype,
+                        int per_op_rounding, void *stream) {
+    using namespace atoma;
+    clear_error();
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("rope_qk_cache: dtype must be f16 or bf16"); return -1; }
+    if (head_dim % 16 != 0) { set_error("rope_qk_cache: head_dim must be a multiple of 16"); return -1; }
+    if (page_size <= 0) { set_error("rope_qk_cache: page_size must be positive"); return -1; }
+    for (int64_t st : {q_token_stride, k_token_stride, v_token_stride, block_stride})
+        if (st % 8 != 0) { set_error("rope_qk_cache: strides must be multiples of 8 elements"); return -1; }
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+                           reinterpret_cast<uintptr_t>(k_cache) | reinterpret_cast<uintptr_t>(v_cache) |
+                           reinterpret_cast<uintptr_t>(cos_table) | reinterpret_cast<uintptr_t>(sin_table);
+    if (ptrs & 15u) { set_error("rope_qk_cache: tensors must be 16-byte aligned"); return -1; }
+    if (num_tokens <= 0 || num_q_heads + num_kv_heads <= 0) return 0;
+    const int64_t work = (num_q_heads + num_kv_heads) * (head_dim / 16) + num_kv_heads * (head_dim / 8);
+    int threads = (int)(cdiv(work, 64) * 64);
+    threads = threads > 256 ? 256 : threads;
+#define ATOMA_RC_LAUNCH(TT, PO)                                                                                          \
+    hipLaunchKernelGGL((rope_cache_kernel<TT, PO>), dim3((unsigned)num_tokens), dim3(threads), 0,                       \
+                       static_cast<hipStream_t>(stream), static_cast<uint16_t *>(q), static_cast<uint16_t *>(k),         \
+                       static_cast<const uint16_t *>(v), static_cast<uint16_t *>(k_cache), static_cast<uint16_t *>(v_cache), \
+                       slot_mapping, static_cast<const uint16_t *>(cos_table), static_cast<const uint16_t *>(sin_table), \
+                       positions, (int)num_q_heads, (int)num_kv_heads, (int)head_dim, q_token_stride, k_token_stride,    \
+                       v_token_stride, block_stride, (int)page_size)
+    if (dtype == ATOMA_BF16) { if (per_op_rounding) ATOMA_RC_LAUNCH(bf16_t, true); else ATOMA_RC_LAUNCH(bf16_t, false); }
+    else { if (per_op_rounding) ATOMA_RC_LAUNCH(f16_t, true); else ATOMA_RC_LAUNCH(f16_t, false); }
+#undef ATOMA_RC_LAUNCH
+    return ATOMA_CHECK_LAUNCH("rope_qk_cache") ? 0 : -1;
 }
 
 // models/src/llama.rs:146-200 (Cache::new): f32 arithmetic throughout, table rounded to the model dtype.

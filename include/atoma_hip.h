@@ -151,6 +151,16 @@ int atoma_rope_qk(void *q, void *k, const void *cos_table, const void *sin_table
                   const int64_t *positions, int64_t num_tokens, int64_t num_q_heads,
                   int64_t num_kv_heads, int64_t head_dim, int64_t q_token_stride,
                   int64_t k_token_stride, int dtype, int per_op_rounding, void *stream);
+/* Fused RoPE(q, k) + KV-cache write: q and k rotated in place (as atoma_rope_qk), the rotated k and v also
+ * stored at slot_mapping[t] of the paged caches (as reshape_and_cache_flash; slot < 0 = padding token, no cache
+ * write).  One launch and one pass over k instead of models/src/llama.rs:273-303 (rope) followed by
+ * csrc/src/cache_manager.rs:404-535 (reshape_and_cache_flash).  Strides in elements, multiples of 8. */
+int atoma_rope_qk_cache(void *q, void *k, const void *v, void *k_cache, void *v_cache, const int64_t *slot_mapping,
+                        const void *cos_table, const void *sin_table, const int64_t *positions, int64_t num_tokens,
+                        int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t q_token_stride,
+                        int64_t k_token_stride, int64_t v_token_stride, int64_t block_stride, int64_t page_size, int dtype,
+                        int per_op_rounding, void *stream);
+
 /* cos/sin table of `Cache::new` (models/src/llama.rs:154-200) built on the HOST into
  * cos_out/sin_out [max_pos, head_dim/2] (storage dtype).  rope_factor <= 0: no Llama-3 scaling. */
 int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head_dim,

@@ -129,11 +129,13 @@ def run_trace(ops, weights, dims, check=None, cmp=None, dense_check=False, steps
             q = np.ascontiguousarray(qkv[:, :D.h * D.d]).reshape(T, D.h, D.d)
             k = np.ascontiguousarray(qkv[:, D.h * D.d:(D.h + D.hk) * D.d]).reshape(T, D.hk, D.d)
             v = np.ascontiguousarray(qkv[:, (D.h + D.hk) * D.d:]).reshape(T, D.hk, D.d)
-            qr, kr = ops.rope_qk(q, k, W.cos, W.sin, pos)
+            fused = hasattr(ops, "rope_qk_cache")        # one launch for RoPE(q, k) + the cache write
+            qr, kr = ops.rope_qk_cache(l, q, k, v, W.cos, W.sin, pos, slots) if fused else ops.rope_qk(q, k, W.cos, W.sin, pos)
             if check:
                 cq, ck = check.rope_qk(q, k, W.cos, W.sin, pos)
                 cmp.rope_exact &= bool(np.array_equal(qr, cq) and np.array_equal(kr, ck))
-            ops.reshape_and_cache(l, kr, v, slots)
+            if not fused:
+                ops.reshape_and_cache(l, kr, v, slots)
             if check:
                 check.reshape_and_cache(l, kr, v, slots)
                 gk, gv = ops.caches(l)

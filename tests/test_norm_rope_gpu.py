@@ -94,3 +94,49 @@ def test_rope_qk_in_place_one_launch(gpu):
     gpu.synchronize()
     assert np.array_equal(dq.numpy(np.uint16, q.shape), NR.rope(q, cos, sin, pos, BF16))
     assert np.array_equal(dk.numpy(np.uint16, k.shape), NR.rope(k, cos, sin, pos, BF16))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("T,h,hk,d,page", [(256, 32, 8, 128, 16), (37, 8, 2, 64, 16), (5, 4, 4, 32, 8), (1, 32, 8, 128, 16)])
+def test_fused_rope_qk_cache_bit_exact(gpu, dtype, T, h, hk, d, page):
+    """atoma_rope_qk_cache == rope(q), rope(k) (Candle per-op rounding) followed by reshape_and_cache_flash(rope(k), v),
+    bit for bit; q and k slices of a fused qkv projection (token stride (h+2hk)*d); padding tokens (slot -1) leave the
+    caches untouched."""
+    from oracle import cache_oracle as CO
+    rng = np.random.default_rng(T + h + d)
+    nb = (T + page - 1) // page + 2
+    qkv = rand_half(rng, (T, (h + 2 * hk) * d), dtype)
+    q = np.ascontiguousarray(qkv[:, :h * d]).reshape(T, h, d)
+    k = np.ascontiguousarray(qkv[:, h * d:(h + hk) * d]).reshape(T, hk, d)
+    v = np.ascontiguousarray(qkv[:, (h + hk) * d:]).reshape(T, hk, d)
+    kc, vc = rand_half(rng, (nb, page, hk, d), dtype), rand_half(rng, (nb, page, hk, d), dtype)
+    cos, sin = NR.rope_table(2048, d, 500000.0, dtype)
+    pos = rng.integers(0, 2048, T).astype(np.int64)
+    slots = rng.permutation(nb * page)[:T].astype(np.int64)
+    if T > 4:
+        slots[rng.integers(0, T, 2)] = -1
+    dqkv, dkc, dvc = (gpu.DeviceBuffer.from_numpy(a) for a in (qkv, kc, vc))
+    dc, ds = gpu.DeviceBuffer.from_numpy(cos), gpu.DeviceBuffer.from_numpy(sin)
+    dp, dsl = gpu.DeviceBuffer.from_numpy(pos), gpu.DeviceBuffer.from_numpy(slots)
+    row = (h + 2 * hk) * d
+    rc = gpu.lib.atoma_rope_qk_cache(dqkv.ptr, dqkv.ptr + h * d * 2, dqkv.ptr + (h + hk) * d * 2, dkc.ptr, dvc.ptr, dsl.ptr,
+                                     dc.ptr, ds.ptr, dp.ptr, T, h, hk, d, row, row, row, page * hk * d, page, dtype, 1, None)
+    assert rc == 0, gpu.last_error()
+    gpu.synchronize()
+    got = dqkv.numpy(np.uint16, qkv.shape)
+    qr, kr = NR.rope(q, cos, sin, pos, dtype), NR.rope(k, cos, sin, pos, dtype)
+    assert np.array_equal(got[:, :h * d].reshape(T, h, d), qr)
+    assert np.array_equal(got[:, h * d:(h + hk) * d].reshape(T, hk, d), kr)
+    assert np.array_equal(got[:, (h + hk) * d:].reshape(T, hk, d), v)          # v is only read
+    CO.reshape_and_cache_flash(kr, v, kc, vc, slots)
+    assert np.array_equal(dkc.numpy(np.uint16, kc.shape), kc) and np.array_equal(dvc.numpy(np.uint16, vc.shape), vc)
+
+
+def test_fused_rope_qk_cache_rejects_bad_arguments(gpu):
+    d = gpu.DeviceBuffer(4096)
+    args = lambda **kw: [d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, 1, 1, 1, kw.get("hd", 64), 64, 64, 64,
+                         kw.get("bs", 1024), kw.get("page", 16), kw.get("dtype", BF16), 1, None]
+    assert gpu.lib.atoma_rope_qk_cache(*args(hd=24)) == -1 and "head_dim" in gpu.last_error()
+    assert gpu.lib.atoma_rope_qk_cache(*args(page=0)) == -1 and "page_size" in gpu.last_error()
+    assert gpu.lib.atoma_rope_qk_cache(*args(dtype=7)) == -1 and "dtype" in gpu.last_error()
+    assert gpu.lib.atoma_rope_qk_cache(*args(bs=1021)) == -1 and "strides" in gpu.last_error()

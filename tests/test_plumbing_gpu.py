@@ -85,9 +85,26 @@ class GpuOps:
         return do.numpy(np.uint16, q.shape)
 
 
-def test_continuous_batching_trace_op_by_op(gpu):
+class GpuOpsFused(GpuOps):
+    """RoPE(q, k) and the KV-cache write in one launch (atoma_rope_qk_cache)."""
+
+    def rope_qk_cache(self, layer, q, k, v, cos, sin, pos, slots):
+        D = self.D
+        dq, dk, dv = (self.g.DeviceBuffer.from_numpy(a) for a in (q, k, v))
+        dc, ds = self.g.DeviceBuffer.from_numpy(cos), self.g.DeviceBuffer.from_numpy(sin)
+        dp = self.g.DeviceBuffer.from_numpy(np.asarray(pos, np.int64))
+        dsl = self.g.DeviceBuffer.from_numpy(np.asarray(slots, np.int64))
+        self._ok(self.g.lib.atoma_rope_qk_cache(dq.ptr, dk.ptr, dv.ptr, self.kc[layer].ptr, self.vc[layer].ptr, dsl.ptr,
+                                                dc.ptr, ds.ptr, dp.ptr, q.shape[0], D.h, D.hk, D.d, D.h * D.d, D.hk * D.d,
+                                                D.hk * D.d, D.page * D.hk * D.d, D.page, BF16, 1, None))
+        self.g.synchronize()
+        return dq.numpy(np.uint16, q.shape), dk.numpy(np.uint16, k.shape)
+
+
+@pytest.mark.parametrize("ops_cls", [GpuOps, GpuOpsFused], ids=["separate-ops", "fused-rope-cache"])
+def test_continuous_batching_trace_op_by_op(gpu, ops_cls):
     cmp = Compare()
-    hist = run_trace(GpuOps(gpu, Dims), Weights(Dims), Dims, check=OracleOps(Dims), cmp=cmp, steps=32)
+    hist = run_trace(ops_cls(gpu, Dims), Weights(Dims), Dims, check=OracleOps(Dims), cmp=cmp, steps=32)
     assert len(hist[0]) == 32 and len(hist[1]) == 10 and len(hist[3]) >= 19
     assert cmp.calls >= 2 * 33
     assert cmp.rope_exact, "RoPE (per-op rounding) must be bit-exact"

@@ -153,6 +153,19 @@ def bench_norm():
         pos = ah.DeviceBuffer.from_numpy(rng.integers(0, 8192, T).astype(np.int64))
         ms = timeit(lambda: ah.lib.atoma_rope_qk(q.ptr, k.ptr, cos.ptr, sin.ptr, pos.ptr, T, h, hk, d, h * d, hk * d, 1, 1, None))
         emit(f"N1 rope q+k T={T}", ms, nbytes=2 * T * (h + hk) * d * 2 + 2 * T * (d // 2) * 2)
+        # fused RoPE(q, k) + KV-cache write vs the two launches it replaces (rope_qk, reshape_and_cache_flash)
+        page, nb = 16, 4096
+        v = rand_dev(rng, T * hk * d * 2)
+        kc, vc = rand_dev(rng, nb * page * hk * d * 2), rand_dev(rng, nb * page * hk * d * 2)
+        slots = ah.DeviceBuffer.from_numpy(rng.permutation(nb * page)[:T].astype(np.int64))
+        ms_f = timeit(lambda: ah.lib.atoma_rope_qk_cache(q.ptr, k.ptr, v.ptr, kc.ptr, vc.ptr, slots.ptr, cos.ptr, sin.ptr, pos.ptr, T, h,
+                                                         hk, d, h * d, hk * d, hk * d, page * hk * d, page, 1, 1, None))
+        def two():
+            ah.lib.atoma_rope_qk(q.ptr, k.ptr, cos.ptr, sin.ptr, pos.ptr, T, h, hk, d, h * d, hk * d, 1, 1, None)
+            ah.lib.reshape_and_cache_flash(k.ptr, v.ptr, kc.ptr, vc.ptr, slots.ptr, page * hk * d, T, hk, d, page, hk * d, hk * d, 1, None)
+        ms_2 = timeit(two)
+        emit(f"N1+K4 fused rope q+k + cache write T={T}", ms_f, nbytes=2 * T * (h + hk) * d * 2 + 3 * T * hk * d * 2 + 2 * T * (d // 2) * 2 + 16 * T,
+             two_launches_ms=round(ms_2, 4))
 
 
 def bench_swap():
