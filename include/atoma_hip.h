@@ -167,6 +167,13 @@ int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head
                      float rope_theta, float rope_factor, float low_freq_factor,
                      float high_freq_factor, int64_t original_max_position_embeddings, int dtype);
 
+/* Greedy token selection on the device: out_idx[r] = argmax over logits[r, 0..vocab) (smallest index among the
+ * maxima, as numpy; NaNs are never selected), out_val[r] (optional) = that logit as f32.  Replaces the per-sequence
+ * `logits.i(idx)` -> LogitsProcessor::sample (ArgMax) -> `to_vec1()[next_token]` device->host copies of
+ * backends/vllm/src/model_executor.rs:206-249.  logits [rows, vocab] in dtype f16 / bf16 / f32, row_stride in elements. */
+int atoma_argmax_rows(const void *logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype, int32_t *out_idx,
+                      float *out_val, void *stream);
+
 /* Tensor-parallel sum all-reduce (models/src/multi_gpu.rs:141-179 `AllReduce::cuda_fwd`,
  * bootstrap backends/vllm/src/model_executor.rs:413,436-439 `Id::new` / `Comm::from_rank`).
  * One process (or thread) per GPU over RCCL/xGMI.  id128: 128-byte ncclUniqueId. */

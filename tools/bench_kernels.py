@@ -5,7 +5,7 @@ Prints one JSON line per workload: achieved GB/s (HBM-bound kernels) or TFLOP/s 
 algorithmic bytes / flops it is computed from, and the fraction of the chip peak.  Timing = HIP events
 on the NULL stream around `iters` back-to-back launches after warm-up.
 
-  python tools/bench_kernels.py [decode prefill cache norm swap]   (default: all)
+  python tools/bench_kernels.py [decode prefill cache norm sampling swap]   (default: all)
 """
 import ctypes as C
 import json
@@ -168,6 +168,16 @@ def bench_norm():
              two_launches_ms=round(ms_2, 4))
 
 
+def bench_sampling():
+    rng = np.random.default_rng(5)
+    vocab = 128256
+    for B, dt, elt, name in ((256, 2, 4, "f32"), (256, 1, 2, "bf16"), (1, 2, 4, "f32")):
+        logits = rand_dev(rng, B * vocab * elt)
+        idx, val = ah.DeviceBuffer(B * 4), ah.DeviceBuffer(B * 4)
+        ms = timeit(lambda: ah.lib.atoma_argmax_rows(logits.ptr, B, vocab, vocab, dt, idx.ptr, val.ptr, None))
+        emit(f"S1 argmax_rows B={B} vocab={vocab} {name}", ms, nbytes=B * vocab * elt + 8 * B)
+
+
 def bench_swap():
     rng = np.random.default_rng(4)
     L, page_bytes, nb = 32, 16 * 8 * 128 * 2, 2048
@@ -196,6 +206,6 @@ def bench_swap():
 
 if __name__ == "__main__":
     ah.set_device(0)
-    which = sys.argv[1:] or ["decode", "prefill", "cache", "norm", "swap"]
+    which = sys.argv[1:] or ["decode", "prefill", "cache", "norm", "sampling", "swap"]
     for w in which:
         globals()["bench_" + w]()
