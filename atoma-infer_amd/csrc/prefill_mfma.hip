@@ -133,21 +133,22 @@ template <int D, int W> struct PfLoader {
     const uint16_t *kbase, *vbase;
     const int *bt;
     int64_t k_page, k_row, v_page, v_row;
-    int page_size, page_shift, last_key, wave;
-    int row[NDMA];                    // tile row this lane fetches in DMA piece u
-    uint32_t kchunk[NDMA], vchunk[NDMA];   // element offset of the (de-swizzled) 16-byte chunk inside the row
-    uint32_t kfast[NDMA], vfast[NDMA];     // byte offset from the tile base, contiguous layout
+    int page_size, page_shift, last_key, wave, lane;
+    uint32_t kfast[NDMA], vfast[NDMA];     // byte offset from the tile base, contiguous layout (the common case: kept in registers)
 
-    __device__ __forceinline__ void init(int lane) {
+    // DMA piece u of this wave: the 16-byte unit of the LDS image this lane fills -> tile row and the element
+    // offset of the (de-swizzled) source chunk inside the row (XOR is its own inverse); recomputed where needed
+    // rather than held in registers across the tile loop
+    __device__ __forceinline__ int row_of(int u) const { return ((wave * NDMA + u) * 64 + lane) / CPR; }
+    __device__ __forceinline__ uint32_t kchunk_of(int u) const { return PfSwz<D>::k(row_of(u), ((wave * NDMA + u) * 64 + lane) % CPR) * 8; }
+    __device__ __forceinline__ uint32_t vchunk_of(int u) const { return PfSwz<D>::v(row_of(u), ((wave * NDMA + u) * 64 + lane) % CPR) * 8; }
+
+    __device__ __forceinline__ void init(int lane_) {
+        lane = lane_;
 #pragma unroll
         for (int u = 0; u < NDMA; ++u) {
-            const int L = (wave * NDMA + u) * 64 + lane;   // 16-byte unit in the LDS image
-            row[u] = L / CPR;
-            const int slot = L % CPR;
-            kchunk[u] = PfSwz<D>::k(row[u], slot) * 8;      // XOR is its own inverse
-            vchunk[u] = PfSwz<D>::v(row[u], slot) * 8;
-            kfast[u] = (uint32_t)(row[u] * k_row * 2) + kchunk[u] * 2;
-            vfast[u] = (uint32_t)(row[u] * v_row * 2) + vchunk[u] * 2;
+            kfast[u] = (uint32_t)(row_of(u) * k_row * 2) + kchunk_of(u) * 2;
+            vfast[u] = (uint32_t)(row_of(u) * v_row * 2) + vchunk_of(u) * 2;
         }
     }
 
@@ -173,8 +174,8 @@ template <int D, int W> struct PfLoader {
         // would otherwise drain the DMA issued just before it)
 #pragma unroll
         for (int u = 0; u < NDMA; ++u) {
-            const int kkey = min(max(kkey0, 0) + row[u], last_key);  // never read past the sequence
-            const int vkey = min(max(vkey0, 0) + row[u], last_key);
+            const int kkey = min(max(kkey0, 0) + row_of(u), last_key);  // never read past the sequence
+            const int vkey = min(max(vkey0, 0) + row_of(u), last_key);
             int64_t koff, voff;
             if (bt) {
                 const int kpi = page_shift >= 0 ? kkey >> page_shift : kkey / page_size;
@@ -186,8 +187,8 @@ template <int D, int W> struct PfLoader {
                 koff = (int64_t)kkey * k_row;
                 voff = (int64_t)vkey * v_row;
             }
-            ksrc[u] = kbase + koff + kchunk[u];
-            vsrc[u] = vbase + voff + vchunk[u];
+            ksrc[u] = kbase + koff + kchunk_of(u);
+            vsrc[u] = vbase + voff + vchunk_of(u);
         }
 #pragma unroll
         for (int u = 0; u < NDMA; ++u) {
@@ -646,7 +647,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
     constexpr int PF_QA = RB * NDB * 16;             // first accumulator register of Q^T
     constexpr int NACC = RB * 96;
     static_assert(PF_QA + RB * NJ * 4 <= NACC, "accumulator map exceeds the clobber list");
-    using Acc = PfAcc<T, NACC>;
+    PfAcc<T, NACC> acc;
     extern __shared__ __attribute__((aligned(1024))) char smem[];  // K tiles [NS] | V tiles [NS]
 
     const int tid = threadIdx.x, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
@@ -700,10 +701,10 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
         for (int j = 0; j < NJ; ++j) qv[j] = *reinterpret_cast<const u32x4_v *>(qp + j * 16);
         static_for<0, NJ>([&](auto Jc) {
             constexpr int j = decltype(Jc)::value;
-            Acc::template write4<PF_QA + (rb * NJ + j) * 4>(qv[j][0], qv[j][1], qv[j][2], qv[j][3]);
+            acc.template write4<PF_QA + (rb * NJ + j) * 4>(qv[j][0], qv[j][1], qv[j][2], qv[j][3]);
         });
     });
-    static_for<0, RB * NDB * 4>([&](auto Ic) { Acc::template write4<decltype(Ic)::value * 4>(0u, 0u, 0u, 0u); });
+    static_for<0, RB * NDB * 4>([&](auto Ic) { acc.template write4<decltype(Ic)::value * 4>(0u, 0u, 0u, 0u); });
 
     const bool paged = p.block_table != nullptr;
     PfLoader<D, W> ld;
@@ -758,7 +759,6 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
     };
     auto fence_s = [&](f32x16_v (&s)[RB][2]) {   // S (MFMA D in VGPRs) is read by VALU code next
         if constexpr (RB == 2) asm volatile("s_nop 11" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[RB - 1][0]), "+v"(s[RB - 1][1]));
-        else asm volatile("s_nop 11" : "+v"(s[0][0]), "+v"(s[0][1]));
     };
 
     // ---- phase B: [s_out = K.Q^T of the tile at kt]  ||  [P = exp2(s_in*scale - m), row sums, pack] ----
@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
                     kf[(j + 1) & 1][1] = read_k(kb_[j + 1] + 32 * ROWB);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                Acc::template qk<j == 0, PF_QA + (rb * NJ + j) * 4>(s_out[rb][blk], kf[j & 1][blk]);
+                acc.template qk<j == 0, PF_QA + (rb * NJ + j) * 4>(s_out[rb][blk], kf[j & 1][blk]);
             }
             if constexpr (SM) {
 #pragma unroll
@@ -839,14 +839,14 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
             need = need || (m > m_run[rb] + PF_DEFER);
         }
         if (__any(need)) {   // rare after the first tiles: rescale O and the row sums to the new reference
-            Acc::fence();
+            acc.fence();
             static_for<0, RB>([&](auto RBc) {
                 constexpr int rb = decltype(RBc)::value;
                 const float mt = fmaxf(m_run[rb], m_new[rb]);
                 const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - (mt == -INFINITY ? 0.f : mt));
                 m_run[rb] = mt;
                 l_part[rb] *= alpha;
-                static_for<0, NDB * 4>([&](auto Ic) { Acc::template scale4<rb * NDB * 16 + decltype(Ic)::value * 4>(alpha); });
+                static_for<0, NDB * 4>([&](auto Ic) { acc.template scale4<rb * NDB * 16 + decltype(Ic)::value * 4>(alpha); });
             });
         }
     };
@@ -858,7 +858,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
         uint32_t vb_[NDB];
 #pragma unroll
         for (int db = 0; db < NDB; ++db) { vb_[db] = vt + voff[db]; asm volatile("" : "+v"(vb_[db])); }
-        constexpr int VLA = 4 / RB;      // operands of lookahead = 4 MFMAs = 128 cycles (an LDS read takes 100+ under load)
+        constexpr int VLA = 2;           // operands of lookahead (an LDS read takes 100+ cycles under load)
         auto vaddr = [&](int n) { const int q = n / NDB; return vb_[n % NDB] + ((q >> 1) * 32 + (q & 1) * 16) * ROWB; };
         u32x4_v vf[VLA + 1];
 #pragma unroll
@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
             }
             static_for<0, RB>([&](auto Rc) {
                 constexpr int rb = decltype(Rc)::value;
-                Acc::template pv<(rb * NDB + db) * 16>(vf[n % (VLA + 1)], pp[rb][blk][kk]);
+                acc.template pv<(rb * NDB + db) * 16>(vf[n % (VLA + 1)], pp[rb][blk][kk]);
                 if constexpr (MX) {
                     constexpr int e0 = (n * RB + rb) * EPM;   // 0 .. 32.RB: elements of the flattened [rb][blk][r]
 #pragma unroll
@@ -967,7 +967,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
     if (p.lse) return;
 #endif
     // ---- epilogue ----
-    Acc::fence();
+    acc.fence();
     static_for<0, RB>([&](auto RBc) {
         constexpr int rb = decltype(RBc)::value;
         const int my_q = my_q0 + RSTEP * rb;
@@ -979,7 +979,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
         static_for<0, NDB * 4>([&](auto Ic) {
             constexpr int db = decltype(Ic)::value >> 2, r4 = decltype(Ic)::value & 3;
             float x0, x1, x2, x3;
-            Acc::template read4<(rb * NDB + db) * 16 + 4 * r4>(x0, x1, x2, x3);
+            acc.template read4<(rb * NDB + db) * 16 + 4 * r4>(x0, x1, x2, x3);
             uint2 w;
             w.x = pack2<T>(x0 * inv, x1 * inv);
             w.y = pack2<T>(x2 * inv, x3 * inv);

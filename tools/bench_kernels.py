@@ -101,8 +101,8 @@ def bench_prefill():
     cfg = int(os.environ.get("ATOMA_PREFILL_CFG", "0"))
     ah.lib.atoma_set_option(b"prefill_cfg", cfg)
     rng = np.random.default_rng(1)
-    h, hk, d = 32, 8, 128
-    for S, nseq in ((2048, 4), (4096, 2), (512, 16), (2048, 16)):
+    for S, nseq, d in ((2048, 4, 128), (4096, 2, 128), (512, 16, 128), (2048, 16, 128), (2048, 16, 64)):
+        h, hk = 32, 8
         T = S * nseq
         q, k, v = rand_dev(rng, T * h * d * 2), rand_dev(rng, T * hk * d * 2), rand_dev(rng, T * hk * d * 2)
         o = ah.DeviceBuffer(T * h * d * 2)
@@ -114,7 +114,7 @@ def bench_prefill():
                        is_causal=1, cu_seqlens_q=cu, cu_seqlens_k=cu)
         ms = timeit(run, iters=10)
         flops = 4 * S * S * h * d / 2 * nseq
-        emit(f"P1 prefill causal varlen S={S} x{nseq} (8B heads) cfg={cfg}", ms, flops=flops, tokens_per_s=round(T / (ms * 1e-3)))
+        emit(f"P1 prefill causal varlen S={S} x{nseq} d={d} (32 q / 8 kv heads) cfg={cfg}", ms, flops=flops, tokens_per_s=round(T / (ms * 1e-3)))
         for b_ in (q, k, v, o, cu):
             b_.free()
 
