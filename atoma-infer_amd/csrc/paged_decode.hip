@@ -30,6 +30,7 @@
 //
 // Algorithmic HBM bytes per call: 2*B*S*h_k*D*2 (K,V once) + 2*B*h*D*2 + 4*B*ceil(S/page) + 4*B.
 #include "attn_params.h"
+#include <type_traits>
 
 #include <mutex>
 #include <stdlib.h>
@@ -465,6 +466,321 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// d = 128 variant with q.K^T on the matrix cores.  With 8 q heads per kv head (Llama-70B) the dot2 kernel
+// above does 8 flop per K/V byte on the VALU and is compute-bound (43 % of the HBM peak, one 512-register
+// wavefront per SIMD).  The scores of a 16-token tile for up to 16 q heads are one small matrix product,
+// S^T[token][head] = K[16 x 128] . Q^T[128 x 16]: four v_mfma_f32_16x16x32 per tile instead of
+// 16.G v_dot2c + 16.G DPP reduction steps.  Layout (lane = 16.grp + col):
+//   * K operand (A): lane reads 16 bytes of token `col`, d chunk 4s + grp, for k-step s = 0..3 -- the same
+//     4 x 1 KiB wave loads per tile as before, rows and chunks assigned differently;
+//   * Q^T operand (B): lane holds q[head col][d chunk 4s + grp] (zero for col >= heads), loaded once;
+//   * result: lane holds S^T[token 4.grp + i][head col], i = 0..3 -- one head per lane, so the online
+//     softmax state is two scalars per lane (per 4-token group, merged at the end);
+//   * P.V stays on v_dot2c over token pairs: lane (grp, col) loads V rows 4.grp + r, 16-byte d chunk `col`,
+//     accumulates O[head][8 d] for every head, and gets each head's packed probabilities from lane
+//     (grp, head) with one DPP row_newbcast per head and token pair.
+// VALU work per tile: ~100 + 16.G instead of ~70.G; 2 wavefronts per SIMD at any G.
+// ------------------------------------------------------------------------------------------
+template <int I, int N, typename F> __device__ __forceinline__ void decode_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        decode_static_for<I + 1, N>(f);
+    }
+}
+// value of lane `H` of this lane's 16-lane row
+template <int H> __device__ __forceinline__ uint32_t row_bcast(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + H, 0xf, 0xf, false);   // row_newbcast:H
+}
+template <int H> __device__ __forceinline__ float row_bcastf(float x) { return __uint_as_float(row_bcast<H>(__float_as_uint(x))); }
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_v;
+template <typename T> __device__ __forceinline__ f32x4_v mfma16(const u32x4 &a, const u32x4 &b, f32x4_v c);
+template <> __device__ __forceinline__ f32x4_v mfma16<bf16_t>(const u32x4 &a, const u32x4 &b, f32x4_v c) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_v mfma16<f16_t>(const u32x4 &a, const u32x4 &b, f32x4_v c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 v8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+
+template <typename T, int G, int P, bool NT>
+__global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodeParams p) {
+    constexpr int D = 128;
+    const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15;
+
+    int id = blockIdx.x;
+    const int hk_chunks = p.h_k * p.gchunks;
+    const int hkc = id % hk_chunks;
+    id /= hk_chunks;
+    const int b = id % p.b;              // split index slowest (see paged_decode_kernel)
+    const int split = id / p.b;
+    const int hk = hkc / p.gchunks, gc = hkc % p.gchunks;
+    const int hq0 = hk * p.g + gc * G;
+    const int nq = min(G, p.g - gc * G);
+
+    const int L = decode_seq_len(p, b);
+    const int64_t kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? p.cu_seqlens_k[b] : 0;
+    const int n_tiles = (L + 15) >> 4;
+    int t0, t1;
+    bool partial;
+    if (p.chunk_tiles > 0) {
+        if (decode_batch_is_ragged(p)) {
+            t0 = split * p.chunk_tiles;
+            t1 = min(t0 + p.chunk_tiles, n_tiles);
+            if (split > 0 && t0 >= n_tiles) return;
+            partial = n_tiles > p.chunk_tiles;
+        } else {
+            if (split > 0) return;
+            t0 = 0;
+            t1 = n_tiles;
+            partial = false;
+        }
+    } else {
+        const int per = (n_tiles + p.num_splits - 1) / p.num_splits;
+        t0 = split * per;
+        t1 = min(t0 + per, n_tiles);
+        partial = p.num_splits > 1;
+    }
+
+    const float sl2 = p.scale_log2;
+    float m = -INFINITY, l = 0.f;        // online softmax state of head `col` over this lane group's tokens
+    float o[G][8];                       // O[head][d = 8.col ..+7] over this lane group's tokens
+#pragma unroll
+    for (int h = 0; h < G; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[h][e] = 0.f;
+
+    if (t0 < t1) {
+        u32x4 qb[4];                     // Q^T operand, k-step s: q[head col][d = 32s + 8.grp ..+7]
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            qb[s4] = u32x4{0, 0, 0, 0};
+            if (col < nq)
+                qb[s4] = *reinterpret_cast<const u32x4 *>(p.q + (int64_t)b * p.q_batch_stride +
+                                                          (int64_t)(hq0 + col) * p.q_head_stride + (4 * s4 + grp) * 8);
+        }
+        const bool has_alibi = p.alibi_slopes != nullptr;
+        const float alibi = (has_alibi && col < nq) ? p.alibi_slopes[b * p.alibi_batch_stride + hq0 + col] * 1.4426950408889634f : 0.f;
+
+        // ---- loader (page ids through the scalar cache, buffer loads: see paged_decode_kernel) ----
+        const bool paged = p.block_table != nullptr;
+        const uint32_t tpp = paged ? (uint32_t)(p.page_size >> 4) : 1u;
+        const uint32_t tpp_magic = tpp > 1 ? (uint32_t)((0x100000000ull + tpp - 1) / tpp) : 0u;
+        const int last_pg = paged ? (L + p.page_size - 1) / p.page_size - 1 : 0;
+        const int *bt_row = paged ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+        const char *kbase = reinterpret_cast<const char *>(p.k + (int64_t)hk * p.k_head_stride);
+        const char *vbase = reinterpret_cast<const char *>(p.v + (int64_t)hk * p.v_head_stride);
+        if (!paged) {
+            const bool cum = p.cu_seqlens_k && p.is_seqlens_k_cumulative;
+            kbase += (cum ? kv_row0 * p.k_row_stride : (int64_t)b * p.k_batch_stride) * 2;
+            vbase += (cum ? kv_row0 * p.v_row_stride : (int64_t)b * p.v_batch_stride) * 2;
+        }
+        const int64_t k_row_bytes = p.k_row_stride * 2, v_row_bytes = p.v_row_stride * 2;
+        const int64_t k_page_bytes = p.k_batch_stride * 2, v_page_bytes = p.v_batch_stride * 2;
+        const uint32_t k_lane_off = (uint32_t)(col * k_row_bytes + grp * 16);        // token col, chunk grp (+ 64 bytes per k-step)
+        const uint32_t v_lane_off = (uint32_t)(4 * grp * v_row_bytes + col * 16);    // token 4.grp (+ one row per load), chunk col
+
+        auto page_of = [&](int tile, uint32_t &tip) -> int {
+            if (tpp == 1) { tip = 0; return tile; }
+            const uint32_t pg = __umulhi((uint32_t)tile, tpp_magic);
+            tip = (uint32_t)tile - pg * tpp;
+            return (int)pg;
+        };
+        auto fetch_pid = [&](int tile) -> int {
+            if (!paged) return 0;
+            uint32_t tip;
+            const int pg = min(page_of(tile, tip), last_pg);
+            return bt_row[pg];
+        };
+        auto tile_bases = [&](int tile, int pid, const char *&kt, const char *&vt) {
+            if (paged) {
+                uint32_t tip;
+                (void)page_of(tile, tip);
+                kt = kbase + (int64_t)pid * k_page_bytes + (int64_t)(tip << 4) * k_row_bytes;
+                vt = vbase + (int64_t)pid * v_page_bytes + (int64_t)(tip << 4) * v_row_bytes;
+            } else {
+                kt = kbase + (int64_t)(tile << 4) * k_row_bytes;
+                vt = vbase + (int64_t)(tile << 4) * v_row_bytes;
+            }
+        };
+        constexpr int AUX = NT ? 2 : 0;
+        auto tile_rsrc = [&](const char *base) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, 0x7fffffff, 0x00020000);
+        };
+        auto issue_fast = [&](u32x4 (&kb)[4], u32x4 (&vb)[4], int tile, int pid) {
+            const char *kt, *vt;
+            tile_bases(tile, pid, kt, vt);
+            const __amdgpu_buffer_rsrc_t kr = tile_rsrc(kt), vr = tile_rsrc(vt);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) kb[s4] = __builtin_amdgcn_raw_buffer_load_b128(kr, k_lane_off, s4 * 64, AUX);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vb[r] = __builtin_amdgcn_raw_buffer_load_b128(vr, v_lane_off, (int)(r * v_row_bytes), AUX);
+        };
+        auto issue_tail = [&](u32x4 (&kb)[4], u32x4 (&vb)[4], int tile, int pid) {   // rows clamped to the sequence's last row
+            const char *kt, *vt;
+            tile_bases(tile, pid, kt, vt);
+            const __amdgpu_buffer_rsrc_t kr = tile_rsrc(kt), vr = tile_rsrc(vt);
+            const int lastrow = paged ? 15 : min(15, L - 1 - (tile << 4));
+            const uint32_t koff = (uint32_t)(min(col, lastrow) * k_row_bytes + grp * 16);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) kb[s4] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff, s4 * 64, AUX);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                vb[r] = __builtin_amdgcn_raw_buffer_load_b128(vr, (uint32_t)(min(4 * grp + r, lastrow) * v_row_bytes + col * 16), 0, AUX);
+        };
+
+        auto compute = [&](const u32x4 (&kb)[4], const u32x4 (&vb)[4], int tile) {
+            f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = mfma16<T>(kb[s4], qb[s4], acc);
+            float s[4];
+            const int tok0 = (tile << 4) + 4 * grp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] = acc[i] * sl2;                       // log2 domain
+            if (has_alibi) {  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] -= alibi * (float)(L - 1 - (tok0 + i));   // mask.h:183, row 0 of 1
+            }
+            if ((tile << 4) + 16 > L) {  // wave-uniform: ragged last tile
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (tok0 + i >= L) s[i] = -INFINITY;
+            }
+            const float mnew = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), m);
+            if (__any(mnew > m)) {  // rescale only when some running max moved
+                const float ms = mnew == -INFINITY ? 0.f : mnew;
+                const float alpha = __builtin_amdgcn_exp2f(m - ms);
+                l *= alpha;
+                m = mnew;
+                decode_static_for<0, G>([&](auto Hc) {
+                    constexpr int h = decltype(Hc)::value;
+                    const float ah = row_bcastf<h>(alpha);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[h][e] *= ah;
+                });
+            }
+            const float ms = m == -INFINITY ? 0.f : m;
+            float pr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pr[i] = __builtin_amdgcn_exp2f(s[i] - ms);
+            l += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+            const uint32_t pk[2] = {pack_pair<T>(pr[0], pr[1]), pack_pair<T>(pr[2], pr[3])};   // head col, token pairs
+            // P.V on token pairs: (V[r0][e], V[r1][e]) . (p[r0], p[r1]) for every head of the group
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                uint32_t ph[G];
+                decode_static_for<0, G>([&](auto Hc) { ph[decltype(Hc)::value] = row_bcast<decltype(Hc)::value>(pk[c]); });
+                const uint32_t a[4] = {vb[2 * c].x, vb[2 * c].y, vb[2 * c].z, vb[2 * c].w};
+                const uint32_t bb[4] = {vb[2 * c + 1].x, vb[2 * c + 1].y, vb[2 * c + 1].z, vb[2 * c + 1].w};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t lo = __builtin_amdgcn_perm(bb[w], a[w], 0x05040100u);  // (a.lo, b.lo)
+                    const uint32_t hi = __builtin_amdgcn_perm(bb[w], a[w], 0x07060302u);  // (a.hi, b.hi)
+#pragma unroll
+                    for (int h = 0; h < G; ++h) {
+                        o[h][2 * w] = dot2<T>(lo, ph[h], o[h][2 * w]);
+                        o[h][2 * w + 1] = dot2<T>(hi, ph[h], o[h][2 * w + 1]);
+                    }
+                }
+            }
+        };
+
+        // ---- software pipeline: P tiles in flight per wave (see paged_decode_kernel) ----
+        u32x4 kb[P][4], vb[P][4];
+        int pid[P];
+        int t = t0;
+        const int steady_end = min(t1, paged ? n_tiles : (L >> 4));
+        if (t0 + 2 * P <= steady_end) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                issue_fast(kb[s], vb[s], t0 + s, pid[s]);
+                pid[s] = fetch_pid(t0 + s + P);
+            }
+            for (; t + 2 * P <= steady_end; t += P) {
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    compute(kb[s], vb[s], t + s);
+                    issue_fast(kb[s], vb[s], t + s + P, pid[s]);
+                    pid[s] = fetch_pid(t + s + 2 * P);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
+#pragma unroll
+            for (int s = 0; s < P; ++s)
+                if (t0 + s < t1) {
+                    issue_tail(kb[s], vb[s], t0 + s, pid[s]);
+                    pid[s] = fetch_pid(t0 + s + P);
+                }
+        }
+        for (; t < t1; t += P) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                if (t + s < t1) {
+                    compute(kb[s], vb[s], t + s);
+                    if (t + s + P < t1) {
+                        issue_tail(kb[s], vb[s], t + s + P, pid[s]);
+                        pid[s] = fetch_pid(t + s + 2 * P);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- merge the four lane groups (each has its own m, l for head col and its own O) ----
+    float mt = m;
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float wgt = __builtin_amdgcn_exp2f(m - (mt == -INFINITY ? 0.f : mt));   // this group's weight for head col
+    float lt = l * wgt;
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    float mh[G], lh[G];
+    decode_static_for<0, G>([&](auto Hc) {
+        constexpr int h = decltype(Hc)::value;
+        const float wh = row_bcastf<h>(wgt);
+        mh[h] = row_bcastf<h>(mt);
+        lh[h] = row_bcastf<h>(lt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = o[h][e] * wh;
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            o[h][e] = x;
+        }
+    });
+
+    if (grp != 0) return;
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        if (h >= nq) continue;
+        const int hq = hq0 + h;
+        const bool empty = !(lh[h] > 0.f);
+        const float inv = empty ? 0.f : 1.f / lh[h];
+        const float lse = empty ? INFINITY : (mh[h] + __builtin_amdgcn_logf(lh[h])) * 0.6931471805599453f;
+        if (!partial) {
+            uint4 w4;
+            w4.x = pack2<T>(o[h][0] * inv, o[h][1] * inv);
+            w4.y = pack2<T>(o[h][2] * inv, o[h][3] * inv);
+            w4.z = pack2<T>(o[h][4] * inv, o[h][5] * inv);
+            w4.w = pack2<T>(o[h][6] * inv, o[h][7] * inv);
+            *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + col * 8) = w4;
+            if (p.lse && col == 0) p.lse[(int64_t)b * p.h + hq] = lse;
+        } else {
+            const int64_t row = ((int64_t)split * p.b + b) * p.h + hq;
+            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + col * 8);
+            dst[0] = make_float4(o[h][0] * inv, o[h][1] * inv, o[h][2] * inv, o[h][3] * inv);
+            dst[1] = make_float4(o[h][4] * inv, o[h][5] * inv, o[h][6] * inv, o[h][7] * inv);
+            if (col == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
+        }
+    }
+}
+
 // LSE-weighted merge of the split partials: /root/reference/csrc/kernels/flash_fwd_kernel.h:1204-1236.
 // One wavefront per (b, q head); lane i owns D/64 output pairs.
 template <typename T, int D>
@@ -578,6 +894,7 @@ struct DecodeOptions {
     int chunk_tiles = env_int("ATOMA_DECODE_CHUNK_TILES", DECODE_CHUNK_TILES);
     int waves_per_cu = env_int("ATOMA_DECODE_WAVES_PER_CU", 0);   // 0 = resident capacity
     int min_tiles = env_int("ATOMA_DECODE_MIN_TILES", 8);
+    int mqk = env_int("ATOMA_DECODE_MQK", 1);   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = smaller groups
 };
 static DecodeOptions &decode_options() {
     static DecodeOptions o;
@@ -592,6 +909,7 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_chunk_tiles") o.chunk_tiles = value;
     else if (name == "decode_waves_per_cu") o.waves_per_cu = value;
     else if (name == "decode_min_tiles") o.min_tiles = value;
+    else if (name == "decode_mqk") o.mqk = value;
     else return false;
     return true;
 }
@@ -600,6 +918,25 @@ template <typename T, int D, int G, int P, int MINW, bool NT>
 static void launch_decode_cfg(const DecodeParams &p, hipStream_t stream) {
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
     hipLaunchKernelGGL((paged_decode_kernel<T, D, G, P, MINW, NT>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+}
+
+// d = 128: scores on the matrix cores (paged_decode_mqk_kernel), any G at two wavefronts per SIMD
+template <typename T, int G>
+static void launch_decode_mqk(const DecodeParams &p, hipStream_t stream) {
+    const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
+    const int cfg_p = decode_options().p;
+    if (decode_options().nt) {
+        if (cfg_p >= 3 && G <= 4) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, 3, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, 2, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    } else {
+        if (cfg_p >= 3 && G <= 4) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, 3, false>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, 2, false>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    }
+    if (!ATOMA_CHECK_LAUNCH("paged_decode_mqk_kernel")) return;
+    if (p.num_splits > 1) {
+        hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)((int64_t)p.b * p.h)), dim3(64), 0, stream, p);
+        ATOMA_CHECK_LAUNCH("decode_combine_kernel");
+    }
 }
 
 template <typename T, int D, int G>
@@ -628,11 +965,14 @@ static void launch_decode_tdg(const DecodeParams &p, hipStream_t stream) {
 template <typename T, int D>
 static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
     const int g = p.g;
-    const int G = g >= 8 ? 8 : (g > 2 ? 4 : (g == 2 ? 2 : 1));
+    // matrix-core scores: d = 128, selected groups (option decode_mqk: bit 0 = groups of 5..8+ q heads, bit 1 = smaller ones)
+    const int mqk_opt = decode_options().mqk;
+    const bool use_mqk = D == 128 && ((g > 4 && (mqk_opt & 1)) || (g <= 4 && (mqk_opt & 2)));
+    const int G = g >= 8 ? 8 : (g > 4 && use_mqk ? 8 : (g > 2 ? 4 : (g == 2 ? 2 : 1)));
     p.gchunks = (int)cdiv(g, G);
     if (p.num_splits <= 0) {
         const int64_t waves = (int64_t)p.b * p.h_k * p.gchunks;
-        const int cap = (G >= 8 && D >= 128) ? 4 : 8;   // resident wavefronts per CU of the variant that will run
+        const int cap = (G >= 8 && D >= 128 && !use_mqk) ? 4 : 8;   // resident wavefronts per CU of the variant that will run
         const int wpc = decode_options().waves_per_cu > 0 ? decode_options().waves_per_cu : cap;
         p.num_splits = decode_num_splits(waves, p.seqlen_k, wpc, std::max(1, decode_options().min_tiles));
         p.chunk_tiles = 0;
@@ -650,6 +990,15 @@ static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
         if (!ws) return;
         p.o_accum = ws;
         p.lse_accum = ws + rows * D;
+    }
+    if (D == 128 && use_mqk) {
+        switch (G) {
+            case 1: launch_decode_mqk<T, 1>(p, stream); break;
+            case 2: launch_decode_mqk<T, 2>(p, stream); break;
+            case 4: launch_decode_mqk<T, 4>(p, stream); break;
+            default: launch_decode_mqk<T, 8>(p, stream); break;
+        }
+        return;
     }
     switch (G) {
         case 1: launch_decode_tdg<T, D, 1>(p, stream); break;
