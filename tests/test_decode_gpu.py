@@ -249,3 +249,80 @@ def test_decode_f16_long_sequences(gpu, dtype):
                       v_strides=(page * hk * d, hk * d, d), o_shape=q.shape, o_strides=(h * d, h * d, d), cu_k=lens,
                       k_cumulative=False, block_table=bt, page=page)
     assert_close(out, ref, dtype, atol=1e-3, what="f16 long decode vs C oracle")
+
+
+# ---- groups of more than 4 q heads at d = 128: q.K^T on the matrix cores (paged_decode_mqk_kernel) ----
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("h,hk,page", [(64, 8, 16), (8, 1, 16), (5, 1, 16), (12, 2, 32), (14, 2, 16), (16, 1, 64)])
+def test_decode_large_groups_matrix_core_scores(gpu, dtype, h, hk, page):
+    """Llama-70B head geometry (64 q / 8 kv heads) and groups of 5, 6, 7, 8 and 16 q heads per kv head (padded
+    columns of the score tile; 16 = two passes of 8), ragged lengths around every tile boundary, empty sequence."""
+    d = 128
+    rng = np.random.default_rng(h * 13 + hk + page)
+    lens = np.array([0, 1, 3, 4, 5, 15, 16, 17, 47, 48, 49, 64, 130, 333], np.int32)
+    nb = int(sum((L + page - 1) // page for L in lens)) + 3
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+    q = rand_half(rng, (len(lens), 1, h, d), dtype)
+    scale = np.float32(d ** -0.5)
+    out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype)
+    for mode in ("f32", "kernel"):
+        ref = A.flash_attn_kv_cache(q, kc, vc, scale, dtype, bt, lens, mode=mode)
+        for i, L in enumerate(lens):
+            assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"decode g={h // hk} L={L} vs {mode} oracle")
+    assert not out[0].any() and np.isposinf(lse[0]).all() and np.isfinite(lse[1:]).all()
+
+
+def test_decode_large_groups_both_kernels_agree(gpu):
+    """The matrix-core and the dot2 kernel compute the same thing in different orders: outputs agree to the P-rounding
+    bound, LSE to f32 rounding; also with ALiBi, a contiguous cache, and the split-KV path (one long sequence)."""
+    rng = np.random.default_rng(77)
+    h, hk, d, page = 16, 2, 128, 16
+    slopes = (2.0 ** -np.linspace(0.5, 8, h)).astype(np.float32)
+    cases = []
+    lens = np.array([70, 33, 500, 16], np.int32)
+    kc, vc, bt = make_paged_cache(rng, 45, page, hk, d, BF16, lens)
+    cases.append(("paged", dict(kc=kc, vc=vc, bt=bt, lens=lens, alibi=None)))
+    cases.append(("paged+alibi", dict(kc=kc, vc=vc, bt=bt, lens=lens, alibi=slopes)))
+    kcc, vcc = rand_half(rng, (4, 100, hk, d), BF16), rand_half(rng, (4, 100, hk, d), BF16)
+    cases.append(("contiguous", dict(kc=kcc, vc=vcc, bt=None, lens=np.array([100, 1, 50, 99], np.int32), alibi=None)))
+    lens1 = np.array([4096], np.int32)
+    kc1, vc1, bt1 = make_paged_cache(rng, 260, page, hk, d, BF16, lens1)
+    cases.append(("split-KV", dict(kc=kc1, vc=vc1, bt=bt1, lens=lens1, alibi=None)))
+    for name, c in cases:
+        q = rand_half(rng, (len(c["lens"]), 1, h, d), BF16)
+        res = {}
+        for mqk in (1, 0):
+            assert gpu.lib.atoma_set_option(b"decode_mqk", mqk) == 0
+            res[mqk] = gpu_decode(gpu, q, c["kc"], c["vc"], c["bt"], c["lens"], 0.088, BF16, alibi=c["alibi"])
+        gpu.lib.atoma_set_option(b"decode_mqk", 1)
+        assert_close(res[1][0], res[0][0], BF16, atol=ATOL_VS_F32[BF16], what=f"{name}: matrix-core vs dot2 kernel")
+        assert np.allclose(res[1][1], res[0][1], rtol=1e-5, atol=1e-5), name
+        ref = A.flash_attn_kv_cache(q, c["kc"], c["vc"], 0.088, BF16, c["bt"], c["lens"], causal=True, alibi_slopes=c["alibi"])
+        assert_close(res[1][0], ref, BF16, atol=ATOL_VS_F32[BF16], what=f"{name}: matrix-core kernel vs oracle")
+
+
+def test_decode_full_size_70b_shape_properties(gpu):
+    """Llama-70B decode shape at full size (B=256, 64 q / 8 kv heads, S=4096): size-independent properties --
+    V constant along d => output constant along d, equal to that constant where V is constant over tokens; block-table
+    permutation invariance, bit for bit."""
+    rng = np.random.default_rng(70)
+    B, S, h, hk, d, page = 256, 4096, 64, 8, 128, 16
+    pps = S // page
+    nb = B * pps
+    kc = rand_half(rng, (nb, page, hk, d), BF16)
+    vrow = rand_half(rng, (nb, page, hk, 1), BF16)
+    vc = np.ascontiguousarray(np.broadcast_to(vrow, (nb, page, hk, d)))
+    bt = rng.permutation(nb).astype(np.int32).reshape(B, pps)
+    lens = np.full(B, S, np.int32)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    out, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
+    assert (out == out[..., :1]).all(), "V constant along d must give outputs constant along d"
+    o32, v32 = to_f32(out, BF16), to_f32(vrow, BF16)
+    assert o32.min() >= v32.min() - 1e-2 and o32.max() <= v32.max() + 1e-2
+    # the same pages listed in another order for every sequence with K and V moved along: identical bits
+    perm = rng.permutation(nb)
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(nb)
+    out2, _ = gpu_decode(gpu, q, kc[perm], vc[perm], inv[bt].astype(np.int32), lens, d ** -0.5, BF16)
+    assert np.array_equal(out, out2)

@@ -90,6 +90,8 @@ def bench_decode():
     decode_case("C2c decode ragged U[2048,4096]", 256, 4096, 32, 8, ragged=True)
     decode_case("decode ragged U[2048,4096] MHA hk=32", 256, 4096, 32, 32, ragged=True)
     decode_case("C2b decode MHA hk=32", 256, 4096, 32, 32)
+    decode_case("C4 decode Llama-70B shape TP=1: B=256 h=64 hk=8 S=4096", 256, 4096, 64, 8)
+    decode_case("C4 decode 70B TP=8 shard: B=256 h=8 hk=1 S=4096", 256, 4096, 8, 1)
     decode_case("decode 70B TP=8 shard: B=64 h=8 hk=1 S=4096 (split-KV)", 64, 4096, 8, 1)
     decode_case("decode B=1 S=4096 (split-KV)", 1, 4096, 32, 8)
     decode_case("decode B=16 S=8192", 16, 8192, 32, 8)
