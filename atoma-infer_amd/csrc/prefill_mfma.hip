@@ -169,6 +169,43 @@ template <int D, int W> struct PfLoader {
             }
             return;
         }
+        if (bt && page_shift >= 0 && (!do_k || kkey0 + PF_BN - 1 <= last_key) && (!do_v || vkey0 + PF_BN - 1 <= last_key)) {
+            // paged cache, full tiles: a 1 KiB piece covers 64 / CPR consecutive rows, which never straddle a page
+            // (pages are multiples of 16 tokens), so its page id is wave-uniform: scalar loads for the block table
+            // (lgkmcnt -- the DMA queue is not drained) and, as above, a uniform base + the lane's constant offset
+            constexpr int RPP = 64 / CPR;   // rows per piece
+            uint64_t kb[NDMA], vb[NDMA];
+            if (page_shift >= 6) {          // pages of 64+ tokens: the whole 64-key tile sits in one page
+                const int kpi = max(kkey0, 0) >> page_shift, vpi = max(vkey0, 0) >> page_shift;
+                const int kpg = __builtin_amdgcn_readfirstlane(bt[kpi]), vpg = __builtin_amdgcn_readfirstlane(bt[vpi]);
+                const uint64_t kb0 = uniform64((uint64_t)(kbase + (int64_t)kpg * k_page + (int64_t)(kkey0 - (kpi << page_shift)) * k_row));
+                const uint64_t vb0 = uniform64((uint64_t)(vbase + (int64_t)vpg * v_page + (int64_t)(vkey0 - (vpi << page_shift)) * v_row));
+#pragma unroll
+                for (int u = 0; u < NDMA; ++u) { kb[u] = kb0; vb[u] = vb0; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NDMA; ++u) {
+                    const int row0 = __builtin_amdgcn_readfirstlane((wave * NDMA + u) * RPP);
+                    if (do_k) {
+                        const int pi = (kkey0 + row0) >> page_shift;
+                        const int pg = __builtin_amdgcn_readfirstlane(bt[pi]);
+                        kb[u] = uniform64((uint64_t)(kbase + (int64_t)pg * k_page + (int64_t)(kkey0 - (pi << page_shift)) * k_row));
+                    }
+                    if (do_v) {
+                        const int pi = (vkey0 + row0) >> page_shift;
+                        const int pg = __builtin_amdgcn_readfirstlane(bt[pi]);
+                        vb[u] = uniform64((uint64_t)(vbase + (int64_t)pg * v_page + (int64_t)(vkey0 - (pi << page_shift)) * v_row));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NDMA; ++u) {
+                const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)((wave * NDMA + u) * 1024));
+                if (do_k) glds16_saddr(kb[u], kfast[u], k_lds + off);
+                if (do_v) glds16_saddr(vb[u], vfast[u], v_lds + off);
+            }
+            return;
+        }
         const uint16_t *ksrc[NDMA], *vsrc[NDMA];
         // all block-table lookups first, then the DMAs back to back (a lookup's vmcnt wait
         // would otherwise drain the DMA issued just before it)

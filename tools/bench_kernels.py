@@ -5,7 +5,7 @@ Prints one JSON line per workload: achieved GB/s (HBM-bound kernels) or TFLOP/s 
 algorithmic bytes / flops it is computed from, and the fraction of the chip peak.  Timing = HIP events
 on the NULL stream around `iters` back-to-back launches after warm-up.
 
-  python tools/bench_kernels.py [decode prefill cache norm sampling swap]   (default: all)
+  python tools/bench_kernels.py [decode prefill prefill_paged cache norm sampling swap]   (default: all)
 """
 import ctypes as C
 import json
@@ -121,6 +121,30 @@ def bench_prefill():
             b_.free()
 
 
+def bench_prefill_paged():
+    """a7: prefill over the paged cache (prefix / chunked prefill, flash_attn_varlen_with_block_table)."""
+    rng = np.random.default_rng(6)
+    h, hk, d, S, nseq = 32, 8, 128, 2048, 16
+    T = S * nseq
+    q, o = rand_dev(rng, T * h * d * 2), ah.DeviceBuffer(T * h * d * 2)
+    cu = ah.DeviceBuffer.from_numpy((np.arange(nseq + 1) * S).astype(np.int32))
+    for page in (16, 64):
+        pps = S // page
+        nb = nseq * pps
+        k, v = rand_dev(rng, nb * page * hk * d * 2), rand_dev(rng, nb * page * hk * d * 2)
+        bt = ah.DeviceBuffer.from_numpy(rng.permutation(nb).astype(np.int32).reshape(nseq, pps))
+
+        def run():
+            ah.run_mha(q, k, v, o, b=nseq, h=h, h_k=hk, d=d, seqlen_q=S, seqlen_k=S, softmax_scale=d ** -0.5, is_bf16=1,
+                       q_strides=(0, h * d, d), o_strides=(0, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                       v_strides=(page * hk * d, hk * d, d), is_causal=1, cu_seqlens_q=cu, cu_seqlens_k=cu, block_table=bt,
+                       block_table_batch_stride=pps, page_block_size=page, force_split_kernel=True)
+        ms = timeit(run, iters=10)
+        emit(f"P2 prefill over the paged cache, causal S={S} x{nseq} d={d} page={page}", ms, flops=4 * S * S * h * d / 2 * nseq)
+        for b_ in (k, v, bt):
+            b_.free()
+
+
 def bench_cache():
     rng = np.random.default_rng(2)
     hk, d, page, nb = 8, 128, 16, 4096
@@ -208,6 +232,6 @@ def bench_swap():
 
 if __name__ == "__main__":
     ah.set_device(0)
-    which = sys.argv[1:] or ["decode", "prefill", "cache", "norm", "sampling", "swap"]
+    which = sys.argv[1:] or ["decode", "prefill", "prefill_paged", "cache", "norm", "sampling", "swap"]
     for w in which:
         globals()["bench_" + w]()
