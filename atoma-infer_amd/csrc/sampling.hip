@@ -112,3 +112,152 @@ extern "C" int atoma_argmax_rows(const void *logits, int64_t rows, int64_t vocab
 #undef ATOMA_ARGMAX
     return ATOMA_CHECK_LAUNCH("argmax_rows") ? 0 : -1;
 }
+
+// ------------------------------------------------------------------------------------------
+// Top-k per row: the k largest logits with their indices, ordered by (value descending, index ascending), so that
+// top-k / top-p sampling on the host needs k values per sequence instead of the vocabulary (model_executor.rs:206-249,
+// candle_transformers LogitsProcessor top-k / top-p branches).  One workgroup per row:
+//   1. histogram of the top 12 bits of an order-preserving key -> the bucket T that holds the k-th largest element;
+//   2. every element of a bucket >= T goes to an LDS candidate list (k + one bucket's population: a few hundred for
+//      real logits), which is sorted (bitonic, (key desc, index asc)) and cut at k;
+//   3. rows whose candidates do not fit (thousands of values in one 1/4096 slice of the number line: constant rows,
+//      all -inf) fall back to k rounds of "largest element after the previous one" -- exact, slow, rare.
+// Index / order work: bit-exact against numpy lexsort.  Reads the row twice (HBM, then MALL / L2).
+// ------------------------------------------------------------------------------------------
+namespace atoma {
+
+constexpr int TOPK_MAX = 1024, TOPK_CAP = 4096, TOPK_THREADS = 1024;
+
+__device__ __forceinline__ uint32_t order_key(float v) {   // larger float <=> larger key; NaN lowest
+    if (v != v) return 0u;
+    const uint32_t u = v == 0.f ? 0u : __float_as_uint(v);   // -0.0 and +0.0 compare equal
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// sort key of a candidate: value key in the high word, inverted index in the low word -> plain descending order
+__device__ __forceinline__ unsigned long long cand(uint32_t key, int idx) { return ((unsigned long long)key << 32) | (uint32_t)(0x7fffffff - idx); }
+
+template <typename T>
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const void *__restrict__ logits, int64_t row_stride_bytes, int vocab, int k,
+                                                                 float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+    __shared__ unsigned int hist[4096];
+    __shared__ unsigned long long cands[TOPK_CAP];
+    __shared__ unsigned int n_cand, t_bucket;
+    const char *row = static_cast<const char *>(logits) + (int64_t)blockIdx.x * row_stride_bytes;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += TOPK_THREADS) hist[i] = 0;
+    if (tid == 0) n_cand = 0;
+    __syncthreads();
+    for (int i = tid; i < vocab; i += TOPK_THREADS) atomicAdd(&hist[order_key(load1<T>(row, i)) >> 20], 1u);
+    __syncthreads();
+    if (tid < 64) {   // one wavefront walks the histogram from the top: 64 buckets per step
+        unsigned int above = 0;
+        int found = -1;
+        for (int base = 4096 - 64; base >= 0 && found < 0; base -= 64) {
+            const unsigned int c = hist[base + tid];
+            // inclusive suffix sum over the 64 lanes (lane 63 = highest bucket)
+            unsigned int suf = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned int o = __shfl_down(suf, off, 64);
+                if (tid + off < 64) suf += o;
+            }
+            const bool hit = above + suf >= (unsigned)k;                    // the k-th largest is in this bucket or a higher one
+            const unsigned long long m = __ballot(hit);
+            if (m) found = base + 63 - __builtin_clzll(m);                  // highest bucket that reaches k
+            above += __shfl(suf, 0, 64);
+        }
+        if (tid == 0) t_bucket = found < 0 ? 0u : (unsigned)found;
+    }
+    __syncthreads();
+    const unsigned int T0 = t_bucket;
+    for (int i = tid; i < vocab; i += TOPK_THREADS) {
+        const uint32_t key = order_key(load1<T>(row, i));
+        if ((key >> 20) >= T0) {
+            const unsigned int pos = atomicAdd(&n_cand, 1u);
+            if (pos < TOPK_CAP) cands[pos] = cand(key, i);
+        }
+    }
+    __syncthreads();
+    const unsigned int n = n_cand;
+    float *ov = out_val + (int64_t)blockIdx.x * k;
+    int32_t *oi = out_idx + (int64_t)blockIdx.x * k;
+    if (n <= TOPK_CAP) {
+        int np2 = 1;
+        while (np2 < (int)n) np2 <<= 1;
+        for (int i = n + tid; i < np2; i += TOPK_THREADS) cands[i] = 0ull;   // padding sorts last
+        __syncthreads();
+        for (int size = 2; size <= np2; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < np2 / 2; i += TOPK_THREADS) {
+                    const int lo = (i / stride) * 2 * stride + (i % stride), hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const unsigned long long a = cands[lo], b = cands[hi];
+                    if ((a < b) == desc) { cands[lo] = b; cands[hi] = a; }
+                }
+                __syncthreads();
+            }
+        for (int j = tid; j < k; j += TOPK_THREADS) {
+            const int idx = 0x7fffffff - (int)(uint32_t)cands[j];
+            oi[j] = idx;
+            ov[j] = load1<T>(row, idx);
+        }
+        return;
+    }
+    // fallback: k rounds of "largest candidate strictly below the previous pick" (lexicographic on (key, -index))
+    __shared__ unsigned long long red[TOPK_THREADS / 64];
+    unsigned long long prev = ~0ull;
+    for (int j = 0; j < k; ++j) {
+        unsigned long long best = 0ull;
+        for (int i = tid; i < vocab; i += TOPK_THREADS) {
+            const unsigned long long c = cand(order_key(load1<T>(row, i)), i);
+            if (c < prev && c > best) best = c;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off, 64);
+            best = o > best ? o : best;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = best;
+        __syncthreads();
+        if (tid < 64) {
+            unsigned long long b = tid < TOPK_THREADS / 64 ? red[tid] : 0ull;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(b, off, 64);
+                b = o > b ? o : b;
+            }
+            if (tid == 0) red[0] = b;
+        }
+        __syncthreads();
+        prev = red[0];
+        __syncthreads();
+        if (tid == 0) {
+            const int idx = 0x7fffffff - (int)(uint32_t)prev;
+            oi[j] = idx;
+            ov[j] = load1<T>(row, idx);
+        }
+    }
+}
+
+}  // namespace atoma
+
+extern "C" int atoma_topk_rows(const void *logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype, int64_t k, float *out_val,
+                               int32_t *out_idx, void *stream) {
+    using namespace atoma;
+    clear_error();
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16 && dtype != ATOMA_F32) { set_error("topk_rows: dtype must be f16, bf16 or f32"); return -1; }
+    if (rows < 0 || vocab <= 0 || vocab > 0x7ffffffe) { set_error("topk_rows: invalid shape"); return -1; }
+    if (k <= 0 || k > TOPK_MAX || k > vocab) { set_error("topk_rows: k must be in [1, min(vocab, 1024)]"); return -1; }
+    if (row_stride < vocab) { set_error("topk_rows: row_stride must be >= vocab"); return -1; }
+    if (!out_val || !out_idx) { set_error("topk_rows: out_val and out_idx are required"); return -1; }
+    if (rows == 0) return 0;
+    const int64_t stride_bytes = row_stride * (dtype == ATOMA_F32 ? 4 : 2);
+    const auto s = static_cast<hipStream_t>(stream);
+    if (dtype == ATOMA_F32)
+        hipLaunchKernelGGL((topk_rows_kernel<float>), dim3((unsigned)rows), dim3(TOPK_THREADS), 0, s, logits, stride_bytes, (int)vocab, (int)k, out_val, out_idx);
+    else if (dtype == ATOMA_BF16)
+        hipLaunchKernelGGL((topk_rows_kernel<bf16_t>), dim3((unsigned)rows), dim3(TOPK_THREADS), 0, s, logits, stride_bytes, (int)vocab, (int)k, out_val, out_idx);
+    else
+        hipLaunchKernelGGL((topk_rows_kernel<f16_t>), dim3((unsigned)rows), dim3(TOPK_THREADS), 0, s, logits, stride_bytes, (int)vocab, (int)k, out_val, out_idx);
+    return ATOMA_CHECK_LAUNCH("topk_rows") ? 0 : -1;
+}

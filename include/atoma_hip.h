@@ -174,6 +174,12 @@ int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head
 int atoma_argmax_rows(const void *logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype, int32_t *out_idx,
                       float *out_val, void *stream);
 
+/* The k largest logits of every row with their indices, ordered by (value descending, index ascending; NaNs last):
+ * what the top-k / top-p branches of the reference's sampler need from a row (model_executor.rs:206-249), k values per
+ * sequence instead of the vocabulary.  out_val / out_idx [rows, k]; k <= 1024. */
+int atoma_topk_rows(const void *logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype, int64_t k, float *out_val,
+                    int32_t *out_idx, void *stream);
+
 /* Tensor-parallel sum all-reduce (models/src/multi_gpu.rs:141-179 `AllReduce::cuda_fwd`,
  * bootstrap backends/vllm/src/model_executor.rs:413,436-439 `Id::new` / `Comm::from_rank`).
  * One process (or thread) per GPU over RCCL/xGMI.  id128: 128-byte ncclUniqueId. */

@@ -63,3 +63,69 @@ def test_argmax_rows_rejects_bad_arguments(gpu):
     assert gpu.lib.atoma_argmax_rows(d.ptr, 1, 16, 8, F32, d.ptr, None, None) == -1 and "row_stride" in gpu.last_error()
     assert gpu.lib.atoma_argmax_rows(d.ptr, 1, 16, 16, F32, None, None, None) == -1 and "out_idx" in gpu.last_error()
     assert gpu.lib.atoma_argmax_rows(d.ptr, 0, 16, 16, F32, d.ptr, None, None) == 0
+
+
+def gpu_topk(gpu, logits, dtype, k, vocab=None, stride=None):
+    rows = logits.shape[0]
+    vocab = vocab or logits.shape[1]
+    stride = stride or logits.shape[1]
+    dl = gpu.DeviceBuffer.from_numpy(logits)
+    dv, di = gpu.DeviceBuffer.zeros((rows, k), np.float32), gpu.DeviceBuffer.zeros((rows, k), np.int32)
+    rc = gpu.lib.atoma_topk_rows(dl.ptr, rows, vocab, stride, dtype, k, dv.ptr, di.ptr, None)
+    assert rc == 0, gpu.last_error()
+    gpu.synchronize()
+    return dv.numpy(np.float32, (rows, k)), di.numpy(np.int32, (rows, k))
+
+
+def np_topk(x32, k):
+    """(value descending, index ascending): numpy lexsort with the index as the secondary key."""
+    idx = np.stack([np.lexsort((np.arange(r.size), -r))[:k] for r in x32]).astype(np.int32)
+    return np.take_along_axis(x32, idx, 1), idx
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16])
+@pytest.mark.parametrize("rows,vocab,k", [(256, 128256, 50), (3, 128256, 1), (2, 128256, 1024), (7, 32000, 40), (5, 97, 97), (4, 50257, 64)])
+def test_topk_rows_matches_numpy(gpu, dtype, rows, vocab, k):
+    rng = np.random.default_rng(rows + vocab + k)
+    if dtype == F32:
+        logits = (rng.standard_normal((rows, vocab)) * 4).astype(np.float32)
+        ref32 = logits
+    else:
+        logits = rand_half(rng, (rows, vocab), dtype, 4.0)      # 16-bit logits: plenty of exact ties around the cut
+        ref32 = to_f32(logits, dtype)
+    val, idx = gpu_topk(gpu, logits, dtype, k)
+    rv, ri = np_topk(ref32, k)
+    assert np.array_equal(idx, ri)
+    assert np.array_equal(val, rv)
+
+
+def test_topk_rows_degenerate_rows_and_strides(gpu):
+    """Constant rows, all -inf, massive ties at the cut (the candidate list overflows: k-round fallback), padded rows."""
+    rng = np.random.default_rng(1)
+    rows, vocab, stride, k = 6, 20000, 20480, 33
+    x = rng.standard_normal((rows, stride)).astype(np.float32)
+    x[:, vocab:] = 1e9                                   # padding columns must be ignored
+    x[0, :vocab] = 2.5                                   # constant row: indices 0..k-1
+    x[1, :vocab] = -np.inf
+    x[2, :vocab] = np.where(rng.random(vocab) < 0.5, 1.0, 0.0)    # two values, 10k ties each
+    x[3, 5000:15000] = 7.0                               # a plateau of 10k equal maxima
+    x[4, 100] = -0.0
+    x[4, 50] = 0.0                                       # signed zeros are equal: index order decides among them
+    val, idx = gpu_topk(gpu, x, F32, k, vocab=vocab, stride=stride)
+    rv, ri = np_topk(x[:, :vocab], k)
+    assert np.array_equal(idx, ri)
+    assert np.array_equal(val, rv)
+    assert idx[0].tolist() == list(range(k)) and idx[3].tolist() == list(range(5000, 5000 + k))
+
+
+def test_topk_rows_k1_equals_argmax_and_rejects_bad_arguments(gpu):
+    rng = np.random.default_rng(2)
+    x = rand_half(rng, (9, 4096), BF16)
+    _, idx = gpu_topk(gpu, x, BF16, 1)
+    a, _ = gpu_argmax(gpu, x, BF16)
+    assert np.array_equal(idx[:, 0], a)
+    d = gpu.DeviceBuffer(4096)
+    assert gpu.lib.atoma_topk_rows(d.ptr, 1, 16, 16, F32, 0, d.ptr, d.ptr, None) == -1 and "k must" in gpu.last_error()
+    assert gpu.lib.atoma_topk_rows(d.ptr, 1, 16, 16, F32, 17, d.ptr, d.ptr, None) == -1
+    assert gpu.lib.atoma_topk_rows(d.ptr, 1, 16, 16, 9, 4, d.ptr, d.ptr, None) == -1 and "dtype" in gpu.last_error()
+    assert gpu.lib.atoma_topk_rows(d.ptr, 1, 16, 16, F32, 4, None, d.ptr, None) == -1

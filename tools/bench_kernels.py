@@ -202,6 +202,11 @@ def bench_sampling():
         idx, val = ah.DeviceBuffer(B * 4), ah.DeviceBuffer(B * 4)
         ms = timeit(lambda: ah.lib.atoma_argmax_rows(logits.ptr, B, vocab, vocab, dt, idx.ptr, val.ptr, None))
         emit(f"S1 argmax_rows B={B} vocab={vocab} {name}", ms, nbytes=B * vocab * elt + 8 * B)
+        k = 50
+        tv, ti = ah.DeviceBuffer(B * k * 4), ah.DeviceBuffer(B * k * 4)
+        ms = timeit(lambda: ah.lib.atoma_topk_rows(logits.ptr, B, vocab, vocab, dt, k, tv.ptr, ti.ptr, None))
+        emit(f"S2 topk_rows k={k} B={B} vocab={vocab} {name}", ms, nbytes=B * vocab * elt + 8 * B * k,
+             note="algorithmic bytes = one read of the logits; the kernel reads them twice (second pass from MALL / L2)")
 
 
 def bench_swap():
