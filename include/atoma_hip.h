@@ -188,9 +188,13 @@ int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128
 int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, int dtype, void *stream);
 int atoma_comm_destroy(void *comm);
 
-/* Tuning knobs for A/B measurements and tests: "decode_p" (K/V tiles in flight per wavefront, 2..4),
- * "decode_nt" (0/1 non-temporal K/V loads), "decode_chunk_tiles" (> 0: cut ragged decode batches into
- * chunks of that many 16-token tiles).  Defaults also come from ATOMA_DECODE_{P,NT,CHUNK_TILES}. */
+/* Tuning knobs for A/B measurements and tests (returns 0, or -1 for an unknown name).  Decode: "decode_p" (K/V tiles
+ * in flight per wavefront, 2..4), "decode_nt" (0/1 non-temporal K/V loads), "decode_chunk_tiles" (> 0: cut ragged
+ * decode batches into chunks of that many 16-token tiles), "decode_waves_per_cu" / "decode_min_tiles" (KV split
+ * heuristic), "decode_mqk" (q.K^T on the matrix cores at head_dim 128: bit 0 = groups of more than 4 q heads per kv
+ * head [default], bit 1 = smaller groups).  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
+ * software-pipelined one-wave-per-SIMD kernel).  Defaults also come from ATOMA_DECODE_{P,NT,CHUNK_TILES,WAVES_PER_CU,
+ * MIN_TILES,MQK}; ATOMA_PREFILL_CFG overrides "prefill_cfg". */
 int atoma_set_option(const char *name, int value);
 
 /* Device helpers used by the host layer, tests and bench (plain HIP runtime, no torch). */
