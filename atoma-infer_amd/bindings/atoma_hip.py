@@ -124,6 +124,12 @@ hip.hipStreamCreate.argtypes = [C.POINTER(_vp)]
 hip.hipStreamSynchronize.argtypes = [_vp]
 hip.hipStreamDestroy.argtypes = [_vp]
 hip.hipSetDevice.argtypes = [_int]
+hip.hipStreamBeginCapture.argtypes = [_vp, _int]
+hip.hipStreamEndCapture.argtypes = [_vp, C.POINTER(_vp)]
+hip.hipGraphInstantiate.argtypes = [C.POINTER(_vp), _vp, _vp, _vp, C.c_size_t]
+hip.hipGraphLaunch.argtypes = [_vp, _vp]
+hip.hipGraphExecDestroy.argtypes = [_vp]
+hip.hipGraphDestroy.argtypes = [_vp]
 hip.hipGetErrorString.restype = C.c_char_p
 hip.hipGetErrorString.argtypes = [_int]
 H2D, D2H, D2D = 1, 2, 3
@@ -213,6 +219,52 @@ class Event:
         ms = _f32()
         hip_check(hip.hipEventElapsedTime(C.byref(ms), self.e, end.e), "hipEventElapsedTime")
         return ms.value
+
+
+class Stream:
+    def __init__(self):
+        s = _vp()
+        hip_check(hip.hipStreamCreate(C.byref(s)), "hipStreamCreate")
+        self.s = s
+
+    def synchronize(self):
+        hip_check(hip.hipStreamSynchronize(self.s), "hipStreamSynchronize")
+
+    def __del__(self):
+        if getattr(self, "s", None):
+            hip.hipStreamDestroy(self.s)
+            self.s = None
+
+
+class Graph:
+    """hipGraph captured from a stream: `with Graph.capture(stream) as g: <launches on stream>`, then g.launch()."""
+
+    def __init__(self, stream):
+        self.stream, self.graph, self.exe = stream, _vp(), _vp()
+
+    @classmethod
+    def capture(cls, stream):
+        return cls(stream)
+
+    def __enter__(self):
+        hip_check(hip.hipStreamBeginCapture(self.stream.s, 0), "hipStreamBeginCapture")   # hipStreamCaptureModeGlobal
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = hip.hipStreamEndCapture(self.stream.s, C.byref(self.graph))
+        if et is None:
+            hip_check(rc, "hipStreamEndCapture")
+            hip_check(hip.hipGraphInstantiate(C.byref(self.exe), self.graph, None, None, 0), "hipGraphInstantiate")
+        return False
+
+    def launch(self):
+        hip_check(hip.hipGraphLaunch(self.exe, self.stream.s), "hipGraphLaunch")
+
+    def __del__(self):
+        if getattr(self, "exe", None):
+            hip.hipGraphExecDestroy(self.exe)
+        if getattr(self, "graph", None):
+            hip.hipGraphDestroy(self.graph)
 
 
 def _ptr(x):

@@ -1,0 +1,68 @@
+"""The launch-bound end of the path (a decode step at small batch: a dozen 5-60 us kernels per layer) is meant to be
+captured in a hipGraph by the caller.  Everything the library does on a stream must therefore be capturable once its
+split-KV workspace exists (one eager call on that stream first): no allocation, synchronisation or legacy-stream
+work inside the entry points.  Replays must read the buffers' current contents."""
+import numpy as np
+import pytest
+
+from oracle import attn_oracle as A
+from oracle.halfs import BF16
+from util import rand_half, make_paged_cache, assert_close, ATOL_VS_F32
+
+pytestmark = pytest.mark.gpu
+
+
+def test_decode_step_ops_capture_and_replay(gpu):
+    rng = np.random.default_rng(5)
+    layers, B, h, hk, d, page, hidden, vocab = 3, 2, 8, 2, 128, 16, 512, 1000
+    lens = np.array([1500, 700], np.int32)
+    nb = int(sum((x + page - 1) // page for x in lens)) + 2
+    st = gpu.Stream()
+    caches, bts = [], None
+    for _ in range(layers):
+        kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens)
+        caches.append((kc, vc, gpu.DeviceBuffer.from_numpy(kc), gpu.DeviceBuffer.from_numpy(vc)))
+        bts = bt
+    dbt, dl = gpu.DeviceBuffer.from_numpy(bts), gpu.DeviceBuffer.from_numpy(lens)
+    x = rand_half(rng, (B, hidden), BF16)
+    w = rand_half(rng, (hidden,), BF16, 0.5)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    logits = rng.standard_normal((B, vocab)).astype(np.float32)
+    dx, dw, dy = gpu.DeviceBuffer.from_numpy(x), gpu.DeviceBuffer.from_numpy(w), gpu.DeviceBuffer(x.nbytes)
+    dq, dlog = gpu.DeviceBuffer.from_numpy(q), gpu.DeviceBuffer.from_numpy(logits)
+    outs = [gpu.DeviceBuffer(q.nbytes) for _ in range(layers)]
+    didx, dval = gpu.DeviceBuffer.zeros((B,), np.int32), gpu.DeviceBuffer.zeros((B,), np.float32)
+
+    def step():
+        for l in range(layers):
+            assert gpu.lib.atoma_rms_norm(dx.ptr, dw.ptr, dy.ptr, B, hidden, hidden, hidden, 1e-5, BF16, st.s) == 0
+            gpu.run_mha(dq, caches[l][2], caches[l][3], outs[l], b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bts.shape[1] * page,
+                        softmax_scale=d ** -0.5, is_bf16=BF16, q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d),
+                        k_strides=(page * hk * d, hk * d, d), v_strides=(page * hk * d, hk * d, d), cu_seqlens_k=dl,
+                        is_seqlens_k_cumulative=False, block_table=dbt, block_table_batch_stride=bts.shape[1], page_block_size=page,
+                        force_split_kernel=True, unpadded_lse=False, stream=st.s)
+        assert gpu.lib.atoma_argmax_rows(dlog.ptr, B, vocab, vocab, 2, didx.ptr, dval.ptr, st.s) == 0
+
+    step()                                   # eager: creates the stream's split-KV workspace
+    st.synchronize()
+    eager = [o.numpy(np.uint16, q.shape) for o in outs]
+    for o in outs:
+        o.fill_bytes(0)
+    with gpu.Graph.capture(st) as g:
+        step()
+    g.launch()
+    st.synchronize()
+    for l in range(layers):
+        assert np.array_equal(outs[l].numpy(np.uint16, q.shape), eager[l]), f"layer {l}: graph replay differs from the eager run"
+    assert np.array_equal(didx.numpy(np.int32, (B,)), logits.argmax(1))
+    # new inputs in the same buffers: the replay must see them
+    q2 = rand_half(rng, (B, 1, h, d), BF16)
+    dq.upload(q2)
+    logits2 = rng.standard_normal((B, vocab)).astype(np.float32)
+    dlog.upload(logits2)
+    g.launch()
+    st.synchronize()
+    for l in range(layers):
+        ref = A.flash_attn_kv_cache(q2, caches[l][0], caches[l][1], d ** -0.5, BF16, bts, lens)
+        assert_close(outs[l].numpy(np.uint16, q.shape), ref, BF16, atol=ATOL_VS_F32[BF16], what=f"graph replay, layer {l}")
+    assert np.array_equal(didx.numpy(np.int32, (B,)), logits2.argmax(1))

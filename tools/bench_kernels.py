@@ -5,7 +5,7 @@ Prints one JSON line per workload: achieved GB/s (HBM-bound kernels) or TFLOP/s 
 algorithmic bytes / flops it is computed from, and the fraction of the chip peak.  Timing = HIP events
 on the NULL stream around `iters` back-to-back launches after warm-up.
 
-  python tools/bench_kernels.py [decode prefill prefill_paged cache norm sampling swap]   (default: all)
+  python tools/bench_kernels.py [decode prefill prefill_paged cache norm sampling graph swap]   (default: all)
 """
 import ctypes as C
 import json
@@ -209,6 +209,55 @@ def bench_sampling():
              note="algorithmic bytes = one read of the logits; the kernel reads them twice (second pass from MALL / L2)")
 
 
+def bench_graph():
+    """A decode step's attention-path kernels for 32 layers (RMSNorm, fused RoPE + cache write, paged decode) at small
+    batch, launched eagerly and replayed from a hipGraph: the launch-bound end of the path."""
+    rng = np.random.default_rng(7)
+    layers, hidden, page = 32, 4096, 16
+    st = ah.Stream()
+    for name, B, S, h, hk in (("8B B=1 S=4096", 1, 4096, 32, 8), ("70B TP=8 shard B=64 S=4096", 64, 4096, 8, 1)):
+        d = 128
+        pps = S // page
+        nb = B * pps + 4
+        kc, vc = rand_dev(rng, nb * page * hk * d * 2), rand_dev(rng, nb * page * hk * d * 2)     # one layer's cache, reused
+        bt = ah.DeviceBuffer.from_numpy(rng.permutation(nb)[:B * pps].astype(np.int32).reshape(B, pps))
+        lens = ah.DeviceBuffer.from_numpy(np.full(B, S, np.int32))
+        x, w, y = rand_dev(rng, B * hidden * 2), rand_dev(rng, hidden * 2), ah.DeviceBuffer(B * hidden * 2)
+        q, k, v = rand_dev(rng, B * h * d * 2), rand_dev(rng, B * hk * d * 2), rand_dev(rng, B * hk * d * 2)
+        o = ah.DeviceBuffer(B * h * d * 2)
+        cos, sin = rand_dev(rng, 8192 * 64 * 2), rand_dev(rng, 8192 * 64 * 2)
+        pos = ah.DeviceBuffer.from_numpy(np.full(B, S - 1, np.int64))
+        slots = ah.DeviceBuffer.from_numpy((bt.numpy(np.int32, (B, pps))[:, -1].astype(np.int64) * page + page - 1))
+
+        def step():
+            for _ in range(layers):
+                ah.lib.atoma_rms_norm(x.ptr, w.ptr, y.ptr, B, hidden, hidden, hidden, 1e-5, 1, st.s)
+                ah.lib.atoma_rope_qk_cache(q.ptr, k.ptr, v.ptr, kc.ptr, vc.ptr, slots.ptr, cos.ptr, sin.ptr, pos.ptr, B, h, hk, d,
+                                           h * d, hk * d, hk * d, page * hk * d, page, 1, 1, st.s)
+                ah.run_mha(q, kc, vc, o, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=pps * page, softmax_scale=d ** -0.5, is_bf16=1,
+                           q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                           v_strides=(page * hk * d, hk * d, d), cu_seqlens_k=lens, is_seqlens_k_cumulative=False, block_table=bt,
+                           block_table_batch_stride=pps, page_block_size=page, force_split_kernel=True, unpadded_lse=False, stream=st.s)
+
+        def timed(fn, iters=10):
+            fn(); st.synchronize()
+            a, b = ah.Event(), ah.Event()
+            a.record(st.s)
+            for _ in range(iters):
+                fn()
+            b.record(st.s)
+            b.synchronize()
+            return a.elapsed_ms(b) / iters
+        ms_eager = timed(step)
+        with ah.Graph.capture(st) as g:
+            step()
+        ms_graph = timed(g.launch)
+        rec = {"workload": f"G1 decode attention path x{layers} layers, {name}", "ms_eager": round(ms_eager, 4), "ms_graph": round(ms_graph, 4),
+               "us_per_layer_eager": round(ms_eager / layers * 1e3, 1), "us_per_layer_graph": round(ms_graph / layers * 1e3, 1),
+               "launches_per_layer": "rms_norm + rope_qk_cache + paged decode + combine"}
+        print(json.dumps(rec), flush=True)
+
+
 def bench_swap():
     rng = np.random.default_rng(4)
     L, page_bytes, nb = 32, 16 * 8 * 128 * 2, 2048
@@ -237,6 +286,6 @@ def bench_swap():
 
 if __name__ == "__main__":
     ah.set_device(0)
-    which = sys.argv[1:] or ["decode", "prefill", "prefill_paged", "cache", "norm", "sampling", "swap"]
+    which = sys.argv[1:] or ["decode", "prefill", "prefill_paged", "cache", "norm", "sampling", "graph", "swap"]
     for w in which:
         globals()["bench_" + w]()
