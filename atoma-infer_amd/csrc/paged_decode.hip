@@ -894,7 +894,7 @@ struct DecodeOptions {
     int chunk_tiles = env_int("ATOMA_DECODE_CHUNK_TILES", DECODE_CHUNK_TILES);
     int waves_per_cu = env_int("ATOMA_DECODE_WAVES_PER_CU", 0);   // 0 = resident capacity
     int min_tiles = env_int("ATOMA_DECODE_MIN_TILES", 8);
-    int mqk = env_int("ATOMA_DECODE_MQK", 1);   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = smaller groups
+    int mqk = env_int("ATOMA_DECODE_MQK", 5);   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches
 };
 static DecodeOptions &decode_options() {
     static DecodeOptions o;
@@ -965,9 +965,13 @@ static void launch_decode_tdg(const DecodeParams &p, hipStream_t stream) {
 template <typename T, int D>
 static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
     const int g = p.g;
-    // matrix-core scores: d = 128, selected groups (option decode_mqk: bit 0 = groups of 5..8+ q heads, bit 1 = smaller ones)
+    // matrix-core scores: d = 128, selected groups (option decode_mqk: bit 0 = groups of 5..8+ q heads, bit 1 = smaller ones, bit 2 below)
     const int mqk_opt = decode_options().mqk;
-    const bool use_mqk = D == 128 && ((g > 4 && (mqk_opt & 1)) || (g <= 4 && (mqk_opt & 2)));
+    // bit 2: groups of 2..4 when the batch is tiny (b * h_k <= 64): every wavefront is latency-bound there and the
+    // matrix-core kernel's instruction stream per tile is 1.5x shorter (B=1: 32 -> 27 us, 70B TP=8 shard B=64: -6 %);
+    // at larger batches the two kernels tie or the dot2 kernel wins by 2-3 %, and MHA always prefers dot2.
+    const bool tiny = g >= 2 && g <= 4 && (int64_t)p.b * p.h_k <= 64;
+    const bool use_mqk = D == 128 && ((g > 4 && (mqk_opt & 1)) || (g <= 4 && (mqk_opt & 2)) || (tiny && (mqk_opt & 4)));
     const int G = g >= 8 ? 8 : (g > 4 && use_mqk ? 8 : (g > 2 ? 4 : (g == 2 ? 2 : 1)));
     p.gchunks = (int)cdiv(g, G);
     if (p.num_splits <= 0) {

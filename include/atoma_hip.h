@@ -192,7 +192,7 @@ int atoma_comm_destroy(void *comm);
  * in flight per wavefront, 2..4), "decode_nt" (0/1 non-temporal K/V loads), "decode_chunk_tiles" (> 0: cut ragged
  * decode batches into chunks of that many 16-token tiles), "decode_waves_per_cu" / "decode_min_tiles" (KV split
  * heuristic), "decode_mqk" (q.K^T on the matrix cores at head_dim 128: bit 0 = groups of more than 4 q heads per kv
- * head [default], bit 1 = smaller groups).  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
+ * head, bit 1 = smaller groups, bit 2 = groups of 2..4 when b * h_k <= 64; default 5).  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
  * software-pipelined one-wave-per-SIMD kernel).  Defaults also come from ATOMA_DECODE_{P,NT,CHUNK_TILES,WAVES_PER_CU,
  * MIN_TILES,MQK}; ATOMA_PREFILL_CFG overrides "prefill_cfg". */
 int atoma_set_option(const char *name, int value);

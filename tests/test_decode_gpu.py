@@ -295,7 +295,7 @@ def test_decode_large_groups_both_kernels_agree(gpu):
         for mqk in (1, 0):
             assert gpu.lib.atoma_set_option(b"decode_mqk", mqk) == 0
             res[mqk] = gpu_decode(gpu, q, c["kc"], c["vc"], c["bt"], c["lens"], 0.088, BF16, alibi=c["alibi"])
-        gpu.lib.atoma_set_option(b"decode_mqk", 1)
+        gpu.lib.atoma_set_option(b"decode_mqk", 5)
         assert_close(res[1][0], res[0][0], BF16, atol=ATOL_VS_F32[BF16], what=f"{name}: matrix-core vs dot2 kernel")
         assert np.allclose(res[1][1], res[0][1], rtol=1e-5, atol=1e-5), name
         ref = A.flash_attn_kv_cache(q, c["kc"], c["vc"], 0.088, BF16, c["bt"], c["lens"], causal=True, alibi_slopes=c["alibi"])
