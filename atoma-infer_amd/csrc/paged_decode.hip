@@ -127,6 +127,50 @@ __device__ __forceinline__ bool decode_batch_is_ragged(const DecodeParams &p) {
     return (long long)mx * p.b * 96 > sum * 100;
 }
 
+// Workgroup (= one wavefront) -> (sequence, kv head, q-head chunk of the group, KV split) and the tile range it
+// owns.  The split index is slowest: the dispatcher places workgroups on CUs round-robin by index, so the
+// wavefronts that exit at once in chunk mode (split > 0 of a balanced batch, chunks past the end of a short
+// sequence) must not be interleaved with the working ones -- measured 2.5x slower with the split index in the
+// middle (only every 4th CU of an XCD got work).
+struct DecodeWork {
+    int b, hk, gc, split;
+    int L, n_tiles, t0, t1;
+    int64_t kv_row0;   // first row of this sequence in a varlen (cumulative) K/V tensor
+    bool partial;      // write fp32 partials for the combine kernel (true) or the final output (false)
+};
+__device__ __forceinline__ bool decode_map_work(const DecodeParams &p, DecodeWork &w) {
+    int id = blockIdx.x;
+    const int hk_chunks = p.h_k * p.gchunks;
+    const int hkc = id % hk_chunks;
+    id /= hk_chunks;
+    w.b = id % p.b;
+    w.split = id / p.b;
+    w.hk = hkc / p.gchunks;
+    w.gc = hkc % p.gchunks;
+    w.L = decode_seq_len(p, w.b);
+    w.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? p.cu_seqlens_k[w.b] : 0;
+    w.n_tiles = (w.L + 15) >> 4;
+    if (p.chunk_tiles > 0) {
+        if (decode_batch_is_ragged(p)) {
+            w.t0 = w.split * p.chunk_tiles;
+            w.t1 = min(w.t0 + p.chunk_tiles, w.n_tiles);
+            if (w.split > 0 && w.t0 >= w.n_tiles) return false;      // this sequence has fewer chunks
+            w.partial = w.n_tiles > p.chunk_tiles;
+        } else {
+            if (w.split > 0) return false;                            // balanced batch: one wave per (sequence, kv head)
+            w.t0 = 0;
+            w.t1 = w.n_tiles;
+            w.partial = false;
+        }
+    } else {
+        const int per = (w.n_tiles + p.num_splits - 1) / p.num_splits;
+        w.t0 = w.split * per;
+        w.t1 = min(w.t0 + per, w.n_tiles);
+        w.partial = p.num_splits > 1;
+    }
+    return true;
+}
+
 template <typename T, int D, int G, int P, int MINW, bool NT>
 __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodeParams p) {
     constexpr int LPR = D / 8;     // lanes per row
@@ -136,44 +180,13 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
     const int lane = threadIdx.x;
     const int sub = lane / LPR, dc = lane % LPR;
 
-    int id = blockIdx.x;
-    const int hk_chunks = p.h_k * p.gchunks;
-    const int hkc = id % hk_chunks;
-    id /= hk_chunks;
-    // split index slowest: the dispatcher places workgroups on CUs round-robin by index, so the
-    // wavefronts that exit at once in chunk mode (split > 0 of a balanced batch, chunks past the end
-    // of a short sequence) must not be interleaved with the working ones -- measured 2.5x slower
-    // with the split index in the middle (only every 4th CU of an XCD got work).
-    const int b = id % p.b;
-    const int split = id / p.b;
-    const int hk = hkc / p.gchunks, gc = hkc % p.gchunks;
+    DecodeWork wk;
+    if (!decode_map_work(p, wk)) return;
+    const int b = wk.b, hk = wk.hk, gc = wk.gc, split = wk.split, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
+    const int64_t kv_row0 = wk.kv_row0;
+    const bool partial = wk.partial;
     const int hq0 = hk * p.g + gc * G;
     const int nq = min(G, p.g - gc * G);
-
-    const int L = decode_seq_len(p, b);
-    // first row of this sequence in a varlen (cumulative) K/V tensor
-    const int64_t kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? p.cu_seqlens_k[b] : 0;
-    const int n_tiles = (L + 15) >> 4;
-    int t0, t1;
-    bool partial;  // write fp32 partials for the combine kernel (true) or the final output (false)
-    if (p.chunk_tiles > 0) {
-        if (decode_batch_is_ragged(p)) {
-            t0 = split * p.chunk_tiles;
-            t1 = min(t0 + p.chunk_tiles, n_tiles);
-            if (split > 0 && t0 >= n_tiles) return;      // this sequence has fewer chunks
-            partial = n_tiles > p.chunk_tiles;
-        } else {
-            if (split > 0) return;                        // balanced batch: one wave per (sequence, kv head)
-            t0 = 0;
-            t1 = n_tiles;
-            partial = false;
-        }
-    } else {
-        const int per = (n_tiles + p.num_splits - 1) / p.num_splits;
-        t0 = split * per;
-        t1 = min(t0 + per, n_tiles);
-        partial = p.num_splits > 1;
-    }
 
     const float sl2 = p.scale_log2;
     float m[G], l[G], o[G][8];
@@ -510,39 +523,13 @@ __global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodePar
     constexpr int D = 128;
     const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15;
 
-    int id = blockIdx.x;
-    const int hk_chunks = p.h_k * p.gchunks;
-    const int hkc = id % hk_chunks;
-    id /= hk_chunks;
-    const int b = id % p.b;              // split index slowest (see paged_decode_kernel)
-    const int split = id / p.b;
-    const int hk = hkc / p.gchunks, gc = hkc % p.gchunks;
+    DecodeWork wk;
+    if (!decode_map_work(p, wk)) return;
+    const int b = wk.b, hk = wk.hk, gc = wk.gc, split = wk.split, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
+    const int64_t kv_row0 = wk.kv_row0;
+    const bool partial = wk.partial;
     const int hq0 = hk * p.g + gc * G;
     const int nq = min(G, p.g - gc * G);
-
-    const int L = decode_seq_len(p, b);
-    const int64_t kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? p.cu_seqlens_k[b] : 0;
-    const int n_tiles = (L + 15) >> 4;
-    int t0, t1;
-    bool partial;
-    if (p.chunk_tiles > 0) {
-        if (decode_batch_is_ragged(p)) {
-            t0 = split * p.chunk_tiles;
-            t1 = min(t0 + p.chunk_tiles, n_tiles);
-            if (split > 0 && t0 >= n_tiles) return;
-            partial = n_tiles > p.chunk_tiles;
-        } else {
-            if (split > 0) return;
-            t0 = 0;
-            t1 = n_tiles;
-            partial = false;
-        }
-    } else {
-        const int per = (n_tiles + p.num_splits - 1) / p.num_splits;
-        t0 = split * per;
-        t1 = min(t0 + per, n_tiles);
-        partial = p.num_splits > 1;
-    }
 
     const float sl2 = p.scale_log2;
     float m = -INFINITY, l = 0.f;        // online softmax state of head `col` over this lane group's tokens
