@@ -46,6 +46,19 @@ template <> __device__ __forceinline__ f32x16_v mfma32<bf16_t>(const uint4 &a, c
 template <> __device__ __forceinline__ f32x16_v mfma32<f16_t>(const uint4 &a, const uint4 &b, f32x16_v c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a), __builtin_bit_cast(f16x8_v, b), c, 0, 0, 0);
 }
+// Lanes l and l + 32 hold the two halves of a query row's keys.  v_permlane32_swap hands every lane both members of
+// its pair in the VALU (tools/probes/permlane_probe.hip); __shfl_xor(x, 32) would go through the LDS (ds_bpermute) and
+// its lgkmcnt(0) wait once per tile.
+__device__ __forceinline__ float pair_max(float x) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair_sum(float x) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 template <typename T> __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi);
 template <> __device__ __forceinline__ uint32_t cvt_pk<bf16_t>(float lo, float hi) {
     f32x2_v v = {lo, hi};
@@ -435,7 +448,7 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[blk][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = pair_max(mx);
         const float m_cand = fmaxf(m_run, mx * sl2);
         const float m_new = m_cand > m_run + PF_DEFER ? m_cand : m_run;   // deferred raise (PF_DEFER)
         const float ms = m_new == -INFINITY ? 0.f : m_new;
@@ -559,7 +572,7 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
     if (p.lse) return;
 #endif
     // ---- epilogue: total row sum = own part + partner lane's part (same running max) ----
-    const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+    const float l_tot = pair_sum(l_part);
     if (my_q >= si.len_q) return;
     const bool empty = !(l_tot > 0.f);
     const float inv = empty ? 0.f : 1.f / l_tot;
@@ -865,7 +878,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
         float m_new[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            const float m = fmaxf(mx[rb], __shfl_xor(mx[rb], 32, 64)) * sl2;
+            const float m = pair_max(mx[rb]) * sl2;
             m_new[rb] = m;
             need = need || (m > m_run[rb] + PF_DEFER);
         }
@@ -1002,7 +1015,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
     static_for<0, RB>([&](auto RBc) {
         constexpr int rb = decltype(RBc)::value;
         const int my_q = my_q0 + RSTEP * rb;
-        const float l_tot = l_part[rb] + __shfl_xor(l_part[rb], 32, 64);
+        const float l_tot = pair_sum(l_part[rb]);
         const bool empty = !(l_tot > 0.f);
         const float inv = empty ? 0.f : 1.f / l_tot;
         uint16_t *op = p.o + si.q_offset(p.o_batch_stride, p.o_row_stride, b) + (int64_t)my_q * p.o_row_stride +
