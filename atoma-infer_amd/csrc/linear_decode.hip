@@ -1,0 +1,192 @@
+// Linear layer of a decode step at small batch: y[b][n] = sum_k x[b][k] * w[n][k], batch <= 16.
+//
+// Replaces candle_nn::Linear::forward on [B, hidden] activations (/root/reference/models/src/llama.rs:269-271,311,364-365:
+// q/k/v/o and the MLP projections), i.e. a cuBLAS GEMM with 1..16 rows.  At these sizes the op is a stream over the
+// weights -- 2.N.K bytes read once, 2.B flop per byte -- so it is laid out around the weight stream like the decode
+// attention kernel, and the arithmetic rides along on the matrix cores: a 16 x 32 slab of W (16 output features,
+// 32 inputs, 1 KiB = one 16-byte load per lane) is the A operand of one v_mfma_f32_16x16x32, x^T (zero-padded to 16
+// columns) the B operand, and the 16 x 16 result tile holds y^T for 16 features x 16 batch rows.
+//   * one wavefront per (16 output features, K split); 4 MFMAs per 128 inputs; P chunks of 4 KiB in flight per wave;
+//   * W: non-temporal buffer loads (read once); x: ordinary loads (128 KiB at most, L2-resident, shared by every wave);
+//   * the K range is split until ~8 wavefronts per CU exist; partial sums go to an fp32 workspace [split][B][N] and a
+//     second small kernel adds them and rounds once -- fp32 accumulation throughout, one rounding to the storage dtype.
+// Parity: unpinned (Candle / cuBLAS are not in the tree); the oracle is the f64-accumulated product rounded once,
+// the kernel differs from it by at most one unit in the last place (accumulation order).
+#include "common.h"
+#include <algorithm>
+
+namespace atoma {
+
+void *workspace(hipStream_t stream, size_t bytes);   // paged_decode.hip: grow-only fp32 scratch per (device, stream)
+
+typedef unsigned int lu32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(4))) float lf32x4;
+
+template <typename T> __device__ __forceinline__ lf32x4 lin_mfma(const lu32x4 &a, const lu32x4 &b, lf32x4 c);
+template <> __device__ __forceinline__ lf32x4 lin_mfma<bf16_t>(const lu32x4 &a, const lu32x4 &b, lf32x4 c) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ lf32x4 lin_mfma<f16_t>(const lu32x4 &a, const lu32x4 &b, lf32x4 c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 v8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+
+struct LinearParams {
+    const uint16_t *x, *w;
+    uint16_t *y;
+    float *partial;              // [splits][batch][n] fp32, or null when splits == 1
+    int64_t x_row_stride, w_row_stride, y_row_stride;   // elements
+    int batch, n, k, splits, chunks_per_split;           // chunk = 128 inputs
+};
+
+// lane = 16.grp + col.  A operand: W[n0 + 16r + col][k0 + 32s + 8.grp ..+7] for the RT row tiles r of the wave;
+// B operand: x[col][same k], shared by the RT tiles; result: lane holds y^T[n0 + 16r + 4.grp + i][batch col], i = 0..3.
+// RT = 4 when more than a couple of batch rows are live: every wave re-reads x (from L2), and with one row tile per
+// wave that is as many load instructions as the weight stream itself.
+template <typename T, int RT, int P>
+__global__ void __launch_bounds__(64) linear_decode_kernel(const LinearParams p) {
+    const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15;
+    const int tiles_n = p.n / (16 * RT);
+    const int tile = blockIdx.x % tiles_n, split = blockIdx.x / tiles_n;
+    const int n0 = tile * 16 * RT;
+    const int c0 = split * p.chunks_per_split, c1 = min(c0 + p.chunks_per_split, p.k >> 7);
+
+    const char *wrow = reinterpret_cast<const char *>(p.w + (int64_t)n0 * p.w_row_stride);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wrow), 0, 0x7fffffff, 0x00020000);
+    uint32_t w_lane[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) w_lane[r] = (uint32_t)((16 * r + col) * p.w_row_stride * 2 + grp * 16);
+    const bool has_x = col < p.batch;
+    const uint16_t *xrow = p.x + (int64_t)(has_x ? col : 0) * p.x_row_stride + grp * 8;
+
+    lu32x4 wb[P][RT][4], xb[P][4];
+    auto issue = [&](int s, int chunk) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wb[s][r][q] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], chunk * 256 + q * 64, 2 /* nt */);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            xb[s][q] = has_x ? *reinterpret_cast<const lu32x4 *>(xrow + chunk * 128 + q * 32) : lu32x4{0, 0, 0, 0};
+    };
+    lf32x4 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = lf32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = lin_mfma<T>(wb[s][r][q], xb[s][q], acc[r]);
+    };
+    // software pipeline: P chunks in flight; unconditional loads in the steady state keep the vmcnt waits exact
+    int c = c0;
+    if (c0 + 2 * P <= c1) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) issue(s, c0 + s);
+        for (; c + 2 * P <= c1; c += P) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                compute(s);
+                issue(s, c + s + P);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < P; ++s)
+            if (c0 + s < c1) issue(s, c0 + s);
+    }
+    for (; c < c1; c += P) {
+#pragma unroll
+        for (int s = 0; s < P; ++s)
+            if (c + s < c1) {
+                compute(s);
+                if (c + s + P < c1) issue(s, c + s + P);
+            }
+    }
+    if (!has_x) return;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int n = n0 + 16 * r + 4 * grp;
+        if (p.partial) {
+            *reinterpret_cast<float4 *>(p.partial + ((int64_t)split * p.batch + col) * p.n + n) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        } else {
+            uint2 o;
+            o.x = pack2<T>(acc[r][0], acc[r][1]);
+            o.y = pack2<T>(acc[r][2], acc[r][3]);
+            *reinterpret_cast<uint2 *>(p.y + (int64_t)col * p.y_row_stride + n) = o;
+        }
+    }
+}
+
+// y[b][n] = round(sum over splits of the fp32 partials); 4 outputs per thread
+template <typename T> __global__ void __launch_bounds__(256) linear_reduce_kernel(const LinearParams p) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4, total = (int64_t)p.batch * p.n;
+    if (i >= total) return;
+    float4 a = *reinterpret_cast<const float4 *>(p.partial + i);
+    for (int s = 1; s < p.splits; ++s) {
+        const float4 b = *reinterpret_cast<const float4 *>(p.partial + (int64_t)s * total + i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int64_t row = i / p.n, n = i - row * p.n;
+    uint2 o;
+    o.x = pack2<T>(a.x, a.y);
+    o.y = pack2<T>(a.z, a.w);
+    *reinterpret_cast<uint2 *>(p.y + row * p.y_row_stride + n) = o;
+}
+
+template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
+    const int64_t chunks = p.k / 128;
+    const int rt = (p.batch > 2 && p.n % 64 == 0) ? 4 : 1;
+    const int64_t tiles_n = p.n / (16 * rt);
+    // split K until about 8 (rt = 1) / 4 (rt = 4: four times the bytes in flight per wave) wavefronts per CU stream the
+    // weights, never below 4 chunks (512 inputs) per split
+    const int64_t target = (int64_t)device_num_cus() * (rt == 4 ? 4 : 8);
+    int64_t splits = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(tiles_n, 1), chunks / 4));
+    p.chunks_per_split = (int)cdiv(chunks, splits);
+    p.splits = (int)cdiv(chunks, p.chunks_per_split);
+    p.partial = nullptr;
+    if (p.splits > 1) {
+        p.partial = static_cast<float *>(workspace(stream, (size_t)p.splits * p.batch * p.n * sizeof(float)));
+        if (!p.partial) return -1;
+    }
+    const dim3 grid((unsigned)(tiles_n * p.splits));
+    if (rt == 4) hipLaunchKernelGGL((linear_decode_kernel<T, 4, 2>), grid, dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL((linear_decode_kernel<T, 1, 3>), grid, dim3(64), 0, stream, p);
+    if (!ATOMA_CHECK_LAUNCH("linear_decode_kernel")) return -1;
+    if (p.splits > 1) {
+        hipLaunchKernelGGL((linear_reduce_kernel<T>), dim3((unsigned)cdiv((int64_t)p.batch * p.n, 1024)), dim3(256), 0, stream, p);
+        if (!ATOMA_CHECK_LAUNCH("linear_reduce_kernel")) return -1;
+    }
+    return 0;
+}
+
+}  // namespace atoma
+
+extern "C" int atoma_linear_decode(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
+                                   int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream) {
+    using namespace atoma;
+    clear_error();
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("linear_decode: dtype must be f16 or bf16"); return -1; }
+    if (batch < 0 || batch > 16) { set_error("linear_decode: batch must be in [0, 16] (larger batches are a GEMM, not a weight stream)"); return -1; }
+    if (in_features <= 0 || in_features % 128 != 0) { set_error("linear_decode: in_features must be a positive multiple of 128"); return -1; }
+    if (out_features <= 0 || out_features % 16 != 0) { set_error("linear_decode: out_features must be a positive multiple of 16"); return -1; }
+    if (x_row_stride < in_features || w_row_stride < in_features || y_row_stride < out_features) {
+        set_error("linear_decode: row strides must cover a row");
+        return -1;
+    }
+    if (x_row_stride % 8 || w_row_stride % 8 || y_row_stride % 4) { set_error("linear_decode: strides must keep rows 16-byte (x, w) / 8-byte (y) aligned"); return -1; }
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15u || reinterpret_cast<uintptr_t>(y) & 7u) {
+        set_error("linear_decode: x and w must be 16-byte aligned, y 8-byte aligned");
+        return -1;
+    }
+    if (batch == 0) return 0;
+    LinearParams p{};
+    p.x = static_cast<const uint16_t *>(x);
+    p.w = static_cast<const uint16_t *>(w);
+    p.y = static_cast<uint16_t *>(y);
+    p.x_row_stride = x_row_stride; p.w_row_stride = w_row_stride; p.y_row_stride = y_row_stride;
+    p.batch = (int)batch; p.n = (int)out_features; p.k = (int)in_features;
+    const auto s = static_cast<hipStream_t>(stream);
+    return dtype == ATOMA_BF16 ? launch_linear<bf16_t>(p, s) : launch_linear<f16_t>(p, s);
+}

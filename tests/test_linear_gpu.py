@@ -1,0 +1,88 @@
+"""Small-batch linear layer (atoma_linear_decode) against the oracle: fp32 accumulation on the matrix cores vs the exactly
+accumulated product, at most one unit in the last place apart."""
+import numpy as np
+import pytest
+
+from oracle import linear_oracle as LO
+from oracle.halfs import F16, BF16, to_f32
+from util import rand_half
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_linear(gpu, x, w, dtype, x_stride=None, y_stride=None):
+    B, K = x.shape[0], w.shape[1]
+    N = w.shape[0]
+    dx, dw = gpu.DeviceBuffer.from_numpy(x), gpu.DeviceBuffer.from_numpy(w)
+    ys = y_stride or N
+    dy = gpu.DeviceBuffer(max(B, 1) * ys * 2)
+    dy.fill_bytes(0xFF)
+    rc = gpu.lib.atoma_linear_decode(dx.ptr, dw.ptr, dy.ptr, B, K, N, x_stride or x.shape[1], K, ys, dtype, None)
+    assert rc == 0, gpu.last_error()
+    gpu.synchronize()
+    return dy.numpy(np.uint16, (max(B, 1), ys))[:B, :N]
+
+
+def check(got, ref, dtype):
+    """fp32 accumulation (error ~ 6e-8 * sqrt(K) * |partial sums| <= 3e-5 for the O(1) outputs of these tests) and
+    one rounding: |got - ref| <= one unit in the last place of the storage dtype + 3e-5 (the absolute part matters for
+    the few outputs that cancel to nearly zero), and nearly all outputs bit-identical."""
+    g, r = to_f32(got, dtype), to_f32(ref, dtype)
+    assert np.isfinite(g).all()
+    ulp = 2.0 ** -7 if dtype == BF16 else 2.0 ** -10
+    err = np.abs(g - r)
+    assert (err <= ulp * np.abs(r) + 3e-5).all(), f"max err {err.max():.3e}"
+    assert (got != ref).mean() < 0.01, f"{(got != ref).mean():.4f} of the outputs differ from the exactly accumulated product"
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("B,K,N", [(1, 4096, 4096), (16, 4096, 6144), (3, 14336, 4096), (7, 128, 16), (16, 2048, 512), (5, 4096, 28672),
+                                   (2, 8192, 1024)])
+def test_linear_decode_llama_projection_shapes(gpu, dtype, B, K, N):
+    """q/k/v (fused), o, gate/up, down projection shapes of Llama-3.x 1B / 8B / 70B at batch 1..16, with and without K splitting."""
+    rng = np.random.default_rng(B * 7 + K + N)
+    x = rand_half(rng, (B, K), dtype)
+    w = rand_half(rng, (N, K), dtype, K ** -0.5)
+    check(gpu_linear(gpu, x, w, dtype), LO.linear(x, w, dtype), dtype)
+
+
+def test_linear_decode_strided_activations_and_padded_output(gpu):
+    """x rows are slices of a wider buffer (token stride > K), y rows land in a wider buffer whose padding stays untouched."""
+    rng = np.random.default_rng(3)
+    B, K, N = 4, 1024, 256
+    wide = rand_half(rng, (B, K + 256), BF16)
+    w = rand_half(rng, (N, K), BF16, K ** -0.5)
+    dx, dw = gpu.DeviceBuffer.from_numpy(wide), gpu.DeviceBuffer.from_numpy(w)
+    ys = N + 64
+    dy = gpu.DeviceBuffer(B * ys * 2)
+    dy.fill_bytes(0xAB)
+    assert gpu.lib.atoma_linear_decode(dx.ptr + 128 * 2, dw.ptr, dy.ptr, B, K, N, K + 256, K, ys, BF16, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    out = dy.numpy(np.uint16, (B, ys))
+    check(out[:, :N], LO.linear(np.ascontiguousarray(wide[:, 128:128 + K]), w, BF16), BF16)
+    assert (out[:, N:] == 0xABAB).all()
+
+
+def test_linear_decode_exact_cases_and_linearity(gpu):
+    """Integer-valued inputs: every partial sum is exact in fp32, so the result is bit-exact whatever the split; and
+    W = identity reproduces x."""
+    rng = np.random.default_rng(4)
+    B, K, N = 16, 2048, 2048
+    from oracle.halfs import from_f32
+    x = from_f32(rng.integers(-4, 5, (B, K)).astype(np.float32), BF16)
+    w = from_f32(rng.integers(-2, 3, (N, K)).astype(np.float32), BF16)
+    assert np.array_equal(gpu_linear(gpu, x, w, BF16), LO.linear(x, w, BF16))
+    eye = from_f32(np.eye(K, dtype=np.float32), BF16)
+    xr = rand_half(rng, (B, K), BF16)
+    assert np.array_equal(gpu_linear(gpu, xr, eye, BF16), xr)
+
+
+def test_linear_decode_rejects_bad_arguments(gpu):
+    d = gpu.DeviceBuffer(1 << 16)
+    call = lambda B=1, K=128, N=16, xs=None, dt=BF16: gpu.lib.atoma_linear_decode(d.ptr, d.ptr, d.ptr, B, K, N, xs or K, K, N, dt, None)
+    assert call(B=17) == -1 and "batch" in gpu.last_error()
+    assert call(K=100) == -1 and "in_features" in gpu.last_error()
+    assert call(N=24) == -1 and "out_features" in gpu.last_error()
+    assert call(xs=64) == -1 and "strides" in gpu.last_error()
+    assert call(dt=2) == -1 and "dtype" in gpu.last_error()
+    assert call(B=0) == 0

@@ -5,7 +5,7 @@ Prints one JSON line per workload: achieved GB/s (HBM-bound kernels) or TFLOP/s 
 algorithmic bytes / flops it is computed from, and the fraction of the chip peak.  Timing = HIP events
 on the NULL stream around `iters` back-to-back launches after warm-up.
 
-  python tools/bench_kernels.py [decode prefill prefill_paged cache norm sampling graph swap]   (default: all)
+  python tools/bench_kernels.py [decode prefill prefill_paged cache norm sampling linear graph swap]   (default: all)
 """
 import ctypes as C
 import json
@@ -258,6 +258,18 @@ def bench_graph():
         print(json.dumps(rec), flush=True)
 
 
+def bench_linear():
+    """f.1: the projections of a decode step at small batch (Llama-3.1-8B shapes): a stream over the weights."""
+    rng = np.random.default_rng(8)
+    for name, N, K in (("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336), ("lm_head", 128256, 4096)):
+        w = rand_dev(rng, N * K * 2)
+        for B in (1, 16):
+            x, y = rand_dev(rng, B * K * 2), ah.DeviceBuffer(B * N * 2)
+            ms = timeit(lambda: ah.lib.atoma_linear_decode(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
+            emit(f"L1 linear_decode {name} [{N} x {K}] batch={B}", ms, nbytes=N * K * 2 + B * K * 2 + B * N * 2)
+        w.free()
+
+
 def bench_swap():
     rng = np.random.default_rng(4)
     L, page_bytes, nb = 32, 16 * 8 * 128 * 2, 2048
@@ -286,6 +298,6 @@ def bench_swap():
 
 if __name__ == "__main__":
     ah.set_device(0)
-    which = sys.argv[1:] or ["decode", "prefill", "prefill_paged", "cache", "norm", "sampling", "graph", "swap"]
+    which = sys.argv[1:] or ["decode", "prefill", "prefill_paged", "cache", "norm", "sampling", "linear", "graph", "swap"]
     for w in which:
         globals()["bench_" + w]()
