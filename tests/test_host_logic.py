@@ -47,3 +47,22 @@ def test_split_heuristic_matches_oracle_exhaustively():
     for b, h, d, sk, sq in [(1, 32, 128, 4096, 1), (64, 8, 128, 4096, 1), (256, 32, 128, 4096, 1), (4, 32, 64, 8192, 1),
                             (2, 16, 256, 1000, 7)]:
         assert lib.atoma_compute_num_splits(b, h, d, sk, sq, 256) == A.compute_num_splits(b, h, d, sk, sq, 256)
+
+
+def test_linear_oracle_small_known_case_and_rounding():
+    """oracle/linear_oracle.py: exactly accumulated product, one rounding (the small-batch projection's checker)."""
+    import numpy as np
+    from oracle import linear_oracle as LO
+    from oracle.halfs import BF16, F16, from_f32, to_f32
+    x = from_f32(np.array([[1.0, 2.0, -3.0, 0.5]], np.float32), BF16)
+    w = from_f32(np.array([[1.0, 1.0, 1.0, 1.0], [0.5, -0.25, 2.0, 4.0], [0, 0, 0, 0]], np.float32), BF16)
+    assert to_f32(LO.linear(x, w, BF16), BF16).tolist() == [[0.5, -4.0, 0.0]]
+    # one rounding at the end: 256 + 1 is not representable in bf16 (8 significant bits) but the sum 257 + 255 = 512 is
+    x2 = from_f32(np.array([[256.0, 1.0, 255.0]], np.float32), BF16)
+    w2 = from_f32(np.ones((1, 3), np.float32), BF16)
+    assert to_f32(LO.linear(x2, w2, BF16), BF16).tolist() == [[512.0]]
+    rng = np.random.default_rng(0)
+    xf, wf = rng.standard_normal((3, 64)).astype(np.float32), rng.standard_normal((5, 64)).astype(np.float32)
+    got = to_f32(LO.linear(from_f32(xf, F16), from_f32(wf, F16), F16), F16)
+    ref = to_f32(from_f32(xf, F16), F16).astype(np.float64) @ to_f32(from_f32(wf, F16), F16).astype(np.float64).T
+    assert np.abs(got - ref).max() <= 2.0 ** -10 * np.abs(ref).max()
