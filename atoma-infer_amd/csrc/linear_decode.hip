@@ -14,6 +14,7 @@
 // the kernel differs from it by at most one unit in the last place (accumulation order).
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace atoma {
 
@@ -44,13 +45,13 @@ struct LinearParams {
 // B operand: x[col][same k], shared by the RT tiles; result: lane holds y^T[n0 + 16r + 4.grp + i][batch col], i = 0..3.
 // RT = 4 when more than a couple of batch rows are live: every wave re-reads x (from L2), and with one row tile per
 // wave that is as many load instructions as the weight stream itself.
-template <typename T, int RT, int P>
+template <typename T, int RT, int P, int CH>   // CH: 128-input chunks per pipeline stage (bytes per row visit = 256.CH)
 __global__ void __launch_bounds__(64) linear_decode_kernel(const LinearParams p) {
     const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15;
     const int tiles_n = p.n / (16 * RT);
     const int tile = blockIdx.x % tiles_n, split = blockIdx.x / tiles_n;
     const int n0 = tile * 16 * RT;
-    const int c0 = split * p.chunks_per_split, c1 = min(c0 + p.chunks_per_split, p.k >> 7);
+    const int c0 = split * p.chunks_per_split / CH, c1 = min(c0 + p.chunks_per_split / CH, (p.k >> 7) / CH);   // in stages of CH chunks
 
     const char *wrow = reinterpret_cast<const char *>(p.w + (int64_t)n0 * p.w_row_stride);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wrow), 0, 0x7fffffff, 0x00020000);
@@ -60,22 +61,22 @@ __global__ void __launch_bounds__(64) linear_decode_kernel(const LinearParams p)
     const bool has_x = col < p.batch;
     const uint16_t *xrow = p.x + (int64_t)(has_x ? col : 0) * p.x_row_stride + grp * 8;
 
-    lu32x4 wb[P][RT][4], xb[P][4];
+    lu32x4 wb[P][RT][4 * CH], xb[P][4 * CH];
     auto issue = [&](int s, int chunk) {
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) wb[s][r][q] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], chunk * 256 + q * 64, 2 /* nt */);
+            for (int q = 0; q < 4 * CH; ++q) wb[s][r][q] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], chunk * 256 * CH + q * 64, 2 /* nt */);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            xb[s][q] = has_x ? *reinterpret_cast<const lu32x4 *>(xrow + chunk * 128 + q * 32) : lu32x4{0, 0, 0, 0};
+        for (int q = 0; q < 4 * CH; ++q)
+            xb[s][q] = has_x ? *reinterpret_cast<const lu32x4 *>(xrow + chunk * 128 * CH + q * 32) : lu32x4{0, 0, 0, 0};
     };
     lf32x4 acc[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = lf32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int s) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4 * CH; ++q)
 #pragma unroll
             for (int r = 0; r < RT; ++r) acc[r] = lin_mfma<T>(wb[s][r][q], xb[s][q], acc[r]);
     };
@@ -135,6 +136,8 @@ template <typename T> __global__ void __launch_bounds__(256) linear_reduce_kerne
     *reinterpret_cast<uint2 *>(p.y + row * p.y_row_stride + n) = o;
 }
 
+// 512 bytes per weight-row visit (two 128-input chunks per pipeline stage) when the split allows: +2-5 % over 256
+static const int linear_ch = getenv("ATOMA_LINEAR_CH") ? atoi(getenv("ATOMA_LINEAR_CH")) : 2;
 template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
     const int64_t chunks = p.k / 128;
     const int rt = (p.batch > 2 && p.n % 64 == 0) ? 4 : 1;
@@ -151,8 +154,10 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
         if (!p.partial) return -1;
     }
     const dim3 grid((unsigned)(tiles_n * p.splits));
-    if (rt == 4) hipLaunchKernelGGL((linear_decode_kernel<T, 4, 2>), grid, dim3(64), 0, stream, p);
-    else hipLaunchKernelGGL((linear_decode_kernel<T, 1, 3>), grid, dim3(64), 0, stream, p);
+    const int ch = (rt == 1 && p.chunks_per_split % 2 == 0 && chunks % 2 == 0) ? linear_ch : 1;
+    if (rt == 4) hipLaunchKernelGGL((linear_decode_kernel<T, 4, 2, 1>), grid, dim3(64), 0, stream, p);
+    else if (ch == 2) hipLaunchKernelGGL((linear_decode_kernel<T, 1, 2, 2>), grid, dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL((linear_decode_kernel<T, 1, 3, 1>), grid, dim3(64), 0, stream, p);
     if (!ATOMA_CHECK_LAUNCH("linear_decode_kernel")) return -1;
     if (p.splits > 1) {
         hipLaunchKernelGGL((linear_reduce_kernel<T>), dim3((unsigned)cdiv((int64_t)p.batch * p.n, 1024)), dim3(256), 0, stream, p);
