@@ -175,6 +175,17 @@ int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head
 int atoma_linear_decode(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
                         int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream);
 
+/* The element-wise ops between the kernels of a decode step.  atoma_embedding: out[t] = table[ids[t]] (ids int32 or
+ * int64, clamped to the table; models/src/llama.rs:456-458).  atoma_add: out = a + b, one rounding (residual adds,
+ * llama.rs:404,409).  atoma_silu_mul: out[t] = silu(gate[t]) * up[t] with the reference's two roundings (llama.rs:364-365);
+ * gate / up / out may be row slices of wider tensors (row strides in elements), e.g. the two halves of a fused gate_up
+ * projection.  Sizes and strides in multiples of 8 elements, 16-byte aligned tensors. */
+int atoma_embedding(const void *ids, int ids_are_i64, const void *table, void *out, int64_t num_tokens, int64_t hidden, int64_t vocab,
+                    int64_t table_row_stride, int dtype, void *stream);
+int atoma_add(const void *a, const void *b, void *out, int64_t count, int dtype, void *stream);
+int atoma_silu_mul(const void *gate, const void *up, void *out, int64_t rows, int64_t width, int64_t gate_row_stride, int64_t up_row_stride,
+                   int64_t out_row_stride, int dtype, void *stream);
+
 /* Greedy token selection on the device: out_idx[r] = argmax over logits[r, 0..vocab) (smallest index among the
  * maxima, as numpy; NaNs are never selected), out_val[r] (optional) = that logit as f32.  Replaces the per-sequence
  * `logits.i(idx)` -> LogitsProcessor::sample (ArgMax) -> `to_vec1()[next_token]` device->host copies of

@@ -1,0 +1,131 @@
+"""A whole Llama decode step on the device (tools/decode_step.py: embedding, RMSNorm, projections, RoPE + cache write,
+paged decode attention, residuals, SiLU.up, lm_head, argmax), every op replayed on the CPU oracle with the inputs the
+device op saw -- models/src/llama.rs:392-478 for decode tokens, at a small model size."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from oracle import attn_oracle as A
+from oracle import cache_oracle as CO
+from oracle import elementwise_oracle as EO
+from oracle import linear_oracle as LO
+from oracle import norm_rope_oracle as NR
+from oracle.halfs import BF16, to_f32
+from util import rand_half, ATOL_FEW_KEYS
+
+pytestmark = pytest.mark.gpu
+
+
+def ulps(a, b):
+    return int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max())
+
+
+def close_linear(got, ref, what):
+    g, r = to_f32(got, BF16), to_f32(ref, BF16)
+    assert (np.abs(g - r) <= 2.0 ** -7 * np.abs(r) + 3e-5).all(), what
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+def test_llama_decode_step_op_by_op(gpu, graph):
+    import decode_step as DS
+    rng = np.random.default_rng(11)
+    cfg = DS.Config(layers=2, hidden=512, heads=4, kv_heads=2, head_dim=128, intermediate=1024, vocab=1008, page=16, max_pos=256)
+    B = 5
+    ctx = np.array([0, 17, 40, 64, 100])                    # tokens already in the cache; the step adds one per sequence
+    lens = (ctx + 1).astype(np.int32)
+    blocks = [(int(L) + cfg.page - 1) // cfg.page for L in lens]
+    num_pages = sum(blocks) + 3
+    perm = rng.permutation(num_pages)
+    bt = np.zeros((B, max(blocks)), np.int32)
+    pos0 = 0
+    for i, n in enumerate(blocks):
+        bt[i, :n] = perm[pos0:pos0 + n]
+        pos0 += n
+    H, I = cfg.hidden, cfg.inter
+    host = dict(
+        emb=rand_half(rng, (cfg.vocab, H), BF16),
+        norm1=[rand_half(rng, (H,), BF16, 0.1) + np.uint16(0) for _ in range(cfg.layers)],
+        wqkv=[rand_half(rng, (cfg.qkv, H), BF16, H ** -0.5) for _ in range(cfg.layers)],
+        wo=[rand_half(rng, (H, cfg.h * cfg.d), BF16, (cfg.h * cfg.d) ** -0.5) for _ in range(cfg.layers)],
+        norm2=[rand_half(rng, (H,), BF16, 0.1) for _ in range(cfg.layers)],
+        wgu=[rand_half(rng, (2 * I, H), BF16, H ** -0.5) for _ in range(cfg.layers)],
+        wdown=[rand_half(rng, (H, I), BF16, I ** -0.5) for _ in range(cfg.layers)],
+        norm_f=rand_half(rng, (H,), BF16, 0.1),
+        lm_head=rand_half(rng, (cfg.vocab, H), BF16, H ** -0.5))
+    for key in ("norm1", "norm2"):                          # norm weights around 1
+        host[key] = [NR.from_f32(1 + to_f32(a, BF16), BF16) for a in host[key]]
+    host["norm_f"] = NR.from_f32(1 + to_f32(host["norm_f"], BF16), BF16)
+    st = gpu.Stream()
+    step = DS.DecodeStep(cfg, B, num_pages, bt.shape[1], DS.upload_weights(cfg, host), st, keep_intermediates=True)
+    kc0 = [rand_half(rng, (num_pages, cfg.page, cfg.hk, cfg.d), BF16) for _ in range(cfg.layers)]
+    vc0 = [rand_half(rng, (num_pages, cfg.page, cfg.hk, cfg.d), BF16) for _ in range(cfg.layers)]
+    for l in range(cfg.layers):
+        step.kc[l].upload(kc0[l])
+        step.vc[l].upload(vc0[l])
+    ids = rng.integers(0, cfg.vocab, B)
+    slots = np.array([CO.slot_mapping_for(bt[i], int(ctx[i]), int(ctx[i]) + 1, cfg.page)[0] for i in range(B)], np.int64)
+    step.set_inputs(ids, ctx, slots, lens, bt)
+    if graph:
+        step.run()                                          # eager once: split-KV workspace of this stream
+        st.synchronize()
+        for l in range(cfg.layers):                         # restore the caches the first run wrote into
+            step.kc[l].upload(kc0[l])
+            step.vc[l].upload(vc0[l])
+        with gpu.Graph.capture(st) as g:
+            step.run()
+        g.launch()
+    else:
+        step.run()
+    st.synchronize()
+
+    cos, sin = DS.rope_tables(cfg)
+    dl = lambda buf, shape: buf.numpy(np.uint16, shape)
+    hd, qw = cfg.h * cfg.d, cfg.qkv
+    name, _, t = step.trace[0]
+    x_prev = dl(t["out"], (B, H))
+    assert np.array_equal(x_prev, EO.embedding(ids, host["emb"]))
+    for (name, l, t) in step.trace[1:-1]:
+        x = dl(t["x"], (B, H))
+        assert np.array_equal(x, x_prev)
+        xn1 = dl(t["xn1"], (B, H))
+        assert ulps(xn1, NR.rms_norm(x, host["norm1"][l], cfg.eps, BF16)) <= 1
+        qkv_pre = dl(t["qkv_pre"], (B, qw))
+        close_linear(qkv_pre, LO.linear(xn1, host["wqkv"][l], BF16), f"layer {l} qkv projection")
+        qkv = dl(t["qkv"], (B, qw))
+        q_pre, k_pre = qkv_pre[:, :hd].reshape(B, cfg.h, cfg.d), qkv_pre[:, hd:hd + cfg.hk * cfg.d].reshape(B, cfg.hk, cfg.d)
+        v = np.ascontiguousarray(qkv_pre[:, hd + cfg.hk * cfg.d:]).reshape(B, cfg.hk, cfg.d)
+        q_rot, k_rot = NR.rope(q_pre, cos, sin, ctx, BF16), NR.rope(k_pre, cos, sin, ctx, BF16)
+        assert np.array_equal(qkv[:, :hd].reshape(B, cfg.h, cfg.d), q_rot) and np.array_equal(qkv[:, hd:hd + cfg.hk * cfg.d].reshape(B, cfg.hk, cfg.d), k_rot)
+        assert np.array_equal(qkv[:, hd + cfg.hk * cfg.d:], qkv_pre[:, hd + cfg.hk * cfg.d:])          # v untouched
+        kc, vc = kc0[l].copy(), vc0[l].copy()
+        CO.reshape_and_cache_flash(k_rot, v, kc, vc, slots)
+        shape = (num_pages, cfg.page, cfg.hk, cfg.d)
+        assert np.array_equal(dl(step.kc[l], shape), kc) and np.array_equal(dl(step.vc[l], shape), vc)
+        att = dl(t["att"], (B, hd))
+        ref = A.flash_attn_kv_cache(q_rot[:, None], kc, vc, cfg.d ** -0.5, BF16, bt, lens)[:, 0].reshape(B, hd)
+        a32, r32 = to_f32(att, BF16), to_f32(ref, BF16)
+        assert (np.abs(a32 - r32) <= ATOL_FEW_KEYS[BF16] + 2.0 ** -7 * np.abs(r32)).all(), f"layer {l} attention"
+        o = dl(t["o"], (B, H))
+        close_linear(o, LO.linear(att, host["wo"][l], BF16), f"layer {l} o projection")
+        x1 = dl(t["x1"], (B, H))
+        assert np.array_equal(x1, EO.add(x, o, BF16))
+        xn2 = dl(t["xn2"], (B, H))
+        assert ulps(xn2, NR.rms_norm(x1, host["norm2"][l], cfg.eps, BF16)) <= 1
+        gu = dl(t["gu"], (B, 2 * I))
+        close_linear(gu, LO.linear(xn2, host["wgu"][l], BF16), f"layer {l} gate/up projection")
+        act = dl(t["act"], (B, I))
+        assert ulps(act, EO.silu_mul(np.ascontiguousarray(gu[:, :I]), np.ascontiguousarray(gu[:, I:]), BF16)) <= 1
+        dn = dl(t["dn"], (B, H))
+        close_linear(dn, LO.linear(act, host["wdown"][l], BF16), f"layer {l} down projection")
+        x2 = dl(t["x2"], (B, H))
+        assert np.array_equal(x2, EO.add(x1, dn, BF16))
+        x_prev = x2
+    _, _, t = step.trace[-1]
+    xf = dl(t["xf"], (B, H))
+    assert ulps(xf, NR.rms_norm(x_prev, host["norm_f"], cfg.eps, BF16)) <= 1
+    logits = dl(t["logits"], (B, cfg.vocab))
+    close_linear(logits, LO.linear(xf, host["lm_head"], BF16), "lm_head")
+    assert np.array_equal(step.next_ids.numpy(np.int32, (B,)), to_f32(logits, BF16).argmax(1))

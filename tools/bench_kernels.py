@@ -5,7 +5,7 @@ Prints one JSON line per workload: achieved GB/s (HBM-bound kernels) or TFLOP/s 
 algorithmic bytes / flops it is computed from, and the fraction of the chip peak.  Timing = HIP events
 on the NULL stream around `iters` back-to-back launches after warm-up.
 
-  python tools/bench_kernels.py [decode prefill prefill_paged cache norm sampling linear graph swap]   (default: all)
+  python tools/bench_kernels.py [decode prefill prefill_paged cache norm sampling linear graph step swap]   (default: all)
 """
 import ctypes as C
 import json
@@ -270,6 +270,52 @@ def bench_linear():
         w.free()
 
 
+def bench_step():
+    """C3-lite: one whole Llama-3.1-8B decode step on the device (tools/decode_step.py) at batch 1 and 16, context 4096,
+    synthetic bf16 weights, eager and replayed from a hipGraph.  Bytes = weights read once + the KV cache of the batch."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import decode_step as DS
+    rng = np.random.default_rng(9)
+    c = DS.LLAMA_3_1_8B
+    cos, sin = DS.rope_tables(c)
+    w = dict(emb=rand_dev(rng, c.vocab * c.hidden * 2), lm_head=rand_dev(rng, c.vocab * c.hidden * 2),
+             norm_f=rand_dev(rng, c.hidden * 2), cos=ah.DeviceBuffer.from_numpy(cos), sin=ah.DeviceBuffer.from_numpy(sin),
+             norm1=[rand_dev(rng, c.hidden * 2) for _ in range(c.layers)], norm2=[rand_dev(rng, c.hidden * 2) for _ in range(c.layers)],
+             wqkv=[], wo=[], wgu=[], wdown=[])
+    scaled = lambda n, k: rand_dev(rng, n * k * 2)         # N(0,1) weights: magnitudes do not matter for timing
+    for _ in range(c.layers):
+        w["wqkv"].append(scaled(c.qkv, c.hidden)); w["wo"].append(scaled(c.hidden, c.h * c.d))
+        w["wgu"].append(scaled(2 * c.inter, c.hidden)); w["wdown"].append(scaled(c.hidden, c.inter))
+    weight_bytes = 2 * (2 * c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden))
+    st = ah.Stream()
+    S = 4096
+    for B in (1, 16):
+        pps = S // c.page + 1
+        step = DS.DecodeStep(c, B, B * pps + 2, pps, w, st)
+        bt = rng.permutation(B * pps).astype(np.int32).reshape(B, pps)
+        ctx = np.full(B, S)
+        slots = bt[:, S // c.page].astype(np.int64) * c.page + S % c.page
+        step.set_inputs(rng.integers(0, c.vocab, B), ctx, slots, ctx + 1, bt)
+
+        def timed(fn, iters=5):
+            fn(); st.synchronize()
+            a, b = ah.Event(), ah.Event()
+            a.record(st.s)
+            for _ in range(iters):
+                fn()
+            b.record(st.s)
+            b.synchronize()
+            return a.elapsed_ms(b) / iters
+        ms_eager = timed(step.run)
+        with ah.Graph.capture(st) as g:
+            step.run()
+        ms_graph = timed(g.launch)
+        nbytes = weight_bytes - 2 * c.vocab * c.hidden + 2 * B * (S + 1) * c.hk * c.d * 2 * c.layers   # embedding table: B rows only
+        emit(f"E1 Llama-3.1-8B decode step, batch={B}, context {S} (hipGraph replay)", ms_graph, nbytes=nbytes, ms_eager=round(ms_eager, 4),
+             tokens_per_s=round(B / (ms_graph * 1e-3)), kernels_per_step=12 * c.layers + 4)
+        del step
+
+
 def bench_swap():
     rng = np.random.default_rng(4)
     L, page_bytes, nb = 32, 16 * 8 * 128 * 2, 2048
@@ -298,6 +344,6 @@ def bench_swap():
 
 if __name__ == "__main__":
     ah.set_device(0)
-    which = sys.argv[1:] or ["decode", "prefill", "prefill_paged", "cache", "norm", "sampling", "linear", "graph", "swap"]
+    which = sys.argv[1:] or ["decode", "prefill", "prefill_paged", "cache", "norm", "sampling", "linear", "graph", "step", "swap"]
     for w in which:
         globals()["bench_" + w]()

@@ -1,0 +1,142 @@
+"""One Llama decode step composed from the C-ABI entry points of libatoma_hip.so (test and bench plumbing).
+
+The op sequence is the reference's `Llama::forward` for decode tokens (models/src/llama.rs:392-410, 253-314, 364-365,
+456-478 and models/src/flash_attention.rs:322-469): embedding -> per layer [RMSNorm -> q/k/v projection -> RoPE(q, k) +
+KV-cache write -> paged decode attention -> o projection -> residual -> RMSNorm -> gate/up projection -> SiLU.up ->
+down projection -> residual] -> RMSNorm -> lm_head -> argmax.  q/k/v and gate/up weights are stored concatenated
+(row blocks of one matrix), which changes nothing in the arithmetic: every output row is an independent dot product.
+Batch <= 16 (atoma_linear_decode).  Everything is enqueued on one stream, so a step can be captured in a hipGraph.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "atoma-infer_amd", "bindings"))
+import atoma_hip as ah  # noqa: E402
+
+BF16 = 1
+
+
+class Config:
+    def __init__(self, layers, hidden, heads, kv_heads, head_dim, intermediate, vocab, page=16, eps=1e-5, theta=500000.0, max_pos=8192):
+        self.layers, self.hidden, self.h, self.hk, self.d = layers, hidden, heads, kv_heads, head_dim
+        self.inter, self.vocab, self.page, self.eps, self.theta, self.max_pos = intermediate, vocab, page, eps, theta, max_pos
+        self.qkv = (heads + 2 * kv_heads) * head_dim
+
+
+LLAMA_3_1_8B = Config(32, 4096, 32, 8, 128, 14336, 128256)
+
+
+class DecodeStep:
+    """Device-resident weights, caches and activations of a model + `run()` = one decode step for `batch` sequences."""
+
+    def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False):
+        c = self.cfg = cfg
+        self.B, self.stream, self.keep = batch, stream, keep_intermediates
+        self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
+        page_elems = c.page * c.hk * c.d
+        self.kc = [ah.DeviceBuffer.zeros((num_pages * page_elems,), np.uint16) for _ in range(c.layers)]
+        self.vc = [ah.DeviceBuffer.zeros((num_pages * page_elems,), np.uint16) for _ in range(c.layers)]
+        self.max_blocks = max_blocks
+        B = batch
+        self.ids = ah.DeviceBuffer.zeros((B,), np.int32)
+        self.pos = ah.DeviceBuffer.zeros((B,), np.int64)
+        self.slots = ah.DeviceBuffer.zeros((B,), np.int64)
+        self.lens = ah.DeviceBuffer.zeros((B,), np.int32)
+        self.bt = ah.DeviceBuffer.zeros((B, max_blocks), np.int32)
+        self.logits = ah.DeviceBuffer(B * c.vocab * 2)
+        self.next_ids = ah.DeviceBuffer.zeros((B,), np.int32)
+        self.next_val = ah.DeviceBuffer.zeros((B,), np.float32)
+        self.trace = []                                    # (op name, layer, dict of buffers) when keep_intermediates
+        self._bufs = {}
+
+    def _buf(self, name, layer, nbytes):
+        key = (name, layer if self.keep else 0)
+        if key not in self._bufs:
+            self._bufs[key] = ah.DeviceBuffer(nbytes)
+        return self._bufs[key]
+
+    def set_inputs(self, ids, positions, slots, seqlens, block_table):
+        self.ids.upload(np.asarray(ids, np.int32))
+        self.pos.upload(np.asarray(positions, np.int64))
+        self.slots.upload(np.asarray(slots, np.int64))
+        self.lens.upload(np.asarray(seqlens, np.int32))
+        bt = np.zeros((self.B, self.max_blocks), np.int32)
+        block_table = np.asarray(block_table, np.int32)
+        bt[:, :block_table.shape[1]] = block_table
+        self.bt.upload(bt)
+
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {ah.last_error()}")
+
+    def run(self):
+        c, B, s, L = self.cfg, self.B, self.stream.s, ah.lib
+        H, qkvw, hd = c.hidden, c.qkv, c.h * c.d
+        self.trace = []
+        x = self._buf("x_emb", 0, B * H * 2)
+        self._ok(L.atoma_embedding(self.ids.ptr, 0, self.w["emb"].ptr, x.ptr, B, H, c.vocab, H, BF16, s), "embedding")
+        if self.keep:
+            self.trace.append(("embedding", 0, dict(out=x)))
+        for l in range(c.layers):
+            xn = self._buf("xn1", l, B * H * 2)
+            self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+            qkv = self._buf("qkv", l, B * qkvw * 2)
+            self._ok(L.atoma_linear_decode(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, B, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
+            qkv_pre = None
+            if self.keep:                                   # RoPE works in place: keep the projection's output for the checker
+                qkv_pre = self._buf("qkv_pre", l, B * qkvw * 2)
+                ah.hip_check(ah.hip.hipMemcpyAsync(qkv_pre.ptr, qkv.ptr, B * qkvw * 2, 3, s), "copy")
+            kptr, vptr = qkv.ptr + hd * 2, qkv.ptr + (hd + c.hk * c.d) * 2
+            self._ok(L.atoma_rope_qk_cache(qkv.ptr, kptr, vptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr, self.w["cos"].ptr,
+                                           self.w["sin"].ptr, self.pos.ptr, B, c.h, c.hk, c.d, qkvw, qkvw, qkvw, c.page * c.hk * c.d,
+                                           c.page, BF16, 1, s), "rope + cache write")
+            att = self._buf("att", l, B * hd * 2)
+            ah.run_mha(qkv, self.kc[l], self.vc[l], att, b=B, h=c.h, h_k=c.hk, d=c.d, seqlen_q=1, seqlen_k=self.max_blocks * c.page,
+                       softmax_scale=c.d ** -0.5, is_bf16=BF16, q_strides=(qkvw, qkvw, c.d), o_strides=(hd, hd, c.d),
+                       k_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d), v_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d),
+                       cu_seqlens_k=self.lens, is_seqlens_k_cumulative=False, block_table=self.bt, block_table_batch_stride=self.max_blocks,
+                       page_block_size=c.page, force_split_kernel=True, unpadded_lse=False, stream=s)
+            o = self._buf("o", l, B * H * 2)
+            self._ok(L.atoma_linear_decode(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
+            x1 = self._buf("x1", l, B * H * 2)
+            self._ok(L.atoma_add(x.ptr, o.ptr, x1.ptr, B * H, BF16, s), "residual add")
+            xn2 = self._buf("xn2", l, B * H * 2)
+            self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+            gu = self._buf("gu", l, B * 2 * c.inter * 2)
+            self._ok(L.atoma_linear_decode(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
+            act = self._buf("act", l, B * c.inter * 2)
+            self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
+            dn = self._buf("dn", l, B * H * 2)
+            self._ok(L.atoma_linear_decode(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
+            x2 = self._buf("x2", l, B * H * 2)
+            self._ok(L.atoma_add(x1.ptr, dn.ptr, x2.ptr, B * H, BF16, s), "residual add")
+            if self.keep:
+                self.trace.append(("layer", l, dict(x=x, xn1=xn, qkv_pre=qkv_pre, qkv=qkv, att=att, o=o, x1=x1, xn2=xn2, gu=gu, act=act, dn=dn, x2=x2)))
+            x = x2
+        xf = self._buf("xf", 0, B * H * 2)
+        self._ok(L.atoma_rms_norm(x.ptr, self.w["norm_f"].ptr, xf.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+        self._ok(L.atoma_linear_decode(xf.ptr, self.w["lm_head"].ptr, self.logits.ptr, B, H, c.vocab, H, H, c.vocab, BF16, s), "lm_head")
+        self._ok(L.atoma_argmax_rows(self.logits.ptr, B, c.vocab, c.vocab, BF16, self.next_ids.ptr, self.next_val.ptr, s), "argmax")
+        if self.keep:
+            self.trace.append(("head", 0, dict(x=x, xf=xf, logits=self.logits)))
+
+
+def rope_tables(cfg):
+    from oracle import norm_rope_oracle as NR
+    return NR.rope_table(cfg.max_pos, cfg.d, cfg.theta, BF16)
+
+
+def upload_weights(cfg, host):
+    """host: dict of numpy uint16 arrays (emb, norm1[l], wqkv[l], wo[l], norm2[l], wgu[l], wdown[l], norm_f, lm_head)."""
+    up = ah.DeviceBuffer.from_numpy
+    w = {k: up(v) for k, v in host.items() if not isinstance(v, list)}
+    for k, v in host.items():
+        if isinstance(v, list):
+            w[k] = [up(a) for a in v]
+    cos, sin = rope_tables(cfg)
+    w["cos"], w["sin"] = up(cos), up(sin)
+    return w
