@@ -92,6 +92,8 @@ _opt("atoma_rope_qk_cache", [_vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _i64p, _i
 _opt("atoma_embedding", [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_add", [_vp, _vp, _vp, _i64, _int, _vp])
 _opt("atoma_silu_mul", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp])
+_opt("atoma_linear_decode_residual", [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
+_opt("atoma_linear_decode_silu_mul", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_linear_decode", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_topk_rows", [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp])
 _opt("atoma_argmax_rows", [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp])

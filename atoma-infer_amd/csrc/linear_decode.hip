@@ -39,6 +39,9 @@ struct LinearParams {
     float *partial;              // [splits][batch][n] fp32, or null when splits == 1
     int64_t x_row_stride, w_row_stride, y_row_stride;   // elements
     int batch, n, k, splits, chunks_per_split;           // chunk = 128 inputs
+    int epilogue;                // 0 none; 1 out = round(y) + aux (residual add); 2 out[:, i] = silu(y[:, i]) * y[:, n/2 + i] (stacked gate / up)
+    const uint16_t *aux;         // epilogue 1: the residual [batch, n]
+    int64_t aux_row_stride;
 };
 
 // lane = 16.grp + col.  A operand: W[n0 + 16r + col][k0 + 32s + 8.grp ..+7] for the RT row tiles r of the wave;
@@ -120,20 +123,35 @@ __global__ void __launch_bounds__(64) linear_decode_kernel(const LinearParams p)
     }
 }
 
-// y[b][n] = round(sum over splits of the fp32 partials); 4 outputs per thread
-template <typename T> __global__ void __launch_bounds__(256) linear_reduce_kernel(const LinearParams p) {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4, total = (int64_t)p.batch * p.n;
-    if (i >= total) return;
+// y[b][n] = round(sum over splits of the fp32 partials); 4 outputs per thread.  The epilogues keep the reference's
+// rounding points: the projection's output is rounded to the storage dtype first, then the next op is applied and rounds again.
+template <typename T> __device__ __forceinline__ float4 linear_sum_splits(const LinearParams &p, int64_t i, int64_t total) {
     float4 a = *reinterpret_cast<const float4 *>(p.partial + i);
     for (int s = 1; s < p.splits; ++s) {
         const float4 b = *reinterpret_cast<const float4 *>(p.partial + (int64_t)s * total + i);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
-    const int64_t row = i / p.n, n = i - row * p.n;
-    uint2 o;
-    o.x = pack2<T>(a.x, a.y);
-    o.y = pack2<T>(a.z, a.w);
-    *reinterpret_cast<uint2 *>(p.y + row * p.y_row_stride + n) = o;
+    return make_float4(round_through<T>(a.x), round_through<T>(a.y), round_through<T>(a.z), round_through<T>(a.w));
+}
+template <typename T> __global__ void __launch_bounds__(256) linear_reduce_kernel(const LinearParams p) {
+    const int64_t total = (int64_t)p.batch * p.n;
+    const int out_n = p.epilogue == 2 ? p.n / 2 : p.n;
+    const int64_t o = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;      // index into the [batch, out_n] result
+    if (o >= (int64_t)p.batch * out_n) return;
+    const int64_t row = o / out_n, n = o - row * out_n;
+    float4 a = linear_sum_splits<T>(p, row * p.n + n, total);
+    if (p.epilogue == 1) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(p.aux + row * p.aux_row_stride + n);
+        a.x += lo_to_f32<T>(r.x); a.y += hi_to_f32<T>(r.x); a.z += lo_to_f32<T>(r.y); a.w += hi_to_f32<T>(r.y);
+    } else if (p.epilogue == 2) {
+        const float4 u = linear_sum_splits<T>(p, row * p.n + out_n + n, total);
+        auto silu = [](float g) { return round_through<T>(g / (1.f + __expf(-g))); };
+        a.x = silu(a.x) * u.x; a.y = silu(a.y) * u.y; a.z = silu(a.z) * u.z; a.w = silu(a.w) * u.w;
+    }
+    uint2 w;
+    w.x = pack2<T>(a.x, a.y);
+    w.y = pack2<T>(a.z, a.w);
+    *reinterpret_cast<uint2 *>(p.y + row * p.y_row_stride + n) = w;
 }
 
 // 512 bytes per weight-row visit (two 128-input chunks per pipeline stage) when the split allows: +2-5 % over 256
@@ -149,7 +167,7 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
     p.chunks_per_split = (int)cdiv(chunks, splits);
     p.splits = (int)cdiv(chunks, p.chunks_per_split);
     p.partial = nullptr;
-    if (p.splits > 1) {
+    if (p.splits > 1 || p.epilogue != 0) {   // an epilogue always runs in the reduce kernel (it needs whole rows of y)
         p.partial = static_cast<float *>(workspace(stream, (size_t)p.splits * p.batch * p.n * sizeof(float)));
         if (!p.partial) return -1;
     }
@@ -159,7 +177,7 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
     else if (ch == 2) hipLaunchKernelGGL((linear_decode_kernel<T, 1, 2, 2>), grid, dim3(64), 0, stream, p);
     else hipLaunchKernelGGL((linear_decode_kernel<T, 1, 3, 1>), grid, dim3(64), 0, stream, p);
     if (!ATOMA_CHECK_LAUNCH("linear_decode_kernel")) return -1;
-    if (p.splits > 1) {
+    if (p.partial) {
         hipLaunchKernelGGL((linear_reduce_kernel<T>), dim3((unsigned)cdiv((int64_t)p.batch * p.n, 1024)), dim3(256), 0, stream, p);
         if (!ATOMA_CHECK_LAUNCH("linear_reduce_kernel")) return -1;
     }
@@ -168,15 +186,23 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
 
 }  // namespace atoma
 
-extern "C" int atoma_linear_decode(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
-                                   int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream) {
+static int linear_decode_entry(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
+                               int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int epilogue, const void *aux,
+                               int64_t aux_row_stride, int dtype, void *stream) {
     using namespace atoma;
     clear_error();
     if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("linear_decode: dtype must be f16 or bf16"); return -1; }
     if (batch < 0 || batch > 16) { set_error("linear_decode: batch must be in [0, 16] (larger batches are a GEMM, not a weight stream)"); return -1; }
     if (in_features <= 0 || in_features % 128 != 0) { set_error("linear_decode: in_features must be a positive multiple of 128"); return -1; }
     if (out_features <= 0 || out_features % 16 != 0) { set_error("linear_decode: out_features must be a positive multiple of 16"); return -1; }
-    if (x_row_stride < in_features || w_row_stride < in_features || y_row_stride < out_features) {
+    const int64_t y_width = epilogue == 2 ? out_features / 2 : out_features;
+    if (epilogue < 0 || epilogue > 2) { set_error("linear_decode: unknown epilogue"); return -1; }
+    if (epilogue == 2 && out_features % 32 != 0) { set_error("linear_decode: the silu.up epilogue needs out_features to be a multiple of 32"); return -1; }
+    if (epilogue == 1 && (!aux || aux_row_stride < out_features || aux_row_stride % 4 || (reinterpret_cast<uintptr_t>(aux) & 7u))) {
+        set_error("linear_decode: the residual epilogue needs an 8-byte aligned [batch, out_features] tensor");
+        return -1;
+    }
+    if (x_row_stride < in_features || w_row_stride < in_features || y_row_stride < y_width) {
         set_error("linear_decode: row strides must cover a row");
         return -1;
     }
@@ -192,6 +218,24 @@ extern "C" int atoma_linear_decode(const void *x, const void *w, void *y, int64_
     p.y = static_cast<uint16_t *>(y);
     p.x_row_stride = x_row_stride; p.w_row_stride = w_row_stride; p.y_row_stride = y_row_stride;
     p.batch = (int)batch; p.n = (int)out_features; p.k = (int)in_features;
+    p.epilogue = epilogue; p.aux = static_cast<const uint16_t *>(aux); p.aux_row_stride = aux_row_stride;
     const auto s = static_cast<hipStream_t>(stream);
     return dtype == ATOMA_BF16 ? launch_linear<bf16_t>(p, s) : launch_linear<f16_t>(p, s);
+}
+
+extern "C" int atoma_linear_decode(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
+                                   int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream) {
+    return linear_decode_entry(x, w, y, batch, in_features, out_features, x_row_stride, w_row_stride, y_row_stride, 0, nullptr, 0, dtype, stream);
+}
+extern "C" int atoma_linear_decode_residual(const void *x, const void *w, const void *residual, void *y, int64_t batch, int64_t in_features,
+                                            int64_t out_features, int64_t x_row_stride, int64_t w_row_stride, int64_t residual_row_stride,
+                                            int64_t y_row_stride, int dtype, void *stream) {
+    return linear_decode_entry(x, w, y, batch, in_features, out_features, x_row_stride, w_row_stride, y_row_stride, 1, residual,
+                               residual_row_stride, dtype, stream);
+}
+extern "C" int atoma_linear_decode_silu_mul(const void *x, const void *w_gate_up, void *y, int64_t batch, int64_t in_features,
+                                            int64_t intermediate, int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype,
+                                            void *stream) {
+    return linear_decode_entry(x, w_gate_up, y, batch, in_features, 2 * intermediate, x_row_stride, w_row_stride, y_row_stride, 2, nullptr, 0,
+                               dtype, stream);
 }

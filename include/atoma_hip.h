@@ -175,6 +175,16 @@ int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head
 int atoma_linear_decode(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
                         int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream);
 
+/* The same with the following op of the layer folded into the kernel that merges the K splits, keeping the reference's
+ * rounding points (projection rounded, then the op, rounded again):  _residual: y = residual + x.w^T (o_proj / down_proj
+ * followed by the residual add, llama.rs:311+404, 366+409);  _silu_mul: w_gate_up = gate rows then up rows
+ * [2.intermediate, in_features], y[b][i] = silu((x.w^T)[b][i]) * (x.w^T)[b][intermediate + i] (llama.rs:364-365). */
+int atoma_linear_decode_residual(const void *x, const void *w, const void *residual, void *y, int64_t batch, int64_t in_features,
+                                 int64_t out_features, int64_t x_row_stride, int64_t w_row_stride, int64_t residual_row_stride,
+                                 int64_t y_row_stride, int dtype, void *stream);
+int atoma_linear_decode_silu_mul(const void *x, const void *w_gate_up, void *y, int64_t batch, int64_t in_features, int64_t intermediate,
+                                 int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream);
+
 /* The element-wise ops between the kernels of a decode step.  atoma_embedding: out[t] = table[ids[t]] (ids int32 or
  * int64, clamped to the table; models/src/llama.rs:456-458).  atoma_add: out = a + b, one rounding (residual adds,
  * llama.rs:404,409).  atoma_silu_mul: out[t] = silu(gate[t]) * up[t] with the reference's two roundings (llama.rs:364-365);

@@ -129,3 +129,47 @@ def test_llama_decode_step_op_by_op(gpu, graph):
     logits = dl(t["logits"], (B, cfg.vocab))
     close_linear(logits, LO.linear(xf, host["lm_head"], BF16), "lm_head")
     assert np.array_equal(step.next_ids.numpy(np.int32, (B,)), to_f32(logits, BF16).argmax(1))
+
+
+def test_llama_decode_step_fused_epilogues_are_bit_identical(gpu):
+    """Residual adds and SiLU.up folded into the projections' split merge keep the reference's rounding points, so the
+    fused step must reproduce the op-by-op step bit for bit (logits, next tokens, caches)."""
+    import decode_step as DS
+    rng = np.random.default_rng(12)
+    cfg = DS.Config(layers=3, hidden=512, heads=4, kv_heads=2, head_dim=128, intermediate=1024, vocab=1008, page=16, max_pos=256)
+    B, ctx = 3, np.array([5, 33, 90])
+    lens = (ctx + 1).astype(np.int32)
+    blocks = [(int(L) + cfg.page - 1) // cfg.page for L in lens]
+    num_pages = sum(blocks) + 1
+    bt = np.zeros((B, max(blocks)), np.int32)
+    perm, p0 = rng.permutation(num_pages), 0
+    for i, n in enumerate(blocks):
+        bt[i, :n] = perm[p0:p0 + n]
+        p0 += n
+    H, I = cfg.hidden, cfg.inter
+    one = lambda: NR.from_f32(1 + 0.1 * rng.standard_normal(H).astype(np.float32), BF16)
+    host = dict(emb=rand_half(rng, (cfg.vocab, H), BF16), norm1=[one() for _ in range(cfg.layers)], norm2=[one() for _ in range(cfg.layers)],
+                wqkv=[rand_half(rng, (cfg.qkv, H), BF16, H ** -0.5) for _ in range(cfg.layers)],
+                wo=[rand_half(rng, (H, cfg.h * cfg.d), BF16, (cfg.h * cfg.d) ** -0.5) for _ in range(cfg.layers)],
+                wgu=[rand_half(rng, (2 * I, H), BF16, H ** -0.5) for _ in range(cfg.layers)],
+                wdown=[rand_half(rng, (H, I), BF16, I ** -0.5) for _ in range(cfg.layers)], norm_f=one(),
+                lm_head=rand_half(rng, (cfg.vocab, H), BF16, H ** -0.5))
+    w = DS.upload_weights(cfg, host)
+    st = gpu.Stream()
+    kc0 = [rand_half(rng, (num_pages, cfg.page, cfg.hk, cfg.d), BF16) for _ in range(cfg.layers)]
+    vc0 = [rand_half(rng, (num_pages, cfg.page, cfg.hk, cfg.d), BF16) for _ in range(cfg.layers)]
+    ids = rng.integers(0, cfg.vocab, B)
+    slots = np.array([CO.slot_mapping_for(bt[i], int(ctx[i]), int(ctx[i]) + 1, cfg.page)[0] for i in range(B)], np.int64)
+    res = []
+    for fused in (False, True):
+        step = DS.DecodeStep(cfg, B, num_pages, bt.shape[1], w, st, fused_epilogues=fused)
+        for l in range(cfg.layers):
+            step.kc[l].upload(kc0[l])
+            step.vc[l].upload(vc0[l])
+        step.set_inputs(ids, ctx, slots, lens, bt)
+        step.run()
+        st.synchronize()
+        res.append((step.logits.numpy(np.uint16, (B, cfg.vocab)), step.next_ids.numpy(np.int32, (B,)),
+                    [step.kc[l].numpy(np.uint16) for l in range(cfg.layers)]))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][2], res[1][2]))

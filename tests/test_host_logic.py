@@ -66,3 +66,16 @@ def test_linear_oracle_small_known_case_and_rounding():
     got = to_f32(LO.linear(from_f32(xf, F16), from_f32(wf, F16), F16), F16)
     ref = to_f32(from_f32(xf, F16), F16).astype(np.float64) @ to_f32(from_f32(wf, F16), F16).astype(np.float64).T
     assert np.abs(got - ref).max() <= 2.0 ** -10 * np.abs(ref).max()
+
+
+def test_elementwise_oracle_known_values():
+    import numpy as np
+    from oracle import elementwise_oracle as EO
+    from oracle.halfs import BF16, from_f32, to_f32
+    table = from_f32(np.arange(12, dtype=np.float32).reshape(4, 3), BF16)
+    assert to_f32(EO.embedding([2, 0, 2], table), BF16).tolist() == [[6, 7, 8], [0, 1, 2], [6, 7, 8]]
+    a, b = from_f32(np.array([1.0, 256.0], np.float32), BF16), from_f32(np.array([2.0, 1.0], np.float32), BF16)
+    assert to_f32(EO.add(a, b, BF16), BF16).tolist() == [3.0, 256.0]          # 257 rounds to even: 256
+    g, u = from_f32(np.array([0.0, 20.0, -20.0], np.float32), BF16), from_f32(np.array([3.0, 2.0, 5.0], np.float32), BF16)
+    out = to_f32(EO.silu_mul(g, u, BF16), BF16)
+    assert out[0] == 0.0 and out[1] == 40.0 and abs(out[2]) < 1e-6            # silu(0)=0, silu(20)~20, silu(-20)~-4e-8

@@ -86,3 +86,31 @@ def test_linear_decode_rejects_bad_arguments(gpu):
     assert call(xs=64) == -1 and "strides" in gpu.last_error()
     assert call(dt=2) == -1 and "dtype" in gpu.last_error()
     assert call(B=0) == 0
+
+
+def test_linear_decode_fused_epilogues_match_the_separate_ops(gpu):
+    """_residual and _silu_mul keep the rounding points of the separate ops, so they must reproduce
+    atoma_linear_decode followed by atoma_add / atoma_silu_mul bit for bit; and both agree with the oracle chain."""
+    from oracle import elementwise_oracle as EO
+    rng = np.random.default_rng(21)
+    B, K, N, I = 7, 1024, 512, 768
+    x = rand_half(rng, (B, K), BF16)
+    w = rand_half(rng, (N, K), BF16, K ** -0.5)
+    res = rand_half(rng, (B, N), BF16)
+    wgu = rand_half(rng, (2 * I, K), BF16, K ** -0.5)
+    dx, dw, dr, dwgu = (gpu.DeviceBuffer.from_numpy(a) for a in (x, w, res, wgu))
+    y, y2, gu, act, act2 = (gpu.DeviceBuffer(n * 2) for n in (B * N, B * N, B * 2 * I, B * I, B * I))
+    L = gpu.lib
+    assert L.atoma_linear_decode(dx.ptr, dw.ptr, y.ptr, B, K, N, K, K, N, BF16, None) == 0
+    assert L.atoma_add(y.ptr, dr.ptr, y.ptr, B * N, BF16, None) == 0
+    assert L.atoma_linear_decode_residual(dx.ptr, dw.ptr, dr.ptr, y2.ptr, B, K, N, K, K, N, N, BF16, None) == 0, gpu.last_error()
+    assert L.atoma_linear_decode(dx.ptr, dwgu.ptr, gu.ptr, B, K, 2 * I, K, K, 2 * I, BF16, None) == 0
+    assert L.atoma_silu_mul(gu.ptr, gu.ptr + I * 2, act.ptr, B, I, 2 * I, 2 * I, I, BF16, None) == 0
+    assert L.atoma_linear_decode_silu_mul(dx.ptr, dwgu.ptr, act2.ptr, B, K, I, K, K, I, BF16, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    assert np.array_equal(y.numpy(np.uint16, (B, N)), y2.numpy(np.uint16, (B, N)))
+    assert np.array_equal(act.numpy(np.uint16, (B, I)), act2.numpy(np.uint16, (B, I)))
+    g = gu.numpy(np.uint16, (B, 2 * I))
+    ref_act = EO.silu_mul(np.ascontiguousarray(g[:, :I]), np.ascontiguousarray(g[:, I:]), BF16)
+    d = np.abs(act.numpy(np.uint16, (B, I)).astype(np.int32) - ref_act.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01

@@ -291,7 +291,7 @@ def bench_step():
     S = 4096
     for B in (1, 16):
         pps = S // c.page + 1
-        step = DS.DecodeStep(c, B, B * pps + 2, pps, w, st)
+        step = DS.DecodeStep(c, B, B * pps + 2, pps, w, st, fused_epilogues=True)
         bt = rng.permutation(B * pps).astype(np.int32).reshape(B, pps)
         ctx = np.full(B, S)
         slots = bt[:, S // c.page].astype(np.int64) * c.page + S % c.page
@@ -312,7 +312,7 @@ def bench_step():
         ms_graph = timed(g.launch)
         nbytes = weight_bytes - 2 * c.vocab * c.hidden + 2 * B * (S + 1) * c.hk * c.d * 2 * c.layers   # embedding table: B rows only
         emit(f"E1 Llama-3.1-8B decode step, batch={B}, context {S} (hipGraph replay)", ms_graph, nbytes=nbytes, ms_eager=round(ms_eager, 4),
-             tokens_per_s=round(B / (ms_graph * 1e-3)), kernels_per_step=12 * c.layers + 4)
+             tokens_per_s=round(B / (ms_graph * 1e-3)), kernels_per_step="13 per layer + 5 (residual adds and SiLU.up folded into the projections' split merge)")
         del step
 
 

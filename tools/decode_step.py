@@ -33,9 +33,10 @@ LLAMA_3_1_8B = Config(32, 4096, 32, 8, 128, 14336, 128256)
 class DecodeStep:
     """Device-resident weights, caches and activations of a model + `run()` = one decode step for `batch` sequences."""
 
-    def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False):
+    def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False, fused_epilogues=False):
         c = self.cfg = cfg
         self.B, self.stream, self.keep = batch, stream, keep_intermediates
+        self.fused = fused_epilogues and not keep_intermediates   # residual adds and SiLU.up inside the projections' split merge
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
         page_elems = c.page * c.hk * c.d
         self.kc = [ah.DeviceBuffer.zeros((num_pages * page_elems,), np.uint16) for _ in range(c.layers)]
@@ -100,20 +101,28 @@ class DecodeStep:
                        k_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d), v_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d),
                        cu_seqlens_k=self.lens, is_seqlens_k_cumulative=False, block_table=self.bt, block_table_batch_stride=self.max_blocks,
                        page_block_size=c.page, force_split_kernel=True, unpadded_lse=False, stream=s)
-            o = self._buf("o", l, B * H * 2)
-            self._ok(L.atoma_linear_decode(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
             x1 = self._buf("x1", l, B * H * 2)
-            self._ok(L.atoma_add(x.ptr, o.ptr, x1.ptr, B * H, BF16, s), "residual add")
             xn2 = self._buf("xn2", l, B * H * 2)
-            self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
-            gu = self._buf("gu", l, B * 2 * c.inter * 2)
-            self._ok(L.atoma_linear_decode(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
             act = self._buf("act", l, B * c.inter * 2)
-            self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
-            dn = self._buf("dn", l, B * H * 2)
-            self._ok(L.atoma_linear_decode(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
-            x2 = self._buf("x2", l, B * H * 2)
-            self._ok(L.atoma_add(x1.ptr, dn.ptr, x2.ptr, B * H, BF16, s), "residual add")
+            # ping-pong the residual stream so that no kernel reads and writes the same buffer
+            x2 = self._buf("x2", l, B * H * 2) if self.keep else self._buf("x2a" if l % 2 == 0 else "x2b", 0, B * H * 2)
+            o = gu = dn = None
+            if self.fused:
+                self._ok(L.atoma_linear_decode_residual(att.ptr, self.w["wo"][l].ptr, x.ptr, x1.ptr, B, hd, H, hd, hd, H, H, BF16, s), "o projection + residual")
+                self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+                self._ok(L.atoma_linear_decode_silu_mul(xn2.ptr, self.w["wgu"][l].ptr, act.ptr, B, H, c.inter, H, H, c.inter, BF16, s), "gate/up projection + silu * up")
+                self._ok(L.atoma_linear_decode_residual(act.ptr, self.w["wdown"][l].ptr, x1.ptr, x2.ptr, B, c.inter, H, c.inter, c.inter, H, H, BF16, s), "down projection + residual")
+            else:
+                o = self._buf("o", l, B * H * 2)
+                self._ok(L.atoma_linear_decode(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
+                self._ok(L.atoma_add(x.ptr, o.ptr, x1.ptr, B * H, BF16, s), "residual add")
+                self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+                gu = self._buf("gu", l, B * 2 * c.inter * 2)
+                self._ok(L.atoma_linear_decode(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
+                self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
+                dn = self._buf("dn", l, B * H * 2)
+                self._ok(L.atoma_linear_decode(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
+                self._ok(L.atoma_add(x1.ptr, dn.ptr, x2.ptr, B * H, BF16, s), "residual add")
             if self.keep:
                 self.trace.append(("layer", l, dict(x=x, xn1=xn, qkv_pre=qkv_pre, qkv=qkv, att=att, o=o, x1=x1, xn2=xn2, gu=gu, act=act, dn=dn, x2=x2)))
             x = x2
