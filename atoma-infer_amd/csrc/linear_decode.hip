@@ -1,7 +1,7 @@
-// Linear layer of a decode step at small batch: y[b][n] = sum_k x[b][k] * w[n][k], batch <= 16.
+// Linear layer of a decode step at small batch: y[b][n] = sum_k x[b][k] * w[n][k], batch <= 64.
 //
 // Replaces candle_nn::Linear::forward on [B, hidden] activations (/root/reference/models/src/llama.rs:269-271,311,364-365:
-// q/k/v/o and the MLP projections), i.e. a cuBLAS GEMM with 1..16 rows.  At these sizes the op is a stream over the
+// q/k/v/o and the MLP projections), i.e. a cuBLAS GEMM with 1..64 rows.  At these sizes the op is a stream over the
 // weights -- 2.N.K bytes read once, 2.B flop per byte -- so it is laid out around the weight stream like the decode
 // attention kernel, and the arithmetic rides along on the matrix cores: a 16 x 32 slab of W (16 output features,
 // 32 inputs, 1 KiB = one 16-byte load per lane) is the A operand of one v_mfma_f32_16x16x32, x^T (zero-padded to 16
@@ -45,10 +45,11 @@ struct LinearParams {
 };
 
 // lane = 16.grp + col.  A operand: W[n0 + 16r + col][k0 + 32s + 8.grp ..+7] for the RT row tiles r of the wave;
-// B operand: x[col][same k], shared by the RT tiles; result: lane holds y^T[n0 + 16r + 4.grp + i][batch col], i = 0..3.
+// B operand: x[16c + col][same k] for the CT column tiles c (batch rows 16c .. 16c+15), each shared by the RT row tiles;
+// result: lane holds y^T[n0 + 16r + 4.grp + i][batch 16c + col], i = 0..3.
 // RT = 4 when more than a couple of batch rows are live: every wave re-reads x (from L2), and with one row tile per
-// wave that is as many load instructions as the weight stream itself.
-template <typename T, int RT, int P, int CH>   // CH: 128-input chunks per pipeline stage (bytes per row visit = 256.CH)
+// wave that is as many load instructions as the weight stream itself.  CT > 1 (batch 17..64): RT = 2.
+template <typename T, int RT, int CT, int P, int CH>   // CH: 128-input chunks per pipeline stage (bytes per row visit = 256.CH)
 __global__ void __launch_bounds__(64) linear_decode_kernel(const LinearParams p) {
     const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15;
     const int tiles_n = p.n / (16 * RT);
@@ -61,27 +62,38 @@ __global__ void __launch_bounds__(64) linear_decode_kernel(const LinearParams p)
     uint32_t w_lane[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) w_lane[r] = (uint32_t)((16 * r + col) * p.w_row_stride * 2 + grp * 16);
-    const bool has_x = col < p.batch;
-    const uint16_t *xrow = p.x + (int64_t)(has_x ? col : 0) * p.x_row_stride + grp * 8;
+    bool has_x[CT];
+    const uint16_t *xrow[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        has_x[c] = 16 * c + col < p.batch;
+        xrow[c] = p.x + (int64_t)(has_x[c] ? 16 * c + col : 0) * p.x_row_stride + grp * 8;
+    }
 
-    lu32x4 wb[P][RT][4 * CH], xb[P][4 * CH];
+    lu32x4 wb[P][RT][4 * CH], xb[P][CT][4 * CH];
     auto issue = [&](int s, int chunk) {
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
             for (int q = 0; q < 4 * CH; ++q) wb[s][r][q] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], chunk * 256 * CH + q * 64, 2 /* nt */);
 #pragma unroll
-        for (int q = 0; q < 4 * CH; ++q)
-            xb[s][q] = has_x ? *reinterpret_cast<const lu32x4 *>(xrow + chunk * 128 * CH + q * 32) : lu32x4{0, 0, 0, 0};
-    };
-    lf32x4 acc[RT];
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = lf32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < 4 * CH; ++q)
+                xb[s][c][q] = has_x[c] ? *reinterpret_cast<const lu32x4 *>(xrow[c] + chunk * 128 * CH + q * 32) : lu32x4{0, 0, 0, 0};
+    };
+    lf32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = lf32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int s) {
 #pragma unroll
         for (int q = 0; q < 4 * CH; ++q)
 #pragma unroll
-            for (int r = 0; r < RT; ++r) acc[r] = lin_mfma<T>(wb[s][r][q], xb[s][q], acc[r]);
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[r][c] = lin_mfma<T>(wb[s][r][q], xb[s][c][q], acc[r][c]);
     };
     // software pipeline: P chunks in flight; unconditional loads in the steady state keep the vmcnt waits exact
     int c = c0;
@@ -108,17 +120,22 @@ __global__ void __launch_bounds__(64) linear_decode_kernel(const LinearParams p)
                 if (c + s + P < c1) issue(s, c + s + P);
             }
     }
-    if (!has_x) return;
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int n = n0 + 16 * r + 4 * grp;
-        if (p.partial) {
-            *reinterpret_cast<float4 *>(p.partial + ((int64_t)split * p.batch + col) * p.n + n) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-        } else {
-            uint2 o;
-            o.x = pack2<T>(acc[r][0], acc[r][1]);
-            o.y = pack2<T>(acc[r][2], acc[r][3]);
-            *reinterpret_cast<uint2 *>(p.y + (int64_t)col * p.y_row_stride + n) = o;
+    for (int ct = 0; ct < CT; ++ct) {
+        if (!has_x[ct]) continue;
+        const int brow = 16 * ct + col;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int n = n0 + 16 * r + 4 * grp;
+            const lf32x4 a = acc[r][ct];
+            if (p.partial) {
+                *reinterpret_cast<float4 *>(p.partial + ((int64_t)split * p.batch + brow) * p.n + n) = make_float4(a[0], a[1], a[2], a[3]);
+            } else {
+                uint2 o;
+                o.x = pack2<T>(a[0], a[1]);
+                o.y = pack2<T>(a[2], a[3]);
+                *reinterpret_cast<uint2 *>(p.y + (int64_t)brow * p.y_row_stride + n) = o;
+            }
         }
     }
 }
@@ -158,11 +175,13 @@ template <typename T> __global__ void __launch_bounds__(256) linear_reduce_kerne
 static const int linear_ch = getenv("ATOMA_LINEAR_CH") ? atoi(getenv("ATOMA_LINEAR_CH")) : 2;
 template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
     const int64_t chunks = p.k / 128;
-    const int rt = (p.batch > 2 && p.n % 64 == 0) ? 4 : 1;
+    const int ct = (p.batch + 15) / 16;                                          // column tiles of 16 batch rows
+    // row tiles per wave: bounded by the 256 registers of two wavefronts per SIMD (x fragments: 16 registers per column tile and chunk in flight)
+    const int rt = ct > 1 ? ((ct < 4 && p.n % 32 == 0) ? 2 : 1) : ((p.batch > 2 && p.n % 64 == 0) ? 4 : 1);
     const int64_t tiles_n = p.n / (16 * rt);
-    // split K until about 8 (rt = 1) / 4 (rt = 4: four times the bytes in flight per wave) wavefronts per CU stream the
-    // weights, never below 4 chunks (512 inputs) per split
-    const int64_t target = (int64_t)device_num_cus() * (rt == 4 ? 4 : 8);
+    // split K until about 8 (one row tile) / 4 (more bytes in flight per wave) wavefronts per CU stream the weights,
+    // never below 4 chunks (512 inputs) per split
+    const int64_t target = (int64_t)device_num_cus() * (rt > 1 ? 4 : 8);
     int64_t splits = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(tiles_n, 1), chunks / 4));
     p.chunks_per_split = (int)cdiv(chunks, splits);
     p.splits = (int)cdiv(chunks, p.chunks_per_split);
@@ -172,10 +191,21 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
         if (!p.partial) return -1;
     }
     const dim3 grid((unsigned)(tiles_n * p.splits));
-    const int ch = (rt == 1 && p.chunks_per_split % 2 == 0 && chunks % 2 == 0) ? linear_ch : 1;
-    if (rt == 4) hipLaunchKernelGGL((linear_decode_kernel<T, 4, 2, 1>), grid, dim3(64), 0, stream, p);
-    else if (ch == 2) hipLaunchKernelGGL((linear_decode_kernel<T, 1, 2, 2>), grid, dim3(64), 0, stream, p);
-    else hipLaunchKernelGGL((linear_decode_kernel<T, 1, 3, 1>), grid, dim3(64), 0, stream, p);
+    const int ch = (rt == 1 && ct == 1 && p.chunks_per_split % 2 == 0 && chunks % 2 == 0) ? linear_ch : 1;
+#define ATOMA_LIN(RT_, CT_, P_, CH_) hipLaunchKernelGGL((linear_decode_kernel<T, RT_, CT_, P_, CH_>), grid, dim3(64), 0, stream, p)
+    if (ct == 1) {
+        if (rt == 4) ATOMA_LIN(4, 1, 2, 1);
+        else if (ch == 2) ATOMA_LIN(1, 1, 2, 2);
+        else ATOMA_LIN(1, 1, 3, 1);
+    } else if (rt == 2) {
+        if (ct == 2) ATOMA_LIN(2, 2, 2, 1);
+        else ATOMA_LIN(2, 3, 2, 1);
+    } else {
+        if (ct == 2) ATOMA_LIN(1, 2, 2, 1);
+        else if (ct == 3) ATOMA_LIN(1, 3, 2, 1);
+        else ATOMA_LIN(1, 4, 2, 1);
+    }
+#undef ATOMA_LIN
     if (!ATOMA_CHECK_LAUNCH("linear_decode_kernel")) return -1;
     if (p.partial) {
         hipLaunchKernelGGL((linear_reduce_kernel<T>), dim3((unsigned)cdiv((int64_t)p.batch * p.n, 1024)), dim3(256), 0, stream, p);
@@ -192,7 +222,7 @@ static int linear_decode_entry(const void *x, const void *w, void *y, int64_t ba
     using namespace atoma;
     clear_error();
     if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("linear_decode: dtype must be f16 or bf16"); return -1; }
-    if (batch < 0 || batch > 16) { set_error("linear_decode: batch must be in [0, 16] (larger batches are a GEMM, not a weight stream)"); return -1; }
+    if (batch < 0 || batch > 64) { set_error("linear_decode: batch must be in [0, 64] (larger batches are a GEMM, not a weight stream)"); return -1; }
     if (in_features <= 0 || in_features % 128 != 0) { set_error("linear_decode: in_features must be a positive multiple of 128"); return -1; }
     if (out_features <= 0 || out_features % 16 != 0) { set_error("linear_decode: out_features must be a positive multiple of 16"); return -1; }
     const int64_t y_width = epilogue == 2 ? out_features / 2 : out_features;

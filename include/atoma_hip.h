@@ -167,8 +167,8 @@ int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head
                      float rope_theta, float rope_factor, float low_freq_factor,
                      float high_freq_factor, int64_t original_max_position_embeddings, int dtype);
 
-/* Linear layer of a decode step at small batch: y[b][n] = sum_k x[b][k] * w[n][k] for batch <= 16, fp32 accumulation,
- * one rounding to dtype.  Replaces candle_nn::Linear::forward (a cuBLAS GEMM with 1..16 rows) for the q/k/v/o and MLP
+/* Linear layer of a decode step at small batch: y[b][n] = sum_k x[b][k] * w[n][k] for batch <= 64, fp32 accumulation,
+ * one rounding to dtype.  Replaces candle_nn::Linear::forward (a cuBLAS GEMM with 1..64 rows) for the q/k/v/o and MLP
  * projections of models/src/llama.rs:269-271,311,364-365: the weights are streamed once at HBM rate, the arithmetic runs on
  * the matrix cores.  x [batch, in_features], w [out_features, in_features] (the nn.Linear layout), y [batch, out_features];
  * row strides in elements; in_features % 128 == 0, out_features % 16 == 0. */

@@ -37,7 +37,8 @@ def check(got, ref, dtype):
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("B,K,N", [(1, 4096, 4096), (16, 4096, 6144), (3, 14336, 4096), (7, 128, 16), (16, 2048, 512), (5, 4096, 28672),
-                                   (2, 8192, 1024)])
+                                   (2, 8192, 1024), (17, 4096, 4096), (32, 2048, 6144), (33, 4096, 1024), (48, 1024, 4112), (64, 4096, 4096),
+                                   (50, 14336, 512)])
 def test_linear_decode_llama_projection_shapes(gpu, dtype, B, K, N):
     """q/k/v (fused), o, gate/up, down projection shapes of Llama-3.x 1B / 8B / 70B at batch 1..16, with and without K splitting."""
     rng = np.random.default_rng(B * 7 + K + N)
@@ -80,7 +81,7 @@ def test_linear_decode_exact_cases_and_linearity(gpu):
 def test_linear_decode_rejects_bad_arguments(gpu):
     d = gpu.DeviceBuffer(1 << 16)
     call = lambda B=1, K=128, N=16, xs=None, dt=BF16: gpu.lib.atoma_linear_decode(d.ptr, d.ptr, d.ptr, B, K, N, xs or K, K, N, dt, None)
-    assert call(B=17) == -1 and "batch" in gpu.last_error()
+    assert call(B=65) == -1 and "batch" in gpu.last_error()
     assert call(K=100) == -1 and "in_features" in gpu.last_error()
     assert call(N=24) == -1 and "out_features" in gpu.last_error()
     assert call(xs=64) == -1 and "strides" in gpu.last_error()

@@ -263,7 +263,7 @@ def bench_linear():
     rng = np.random.default_rng(8)
     for name, N, K in (("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336), ("lm_head", 128256, 4096)):
         w = rand_dev(rng, N * K * 2)
-        for B in (1, 16):
+        for B in (1, 16, 64):
             x, y = rand_dev(rng, B * K * 2), ah.DeviceBuffer(B * N * 2)
             ms = timeit(lambda: ah.lib.atoma_linear_decode(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
             emit(f"L1 linear_decode {name} [{N} x {K}] batch={B}", ms, nbytes=N * K * 2 + B * K * 2 + B * N * 2)
@@ -289,7 +289,7 @@ def bench_step():
     weight_bytes = 2 * (2 * c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden))
     st = ah.Stream()
     S = 4096
-    for B in (1, 16):
+    for B in (1, 16, 64):
         pps = S // c.page + 1
         step = DS.DecodeStep(c, B, B * pps + 2, pps, w, st, fused_epilogues=True)
         bt = rng.permutation(B * pps).astype(np.int32).reshape(B, pps)
