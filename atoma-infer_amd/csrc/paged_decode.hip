@@ -41,9 +41,6 @@
 #ifndef DECODE_DEFAULT_NT
 #define DECODE_DEFAULT_NT 1
 #endif
-#ifndef DECODE_CHUNK_TILES
-#define DECODE_CHUNK_TILES 0    // experimental: 64 = cut ragged batches into 1024-token chunks (no gain measured: see DESIGN.md 4.1)
-#endif
 
 namespace atoma {
 
@@ -67,7 +64,9 @@ struct DecodeParams {
     int seqlen_k;
     int is_seqlens_k_cumulative;
     int num_splits;        // KV splits per sequence (grid slots)
-    int chunk_tiles;       // > 0: fixed-size chunks of this many 16-token tiles, used only when the batch is ragged
+    int stream_waves;      // > 0: balanced mode available -- this many wavefronts share the batch's tiles evenly (decode_run_items)
+    int group_tile;        // q heads per wavefront (the kernel's G)
+    int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence
     float scale, scale_log2;
 };
 
@@ -95,51 +94,32 @@ template <> __device__ __forceinline__ uint32_t pack_pair<f16_t>(float lo, float
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_v));   // v_cvt_pk_f16_f32 (RNE)
 }
 
+// Read-only metadata (block table, lengths) through the constant address space: a wave-uniform index then always
+// becomes a scalar load (s_load), also inside the segment loop of the balanced mode where the compiler would
+// otherwise fall back to vector loads because output stores of the previous segment precede them.
+template <typename X> __device__ __forceinline__ X load_ro(const X *ptr) {
+    return *(const X __attribute__((address_space(4))) *)ptr;
+}
 // sequence length of batch entry b: /root/reference/csrc/kernels/block_info.h:16-23
 __device__ __forceinline__ int decode_seq_len(const DecodeParams &p, int b) {
-    if (p.seqused_k) return p.seqused_k[b];
+    if (p.seqused_k) return load_ro(p.seqused_k + b);
     if (p.cu_seqlens_k == nullptr) return p.seqlen_k;
-    if (p.is_seqlens_k_cumulative) return p.cu_seqlens_k[b + 1] - p.cu_seqlens_k[b];
-    return p.cu_seqlens_k[b];
-}
-
-// Is the batch ragged enough for fixed-size chunks to pay?  Every wavefront of the launch (and of
-// the combine kernel) evaluates this on the same data, so they all agree.  One wavefront per
-// (sequence, kv head) is perfectly balanced when all sequences are equally long and then needs no
-// split scratch and no combine; with ragged lengths the longest sequence sets the time of the
-// whole launch, so sequences are cut into chunk_tiles-sized pieces that the dispatcher balances
-// over the CUs.  Threshold: idle share (1 - mean/max) above 4 % (the combine costs ~2 %).
-__device__ __forceinline__ bool decode_batch_is_ragged(const DecodeParams &p) {
-    if (p.chunk_tiles <= 0 || (p.cu_seqlens_k == nullptr && p.seqused_k == nullptr)) return false;
-    const int lane = threadIdx.x & 63;
-    int mx = 0;
-    long long sum = 0;
-    for (int i = lane; i < p.b; i += 64) {
-        const int L = decode_seq_len(p, i);
-        mx = max(mx, L);
-        sum += L;
-    }
-#pragma unroll
-    for (int off = 32; off; off >>= 1) {
-        mx = max(mx, __shfl_xor(mx, off, 64));
-        sum += __shfl_xor(sum, off, 64);
-    }
-    return (long long)mx * p.b * 96 > sum * 100;
+    if (p.is_seqlens_k_cumulative) return load_ro(p.cu_seqlens_k + b + 1) - load_ro(p.cu_seqlens_k + b);
+    return load_ro(p.cu_seqlens_k + b);
 }
 
 // Workgroup (= one wavefront) -> (sequence, kv head, q-head chunk of the group, KV split) and the tile range it
-// owns.  The split index is slowest: the dispatcher places workgroups on CUs round-robin by index, so the
-// wavefronts that exit at once in chunk mode (split > 0 of a balanced batch, chunks past the end of a short
-// sequence) must not be interleaved with the working ones -- measured 2.5x slower with the split index in the
-// middle (only every 4th CU of an XCD got work).
+// owns.  The split index is slowest: the dispatcher places workgroups on CUs round-robin by index, so
+// wavefronts that exit at once must not be interleaved with the working ones -- measured 2.5x slower with the
+// split index in the middle (only every 4th CU of an XCD got work).
 struct DecodeWork {
     int b, hk, gc, split;
     int L, n_tiles, t0, t1;
     int64_t kv_row0;   // first row of this sequence in a varlen (cumulative) K/V tensor
+    int64_t prow;      // row of q head hq0's fp32 partial in o_accum / lse_accum (head hq0 + i: prow + i)
     bool partial;      // write fp32 partials for the combine kernel (true) or the final output (false)
 };
-__device__ __forceinline__ bool decode_map_work(const DecodeParams &p, DecodeWork &w) {
-    int id = blockIdx.x;
+__device__ __forceinline__ void decode_map_work(const DecodeParams &p, int id, DecodeWork &w) {
     const int hk_chunks = p.h_k * p.gchunks;
     const int hkc = id % hk_chunks;
     id /= hk_chunks;
@@ -148,31 +128,147 @@ __device__ __forceinline__ bool decode_map_work(const DecodeParams &p, DecodeWor
     w.hk = hkc / p.gchunks;
     w.gc = hkc % p.gchunks;
     w.L = decode_seq_len(p, w.b);
-    w.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? p.cu_seqlens_k[w.b] : 0;
+    w.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + w.b) : 0;
     w.n_tiles = (w.L + 15) >> 4;
-    if (p.chunk_tiles > 0) {
-        if (decode_batch_is_ragged(p)) {
-            w.t0 = w.split * p.chunk_tiles;
-            w.t1 = min(w.t0 + p.chunk_tiles, w.n_tiles);
-            if (w.split > 0 && w.t0 >= w.n_tiles) return false;      // this sequence has fewer chunks
-            w.partial = w.n_tiles > p.chunk_tiles;
-        } else {
-            if (w.split > 0) return false;                            // balanced batch: one wave per (sequence, kv head)
-            w.t0 = 0;
-            w.t1 = w.n_tiles;
-            w.partial = false;
-        }
-    } else {
-        const int per = (w.n_tiles + p.num_splits - 1) / p.num_splits;
-        w.t0 = w.split * per;
-        w.t1 = min(w.t0 + per, w.n_tiles);
-        w.partial = p.num_splits > 1;
-    }
-    return true;
+    const int per = (w.n_tiles + p.num_splits - 1) / p.num_splits;
+    w.t0 = w.split * per;
+    w.t1 = min(w.t0 + per, w.n_tiles);
+    w.partial = p.num_splits > 1;
+    w.prow = ((int64_t)w.split * p.b + w.b) * p.h + w.hk * p.g + w.gc * p.group_tile;
 }
 
-template <typename T, int D, int G, int P, int MINW, bool NT>
-__global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodeParams p) {
+// Balanced ("stream") mode for batches that fill the chip without KV splitting (b . h_k >= resident wavefronts / 2)
+// and whose lengths live on the device.  Why: the bandwidth of this kernel against the number of ACTIVE wavefronts
+// is concave (tools/probes/decode_curve.py: 1024 wavefronts reach 82 % of what 2048 do, 512 reach 52 %), so one
+// wavefront per (sequence, kv head) spends the second half of a ragged launch below the HBM rate, a single long
+// straggler streams alone at ~6 GB/s, and a batch of 1.2 x the resident wavefronts takes two rounds.  Instead all
+// tiles of the batch are laid on one line -- position = (kv head, q-head chunk) . T + prefix[b] + tile, T = tiles of
+// the batch -- and each of W wavefronts takes the same number of consecutive tiles (ceil(total / W), at least
+// DECODE_MIN_SHARE).  A wavefront's range covers the end of one sequence, whole sequences, and the beginning of
+// one more: whole sequences are written directly, the (at most two) cut pieces go to fp32 partial slots
+// [wavefront][first / last] and decode_combine_kernel merges the pieces of each cut sequence.  No atomics, no
+// queue, deterministic; every wavefront finishes at the same time by construction.
+// Uniform batches that are resident at once keep the one-wavefront-per-sequence path (same kernel, no partials).
+#define DECODE_STREAM_MAX_B 1024
+#define DECODE_MIN_SHARE 8
+struct DecodePlan {
+    int T;          // tiles of the batch (one kv head)
+    int share;      // tiles per wavefront
+    bool stream;    // balanced mode taken
+};
+// Prefix of tiles per sequence into LDS (cum[b], cum[p.b] = T); every wavefront computes the same plan.
+__device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, int *cum) {
+    const int lane = threadIdx.x & 63;
+    const int per = (p.b + 63) >> 6;
+    int local = 0, mx = 0;
+    for (int j = 0; j < per; ++j) {
+        const int b = lane * per + j;
+        const int n = b < p.b ? (decode_seq_len(p, b) + 15) >> 4 : 0;
+        local += n;
+        mx = max(mx, n);
+    }
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
+        mx = max(mx, __shfl_xor(mx, off, 64));
+    }
+    int run = incl - local;
+    for (int j = 0; j < per; ++j) {
+        const int b = lane * per + j;
+        if (b < p.b) {
+            cum[b] = run;
+            run += (decode_seq_len(p, b) + 15) >> 4;
+        }
+    }
+    mx = __builtin_amdgcn_readfirstlane(mx);   // every lane holds the maximum: make it a scalar for the compiler
+    DecodePlan pl;
+    pl.T = __builtin_amdgcn_readlane(incl, 63);
+    if (lane == 0) cum[p.b] = pl.T;
+    const int hk_chunks = p.h_k * p.gchunks;
+    const int64_t total = (int64_t)pl.T * hk_chunks;
+    pl.share = (int)max((total + p.stream_waves - 1) / p.stream_waves, (int64_t)DECODE_MIN_SHARE);
+    // one wavefront per (sequence, kv head) is already balanced when every sequence is (nearly) as long as the
+    // longest and all of them are resident at once: idle share 1 - mean/max below 4 %
+    const bool ragged = (int64_t)mx * p.b * 96 > (int64_t)pl.T * 100;
+    pl.stream = ragged || p.b * hk_chunks > p.stream_waves;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS writes above
+    __builtin_amdgcn_wave_barrier();
+    return pl;
+}
+
+// `item(p, wk)` is inlined exactly once.  In the balanced variant the kernel arguments are re-read through a pointer
+// the compiler cannot see through at the top of every segment: hoisting every field of DecodeParams out of the
+// segment loop costs ~20 SGPRs more than the 102 there are and the spills (v_readlane in the tile loop) cost 5 %.
+template <bool STREAM, typename F> __device__ __forceinline__ void decode_run_items(const DecodeParams &p0, F &&item) {
+    DecodeWork wk;
+    if constexpr (!STREAM) {
+        decode_map_work(p0, blockIdx.x, wk);
+        item(p0, wk);
+    } else {
+        __shared__ int cum[DECODE_STREAM_MAX_B + 1];
+        const DecodePlan pl = decode_make_plan(p0, cum);
+        if (blockIdx.x == 0) {   // for the combine kernel
+            for (int i = threadIdx.x; i <= p0.b; i += 64) p0.plan[2 + i] = cum[i];
+            if (threadIdx.x == 0) { p0.plan[0] = pl.T; p0.plan[1] = pl.stream ? 1 : 0; }
+        }
+        const bool stream = pl.stream;
+        int pos = 0, end = 1, hkc = 0, r = 0, b = 0;       // host guarantees total < 2^31
+        bool first = true;
+        if (stream) {
+            const int64_t total = (int64_t)pl.T * p0.h_k * p0.gchunks;
+            const int64_t start = (int64_t)blockIdx.x * pl.share;
+            if (start >= total) return;
+            pos = (int)start;
+            end = (int)min(start + pl.share, total);
+            hkc = pos / pl.T;
+            r = pos - hkc * pl.T;
+            int lo = 0, hi = p0.b;               // largest b with cum[b] <= r (the last of equal entries: empty sequences own no tile)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (__builtin_amdgcn_readfirstlane(cum[mid]) <= r) lo = mid; else hi = mid;   // LDS values are wave-uniform here
+            }
+            b = lo;
+        }
+        typedef const DecodeParams __attribute__((address_space(4))) *KernArg;
+        KernArg kp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+        for (;;) {
+            asm volatile("" : "+s"(kp));
+            const DecodeParams &p = *(const DecodeParams *)kp;
+            int seg = 1;
+            if (stream) {
+                const int c0 = __builtin_amdgcn_readfirstlane(cum[b]), c1 = __builtin_amdgcn_readfirstlane(cum[b + 1]);
+                seg = min(c1 - r, end - pos);
+                wk.b = b;
+                wk.hk = hkc / p.gchunks;
+                wk.gc = hkc % p.gchunks;
+                wk.split = 0;
+                wk.L = decode_seq_len(p, b);
+                wk.n_tiles = c1 - c0;
+                wk.t0 = r - c0;
+                wk.t1 = wk.t0 + seg;
+                wk.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + b) : 0;
+                wk.partial = seg != wk.n_tiles;
+                wk.prow = ((int64_t)blockIdx.x * 2 + (first ? 0 : 1)) * p.group_tile;
+            } else {
+                decode_map_work(p, blockIdx.x, wk);   // one wavefront per (sequence, kv head), final output
+            }
+            item(p, wk);
+            if (!stream) break;
+            first = false;
+            pos += seg;
+            r += seg;
+            if (pos >= end) break;
+            while (r == __builtin_amdgcn_readfirstlane(cum[b + 1])) {   // next sequence that owns tiles (or the next kv head's line)
+                if (++b == p.b) { b = 0; r = 0; ++hkc; }
+            }
+        }
+    }
+}
+
+template <typename T, int D, int G, int P, bool NT>
+__device__ __forceinline__ void paged_decode_item(const DecodeParams &p, const DecodeWork &wk) {
     constexpr int LPR = D / 8;     // lanes per row
     constexpr int RPI = 64 / LPR;  // rows per load instruction
     constexpr int IPP = 16 / RPI;  // load instructions per 16-token tile
@@ -180,9 +276,7 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
     const int lane = threadIdx.x;
     const int sub = lane / LPR, dc = lane % LPR;
 
-    DecodeWork wk;
-    if (!decode_map_work(p, wk)) return;
-    const int b = wk.b, hk = wk.hk, gc = wk.gc, split = wk.split, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
+    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
     const int64_t kv_row0 = wk.kv_row0;
     const bool partial = wk.partial;
     const int hq0 = hk * p.g + gc * G;
@@ -247,7 +341,7 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
             if (!paged) return 0;
             uint32_t tip;
             const int pg = min(page_of(tile, tip), last_pg);
-            return bt_row[pg];
+            return load_ro(bt_row + pg);
         };
         auto tile_bases = [&](int tile, int pid, const char *&kt, const char *&vt) {
             if (paged) {
@@ -470,13 +564,18 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
             *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + dc * 8) = w4;
             if (p.lse && dc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
         } else {
-            const int64_t row = ((int64_t)split * p.b + b) * p.h + hq;
+            const int64_t row = wk.prow + gq;
             float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + dc * 8);
             dst[0] = make_float4(o[gq][0] * inv, o[gq][1] * inv, o[gq][2] * inv, o[gq][3] * inv);
             dst[1] = make_float4(o[gq][4] * inv, o[gq][5] * inv, o[gq][6] * inv, o[gq][7] * inv);
             if (dc == 0) p.lse_accum[row] = empty ? -INFINITY : lse;  // flash_fwd_kernel.h:543-582
         }
     }
+}
+
+template <typename T, int D, int G, int P, int MINW, bool NT, bool STREAM>
+__global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodeParams p) {
+    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_item<T, D, G, P, NT>(pp, wk); });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -519,13 +618,11 @@ template <> __device__ __forceinline__ f32x4_v mfma16<f16_t>(const u32x4 &a, con
 }
 
 template <typename T, int G, int P, bool NT>
-__global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodeParams p) {
+__device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, const DecodeWork &wk) {
     constexpr int D = 128;
     const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15;
 
-    DecodeWork wk;
-    if (!decode_map_work(p, wk)) return;
-    const int b = wk.b, hk = wk.hk, gc = wk.gc, split = wk.split, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
+    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
     const int64_t kv_row0 = wk.kv_row0;
     const bool partial = wk.partial;
     const int hq0 = hk * p.g + gc * G;
@@ -579,7 +676,7 @@ __global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodePar
             if (!paged) return 0;
             uint32_t tip;
             const int pg = min(page_of(tile, tip), last_pg);
-            return bt_row[pg];
+            return load_ro(bt_row + pg);
         };
         auto tile_bases = [&](int tile, int pid, const char *&kt, const char *&vt) {
             if (paged) {
@@ -759,13 +856,18 @@ __global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodePar
             *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + col * 8) = w4;
             if (p.lse && col == 0) p.lse[(int64_t)b * p.h + hq] = lse;
         } else {
-            const int64_t row = ((int64_t)split * p.b + b) * p.h + hq;
+            const int64_t row = wk.prow + h;
             float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + col * 8);
             dst[0] = make_float4(o[h][0] * inv, o[h][1] * inv, o[h][2] * inv, o[h][3] * inv);
             dst[1] = make_float4(o[h][4] * inv, o[h][5] * inv, o[h][6] * inv, o[h][7] * inv);
             if (col == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
         }
     }
+}
+
+template <typename T, int G, int P, bool NT, bool STREAM>
+__global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodeParams p) {
+    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_mqk_item<T, G, P, NT>(pp, wk); });
 }
 
 // LSE-weighted merge of the split partials: /root/reference/csrc/kernels/flash_fwd_kernel.h:1204-1236.
@@ -777,19 +879,35 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
     const int b = (int)(bh / p.h), hq = (int)(bh % p.h);
     const int64_t stride = (int64_t)p.b * p.h;
     int nsp = p.num_splits;
-    if (p.chunk_tiles > 0) {  // chunk mode: only ragged batches split, and only sequences longer than a chunk
-        if (!decode_batch_is_ragged(p)) return;
-        const int n_tiles = (decode_seq_len(p, b) + 15) >> 4;
-        if (n_tiles <= p.chunk_tiles) return;
-        nsp = (n_tiles + p.chunk_tiles - 1) / p.chunk_tiles;
+    int64_t row0 = bh, row_step = stride, row1 = bh;   // partial row of piece s: s == 0 ? row0 : row1 + s * row_step
+    if (p.stream_waves > 0) {   // balanced mode: merge the pieces of a sequence that was cut between wavefronts
+        if (p.plan[1] == 0) return;                   // one wavefront per sequence was taken: outputs are final
+        const int tiles = p.plan[0], c0 = p.plan[2 + b], n = p.plan[3 + b] - c0;
+        uint16_t *dst = p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride;
+        if (n == 0) {                                 // empty sequence: no wavefront saw it (flash_fwd_kernel.h:543-582)
+            for (int e = lane; e < D; e += 64) dst[e] = 0;
+            if (p.lse && lane == 0) p.lse[bh] = INFINITY;
+            return;
+        }
+        const int hk = hq / p.g, in_group = hq - hk * p.g;
+        const int hkc = hk * p.gchunks + in_group / p.group_tile, gq = in_group % p.group_tile;
+        const int64_t total = (int64_t)tiles * p.h_k * p.gchunks;
+        const int64_t share = max((total + p.stream_waves - 1) / p.stream_waves, (int64_t)DECODE_MIN_SHARE);
+        const int64_t s0 = (int64_t)hkc * tiles + c0, w0 = s0 / share, w1 = (s0 + n - 1) / share;
+        if (w0 == w1) return;                         // whole sequence inside one wavefront's range: written directly
+        nsp = (int)(w1 - w0 + 1);
+        row0 = (w0 * 2 + (s0 > w0 * share ? 1 : 0)) * p.group_tile + gq;   // the first piece is that wavefront's last segment unless it starts its range
+        row_step = 2 * p.group_tile;
+        row1 = w0 * 2 * p.group_tile + gq;
     }
+    auto prow = [&](int s) -> int64_t { return s == 0 ? row0 : row1 + s * row_step; };
     float mx = -INFINITY;
-    for (int s = lane; s < nsp; s += 64) mx = fmaxf(mx, p.lse_accum[s * stride + bh]);
+    for (int s = lane; s < nsp; s += 64) mx = fmaxf(mx, p.lse_accum[prow(s)]);
 #pragma unroll
     for (int off = 32; off; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     const float ms = mx == -INFINITY ? 0.f : mx;
     float tot = 0.f;
-    for (int s = lane; s < nsp; s += 64) tot += __expf(p.lse_accum[s * stride + bh] - ms);
+    for (int s = lane; s < nsp; s += 64) tot += __expf(p.lse_accum[prow(s)] - ms);
 #pragma unroll
     for (int off = 32; off; off >>= 1) tot += __shfl_xor(tot, off, 64);
     const bool empty = !(tot > 0.f);
@@ -799,9 +917,9 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     for (int s = 0; s < nsp; ++s) {
-        const float ls = p.lse_accum[s * stride + bh];
+        const float ls = p.lse_accum[prow(s)];
         const float w = empty ? 0.f : __expf(ls - lse);
-        const float *src = p.o_accum + (s * stride + bh) * D + lane * EPL;
+        const float *src = p.o_accum + prow(s) * D + lane * EPL;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] += w * src[e];
     }
@@ -870,7 +988,7 @@ int decode_num_splits(int64_t waves_per_split, int max_seqlen_k, int waves_per_c
 // Tuning knobs (atoma_set_option / environment, for A/B runs and tests):
 //   decode_p            ATOMA_DECODE_P            tiles in flight per wave (2..4)
 //   decode_nt           ATOMA_DECODE_NT           0/1 non-temporal K/V loads
-//   decode_chunk_tiles  ATOMA_DECODE_CHUNK_TILES  > 0: cut ragged batches into chunks of that many tiles
+//   decode_stream       ATOMA_DECODE_STREAM       0/1 balanced mode for large batches with device-side lengths (decode_run_items)
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -878,7 +996,8 @@ static int env_int(const char *name, int dflt) {
 struct DecodeOptions {
     int p = env_int("ATOMA_DECODE_P", DECODE_DEFAULT_P);
     int nt = env_int("ATOMA_DECODE_NT", DECODE_DEFAULT_NT);
-    int chunk_tiles = env_int("ATOMA_DECODE_CHUNK_TILES", DECODE_CHUNK_TILES);
+    int stream = env_int("ATOMA_DECODE_STREAM", 1);
+    int stream_waves_per_cu = env_int("ATOMA_DECODE_STREAM_WAVES_PER_CU", 0);   // 0 = resident capacity
     int waves_per_cu = env_int("ATOMA_DECODE_WAVES_PER_CU", 0);   // 0 = resident capacity
     int min_tiles = env_int("ATOMA_DECODE_MIN_TILES", 8);
     int mqk = env_int("ATOMA_DECODE_MQK", 5);   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches
@@ -893,7 +1012,8 @@ bool set_decode_option(const std::string &name, int value) {
     if (name == "prefill_cfg") { prefill_cfg = value; return true; }
     if (name == "decode_p") o.p = value;
     else if (name == "decode_nt") o.nt = value;
-    else if (name == "decode_chunk_tiles") o.chunk_tiles = value;
+    else if (name == "decode_stream") o.stream = value;
+    else if (name == "decode_stream_waves_per_cu") o.stream_waves_per_cu = value;
     else if (name == "decode_waves_per_cu") o.waves_per_cu = value;
     else if (name == "decode_min_tiles") o.min_tiles = value;
     else if (name == "decode_mqk") o.mqk = value;
@@ -901,33 +1021,52 @@ bool set_decode_option(const std::string &name, int value) {
     return true;
 }
 
+// Balanced mode: as many wavefronts share the batch as THIS kernel keeps resident (its register count decides: 8 per CU
+// for the 4-head variants, 12 for one head per wavefront); the workspace was sized for the upper bound of 16.
+#define DECODE_STREAM_MAX_WAVES_PER_CU 16
+template <typename K> static int resident_waves_per_cu(K kernel) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 64, 0) != hipSuccess || n <= 0) n = 8;
+    return std::min(n, DECODE_STREAM_MAX_WAVES_PER_CU);
+}
+static void set_stream_waves(DecodeParams &p, int occupancy) {
+    const int opt = decode_options().stream_waves_per_cu;
+    const int wpc = opt > 0 ? std::min(opt, DECODE_STREAM_MAX_WAVES_PER_CU) : occupancy;
+    p.stream_waves = (int)std::min<int64_t>((int64_t)p.b * p.h_k * p.gchunks, (int64_t)device_num_cus() * wpc);
+}
+
 template <typename T, int D, int G, int P, int MINW, bool NT>
-static void launch_decode_cfg(const DecodeParams &p, hipStream_t stream) {
+static void launch_decode_cfg(DecodeParams &p, hipStream_t stream) {
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
-    hipLaunchKernelGGL((paged_decode_kernel<T, D, G, P, MINW, NT>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    if (p.stream_waves > 0) {
+        static const int occ = resident_waves_per_cu(paged_decode_kernel<T, D, G, P, MINW, NT, true>);
+        set_stream_waves(p, occ);
+    }
+    if (p.stream_waves > 0) hipLaunchKernelGGL((paged_decode_kernel<T, D, G, P, MINW, NT, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    else hipLaunchKernelGGL((paged_decode_kernel<T, D, G, P, MINW, NT, false>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
 }
 
 // d = 128: scores on the matrix cores (paged_decode_mqk_kernel), any G at two wavefronts per SIMD
 template <typename T, int G>
-static void launch_decode_mqk(const DecodeParams &p, hipStream_t stream) {
+static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
-    const int cfg_p = decode_options().p;
-    if (decode_options().nt) {
-        if (cfg_p >= 3 && G <= 4) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, 3, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
-        else hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, 2, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
-    } else {
-        if (cfg_p >= 3 && G <= 4) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, 3, false>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
-        else hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, 2, false>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
-    }
+    if (p.stream_waves > 0) set_stream_waves(p, 8);   // __launch_bounds__(64, 2)
+    const bool p3 = decode_options().p >= 3 && G <= 4, nt = decode_options().nt != 0;
+#define ATOMA_MQK(P_, NT_, S_) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, P_, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p)
+#define ATOMA_MQK_S(P_, NT_) do { if (p.stream_waves > 0) ATOMA_MQK(P_, NT_, true); else ATOMA_MQK(P_, NT_, false); } while (0)
+    if (nt) { if (p3) ATOMA_MQK_S(3, true); else ATOMA_MQK_S(2, true); }
+    else { if (p3) ATOMA_MQK_S(3, false); else ATOMA_MQK_S(2, false); }
+#undef ATOMA_MQK_S
+#undef ATOMA_MQK
     if (!ATOMA_CHECK_LAUNCH("paged_decode_mqk_kernel")) return;
-    if (p.num_splits > 1) {
+    if (p.num_splits > 1 || p.stream_waves > 0) {
         hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)((int64_t)p.b * p.h)), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
 }
 
 template <typename T, int D, int G>
-static void launch_decode_tdg(const DecodeParams &p, hipStream_t stream) {
+static void launch_decode_tdg(DecodeParams &p, hipStream_t stream) {
     // tiles in flight per wave / waves per SIMD the register budget is capped for: G = 8 at
     // D = 128 needs more than 256 VGPRs (64 for O, 32 for q, 64 per K+V pair in flight).
     constexpr int MINW = (G >= 8 && D >= 128) ? 1 : 2;
@@ -943,7 +1082,7 @@ static void launch_decode_tdg(const DecodeParams &p, hipStream_t stream) {
         else launch_decode_cfg<T, D, G, 2, MINW, false>(p, stream);
     }
     if (!ATOMA_CHECK_LAUNCH("paged_decode_kernel")) return;
-    if (p.num_splits > 1) {
+    if (p.num_splits > 1 || p.stream_waves > 0) {
         hipLaunchKernelGGL((decode_combine_kernel<T, D>), dim3((unsigned)((int64_t)p.b * p.h)), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
@@ -966,21 +1105,22 @@ static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
         const int cap = (G >= 8 && D >= 128 && !use_mqk) ? 4 : 8;   // resident wavefronts per CU of the variant that will run
         const int wpc = decode_options().waves_per_cu > 0 ? decode_options().waves_per_cu : cap;
         p.num_splits = decode_num_splits(waves, p.seqlen_k, wpc, std::max(1, decode_options().min_tiles));
-        p.chunk_tiles = 0;
-        const int chunk_cfg = decode_options().chunk_tiles;
-        const int64_t max_tiles = cdiv(p.seqlen_k, 16);
-        if (p.num_splits == 1 && chunk_cfg > 0 && max_tiles >= 2 * chunk_cfg && (p.cu_seqlens_k || p.seqused_k)) {
-            // enough wavefronts without splitting: split only if the kernel finds the batch ragged
-            p.chunk_tiles = chunk_cfg;
-            p.num_splits = (int)cdiv(max_tiles, chunk_cfg);
-        }
     }
-    if (p.num_splits > 1) {
-        const size_t rows = (size_t)p.num_splits * p.b * p.h;
-        float *ws = static_cast<float *>(workspace(stream, rows * (D + 1) * sizeof(float)));
+    p.group_tile = G;
+    p.stream_waves = 0;
+    const int64_t hk_chunks = (int64_t)p.h_k * p.gchunks, max_tiles = cdiv(p.seqlen_k, 16);
+    if (p.num_splits == 1 && decode_options().stream && (p.cu_seqlens_k || p.seqused_k) && p.b <= DECODE_STREAM_MAX_B &&
+        p.b * hk_chunks * max_tiles < (int64_t)1 << 31) {
+        // enough wavefronts without splitting and the lengths are on the device: the kernel balances ragged batches itself
+        p.stream_waves = (int)std::min<int64_t>(p.b * hk_chunks, (int64_t)device_num_cus() * DECODE_STREAM_MAX_WAVES_PER_CU);   // upper bound, set per kernel at launch
+    }
+    if (p.num_splits > 1 || p.stream_waves > 0) {
+        const size_t rows = p.stream_waves > 0 ? (size_t)p.stream_waves * 2 * G : (size_t)p.num_splits * p.b * p.h;
+        float *ws = static_cast<float *>(workspace(stream, rows * (D + 1) * sizeof(float) + (p.b + 2) * sizeof(int)));
         if (!ws) return;
         p.o_accum = ws;
         p.lse_accum = ws + rows * D;
+        p.plan = reinterpret_cast<int *>(ws + rows * (D + 1));
     }
     if (D == 128 && use_mqk) {
         switch (G) {

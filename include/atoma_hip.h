@@ -218,11 +218,12 @@ int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, in
 int atoma_comm_destroy(void *comm);
 
 /* Tuning knobs for A/B measurements and tests (returns 0, or -1 for an unknown name).  Decode: "decode_p" (K/V tiles
- * in flight per wavefront, 2..4), "decode_nt" (0/1 non-temporal K/V loads), "decode_chunk_tiles" (> 0: cut ragged
- * decode batches into chunks of that many 16-token tiles), "decode_waves_per_cu" / "decode_min_tiles" (KV split
+ * in flight per wavefront, 2..4), "decode_nt" (0/1 non-temporal K/V loads), "decode_stream" (0/1, default 1: large batches
+ * with device-side lengths share the batch's tiles evenly between the resident wavefronts; 0 = one wavefront per
+ * (sequence, kv head)), "decode_stream_waves_per_cu", "decode_waves_per_cu" / "decode_min_tiles" (KV split
  * heuristic), "decode_mqk" (q.K^T on the matrix cores at head_dim 128: bit 0 = groups of more than 4 q heads per kv
  * head, bit 1 = smaller groups, bit 2 = groups of 2..4 when b * h_k <= 64; default 5).  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
- * software-pipelined one-wave-per-SIMD kernel).  Defaults also come from ATOMA_DECODE_{P,NT,CHUNK_TILES,WAVES_PER_CU,
+ * software-pipelined one-wave-per-SIMD kernel).  Defaults also come from ATOMA_DECODE_{P,NT,STREAM,WAVES_PER_CU,
  * MIN_TILES,MQK}; ATOMA_PREFILL_CFG overrides "prefill_cfg". */
 int atoma_set_option(const char *name, int value);
 

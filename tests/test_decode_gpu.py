@@ -102,34 +102,101 @@ def test_decode_split_kv_small_batch(gpu, B, L):
     assert np.isfinite(lse).all()
 
 
-def test_decode_ragged_large_batch_chunk_mode(gpu):
-    """A batch big enough to fill the chip without splitting (B*h_k >= 1024) but ragged: the kernel
-    itself detects the imbalance and cuts sequences into 1024-token chunks merged by the combine
-    kernel; sequences shorter than a chunk are written directly.  Same answer as the oracle."""
-    assert gpu.lib.atoma_set_option(b"decode_chunk_tiles", 64) == 0     # experimental mode, off by default
+def _oracle_decode(q, kc, vc, bt, lens, dtype):
+    B, _, h, d = q.shape
+    hk, page = kc.shape[2], kc.shape[1]
+    return c_attention(q, kc, vc, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bt.shape[1] * page, scale=d ** -0.5,
+                       is_bf16=dtype, q_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                       v_strides=(page * hk * d, hk * d, d), o_shape=q.shape, o_strides=(h * d, h * d, d), cu_k=lens,
+                       k_cumulative=False, block_table=bt, page=page)
+
+
+@pytest.mark.parametrize("kind", ["ragged", "straggler", "more_than_resident", "mostly_empty"])
+def test_decode_large_batch_balanced_mode(gpu, kind):
+    """A batch big enough to fill the chip without KV splitting (B * h_k > 1024): the kernel lays all tiles of the
+    batch on one line and gives every wavefront the same share; sequences cut between wavefronts are merged by the
+    combine kernel, whole ones are written directly, empty ones by the combine kernel.  Same answer as the oracle,
+    and as the one-wavefront-per-sequence route (option decode_stream = 0)."""
     rng = np.random.default_rng(99)
-    B, h, hk, d, page = 272, 4, 4, 64, 16
-    lens = rng.integers(16, 3000, B).astype(np.int32)
-    lens[:4] = [0, 1, 1024, 1025]                        # empty / single token / exactly one chunk / just over
+    h, hk, d, page = 4, 4, 64, 16
+    if kind == "ragged":
+        B = 272
+        lens = rng.integers(16, 3000, B).astype(np.int32)
+        lens[:6] = [0, 1, 1024, 1025, 16, 17]            # empty / single token / tile boundaries
+    elif kind == "straggler":
+        B = 300
+        lens = rng.integers(1, 200, B).astype(np.int32)
+        lens[123] = 20000                                   # one sequence as long as the rest of the batch together
+    elif kind == "more_than_resident":
+        B = 600                                             # 2400 (sequence, kv head) pairs > 2048 resident wavefronts, uniform
+        lens = np.full(B, 700, np.int32)
+    else:
+        B = 272
+        lens = np.zeros(B, np.int32)
+        lens[[3, 100, 271]] = [5000, 33, 1]
     nb = int(sum((int(x) + page - 1) // page for x in lens)) + 1
     kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens)
     q = rand_half(rng, (B, 1, h, d), BF16)
+    ref = _oracle_decode(q, kc, vc, bt, lens, BF16)
     out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
-    ref = c_attention(q, kc, vc, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bt.shape[1] * page, scale=d ** -0.5,
-                      is_bf16=1, q_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
-                      v_strides=(page * hk * d, hk * d, d), o_shape=q.shape, o_strides=(h * d, h * d, d), cu_k=lens,
-                      k_cumulative=False, block_table=bt, page=page)
+    out_again, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
+    assert np.array_equal(out, out_again), "balanced mode is deterministic"
     for i, L in enumerate(lens):
-        assert_close(out[i], ref[i], BF16, atol=attn_atol(BF16, L), what=f"ragged batch seq {i} (L={L})")
-    assert not out[0].any() and np.isposinf(lse[0]).all() and np.isfinite(lse[1:]).all()
-    # and a uniform batch of the same shape takes the unsplit route with identical numbers per sequence
-    lens_u = np.full(B, 1500, np.int32)
-    out_u, _ = gpu_decode(gpu, q, kc, vc, bt[:, :94].copy() % nb, lens_u, d ** -0.5, BF16)
-    assert np.isfinite(to_f32(out_u, BF16)).all()
-    assert gpu.lib.atoma_set_option(b"decode_chunk_tiles", 0) == 0
-    out2, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)        # default route, same batch
+        assert_close(out[i], ref[i], BF16, atol=attn_atol(BF16, L), what=f"{kind} batch seq {i} (L={L})")
+    empty = lens == 0
+    assert not out[empty].any() and np.isposinf(lse[empty]).all() and np.isfinite(lse[~empty]).all()
+    assert gpu.lib.atoma_set_option(b"decode_stream", 0) == 0
+    try:
+        out2, lse2 = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)        # one wavefront per (sequence, kv head)
+    finally:
+        assert gpu.lib.atoma_set_option(b"decode_stream", 1) == 0
     for i, L in enumerate(lens):
-        assert_close(out2[i], ref[i], BF16, atol=attn_atol(BF16, L), what=f"ragged batch (unsplit) seq {i} (L={L})")
+        assert_close(out2[i], ref[i], BF16, atol=attn_atol(BF16, L), what=f"{kind} batch (unbalanced route) seq {i} (L={L})")
+    np.testing.assert_allclose(lse[~empty], lse2[~empty], rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype,h,hk", [(BF16, 16, 2), (F16, 8, 8), (BF16, 12, 2)])
+def test_decode_balanced_mode_head_layouts(gpu, dtype, h, hk):
+    """Balanced mode with the matrix-core kernel (groups of 8 and 6), MHA, f16, d = 128, page 32, ALiBi off."""
+    rng = np.random.default_rng(7)
+    d, page = 128, 32
+    B = 1100 // hk + 3
+    lens = rng.integers(1, 400, B).astype(np.int32)
+    lens[5], lens[B // 2] = 0, 4000
+    nb = int(sum((int(x) + page - 1) // page for x in lens)) + 1
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+    q = rand_half(rng, (B, 1, h, d), dtype)
+    ref = _oracle_decode(q, kc, vc, bt, lens, dtype)
+    out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+    for i, L in enumerate(lens):
+        assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"seq {i} (L={L})")
+    assert not out[5].any() and np.isposinf(lse[5]).all()
+
+
+def test_decode_balanced_mode_cumulative_varlen(gpu):
+    """Balanced mode over a contiguous varlen K/V addressed by cumulative cu_seqlens_k (block_info.h:16-23)."""
+    rng = np.random.default_rng(8)
+    B, h, hk, d = 300, 4, 4, 64
+    lens = rng.integers(0, 300, B).astype(np.int32)
+    lens[17] = 3000
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    k, v = rand_half(rng, (int(cu[-1]), hk, d), BF16), rand_half(rng, (int(cu[-1]), hk, d), BF16)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    dq, dk, dv = (gpu.DeviceBuffer.from_numpy(a) for a in (q, k, v))
+    do = gpu.DeviceBuffer(q.nbytes)
+    do.fill_bytes(0xFF)
+    dcu = gpu.DeviceBuffer.from_numpy(cu)
+    gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=3000, softmax_scale=0.125, is_bf16=1,
+                q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(0, hk * d, d),
+                v_strides=(0, hk * d, d), cu_seqlens_k=dcu, is_seqlens_k_cumulative=True, unpadded_lse=False)
+    gpu.synchronize()
+    out = do.numpy(np.uint16, q.shape)
+    for b in range(B):
+        if lens[b] == 0:
+            assert not out[b].any()
+            continue
+        ref = A.flash_attn_kv_cache(q[b:b + 1], k[cu[b]: cu[b + 1]][None], v[cu[b]: cu[b + 1]][None], 0.125, BF16)
+        assert_close(out[b:b + 1], ref, BF16, atol=attn_atol(BF16, lens[b]), what=f"cumulative lens seq {b}")
 
 
 def test_decode_contiguous_cache_without_block_table(gpu):

@@ -60,12 +60,23 @@ def emit(name, ms, nbytes=None, flops=None, **extra):
     print(json.dumps(rec), flush=True)
 
 
-def decode_case(name, B, S, h, hk, d=128, page=16, identity=False, ragged=False, seed=0):
+def decode_case(name, B, S, h, hk, d=128, page=16, identity=False, ragged=False, seed=0, lens=None):
     rng = np.random.default_rng(seed)
     pps = (S + page - 1) // page
-    n_pages = int(B * pps * 1.125)
-    bt = (np.arange(B * pps) if identity else rng.permutation(n_pages)[: B * pps]).astype(np.int32).reshape(B, pps)
-    lens = (rng.integers(S // 2, S + 1, B) if ragged else np.full(B, S)).astype(np.int32)
+    if lens is not None:       # explicit lengths (max S): only the pages the sequences own exist
+        lens = np.asarray(lens, np.int32)
+        need = (lens.astype(np.int64) + page - 1) // page
+        n_pages = int(need.sum() * 1.125) + 1
+        perm = rng.permutation(n_pages).astype(np.int32)
+        bt = np.zeros((B, pps), np.int32)
+        o = 0
+        for i, n in enumerate(need):
+            bt[i, :n] = perm[o:o + n]
+            o += int(n)
+    else:
+        n_pages = int(B * pps * 1.125)
+        bt = (np.arange(B * pps) if identity else rng.permutation(n_pages)[: B * pps]).astype(np.int32).reshape(B, pps)
+        lens = (rng.integers(S // 2, S + 1, B) if ragged else np.full(B, S)).astype(np.int32)
     kc, vc = rand_dev(rng, n_pages * page * hk * d * 2), rand_dev(rng, n_pages * page * hk * d * 2)
     q = rand_dev(rng, B * h * d * 2)
     o = ah.DeviceBuffer(B * h * d * 2)

@@ -5,7 +5,7 @@ The op sequence is the reference's `Llama::forward` for decode tokens (models/sr
 KV-cache write -> paged decode attention -> o projection -> residual -> RMSNorm -> gate/up projection -> SiLU.up ->
 down projection -> residual] -> RMSNorm -> lm_head -> argmax.  q/k/v and gate/up weights are stored concatenated
 (row blocks of one matrix), which changes nothing in the arithmetic: every output row is an independent dot product.
-Batch <= 16 (atoma_linear_decode).  Everything is enqueued on one stream, so a step can be captured in a hipGraph.
+Batch <= 64 (atoma_linear_decode).  Everything is enqueued on one stream, so a step can be captured in a hipGraph.
 """
 import os
 import sys
