@@ -1,0 +1,153 @@
+// Linear layer at any batch: y[b][n] = sum_k x[b][k] * w[n][k]  (SURVEY.md 8f item 1).
+//
+// candle_nn::Linear::forward on [T, hidden] activations (/root/reference/models/src/llama.rs:269-271,311,364-365) is a
+// cuBLAS GEMM in the reference.  A plain GEMM goes to the vendor library, hipBLASLt (bf16 / f16 inputs, fp32
+// accumulation, one rounding); the hand-written weight-streaming kernel (linear_decode.hip) keeps the batches where it is
+// level with the library and its fused epilogues save launches (1..4 rows; measured crossover: at 16 rows hipBLASLt
+// is 15-30 % faster).  GEMM layout: in column-major terms y^T[N x B] = W[N x K] . x^T[K x B], i.e. the "TN" layout with
+// A = the weight memory (K x N, ld = w_row_stride), B = the activation memory (K x B, ld = x_row_stride),
+// C = the output memory (N x B, ld = y_row_stride).  hipBLASLt is loaded on first use (dlopen), one handle, one
+// 64 MiB workspace and a cache of (problem -> algorithm) per device.
+// Parity: unpinned (Candle / cuBLAS are not in the tree); the oracle is the f64-accumulated product rounded once.
+#include "common.h"
+#include <dlfcn.h>
+#include <hipblaslt/hipblaslt.h>
+#include <map>
+#include <mutex>
+#include <stdlib.h>
+#include <tuple>
+
+extern "C" int atoma_linear_decode(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
+                                   int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream);
+
+namespace atoma {
+
+struct LtApi {
+    void *lib = nullptr;
+    decltype(&hipblasLtCreate) create = nullptr;
+    decltype(&hipblasLtMatmulDescCreate) desc_create = nullptr;
+    decltype(&hipblasLtMatmulDescSetAttribute) desc_set = nullptr;
+    decltype(&hipblasLtMatrixLayoutCreate) layout_create = nullptr;
+    decltype(&hipblasLtMatmulPreferenceCreate) pref_create = nullptr;
+    decltype(&hipblasLtMatmulPreferenceSetAttribute) pref_set = nullptr;
+    decltype(&hipblasLtMatmulPreferenceDestroy) pref_destroy = nullptr;
+    decltype(&hipblasLtMatmulAlgoGetHeuristic) heuristic = nullptr;
+    decltype(&hipblasLtMatmul) matmul = nullptr;
+    bool ok = false;
+};
+
+static LtApi &lt_api() {
+    static LtApi api = [] {
+        LtApi a;
+        a.lib = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) a.lib = dlopen("libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
+        if (!a.lib) return a;
+#define ATOMA_LT_SYM(field, name) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, #name))
+        ATOMA_LT_SYM(create, hipblasLtCreate);
+        ATOMA_LT_SYM(desc_create, hipblasLtMatmulDescCreate);
+        ATOMA_LT_SYM(desc_set, hipblasLtMatmulDescSetAttribute);
+        ATOMA_LT_SYM(layout_create, hipblasLtMatrixLayoutCreate);
+        ATOMA_LT_SYM(pref_create, hipblasLtMatmulPreferenceCreate);
+        ATOMA_LT_SYM(pref_set, hipblasLtMatmulPreferenceSetAttribute);
+        ATOMA_LT_SYM(pref_destroy, hipblasLtMatmulPreferenceDestroy);
+        ATOMA_LT_SYM(heuristic, hipblasLtMatmulAlgoGetHeuristic);
+        ATOMA_LT_SYM(matmul, hipblasLtMatmul);
+#undef ATOMA_LT_SYM
+        a.ok = a.create && a.desc_create && a.desc_set && a.layout_create && a.pref_create && a.pref_set && a.pref_destroy &&
+               a.heuristic && a.matmul;
+        return a;
+    }();
+    return api;
+}
+
+struct GemmPlan {
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
+    hipblasLtMatmulAlgo_t algo;
+    size_t workspace = 0;
+};
+struct LtDevice {
+    hipblasLtHandle_t handle = nullptr;
+    void *workspace = nullptr;
+    std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t>, GemmPlan> plans;
+};
+static const size_t LT_WORKSPACE_BYTES = 64u << 20;
+static std::mutex *g_lt_mu = new std::mutex;
+static std::map<int, LtDevice> *g_lt_devices = new std::map<int, LtDevice>;
+
+static bool lt_ok(hipblasStatus_t st, const char *what) {
+    if (st == HIPBLAS_STATUS_SUCCESS) return true;
+    set_error(std::string("linear: hipBLASLt ") + what + " failed with status " + std::to_string((int)st));
+    return false;
+}
+
+// y^T[n x batch] = W[n x k] . x^T[k x batch]
+static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t k, int64_t n, int64_t ldx, int64_t ldw, int64_t ldy,
+                   int dtype, hipStream_t stream) {
+    LtApi &api = lt_api();
+    if (!api.ok) { set_error("linear: libhipblaslt.so could not be loaded (needed for batches above the weight-streaming kernel's range)"); return -1; }
+    int dev = 0;
+    if (!check_hip(hipGetDevice(&dev), "hipGetDevice")) return -1;
+    std::lock_guard<std::mutex> lock(*g_lt_mu);
+    LtDevice &d = (*g_lt_devices)[dev];
+    if (!d.handle) {
+        if (!lt_ok(api.create(&d.handle), "hipblasLtCreate")) { d.handle = nullptr; return -1; }
+        if (!check_hip(hipMalloc(&d.workspace, LT_WORKSPACE_BYTES), "linear: workspace hipMalloc")) return -1;
+    }
+    const auto key = std::make_tuple(dtype, batch, k, n, ldx, ldw, ldy);
+    auto it = d.plans.find(key);
+    if (it == d.plans.end()) {
+        GemmPlan pl;
+        const hipDataType t = dtype == ATOMA_BF16 ? HIP_R_16BF : HIP_R_16F;
+        if (!lt_ok(api.desc_create(&pl.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F), "MatmulDescCreate")) return -1;
+        const int32_t op_t = HIPBLAS_OP_T, op_n = HIPBLAS_OP_N;
+        if (!lt_ok(api.desc_set(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op_t, sizeof op_t), "MatmulDescSetAttribute(TRANSA)")) return -1;
+        if (!lt_ok(api.desc_set(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op_n, sizeof op_n), "MatmulDescSetAttribute(TRANSB)")) return -1;
+        if (!lt_ok(api.layout_create(&pl.a, t, (uint64_t)k, (uint64_t)n, ldw), "MatrixLayoutCreate(W)")) return -1;
+        if (!lt_ok(api.layout_create(&pl.b, t, (uint64_t)k, (uint64_t)batch, ldx), "MatrixLayoutCreate(x)")) return -1;
+        if (!lt_ok(api.layout_create(&pl.c, t, (uint64_t)n, (uint64_t)batch, ldy), "MatrixLayoutCreate(y)")) return -1;
+        hipblasLtMatmulPreference_t pref = nullptr;
+        if (!lt_ok(api.pref_create(&pref), "MatmulPreferenceCreate")) return -1;
+        const uint64_t ws = LT_WORKSPACE_BYTES;
+        bool ok = lt_ok(api.pref_set(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof ws), "MatmulPreferenceSetAttribute");
+        hipblasLtMatmulHeuristicResult_t res[1];
+        int found = 0;
+        ok = ok && lt_ok(api.heuristic(d.handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, 1, res, &found), "MatmulAlgoGetHeuristic");
+        api.pref_destroy(pref);
+        if (!ok) return -1;
+        if (found < 1) { set_error("linear: hipBLASLt has no algorithm for this problem"); return -1; }
+        pl.algo = res[0].algo;
+        pl.workspace = res[0].workspaceSize;
+        it = d.plans.emplace(key, pl).first;
+    }
+    const GemmPlan &pl = it->second;
+    const float alpha = 1.f, beta = 0.f;
+    if (!lt_ok(api.matmul(d.handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &pl.algo, d.workspace,
+                          LT_WORKSPACE_BYTES, stream), "Matmul"))
+        return -1;
+    return 0;
+}
+
+// batches up to this many rows take the weight-streaming kernel (measured crossover, tools/bench_kernels.py linear)
+static const int linear_stream_max_batch = getenv("ATOMA_LINEAR_STREAM_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_STREAM_MAX_BATCH")) : 4;
+
+}  // namespace atoma
+
+extern "C" int atoma_linear(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
+                            int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream) {
+    using namespace atoma;
+    clear_error();
+    if (batch >= 0 && batch <= std::min(linear_stream_max_batch, 64))
+        return atoma_linear_decode(x, w, y, batch, in_features, out_features, x_row_stride, w_row_stride, y_row_stride, dtype, stream);
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("linear: dtype must be f16 or bf16"); return -1; }
+    if (batch < 0 || batch > (1 << 20)) { set_error("linear: batch out of range"); return -1; }
+    if (in_features <= 0 || in_features % 8 != 0) { set_error("linear: in_features must be a positive multiple of 8"); return -1; }
+    if (out_features <= 0 || out_features % 8 != 0) { set_error("linear: out_features must be a positive multiple of 8"); return -1; }
+    if (x_row_stride < in_features || w_row_stride < in_features || y_row_stride < out_features) { set_error("linear: row strides must cover a row"); return -1; }
+    if (x_row_stride % 8 || w_row_stride % 8 || y_row_stride % 8) { set_error("linear: row strides must be multiples of 8 elements"); return -1; }
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y)) & 15u) {
+        set_error("linear: x, w and y must be 16-byte aligned");
+        return -1;
+    }
+    return gemm_tn(x, w, y, batch, in_features, out_features, x_row_stride, w_row_stride, y_row_stride, dtype, static_cast<hipStream_t>(stream));
+}

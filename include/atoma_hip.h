@@ -185,6 +185,13 @@ int atoma_linear_decode_residual(const void *x, const void *w, const void *resid
 int atoma_linear_decode_silu_mul(const void *x, const void *w_gate_up, void *y, int64_t batch, int64_t in_features, int64_t intermediate,
                                  int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream);
 
+/* The same product at any batch (candle_nn::Linear::forward = a cuBLAS GEMM in the reference, llama.rs:269-271,311,364-365):
+ * up to 4 rows (ATOMA_LINEAR_STREAM_MAX_BATCH) it is atoma_linear_decode, above that a plain TN GEMM in the vendor
+ * library (hipBLASLt, loaded on first use; bf16 / f16 inputs, fp32 accumulation, one rounding).  Sizes and strides in
+ * multiples of 8 elements on the GEMM route, 16-byte aligned tensors. */
+int atoma_linear(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
+                 int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream);
+
 /* The element-wise ops between the kernels of a decode step.  atoma_embedding: out[t] = table[ids[t]] (ids int32 or
  * int64, clamped to the table; models/src/llama.rs:456-458).  atoma_add: out = a + b, one rounding (residual adds,
  * llama.rs:404,409).  atoma_silu_mul: out[t] = silu(gate[t]) * up[t] with the reference's two roundings (llama.rs:364-365);

@@ -115,3 +115,52 @@ def test_linear_decode_fused_epilogues_match_the_separate_ops(gpu):
     ref_act = EO.silu_mul(np.ascontiguousarray(g[:, :I]), np.ascontiguousarray(g[:, I:]), BF16)
     d = np.abs(act.numpy(np.uint16, (B, I)).astype(np.int32) - ref_act.astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 0.01
+
+
+def gpu_linear_any(gpu, x, w, dtype, x_stride=None, y_stride=None):
+    B, K, N = x.shape[0], w.shape[1], w.shape[0]
+    dx, dw = gpu.DeviceBuffer.from_numpy(x), gpu.DeviceBuffer.from_numpy(w)
+    ys = y_stride or N
+    dy = gpu.DeviceBuffer(max(B, 1) * ys * 2)
+    dy.fill_bytes(0xAB)
+    rc = gpu.lib.atoma_linear(dx.ptr, dw.ptr, dy.ptr, B, K, N, x_stride or x.shape[1], K, ys, dtype, None)
+    assert rc == 0, gpu.last_error()
+    gpu.synchronize()
+    return dy.numpy(np.uint16, (max(B, 1), ys))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("B,K,N", [(4, 1024, 512), (5, 4096, 1024), (16, 4096, 6144), (33, 4096, 1024), (64, 4096, 4096), (128, 2048, 6144), (256, 4096, 1024), (300, 1024, 4112),
+                                   (2048, 512, 256)])
+def test_linear_any_batch_gemm_route(gpu, dtype, B, K, N):
+    """atoma_linear: the weight-streaming kernel up to 4 rows, the vendor GEMM (fp32 accumulation, one rounding) above:
+    same bound against the exactly accumulated product -- one unit in the last place."""
+    rng = np.random.default_rng(B + K + N)
+    x = rand_half(rng, (B, K), dtype)
+    w = rand_half(rng, (N, K), dtype, K ** -0.5)
+    check(gpu_linear_any(gpu, x, w, dtype), LO.linear(x, w, dtype), dtype)
+
+
+def test_linear_any_batch_strides_exactness_and_errors(gpu):
+    """GEMM route: strided x rows, padded y rows left untouched; integer-valued inputs are bit-exact; W = I reproduces x."""
+    rng = np.random.default_rng(12)
+    from oracle.halfs import from_f32
+    B, K, N = 96, 1024, 256
+    wide = from_f32(rng.integers(-4, 5, (B, K + 64)).astype(np.float32), BF16)
+    w = from_f32(rng.integers(-2, 3, (N, K)).astype(np.float32), BF16)
+    dx, dw = gpu.DeviceBuffer.from_numpy(wide), gpu.DeviceBuffer.from_numpy(w)
+    ys = N + 64
+    dy = gpu.DeviceBuffer(B * ys * 2)
+    dy.fill_bytes(0xAB)
+    assert gpu.lib.atoma_linear(dx.ptr + 32 * 2, dw.ptr, dy.ptr, B, K, N, K + 64, K, ys, BF16, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    out = dy.numpy(np.uint16, (B, ys))
+    assert np.array_equal(out[:, :N], LO.linear(np.ascontiguousarray(wide[:, 32:32 + K]), w, BF16))
+    assert (out[:, N:] == 0xABAB).all()
+    eye = from_f32(np.eye(512, dtype=np.float32), F16)
+    x = rand_half(rng, (100, 512), F16)
+    assert np.array_equal(gpu_linear_any(gpu, x, eye, F16), x)
+    assert gpu.lib.atoma_linear(dx.ptr, dw.ptr, dy.ptr, 100, 1028, N, 1028, 1028, ys, BF16, None) == -1
+    assert "multiple of 8" in gpu.last_error()
+    assert gpu.lib.atoma_linear(dx.ptr + 2, dw.ptr, dy.ptr, 100, K, N, K + 64, K, ys, BF16, None) == -1
+    assert "aligned" in gpu.last_error()

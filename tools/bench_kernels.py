@@ -278,6 +278,14 @@ def bench_linear():
             x, y = rand_dev(rng, B * K * 2), ah.DeviceBuffer(B * N * 2)
             ms = timeit(lambda: ah.lib.atoma_linear_decode(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
             emit(f"L1 linear_decode {name} [{N} x {K}] batch={B}", ms, nbytes=N * K * 2 + B * K * 2 + B * N * 2)
+        smax = int(os.environ.get("ATOMA_LINEAR_STREAM_MAX_BATCH", "4"))
+        for B in (1, 16, 32, 64, 128, 256, 2048):        # atoma_linear: streaming kernel up to smax rows, vendor GEMM above; 2048 = a prefill chunk
+            if B <= min(smax, 64):
+                continue                                  # measured above
+            x, y = rand_dev(rng, B * K * 2), ah.DeviceBuffer(B * N * 2)
+            route = "streaming route" if B <= min(smax, 64) else "hipBLASLt route"
+            ms = timeit(lambda: ah.lib.atoma_linear(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
+            emit(f"L2 linear ({route}) {name} [{N} x {K}] batch={B}", ms, nbytes=N * K * 2 + B * K * 2 + B * N * 2, flops=2 * B * N * K)
         w.free()
 
 
@@ -300,7 +308,7 @@ def bench_step():
     weight_bytes = 2 * (2 * c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden))
     st = ah.Stream()
     S = 4096
-    for B in (1, 16, 64):
+    for B in (1, 16, 64, 256):
         pps = S // c.page + 1
         step = DS.DecodeStep(c, B, B * pps + 2, pps, w, st, fused_epilogues=True)
         bt = rng.permutation(B * pps).astype(np.int32).reshape(B, pps)
@@ -323,7 +331,7 @@ def bench_step():
         ms_graph = timed(g.launch)
         nbytes = weight_bytes - 2 * c.vocab * c.hidden + 2 * B * (S + 1) * c.hk * c.d * 2 * c.layers   # embedding table: B rows only
         emit(f"E1 Llama-3.1-8B decode step, batch={B}, context {S} (hipGraph replay)", ms_graph, nbytes=nbytes, ms_eager=round(ms_eager, 4),
-             tokens_per_s=round(B / (ms_graph * 1e-3)), kernels_per_step="13 per layer + 5 (residual adds and SiLU.up folded into the projections' split merge)")
+             tokens_per_s=round(B / (ms_graph * 1e-3)), projections="weight-streaming kernel with fused residual / SiLU.up epilogues" if step.fused else "hipBLASLt + separate residual / SiLU.up kernels")
         del step
 
 

@@ -5,7 +5,7 @@ The op sequence is the reference's `Llama::forward` for decode tokens (models/sr
 KV-cache write -> paged decode attention -> o projection -> residual -> RMSNorm -> gate/up projection -> SiLU.up ->
 down projection -> residual] -> RMSNorm -> lm_head -> argmax.  q/k/v and gate/up weights are stored concatenated
 (row blocks of one matrix), which changes nothing in the arithmetic: every output row is an independent dot product.
-Batch <= 64 (atoma_linear_decode).  Everything is enqueued on one stream, so a step can be captured in a hipGraph.
+Projections: atoma_linear (weight streaming up to 4 rows, hipBLASLt above).  Everything is enqueued on one stream, so a step can be captured in a hipGraph.
 """
 import os
 import sys
@@ -36,7 +36,7 @@ class DecodeStep:
     def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False, fused_epilogues=False):
         c = self.cfg = cfg
         self.B, self.stream, self.keep = batch, stream, keep_intermediates
-        self.fused = fused_epilogues and not keep_intermediates   # residual adds and SiLU.up inside the projections' split merge
+        self.fused = fused_epilogues and not keep_intermediates and batch <= 4   # residual adds and SiLU.up inside the projections' split merge (weight-streaming kernel: batches it serves)
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
         page_elems = c.page * c.hk * c.d
         self.kc = [ah.DeviceBuffer.zeros((num_pages * page_elems,), np.uint16) for _ in range(c.layers)]
@@ -86,7 +86,7 @@ class DecodeStep:
             xn = self._buf("xn1", l, B * H * 2)
             self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
             qkv = self._buf("qkv", l, B * qkvw * 2)
-            self._ok(L.atoma_linear_decode(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, B, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
+            self._ok(L.atoma_linear(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, B, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
             qkv_pre = None
             if self.keep:                                   # RoPE works in place: keep the projection's output for the checker
                 qkv_pre = self._buf("qkv_pre", l, B * qkvw * 2)
@@ -114,21 +114,21 @@ class DecodeStep:
                 self._ok(L.atoma_linear_decode_residual(act.ptr, self.w["wdown"][l].ptr, x1.ptr, x2.ptr, B, c.inter, H, c.inter, c.inter, H, H, BF16, s), "down projection + residual")
             else:
                 o = self._buf("o", l, B * H * 2)
-                self._ok(L.atoma_linear_decode(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
+                self._ok(L.atoma_linear(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
                 self._ok(L.atoma_add(x.ptr, o.ptr, x1.ptr, B * H, BF16, s), "residual add")
                 self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
                 gu = self._buf("gu", l, B * 2 * c.inter * 2)
-                self._ok(L.atoma_linear_decode(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
+                self._ok(L.atoma_linear(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
                 self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
                 dn = self._buf("dn", l, B * H * 2)
-                self._ok(L.atoma_linear_decode(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
+                self._ok(L.atoma_linear(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
                 self._ok(L.atoma_add(x1.ptr, dn.ptr, x2.ptr, B * H, BF16, s), "residual add")
             if self.keep:
                 self.trace.append(("layer", l, dict(x=x, xn1=xn, qkv_pre=qkv_pre, qkv=qkv, att=att, o=o, x1=x1, xn2=xn2, gu=gu, act=act, dn=dn, x2=x2)))
             x = x2
         xf = self._buf("xf", 0, B * H * 2)
         self._ok(L.atoma_rms_norm(x.ptr, self.w["norm_f"].ptr, xf.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
-        self._ok(L.atoma_linear_decode(xf.ptr, self.w["lm_head"].ptr, self.logits.ptr, B, H, c.vocab, H, H, c.vocab, BF16, s), "lm_head")
+        self._ok(L.atoma_linear(xf.ptr, self.w["lm_head"].ptr, self.logits.ptr, B, H, c.vocab, H, H, c.vocab, BF16, s), "lm_head")
         self._ok(L.atoma_argmax_rows(self.logits.ptr, B, c.vocab, c.vocab, BF16, self.next_ids.ptr, self.next_val.ptr, s), "argmax")
         if self.keep:
             self.trace.append(("head", 0, dict(x=x, xf=xf, logits=self.logits)))
