@@ -375,3 +375,65 @@ def ref(t):
 def tensor_array(ts):
     arr = (_TP * len(ts))(*[C.pointer(t) for t in ts])
     return arr
+
+
+# ---- host-side batch preparation (atoma_prepare_inputs) ----
+class SeqDesc(C.Structure):
+    _fields_ = [("is_prompt", C.c_int32), ("no_block_tables", C.c_int32), ("length", C.c_int64), ("num_computed_tokens", C.c_int64),
+                ("token_chunk_size", C.c_int64), ("token_ids", C.POINTER(C.c_uint32)), ("block_table", C.POINTER(C.c_uint32)),
+                ("block_table_len", C.c_int64)]
+
+
+class BatchLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "num_sequences", "num_tokens", "num_slots", "num_prefills", "num_prefill_tokens", "num_decode_tokens", "max_query_len",
+        "max_prefill_seq_len", "max_decode_seq_len", "max_block_table_len", "off_input_tokens", "off_input_positions", "off_slot_mapping",
+        "off_seq_lens", "off_context_lens", "off_query_start_loc", "off_seq_start_loc", "off_block_tables", "total_bytes")]
+
+
+_opt("atoma_prepare_inputs", [C.POINTER(SeqDesc), _i64, _i64, _i64, _int, _vp, _i64, _vp, _i64, C.POINTER(BatchLayout), _vp])
+
+
+def make_seq_descs(seqs):
+    """seqs: dicts as in oracle/batch_prep_oracle.py.  Returns (ctypes array, keep-alive list)."""
+    arr = (SeqDesc * len(seqs))()
+    keep = []
+    for d, s in zip(arr, seqs):
+        toks = np.ascontiguousarray(s["tokens"], np.uint32)
+        keep.append(toks)
+        d.is_prompt, d.no_block_tables = int(s["is_prompt"]), int(bool(s.get("no_block_tables")))
+        d.length, d.num_computed_tokens, d.token_chunk_size = len(toks), int(s.get("num_computed", 0)), int(s["chunk"])
+        d.token_ids = toks.ctypes.data_as(C.POINTER(C.c_uint32)) if len(toks) else None
+        bt = s.get("block_table")
+        if bt is not None:
+            bt = np.ascontiguousarray(bt, np.uint32)
+            keep.append(bt)
+            d.block_table, d.block_table_len = bt.ctypes.data_as(C.POINTER(C.c_uint32)), len(bt)
+    return arr, keep
+
+
+def unpack_batch(buf, lay):
+    """Views of the packed buffer (numpy uint8 array) as the tensors of ModelInput / FlashAttentionMetadata."""
+    n = lay.num_sequences
+    view = lambda off, count, dt: buf[off: off + count * np.dtype(dt).itemsize].view(dt)
+    return dict(input_tokens=view(lay.off_input_tokens, lay.num_tokens, np.uint32), input_positions=view(lay.off_input_positions, lay.num_tokens, np.int64),
+                slot_mapping=view(lay.off_slot_mapping, lay.num_slots, np.int64), seq_lens=view(lay.off_seq_lens, n, np.uint32),
+                context_lens=view(lay.off_context_lens, n, np.uint32), query_start_loc=view(lay.off_query_start_loc, n + 1, np.uint32),
+                seq_start_loc=view(lay.off_seq_start_loc, n + 1, np.uint32),
+                block_tables=view(lay.off_block_tables, n * lay.max_block_table_len, np.uint32).reshape(n, lay.max_block_table_len),
+                num_prefills=lay.num_prefills, num_prefill_tokens=lay.num_prefill_tokens, num_decode_tokens=lay.num_decode_tokens,
+                max_query_len=lay.max_query_len, max_prefill_seq_len=lay.max_prefill_seq_len, max_decode_seq_len=lay.max_decode_seq_len)
+
+
+def prepare_inputs_host(seqs, block_size, sliding_window=None, enable_chunked_prefill=False):
+    """Pack on the host only (no device needed).  Returns (dict of arrays, layout) or raises RuntimeError(last_error())."""
+    arr, keep = make_seq_descs(seqs)
+    lay = BatchLayout()
+    sw = int(sliding_window or 0)
+    if lib.atoma_prepare_inputs(arr, len(seqs), block_size, sw, int(enable_chunked_prefill), None, 0, None, 0, C.byref(lay), None) != 0:
+        raise RuntimeError(last_error())
+    buf = np.zeros(lay.total_bytes, np.uint8)
+    if lib.atoma_prepare_inputs(arr, len(seqs), block_size, sw, int(enable_chunked_prefill), buf.ctypes.data, buf.nbytes, None, 0,
+                                C.byref(lay), None) != 0:
+        raise RuntimeError(last_error())
+    return unpack_batch(buf, lay), lay

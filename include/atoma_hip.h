@@ -224,6 +224,41 @@ int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128
 int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, int dtype, void *stream);
 int atoma_comm_destroy(void *comm);
 
+/* ---- host-side batch preparation (backends/vllm/src/worker.rs:224-460, ModelWorker::prepare_input_tensors) ----
+ * One sequence of the step as the scheduler describes it (SequenceGroupMetadata / SequenceData): is_prompt,
+ * length = sequence_data.length(), num_computed_tokens (prompts), token_chunk_size, all token ids of the sequence,
+ * its block table (null for a prompt without chunked prefill), no_block_tables = the group's block-table map is
+ * empty (memory profiling: slots are padded with -1). */
+typedef struct atoma_seq_desc {
+    int32_t is_prompt;
+    int32_t no_block_tables;
+    int64_t length;
+    int64_t num_computed_tokens;
+    int64_t token_chunk_size;
+    const uint32_t *token_ids;
+    const uint32_t *block_table;
+    int64_t block_table_len;
+} atoma_seq_desc;
+/* Where each tensor of ModelInput / FlashAttentionMetadata lies in the packed buffer (byte offsets, 256-byte aligned)
+ * and the scalars the reference keeps beside them.  input_tokens u32[num_tokens], input_positions i64[num_tokens],
+ * slot_mapping i64[num_slots], seq_lens / context_lens u32[n], query_start_loc / seq_start_loc u32[n + 1],
+ * block_tables u32[n][max_block_table_len] padded with 0. */
+typedef struct atoma_batch_layout {
+    int64_t num_sequences, num_tokens, num_slots, num_prefills, num_prefill_tokens, num_decode_tokens;
+    int64_t max_query_len, max_prefill_seq_len, max_decode_seq_len, max_block_table_len;
+    int64_t off_input_tokens, off_input_positions, off_slot_mapping, off_seq_lens, off_context_lens;
+    int64_t off_query_start_loc, off_seq_start_loc, off_block_tables;
+    int64_t total_bytes;
+} atoma_batch_layout;
+/* Builds all of the above in `host_staging` (pinned memory for an asynchronous copy) and sends them to
+ * `device_buffer` with ONE hipMemcpyAsync on `stream` (the reference: one H2D copy per tensor plus one per sequence
+ * for the padded block table, worker.rs:411-441,670-683).  host_staging == NULL: only fills `layout` (sizing query);
+ * device_buffer == NULL: packs on the host only.  sliding_window 0 = none.  Returns 0, or -1 with the reference's
+ * message for an empty decode sequence / a missing block table. */
+int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int64_t block_size, int64_t sliding_window,
+                         int enable_chunked_prefill, void *host_staging, int64_t host_capacity, void *device_buffer,
+                         int64_t device_capacity, atoma_batch_layout *layout, void *stream);
+
 /* Tuning knobs for A/B measurements and tests (returns 0, or -1 for an unknown name).  Decode: "decode_p" (K/V tiles
  * in flight per wavefront, 2..4), "decode_nt" (0/1 non-temporal K/V loads), "decode_stream" (0/1, default 1: large batches
  * with device-side lengths share the batch's tiles evenly between the resident wavefronts; 0 = one wavefront per

@@ -335,6 +335,69 @@ def bench_step():
         del step
 
 
+def bench_prep():
+    """f.2: the metadata of one engine step (worker.rs:224-460) for 256 decode sequences at context ~2304: packed on the
+    host and sent with one copy from pinned memory (atoma_prepare_inputs), against the reference's pattern -- one
+    synchronous H2D copy per tensor plus one per sequence for the padded block table, from pageable memory."""
+    import time
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    B, page = 256, 16
+    seqs = []
+    nxt = 0
+    for _ in range(B):
+        L = int(rng.integers(512, 4097))
+        n = (L + page - 1) // page
+        seqs.append(dict(is_prompt=False, tokens=rng.integers(0, 128256, L), chunk=1, block_table=np.arange(nxt, nxt + n)))
+        nxt += n
+    arr, keep = ah.make_seq_descs(seqs)
+    lay = ah.BatchLayout()
+    assert ah.lib.atoma_prepare_inputs(arr, B, page, 0, 0, None, 0, None, 0, C.byref(lay), None) == 0
+    host = ah.lib.atoma_host_alloc(lay.total_bytes)
+    dev = ah.DeviceBuffer(lay.total_bytes)
+    st = ah.Stream()
+
+    def packed():
+        assert ah.lib.atoma_prepare_inputs(arr, B, page, 0, 0, host, lay.total_bytes, dev.ptr, lay.total_bytes, C.byref(lay), st.s) == 0
+        st.synchronize()
+    for _ in range(3):
+        packed()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        packed()
+    us_packed = (time.perf_counter() - t0) / 50 * 1e6
+    # the reference's pattern with the same contents: tokens, positions, slots, seq_lens, context_lens, query_lens (+ 2 zeros
+    # tensors and 2 cumsums on the device, not counted), and B block-table rows of max_len entries each
+    ref = BO_prepare(seqs, page)
+    small = [ref[k] for k in ("input_tokens", "input_positions", "slot_mapping", "seq_lens", "context_lens", "query_start_loc", "seq_start_loc")]
+    rows = [np.ascontiguousarray(r) for r in ref["block_tables"]]
+    dsmall = [ah.DeviceBuffer(a.nbytes) for a in small]
+    drows = ah.DeviceBuffer(ref["block_tables"].nbytes)
+    row_bytes = rows[0].nbytes
+
+    def per_tensor():
+        for a, d in zip(small, dsmall):
+            ah.hip.hipMemcpy(d.ptr, a.ctypes.data, a.nbytes, ah.H2D)
+        for i, r in enumerate(rows):
+            ah.hip.hipMemcpy(drows.ptr + i * row_bytes, r.ctypes.data, row_bytes, ah.H2D)
+    for _ in range(3):
+        per_tensor()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        per_tensor()
+    us_ref = (time.perf_counter() - t0) / 20 * 1e6
+    print(json.dumps({"workload": f"H1 batch prep, {B} decode sequences, context 512..4096: pack + ONE pinned H2D copy", "us_per_step": round(us_packed, 1),
+                      "bytes": int(lay.total_bytes), "reference_pattern_us": round(us_ref, 1), "reference_pattern": f"{len(small)} + {B} synchronous pageable H2D copies (host-side packing not counted)",
+                      "speedup": round(us_ref / us_packed, 1)}), flush=True)
+    ah.lib.atoma_host_free(host)
+
+
+def BO_prepare(seqs, page):
+    sys.path.insert(0, ROOT)
+    from oracle import batch_prep_oracle as BO   # bench-only: builds the contents of the emulated reference copies
+    return BO.prepare_inputs(seqs, page)
+
+
 def bench_swap():
     rng = np.random.default_rng(4)
     L, page_bytes, nb = 32, 16 * 8 * 128 * 2, 2048
@@ -363,6 +426,6 @@ def bench_swap():
 
 if __name__ == "__main__":
     ah.set_device(0)
-    which = sys.argv[1:] or ["decode", "prefill", "prefill_paged", "cache", "norm", "sampling", "linear", "graph", "step", "swap"]
+    which = sys.argv[1:] or ["decode", "prefill", "prefill_paged", "cache", "norm", "sampling", "linear", "graph", "step", "prep", "swap"]
     for w in which:
         globals()["bench_" + w]()
