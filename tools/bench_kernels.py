@@ -308,12 +308,13 @@ def bench_step():
     weight_bytes = 2 * (2 * c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden))
     st = ah.Stream()
     S = 4096
-    for B in (1, 16, 64, 256):
+    for B, ragged in ((1, False), (16, False), (64, False), (256, False), (256, True)):
         pps = S // c.page + 1
         step = DS.DecodeStep(c, B, B * pps + 2, pps, w, st, fused_epilogues=True)
         bt = rng.permutation(B * pps).astype(np.int32).reshape(B, pps)
-        ctx = np.full(B, S)
-        slots = bt[:, S // c.page].astype(np.int64) * c.page + S % c.page
+        # ragged: the C3 trace mid-flight -- prompts of 2048 tokens, sequences 0..511 tokens into their generation
+        ctx = rng.integers(2048, 2560, B) if ragged else np.full(B, S)
+        slots = bt[np.arange(B), ctx // c.page].astype(np.int64) * c.page + ctx % c.page
         step.set_inputs(rng.integers(0, c.vocab, B), ctx, slots, ctx + 1, bt)
 
         def timed(fn, iters=5):
@@ -329,8 +330,8 @@ def bench_step():
         with ah.Graph.capture(st) as g:
             step.run()
         ms_graph = timed(g.launch)
-        nbytes = weight_bytes - 2 * c.vocab * c.hidden + 2 * B * (S + 1) * c.hk * c.d * 2 * c.layers   # embedding table: B rows only
-        emit(f"E1 Llama-3.1-8B decode step, batch={B}, context {S} (hipGraph replay)", ms_graph, nbytes=nbytes, ms_eager=round(ms_eager, 4),
+        nbytes = weight_bytes - 2 * c.vocab * c.hidden + 2 * int((ctx + 1).sum()) * c.hk * c.d * 2 * c.layers   # embedding table: B rows only
+        emit(f"E1 Llama-3.1-8B decode step, batch={B}, context {'U[2048,2560) (C3 mid-trace)' if ragged else S} (hipGraph replay)", ms_graph, nbytes=nbytes, ms_eager=round(ms_eager, 4),
              tokens_per_s=round(B / (ms_graph * 1e-3)), projections="weight-streaming kernel with fused residual / SiLU.up epilogues" if step.fused else "hipBLASLt + separate residual / SiLU.up kernels")
         del step
 
