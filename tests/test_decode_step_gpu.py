@@ -173,3 +173,50 @@ def test_llama_decode_step_fused_epilogues_are_bit_identical(gpu):
                     [step.kc[l].numpy(np.uint16) for l in range(cfg.layers)]))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert all(np.array_equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+
+
+def test_prefill_step_matches_token_by_token_decode(gpu):
+    """PrefillStep (GEMM projections + causal prefill attention over the prompt) leaves the same KV cache and predicts the same
+    next token as feeding the prompt one token at a time through DecodeStep (streaming projections + paged decode attention):
+    two routes through different kernels, equal up to the rounding of their accumulation orders."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import decode_step as DS
+    from oracle.halfs import from_f32, to_f32, BF16 as BF
+    rng = np.random.default_rng(77)
+    c = DS.Config(2, 256, 4, 2, 64, 512, 1024, page=16, max_pos=256)
+    bf = lambda shape, scale: from_f32((rng.standard_normal(shape) * scale).astype(np.float32), BF)
+    host = dict(emb=bf((c.vocab, c.hidden), 1.0), lm_head=bf((c.vocab, c.hidden), c.hidden ** -0.5), norm_f=bf((c.hidden,), 0.1),
+                norm1=[from_f32(np.ones(c.hidden, np.float32), BF) for _ in range(c.layers)], norm2=[from_f32(np.ones(c.hidden, np.float32), BF) for _ in range(c.layers)],
+                wqkv=[bf((c.qkv, c.hidden), c.hidden ** -0.5) for _ in range(c.layers)], wo=[bf((c.hidden, c.h * c.d), (c.h * c.d) ** -0.5) for _ in range(c.layers)],
+                wgu=[bf((2 * c.inter, c.hidden), c.hidden ** -0.5) for _ in range(c.layers)], wdown=[bf((c.hidden, c.inter), c.inter ** -0.5) for _ in range(c.layers)])
+    host["norm_f"] = from_f32(np.ones(c.hidden, np.float32), BF)
+    T, pages = 40, 4
+    ids = rng.integers(0, c.vocab, T)
+    table = np.array([[2, 0, 3, 1]], np.int32)
+    slots = table[0, np.arange(T) // c.page].astype(np.int64) * c.page + np.arange(T) % c.page
+
+    def fresh():
+        st = gpu.Stream()
+        return st, DS.DecodeStep(c, 1, pages, pages, DS.upload_weights(c, host), st)
+    st, step = fresh()
+    pre = DS.PrefillStep(c, T, step, st)
+    pre.set_inputs(ids, slots)
+    pre.run()
+    st.synchronize()
+    tok_prefill = int(pre.next_id.numpy(np.int32, (1,))[0])
+    logits_prefill = to_f32(pre.logits.numpy(np.uint16, (c.vocab,)), BF)
+    kc_prefill = [to_f32(b.numpy(np.uint16, (pages * c.page, c.hk, c.d)), BF) for b in step.kc]
+    vc_prefill = [to_f32(b.numpy(np.uint16, (pages * c.page, c.hk, c.d)), BF) for b in step.vc]
+    st2, step2 = fresh()
+    for t in range(T):
+        step2.set_inputs([ids[t]], [t], [slots[t]], [t + 1], table)
+        step2.run()
+    st2.synchronize()
+    logits_decode = to_f32(step2.logits.numpy(np.uint16, (c.vocab,)), BF)
+    for l in range(c.layers):
+        for a, b_, name in ((kc_prefill[l], step2.kc[l], "K"), (vc_prefill[l], step2.vc[l], "V")):
+            b2 = to_f32(b_.numpy(np.uint16, (pages * c.page, c.hk, c.d)), BF)
+            assert np.abs(a[slots] - b2[slots]).max() <= 0.06 * max(1.0, np.abs(b2[slots]).max()), f"layer {l} {name} cache"
+            assert (np.abs(a[slots] - b2[slots]) <= 2.0 ** -6 * np.abs(b2[slots]) + 1e-2).mean() > 0.99, f"layer {l} {name} cache"
+    assert np.abs(logits_prefill - logits_decode).max() < 0.1
+    assert tok_prefill == int(step2.next_ids.numpy(np.int32, (1,))[0]) or np.sort(logits_decode)[-1] - np.sort(logits_decode)[-2] < 0.1

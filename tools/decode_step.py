@@ -70,6 +70,15 @@ class DecodeStep:
         bt[:, :block_table.shape[1]] = block_table
         self.bt.upload(bt)
 
+    def bind_metadata(self, ids, positions, slots, seqlens, block_table, max_blocks):
+        """Use tensors that live elsewhere on the device (raw pointers), e.g. the packed buffer atoma_prepare_inputs uploads."""
+        P = type("P", (), {})
+        for name, ptr in (("ids", ids), ("pos", positions), ("slots", slots), ("lens", seqlens), ("bt", block_table)):
+            o = P()
+            o.ptr = int(ptr)
+            setattr(self, name, o)
+        self.max_blocks = max_blocks
+
     def _ok(self, rc, what):
         if rc != 0:
             raise RuntimeError(f"{what}: {ah.last_error()}")
@@ -99,7 +108,7 @@ class DecodeStep:
             ah.run_mha(qkv, self.kc[l], self.vc[l], att, b=B, h=c.h, h_k=c.hk, d=c.d, seqlen_q=1, seqlen_k=self.max_blocks * c.page,
                        softmax_scale=c.d ** -0.5, is_bf16=BF16, q_strides=(qkvw, qkvw, c.d), o_strides=(hd, hd, c.d),
                        k_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d), v_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d),
-                       cu_seqlens_k=self.lens, is_seqlens_k_cumulative=False, block_table=self.bt, block_table_batch_stride=self.max_blocks,
+                       cu_seqlens_k=self.lens.ptr, is_seqlens_k_cumulative=False, block_table=self.bt.ptr, block_table_batch_stride=self.max_blocks,
                        page_block_size=c.page, force_split_kernel=True, unpadded_lse=False, stream=s)
             x1 = self._buf("x1", l, B * H * 2)
             xn2 = self._buf("xn2", l, B * H * 2)
@@ -132,6 +141,65 @@ class DecodeStep:
         self._ok(L.atoma_argmax_rows(self.logits.ptr, B, c.vocab, c.vocab, BF16, self.next_ids.ptr, self.next_val.ptr, s), "argmax")
         if self.keep:
             self.trace.append(("head", 0, dict(x=x, xf=xf, logits=self.logits)))
+
+
+class PrefillStep:
+    """One whole prompt of T tokens of ONE sequence through the model (the reference prefills with flash_attn_varlen over
+    cu_seqlens, flash_attention.rs:369-409): embedding -> per layer [RMSNorm -> q/k/v GEMM -> RoPE + cache write -> causal
+    prefill attention over the prompt's own K/V -> o GEMM -> residual -> RMSNorm -> gate/up GEMM -> SiLU.up -> down GEMM ->
+    residual] -> RMSNorm of the last token -> lm_head -> argmax.  Shares the KV caches of a DecodeStep."""
+
+    def __init__(self, cfg, T, decode_step, stream):
+        c = self.cfg = cfg
+        self.T, self.stream, self.w, self.kc, self.vc = T, stream, decode_step.w, decode_step.kc, decode_step.vc
+        self.ids = ah.DeviceBuffer.zeros((T,), np.int32)
+        self.pos = ah.DeviceBuffer.from_numpy(np.arange(T, dtype=np.int64))
+        self.slots = ah.DeviceBuffer.zeros((T,), np.int64)
+        self.cu = ah.DeviceBuffer.from_numpy(np.array([0, T], np.int32))
+        H = c.hidden
+        buf = lambda n: ah.DeviceBuffer(T * n * 2)
+        self.x, self.x1, self.x2, self.xn, self.qkv, self.att = buf(H), buf(H), buf(H), buf(H), buf(c.qkv), buf(c.h * c.d)
+        self.o, self.gu, self.act = buf(H), buf(2 * c.inter), buf(c.inter)
+        self.xf = ah.DeviceBuffer(H * 2)
+        self.logits = ah.DeviceBuffer(c.vocab * 2)
+        self.next_id = ah.DeviceBuffer.zeros((1,), np.int32)
+        self.next_val = ah.DeviceBuffer.zeros((1,), np.float32)
+
+    def set_inputs(self, ids, slots):
+        self.ids.upload(np.asarray(ids, np.int32))
+        self.slots.upload(np.asarray(slots, np.int64))
+
+    def _ok(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {ah.last_error()}")
+
+    def run(self):
+        c, T, s, L = self.cfg, self.T, self.stream.s, ah.lib
+        H, qkvw, hd = c.hidden, c.qkv, c.h * c.d
+        x, x1, x2 = self.x, self.x1, self.x2
+        self._ok(L.atoma_embedding(self.ids.ptr, 0, self.w["emb"].ptr, x.ptr, T, H, c.vocab, H, BF16, s), "embedding")
+        for l in range(c.layers):
+            self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, self.xn.ptr, T, H, H, H, c.eps, BF16, s), "rms_norm")
+            self._ok(L.atoma_linear(self.xn.ptr, self.w["wqkv"][l].ptr, self.qkv.ptr, T, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
+            kptr, vptr = self.qkv.ptr + hd * 2, self.qkv.ptr + (hd + c.hk * c.d) * 2
+            self._ok(L.atoma_rope_qk_cache(self.qkv.ptr, kptr, vptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr, self.w["cos"].ptr,
+                                           self.w["sin"].ptr, self.pos.ptr, T, c.h, c.hk, c.d, qkvw, qkvw, qkvw, c.page * c.hk * c.d,
+                                           c.page, BF16, 1, s), "rope + cache write")
+            ah.run_mha(self.qkv.ptr, kptr, vptr, self.att, b=1, h=c.h, h_k=c.hk, d=c.d, seqlen_q=T, seqlen_k=T, softmax_scale=c.d ** -0.5,
+                       is_bf16=BF16, q_strides=(0, qkvw, c.d), k_strides=(0, qkvw, c.d), v_strides=(0, qkvw, c.d), o_strides=(0, hd, c.d),
+                       is_causal=1, cu_seqlens_q=self.cu, cu_seqlens_k=self.cu, stream=s)
+            self._ok(L.atoma_linear(self.att.ptr, self.w["wo"][l].ptr, self.o.ptr, T, hd, H, hd, hd, H, BF16, s), "o projection")
+            self._ok(L.atoma_add(x.ptr, self.o.ptr, x1.ptr, T * H, BF16, s), "residual add")
+            self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, self.xn.ptr, T, H, H, H, c.eps, BF16, s), "rms_norm")
+            self._ok(L.atoma_linear(self.xn.ptr, self.w["wgu"][l].ptr, self.gu.ptr, T, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
+            self._ok(L.atoma_silu_mul(self.gu.ptr, self.gu.ptr + c.inter * 2, self.act.ptr, T, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
+            self._ok(L.atoma_linear(self.act.ptr, self.w["wdown"][l].ptr, self.o.ptr, T, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
+            self._ok(L.atoma_add(x1.ptr, self.o.ptr, x2.ptr, T * H, BF16, s), "residual add")
+            x, x2 = x2, x
+        last = x.ptr + (T - 1) * H * 2
+        self._ok(L.atoma_rms_norm(last, self.w["norm_f"].ptr, self.xf.ptr, 1, H, H, H, c.eps, BF16, s), "rms_norm")
+        self._ok(L.atoma_linear(self.xf.ptr, self.w["lm_head"].ptr, self.logits.ptr, 1, H, c.vocab, H, H, c.vocab, BF16, s), "lm_head")
+        self._ok(L.atoma_argmax_rows(self.logits.ptr, 1, c.vocab, c.vocab, BF16, self.next_id.ptr, self.next_val.ptr, s), "argmax")
 
 
 def rope_tables(cfg):

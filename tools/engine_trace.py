@@ -1,0 +1,132 @@
+"""C3-lite: a continuous-batching trace on one GPU, composed from the C-ABI entry points (bench plumbing, Python host loop).
+
+SURVEY.md 8d C3: Llama-3.1-8B shapes, synthetic bf16 weights, 256 requests with 2048-token prompts and 512 decode steps,
+batch <= 256, block size 16.  Phase 1 prefills the prompts one per launch sequence (a hipGraph of PrefillStep replayed per
+request); phase 2 runs the decode steps at batch 256: per step the sampled tokens come back to the host (1 KiB), the
+step's metadata is rebuilt by atoma_prepare_inputs (packed, one pinned H2D copy) and the captured decode graph is replayed
+on the uploaded tensors.  Prints one JSON line: prefill tokens/s, decode tokens/s, whole-trace tokens/s.
+
+    python tools/engine_trace.py [--requests 256] [--prompt 2048] [--decode-steps 512]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_kernels as bk  # noqa: E402
+import decode_step as DS  # noqa: E402
+
+ah = bk.ah
+
+
+def random_weights(rng, c):
+    w = dict(emb=bk.rand_dev(rng, c.vocab * c.hidden * 2), lm_head=bk.rand_dev(rng, c.vocab * c.hidden * 2), norm_f=bk.rand_dev(rng, c.hidden * 2),
+             norm1=[bk.rand_dev(rng, c.hidden * 2) for _ in range(c.layers)], norm2=[bk.rand_dev(rng, c.hidden * 2) for _ in range(c.layers)],
+             wqkv=[], wo=[], wgu=[], wdown=[])
+    cos, sin = DS.rope_tables(c)
+    w["cos"], w["sin"] = ah.DeviceBuffer.from_numpy(cos), ah.DeviceBuffer.from_numpy(sin)
+    for _ in range(c.layers):
+        w["wqkv"].append(bk.rand_dev(rng, c.qkv * c.hidden * 2))
+        w["wo"].append(bk.rand_dev(rng, c.hidden * c.h * c.d * 2))
+        w["wgu"].append(bk.rand_dev(rng, 2 * c.inter * c.hidden * 2))
+        w["wdown"].append(bk.rand_dev(rng, c.hidden * c.inter * 2))
+    return w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--requests", type=int, default=256)
+    ap.add_argument("--prompt", type=int, default=2048)
+    ap.add_argument("--decode-steps", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=0, help="override the layer count (quick runs)")
+    a = ap.parse_args()
+    ah.set_device(0)
+    rng = np.random.default_rng(3)
+    c = DS.LLAMA_3_1_8B
+    if a.layers:
+        c = DS.Config(a.layers, c.hidden, c.h, c.hk, c.d, c.inter, c.vocab)
+    B, P, N = a.requests, a.prompt, a.decode_steps
+    pps = (P + N + c.page - 1) // c.page                                  # pages a request owns (reserved up front)
+    num_pages = B * pps + 1
+    w = random_weights(rng, c)
+    st = ah.Stream()
+    step = DS.DecodeStep(c, B, num_pages, pps, w, st, fused_epilogues=True)
+    pre = DS.PrefillStep(c, P, step, st)
+    tables = (1 + rng.permutation(B * pps)).astype(np.uint32).reshape(B, pps)   # page 0 is never used
+    tokens = np.zeros((B, P + N + 1), np.uint32)
+    tokens[:, :P] = rng.integers(0, c.vocab, (B, P))
+    lengths = np.full(B, P, np.int64)
+
+    # ---- phase 1: prefill, one prompt per graph replay ----
+    slots_of = lambda r: (tables[r, np.arange(P) // c.page].astype(np.int64) * c.page + np.arange(P) % c.page)
+    pre.set_inputs(tokens[0, :P], slots_of(0))
+    pre.run(); st.synchronize()                                          # warm-up: workspaces, hipBLASLt plans
+    with ah.Graph.capture(st) as gpre:
+        pre.run()
+    first = np.zeros(B, np.int32)
+    t0 = time.perf_counter()
+    for r in range(B):
+        pre.set_inputs(tokens[r, :P], slots_of(r))
+        gpre.launch()
+        st.synchronize()
+        first[r] = pre.next_id.numpy(np.int32, (1,))[0]
+    t_prefill = time.perf_counter() - t0
+    tokens[:, P] = first
+    lengths += 1
+
+    # ---- phase 2: decode at batch B, metadata through atoma_prepare_inputs ----
+    descs = (ah.SeqDesc * B)()
+    for r in range(B):
+        d = descs[r]
+        d.is_prompt, d.no_block_tables, d.length, d.num_computed_tokens, d.token_chunk_size = 0, 0, int(lengths[r]), 0, 1
+        d.token_ids = tokens[r].ctypes.data_as(C.POINTER(C.c_uint32))
+        d.block_table, d.block_table_len = tables[r].ctypes.data_as(C.POINTER(C.c_uint32)), pps
+    desc_view = np.frombuffer(descs, dtype=np.dtype([("is_prompt", "<i4"), ("nbt", "<i4"), ("length", "<i8"), ("computed", "<i8"), ("chunk", "<i8"),
+                                                     ("tok", "<u8"), ("bt", "<u8"), ("btlen", "<i8")]))
+    lay = ah.BatchLayout()
+    assert ah.lib.atoma_prepare_inputs(descs, B, c.page, 0, 0, None, 0, None, 0, C.byref(lay), None) == 0, ah.last_error()
+    host = ah.lib.atoma_host_alloc(lay.total_bytes)
+    meta = ah.DeviceBuffer(lay.total_bytes)
+    step.bind_metadata(meta.ptr + lay.off_input_tokens, meta.ptr + lay.off_input_positions, meta.ptr + lay.off_slot_mapping,
+                       meta.ptr + lay.off_seq_lens, meta.ptr + lay.off_block_tables, int(lay.max_block_table_len))
+
+    def upload_metadata():
+        assert ah.lib.atoma_prepare_inputs(descs, B, c.page, 0, 0, host, lay.total_bytes, meta.ptr, lay.total_bytes, C.byref(lay), st.s) == 0, ah.last_error()
+    upload_metadata()
+    step.run(); st.synchronize()
+    with ah.Graph.capture(st) as gdec:
+        step.run()
+    rows = np.arange(B)
+    host_s = 0.0
+    t0 = time.perf_counter()
+    for i in range(N):
+        h0 = time.perf_counter()
+        upload_metadata()
+        host_s += time.perf_counter() - h0
+        gdec.launch()
+        st.synchronize()
+        nxt = step.next_ids.numpy(np.int32, (B,))                        # sampled tokens back to the host (detokenizer, stop checks)
+        h0 = time.perf_counter()
+        tokens[rows, lengths] = nxt
+        lengths += 1
+        desc_view["length"] = lengths
+        host_s += time.perf_counter() - h0
+    t_decode = time.perf_counter() - t0
+    out = {"workload": f"C3-lite trace: Llama-3.1-8B shapes ({c.layers} layers), {B} requests, prompt {P}, {N} decode steps, block {c.page}",
+           "prefill_s": round(t_prefill, 3), "prefill_tokens_per_s": round(B * P / t_prefill), "prefill_ms_per_prompt": round(t_prefill / B * 1e3, 2),
+           "decode_s": round(t_decode, 3), "decode_ms_per_step": round(t_decode / N * 1e3, 3), "decode_tokens_per_s": round(B * N / t_decode),
+           "host_metadata_ms_per_step": round(host_s / N * 1e3, 4), "trace_s": round(t_prefill + t_decode, 3),
+           "generated_tokens_per_s_over_trace": round(B * (N + 1) / (t_prefill + t_decode)),
+           "decode_roofline_tokens_per_s": round(B / ((16.06e9 + B * (P + N / 2) * 131072) / 8e12)),
+           "data": "synthetic weights and prompts; greedy sampling on the device"}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
