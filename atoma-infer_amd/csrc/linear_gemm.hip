@@ -16,6 +16,7 @@
 #include <mutex>
 #include <stdlib.h>
 #include <tuple>
+#include <vector>
 
 extern "C" int atoma_linear_decode(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
                                    int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream);
@@ -72,6 +73,9 @@ struct LtDevice {
     std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t>, GemmPlan> plans;
 };
 static const size_t LT_WORKSPACE_BYTES = 64u << 20;
+static const int LT_CANDIDATES = 16, LT_TIMED_REPS = 10;
+// time the library's candidate algorithms on first use of a problem (ATOMA_LINEAR_AUTOTUNE=0: take the heuristic's first choice)
+static const int linear_autotune = getenv("ATOMA_LINEAR_AUTOTUNE") ? atoi(getenv("ATOMA_LINEAR_AUTOTUNE")) : 1;
 static std::mutex *g_lt_mu = new std::mutex;
 static std::map<int, LtDevice> *g_lt_devices = new std::map<int, LtDevice>;
 
@@ -110,14 +114,64 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
         if (!lt_ok(api.pref_create(&pref), "MatmulPreferenceCreate")) return -1;
         const uint64_t ws = LT_WORKSPACE_BYTES;
         bool ok = lt_ok(api.pref_set(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof ws), "MatmulPreferenceSetAttribute");
-        hipblasLtMatmulHeuristicResult_t res[1];
-        int found = 0;
+        // The heuristic's first choice is often not the fastest kernel for a skinny problem: take its candidates, time
+        // each once on this problem (first use only; y is overwritten with the same product every time) and keep the best.
+        // candidate 0 = the library's own single choice; the longer list it returns is ordered differently and need not contain it
+        hipblasLtMatmulHeuristicResult_t res[LT_CANDIDATES + 1];
+        int found = 0, more = 0;
         ok = ok && lt_ok(api.heuristic(d.handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, 1, res, &found), "MatmulAlgoGetHeuristic");
+        if (ok && found == 1 && linear_autotune &&
+            api.heuristic(d.handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, LT_CANDIDATES, res + 1, &more) == HIPBLAS_STATUS_SUCCESS)
+            found += more;
         api.pref_destroy(pref);
         if (!ok) return -1;
         if (found < 1) { set_error("linear: hipBLASLt has no algorithm for this problem"); return -1; }
-        pl.algo = res[0].algo;
-        pl.workspace = res[0].workspaceSize;
+        int best = 0;
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &capturing);
+        if (found > 1 && capturing == hipStreamCaptureStatusNone) {
+            const float alpha = 1.f, beta = 0.f;
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            auto run = [&](int c, int reps, float *ms) -> bool {          // `reps` back-to-back launches of candidate c
+                bool good = true;
+                (void)hipEventRecord(e0, stream);
+                for (int rep = 0; rep < reps && good; ++rep)
+                    good = api.matmul(d.handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &res[c].algo, d.workspace,
+                                      LT_WORKSPACE_BYTES, stream) == HIPBLAS_STATUS_SUCCESS;
+                (void)hipEventRecord(e1, stream);
+                if (hipEventSynchronize(e1) != hipSuccess || !good) { (void)hipGetLastError(); return false; }
+                (void)hipEventElapsedTime(ms, e0, e1);
+                return true;
+            };
+            // clocks first: a cold GPU makes whichever candidate is timed first look slow
+            float warm = 0.f, ms = 0.f;
+            for (int i = 0; i < 40 && warm < 5.f; ++i) {
+                if (!run(0, 10, &ms)) break;
+                warm += ms;
+            }
+            // launches of less than ~30 us cannot be ranked reliably from the host (clock and dispatch jitter exceed the
+            // differences between candidates, measured): keep the library's choice there; otherwise time windows of >= 1 ms
+            float per_launch = 1e30f;
+            if (run(0, 20, &ms)) per_launch = ms / 20.f;
+            const int reps = per_launch < 0.03f ? 0 : std::max(LT_TIMED_REPS, std::min(50, (int)(1.f / per_launch)));
+            std::vector<float> t((size_t)found, 1e30f);
+            for (int round = 0; round < 3 && reps > 0; ++round)
+                for (int c = 0; c < found; ++c) {
+                    if (res[c].state != HIPBLAS_STATUS_SUCCESS || res[c].workspaceSize > LT_WORKSPACE_BYTES) continue;
+                    if (round == 0 && !run(c, 2, &ms)) { res[c].state = HIPBLAS_STATUS_NOT_SUPPORTED; continue; }   // code load
+                    if (run(c, reps, &ms)) t[(size_t)c] = std::min(t[(size_t)c], ms);
+                    else res[c].state = HIPBLAS_STATUS_NOT_SUPPORTED;
+                }
+            for (int c = 1; c < found; ++c)
+                if (t[(size_t)c] < t[(size_t)best]) best = c;
+            if (best != 0 && t[(size_t)best] > 0.97f * t[0]) best = 0;   // keep the heuristic's choice unless another is clearly faster
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        pl.algo = res[best].algo;
+        pl.workspace = res[best].workspaceSize;
         it = d.plans.emplace(key, pl).first;
     }
     const GemmPlan &pl = it->second;

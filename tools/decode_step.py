@@ -149,21 +149,23 @@ class PrefillStep:
     prefill attention over the prompt's own K/V -> o GEMM -> residual -> RMSNorm -> gate/up GEMM -> SiLU.up -> down GEMM ->
     residual] -> RMSNorm of the last token -> lm_head -> argmax.  Shares the KV caches of a DecodeStep."""
 
-    def __init__(self, cfg, T, decode_step, stream):
+    def __init__(self, cfg, T, decode_step, stream, prompts=1):
+        """T tokens in all = `prompts` prompts of T / prompts tokens each, back to back (varlen batch)."""
         c = self.cfg = cfg
-        self.T, self.stream, self.w, self.kc, self.vc = T, stream, decode_step.w, decode_step.kc, decode_step.vc
+        assert T % prompts == 0
+        self.T, self.n, self.stream, self.w, self.kc, self.vc = T, prompts, stream, decode_step.w, decode_step.kc, decode_step.vc
         self.ids = ah.DeviceBuffer.zeros((T,), np.int32)
-        self.pos = ah.DeviceBuffer.from_numpy(np.arange(T, dtype=np.int64))
+        self.pos = ah.DeviceBuffer.from_numpy(np.tile(np.arange(T // prompts, dtype=np.int64), prompts))
         self.slots = ah.DeviceBuffer.zeros((T,), np.int64)
-        self.cu = ah.DeviceBuffer.from_numpy(np.array([0, T], np.int32))
+        self.cu = ah.DeviceBuffer.from_numpy((np.arange(prompts + 1) * (T // prompts)).astype(np.int32))
         H = c.hidden
         buf = lambda n: ah.DeviceBuffer(T * n * 2)
         self.x, self.x1, self.x2, self.xn, self.qkv, self.att = buf(H), buf(H), buf(H), buf(H), buf(c.qkv), buf(c.h * c.d)
         self.o, self.gu, self.act = buf(H), buf(2 * c.inter), buf(c.inter)
-        self.xf = ah.DeviceBuffer(H * 2)
-        self.logits = ah.DeviceBuffer(c.vocab * 2)
-        self.next_id = ah.DeviceBuffer.zeros((1,), np.int32)
-        self.next_val = ah.DeviceBuffer.zeros((1,), np.float32)
+        self.xf = ah.DeviceBuffer(prompts * H * 2)
+        self.logits = ah.DeviceBuffer(prompts * c.vocab * 2)
+        self.next_id = ah.DeviceBuffer.zeros((prompts,), np.int32)
+        self.next_val = ah.DeviceBuffer.zeros((prompts,), np.float32)
 
     def set_inputs(self, ids, slots):
         self.ids.upload(np.asarray(ids, np.int32))
@@ -185,7 +187,7 @@ class PrefillStep:
             self._ok(L.atoma_rope_qk_cache(self.qkv.ptr, kptr, vptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr, self.w["cos"].ptr,
                                            self.w["sin"].ptr, self.pos.ptr, T, c.h, c.hk, c.d, qkvw, qkvw, qkvw, c.page * c.hk * c.d,
                                            c.page, BF16, 1, s), "rope + cache write")
-            ah.run_mha(self.qkv.ptr, kptr, vptr, self.att, b=1, h=c.h, h_k=c.hk, d=c.d, seqlen_q=T, seqlen_k=T, softmax_scale=c.d ** -0.5,
+            ah.run_mha(self.qkv.ptr, kptr, vptr, self.att, b=self.n, h=c.h, h_k=c.hk, d=c.d, seqlen_q=T // self.n, seqlen_k=T // self.n, softmax_scale=c.d ** -0.5,
                        is_bf16=BF16, q_strides=(0, qkvw, c.d), k_strides=(0, qkvw, c.d), v_strides=(0, qkvw, c.d), o_strides=(0, hd, c.d),
                        is_causal=1, cu_seqlens_q=self.cu, cu_seqlens_k=self.cu, stream=s)
             self._ok(L.atoma_linear(self.att.ptr, self.w["wo"][l].ptr, self.o.ptr, T, hd, H, hd, hd, H, BF16, s), "o projection")
@@ -196,10 +198,11 @@ class PrefillStep:
             self._ok(L.atoma_linear(self.act.ptr, self.w["wdown"][l].ptr, self.o.ptr, T, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
             self._ok(L.atoma_add(x1.ptr, self.o.ptr, x2.ptr, T * H, BF16, s), "residual add")
             x, x2 = x2, x
-        last = x.ptr + (T - 1) * H * 2
-        self._ok(L.atoma_rms_norm(last, self.w["norm_f"].ptr, self.xf.ptr, 1, H, H, H, c.eps, BF16, s), "rms_norm")
-        self._ok(L.atoma_linear(self.xf.ptr, self.w["lm_head"].ptr, self.logits.ptr, 1, H, c.vocab, H, H, c.vocab, BF16, s), "lm_head")
-        self._ok(L.atoma_argmax_rows(self.logits.ptr, 1, c.vocab, c.vocab, BF16, self.next_id.ptr, self.next_val.ptr, s), "argmax")
+        Ts, n = T // self.n, self.n
+        last = x.ptr + (Ts - 1) * H * 2                      # the last token of every prompt: rows Ts - 1, 2 Ts - 1, ...
+        self._ok(L.atoma_rms_norm(last, self.w["norm_f"].ptr, self.xf.ptr, n, H, Ts * H, H, c.eps, BF16, s), "rms_norm")
+        self._ok(L.atoma_linear(self.xf.ptr, self.w["lm_head"].ptr, self.logits.ptr, n, H, c.vocab, H, H, c.vocab, BF16, s), "lm_head")
+        self._ok(L.atoma_argmax_rows(self.logits.ptr, n, c.vocab, c.vocab, BF16, self.next_id.ptr, self.next_val.ptr, s), "argmax")
 
 
 def rope_tables(cfg):

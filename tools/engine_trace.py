@@ -1,8 +1,8 @@
 """C3-lite: a continuous-batching trace on one GPU, composed from the C-ABI entry points (bench plumbing, Python host loop).
 
 SURVEY.md 8d C3: Llama-3.1-8B shapes, synthetic bf16 weights, 256 requests with 2048-token prompts and 512 decode steps,
-batch <= 256, block size 16.  Phase 1 prefills the prompts one per launch sequence (a hipGraph of PrefillStep replayed per
-request); phase 2 runs the decode steps at batch 256: per step the sampled tokens come back to the host (1 KiB), the
+batch <= 256, block size 16.  Phase 1 prefills the prompts two at a time (a hipGraph of PrefillStep replayed per
+pair); phase 2 runs the decode steps at batch 256: per step the sampled tokens come back to the host (1 KiB), the
 step's metadata is rebuilt by atoma_prepare_inputs (packed, one pinned H2D copy) and the captured decode graph is replayed
 on the uploaded tensors.  Prints one JSON line: prefill tokens/s, decode tokens/s, whole-trace tokens/s.
 
@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--prompt", type=int, default=2048)
     ap.add_argument("--decode-steps", type=int, default=512)
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (quick runs)")
+    ap.add_argument("--prompts-per-launch", type=int, default=2, help="prompts prefilled together (one varlen batch per graph replay)")
     a = ap.parse_args()
     ah.set_device(0)
     rng = np.random.default_rng(3)
@@ -57,7 +58,9 @@ def main():
     w = random_weights(rng, c)
     st = ah.Stream()
     step = DS.DecodeStep(c, B, num_pages, pps, w, st, fused_epilogues=True)
-    pre = DS.PrefillStep(c, P, step, st)
+    G = a.prompts_per_launch
+    assert B % G == 0
+    pre = DS.PrefillStep(c, P * G, step, st, prompts=G)
     tables = (1 + rng.permutation(B * pps)).astype(np.uint32).reshape(B, pps)   # page 0 is never used
     tokens = np.zeros((B, P + N + 1), np.uint32)
     tokens[:, :P] = rng.integers(0, c.vocab, (B, P))
@@ -65,17 +68,18 @@ def main():
 
     # ---- phase 1: prefill, one prompt per graph replay ----
     slots_of = lambda r: (tables[r, np.arange(P) // c.page].astype(np.int64) * c.page + np.arange(P) % c.page)
-    pre.set_inputs(tokens[0, :P], slots_of(0))
-    pre.run(); st.synchronize()                                          # warm-up: workspaces, hipBLASLt plans
+    group = lambda r: (tokens[r:r + G, :P].reshape(-1), np.concatenate([slots_of(i) for i in range(r, r + G)]))
+    pre.set_inputs(*group(0))
+    pre.run(); st.synchronize()                                          # warm-up: workspaces, hipBLASLt plans (autotuned on first use)
     with ah.Graph.capture(st) as gpre:
         pre.run()
     first = np.zeros(B, np.int32)
     t0 = time.perf_counter()
-    for r in range(B):
-        pre.set_inputs(tokens[r, :P], slots_of(r))
+    for r in range(0, B, G):
+        pre.set_inputs(*group(r))
         gpre.launch()
         st.synchronize()
-        first[r] = pre.next_id.numpy(np.int32, (1,))[0]
+        first[r:r + G] = pre.next_id.numpy(np.int32, (G,))
     t_prefill = time.perf_counter() - t0
     tokens[:, P] = first
     lengths += 1
