@@ -875,13 +875,14 @@ __global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodePar
 template <typename T, int D>
 __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p) {
     const int lane = threadIdx.x;
-    const int64_t bh = blockIdx.x;  // b * h + hq
-    const int b = (int)(bh / p.h), hq = (int)(bh % p.h);
+    if (p.stream_waves > 0 && p.plan[1] == 0) return;    // balanced mode, but one wavefront per sequence was taken: outputs are final
     const int64_t stride = (int64_t)p.b * p.h;
+    // grid-stride over (b, q head): a uniform batch launches this kernel only to find nothing to merge, so keep the grid small
+    for (int64_t bh = blockIdx.x; bh < stride; bh += gridDim.x) [&] {
+    const int b = (int)(bh / p.h), hq = (int)(bh % p.h);
     int nsp = p.num_splits;
     int64_t row0 = bh, row_step = stride, row1 = bh;   // partial row of piece s: s == 0 ? row0 : row1 + s * row_step
     if (p.stream_waves > 0) {   // balanced mode: merge the pieces of a sequence that was cut between wavefronts
-        if (p.plan[1] == 0) return;                   // one wavefront per sequence was taken: outputs are final
         const int tiles = p.plan[0], c0 = p.plan[2 + b], n = p.plan[3 + b] - c0;
         uint16_t *dst = p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride;
         if (n == 0) {                                 // empty sequence: no wavefront saw it (flash_fwd_kernel.h:543-582)
@@ -932,6 +933,7 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
         for (int e = 0; e < EPL; ++e) dst[e] = (uint16_t)f32_to_bits<T>(acc[e]);
     }
     if (p.lse && lane == 0) p.lse[bh] = lse;
+    }();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1060,7 +1062,7 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
 #undef ATOMA_MQK
     if (!ATOMA_CHECK_LAUNCH("paged_decode_mqk_kernel")) return;
     if (p.num_splits > 1 || p.stream_waves > 0) {
-        hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)((int64_t)p.b * p.h)), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, 4 * device_num_cus())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
 }
@@ -1083,7 +1085,7 @@ static void launch_decode_tdg(DecodeParams &p, hipStream_t stream) {
     }
     if (!ATOMA_CHECK_LAUNCH("paged_decode_kernel")) return;
     if (p.num_splits > 1 || p.stream_waves > 0) {
-        hipLaunchKernelGGL((decode_combine_kernel<T, D>), dim3((unsigned)((int64_t)p.b * p.h)), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((decode_combine_kernel<T, D>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, 4 * device_num_cus())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
 }
