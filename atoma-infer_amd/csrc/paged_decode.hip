@@ -902,6 +902,7 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
         row1 = w0 * 2 * p.group_tile + gq;
     }
     auto prow = [&](int s) -> int64_t { return s == 0 ? row0 : row1 + s * row_step; };
+    // LSE pass: lane s owns piece s (pieces beyond 64 wrap around)
     float mx = -INFINITY;
     for (int s = lane; s < nsp; s += 64) mx = fmaxf(mx, p.lse_accum[prow(s)]);
 #pragma unroll
@@ -913,24 +914,51 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
     for (int off = 32; off; off >>= 1) tot += __shfl_xor(tot, off, 64);
     const bool empty = !(tot > 0.f);
     const float lse = empty ? INFINITY : __logf(tot) + ms;
-    constexpr int EPL = D / 64;  // elements per lane
+    // O pass: 16 lanes per partial row (EPL floats each), four rows per step and four steps unrolled, so 16 independent
+    // row loads are in flight per wavefront -- merging 32 pieces one dependent load at a time took 8-16 us, longer than
+    // the decode kernel itself at batch 1.
+    constexpr int EPL = D / 16;
+    const int grp = lane >> 4, col = lane & 15;
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int s = 0; s < nsp; ++s) {
-        const float ls = p.lse_accum[prow(s)];
-        const float w = empty ? 0.f : __expf(ls - lse);
-        const float *src = p.o_accum + prow(s) * D + lane * EPL;
+    for (int c0 = 0; c0 < nsp; c0 += 64) {
+        const int mine = c0 + lane;
+        const float wl = (mine < nsp && !empty) ? __expf(p.lse_accum[prow(mine)] - lse) : 0.f;   // weight of piece c0 + lane
+        const int chunk = min(64, nsp - c0);
+        for (int j0 = 0; j0 < chunk; j0 += 16) {
+            float4 v[4][EPL / 4];
+            float wgt[4];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] += w * src[e];
+            for (int u = 0; u < 4; ++u) {
+                const int sl = j0 + 4 * u + grp;                       // piece (within the chunk) of this lane group
+                wgt[u] = __shfl(wl, sl & 63, 64);
+                const bool on = sl < chunk;
+                if (!on) wgt[u] = 0.f;
+                const float4 *src = reinterpret_cast<const float4 *>(p.o_accum + prow(on ? c0 + sl : c0) * D + col * EPL);
+#pragma unroll
+                for (int q = 0; q < EPL / 4; ++q) v[u][q] = src[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < EPL / 4; ++q) {
+                    acc[4 * q + 0] += wgt[u] * v[u][q].x;
+                    acc[4 * q + 1] += wgt[u] * v[u][q].y;
+                    acc[4 * q + 2] += wgt[u] * v[u][q].z;
+                    acc[4 * q + 3] += wgt[u] * v[u][q].w;
+                }
+        }
     }
-    uint16_t *dst = p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + lane * EPL;
-    if constexpr (EPL % 2 == 0) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if (grp == 0) {
+        uint16_t *dst = p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + col * EPL;
 #pragma unroll
         for (int e = 0; e < EPL; e += 2) *reinterpret_cast<uint32_t *>(dst + e) = pack2<T>(acc[e], acc[e + 1]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) dst[e] = (uint16_t)f32_to_bits<T>(acc[e]);
     }
     if (p.lse && lane == 0) p.lse[bh] = lse;
     }();

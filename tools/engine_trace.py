@@ -45,11 +45,14 @@ def main():
     ap.add_argument("--prompt", type=int, default=2048)
     ap.add_argument("--decode-steps", type=int, default=512)
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (quick runs)")
+    ap.add_argument("--model", default="8b", choices=["8b", "70b-tp8-shard"],
+                    help="70b-tp8-shard: what ONE rank of a TP=8 Llama-3.1-70B job computes (8 q heads / 1 kv head, 1/8 of the MLP and of "
+                         "the vocabulary); the two all-reduces of [batch, 8192] per layer are NOT included (single-GPU box)")
     ap.add_argument("--prompts-per-launch", type=int, default=2, help="prompts prefilled together (one varlen batch per graph replay)")
     a = ap.parse_args()
     ah.set_device(0)
     rng = np.random.default_rng(3)
-    c = DS.LLAMA_3_1_8B
+    c = DS.LLAMA_3_1_8B if a.model == "8b" else DS.Config(80, 8192, 8, 1, 128, 28672 // 8, 128256 // 8)
     if a.layers:
         c = DS.Config(a.layers, c.hidden, c.h, c.hk, c.d, c.inter, c.vocab)
     B, P, N = a.requests, a.prompt, a.decode_steps
@@ -122,12 +125,15 @@ def main():
         desc_view["length"] = lengths
         host_s += time.perf_counter() - h0
     t_decode = time.perf_counter() - t0
-    out = {"workload": f"C3-lite trace: Llama-3.1-8B shapes ({c.layers} layers), {B} requests, prompt {P}, {N} decode steps, block {c.page}",
+    weight_bytes = 2 * (c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden))   # lm_head + layers
+    kv_bytes_per_token = 2 * c.layers * c.hk * c.d * 2
+    name = "C3-lite trace: Llama-3.1-8B shapes" if a.model == "8b" else "C4-lite trace: one rank of Llama-3.1-70B TP=8 (no all-reduce)"
+    out = {"workload": f"{name} ({c.layers} layers), {B} requests, prompt {P}, {N} decode steps, block {c.page}",
            "prefill_s": round(t_prefill, 3), "prefill_tokens_per_s": round(B * P / t_prefill), "prefill_ms_per_prompt": round(t_prefill / B * 1e3, 2),
            "decode_s": round(t_decode, 3), "decode_ms_per_step": round(t_decode / N * 1e3, 3), "decode_tokens_per_s": round(B * N / t_decode),
            "host_metadata_ms_per_step": round(host_s / N * 1e3, 4), "trace_s": round(t_prefill + t_decode, 3),
            "generated_tokens_per_s_over_trace": round(B * (N + 1) / (t_prefill + t_decode)),
-           "decode_roofline_tokens_per_s": round(B / ((16.06e9 + B * (P + N / 2) * 131072) / 8e12)),
+           "decode_roofline_tokens_per_s": round(B / ((weight_bytes + B * (P + N / 2) * kv_bytes_per_token) / 8e12)),
            "data": "synthetic weights and prompts; greedy sampling on the device"}
     print(json.dumps(out), flush=True)
 
