@@ -171,9 +171,134 @@ template <typename T> __global__ void __launch_bounds__(256) linear_reduce_kerne
     *reinterpret_cast<uint2 *>(p.y + row * p.y_row_stride + n) = w;
 }
 
+// Batches of 1..4 rows, one launch: a workgroup of NW wavefronts owns 16 output features (PAIR: 16 gate + the 16 matching
+// up features of a stacked gate / up matrix); wavefront w streams the w-th part of K, the NW accumulator tiles are added
+// through LDS and the epilogue (none / + residual / silu(gate).up) runs in the workgroup -- no fp32 partials in HBM and no
+// second kernel, which on the 33-120 MB projections of one layer is 3-5 us of a 11-30 us op.
+template <typename T, int NW, bool PAIR, int P>
+__global__ void __launch_bounds__(64 * NW) linear_wg_kernel(const LinearParams p) {
+    constexpr int RT = PAIR ? 2 : 1;
+    __shared__ float red[NW > 1 ? NW - 1 : 1][RT][64][4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), grp = lane >> 4, col = lane & 15;
+    const int n0 = blockIdx.x * 16;
+    const int out_n = PAIR ? p.n / 2 : p.n;
+    const int chunks = p.k >> 7, per = (chunks + NW - 1) / NW;
+    const int c0 = wave * per, c1 = min(c0 + per, chunks);
+
+    const char *wrow = reinterpret_cast<const char *>(p.w + (int64_t)n0 * p.w_row_stride);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wrow), 0, 0x7fffffff, 0x00020000);
+    uint32_t w_lane[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) w_lane[r] = (uint32_t)(((int64_t)r * out_n + col) * p.w_row_stride * 2 + grp * 16);
+    const bool has_x = col < p.batch;
+    const uint16_t *xrow = p.x + (int64_t)(has_x ? col : 0) * p.x_row_stride + grp * 8;
+
+    lu32x4 wb[P][RT][4], xb[P][4];
+    auto issue = [&](int s, int chunk) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wb[s][r][q] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], chunk * 256 + q * 64, 2 /* nt */);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xb[s][q] = has_x ? *reinterpret_cast<const lu32x4 *>(xrow + chunk * 128 + q * 32) : lu32x4{0, 0, 0, 0};
+    };
+    lf32x4 acc[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) acc[r] = lf32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r] = lin_mfma<T>(wb[s][r][q], xb[s][q], acc[r]);
+    };
+    int c = c0;
+    if (c0 + 2 * P <= c1) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) issue(s, c0 + s);
+        for (; c + 2 * P <= c1; c += P) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                compute(s);
+                issue(s, c + s + P);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < P; ++s)
+            if (c0 + s < c1) issue(s, c0 + s);
+    }
+    for (; c < c1; c += P) {
+#pragma unroll
+        for (int s = 0; s < P; ++s)
+            if (c + s < c1) {
+                compute(s);
+                if (c + s + P < c1) issue(s, c + s + P);
+            }
+    }
+    // add the NW accumulator tiles: wavefronts 1.. write, wavefront 0 sums (fixed order: deterministic)
+    if constexpr (NW > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) *reinterpret_cast<lf32x4 *>(red[wave - 1][r][lane]) = acc[r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const lf32x4 o = *reinterpret_cast<const lf32x4 *>(red[w][r][lane]);
+                acc[r] += o;
+            }
+    }
+    if (!has_x) return;
+    // lane holds y^T[n0 + 4.grp + i][batch row col]; rounding points as in linear_reduce_kernel
+    const int n = n0 + 4 * grp;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = round_through<T>(acc[0][i]);
+    if (p.epilogue == 1) {
+        const uint2 r = *reinterpret_cast<const uint2 *>(p.aux + (int64_t)col * p.aux_row_stride + n);
+        v[0] += lo_to_f32<T>(r.x); v[1] += hi_to_f32<T>(r.x); v[2] += lo_to_f32<T>(r.y); v[3] += hi_to_f32<T>(r.y);
+    }
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = round_through<T>(v[i] / (1.f + __expf(-v[i]))) * round_through<T>(acc[1][i]);
+    }
+    uint2 o;
+    o.x = pack2<T>(v[0], v[1]);
+    o.y = pack2<T>(v[2], v[3]);
+    *reinterpret_cast<uint2 *>(p.y + (int64_t)col * p.y_row_stride + n) = o;
+}
+
+static const int linear_wg = getenv("ATOMA_LINEAR_WG") ? atoi(getenv("ATOMA_LINEAR_WG")) : 1;
+// wavefronts per workgroup: as many as keep ~8 wavefronts per CU streaming, each with at least 4 chunks (512 inputs)
+template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t stream) {
+    const bool pair = p.epilogue == 2;
+    const int64_t tiles = (pair ? p.n / 2 : p.n) / 16, chunks = p.k / 128;
+    int nw = 1;
+    while (nw < 8 && tiles * nw * 2 <= (int64_t)device_num_cus() * 8 && chunks / (nw * 2) >= 4) nw *= 2;
+    if (nw == 1 && p.epilogue == 0) return 1;   // already one launch on the split-free path, which visits 512 bytes per row: 3-5 % faster
+    const dim3 grid((unsigned)tiles), block(64 * nw);
+#define ATOMA_LWG(NW_) do { if (pair) hipLaunchKernelGGL((linear_wg_kernel<T, NW_, true, 2>), grid, block, 0, stream, p); \
+                            else hipLaunchKernelGGL((linear_wg_kernel<T, NW_, false, 3>), grid, block, 0, stream, p); } while (0)
+    switch (nw) {
+        case 1: ATOMA_LWG(1); break;
+        case 2: ATOMA_LWG(2); break;
+        case 4: ATOMA_LWG(4); break;
+        default: ATOMA_LWG(8); break;
+    }
+#undef ATOMA_LWG
+    return ATOMA_CHECK_LAUNCH("linear_wg_kernel") ? 0 : -1;
+}
+
 // 512 bytes per weight-row visit (two 128-input chunks per pipeline stage) when the split allows: +2-5 % over 256
 static const int linear_ch = getenv("ATOMA_LINEAR_CH") ? atoi(getenv("ATOMA_LINEAR_CH")) : 2;
 template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
+    if (linear_wg && p.batch <= 4) {
+        const int rc = launch_linear_wg<T>(p, stream);
+        if (rc <= 0) return rc;
+    }
     const int64_t chunks = p.k / 128;
     const int ct = (p.batch + 15) / 16;                                          // column tiles of 16 batch rows
     // row tiles per wave: bounded by the 256 registers of two wavefronts per SIMD (x fragments: 16 registers per column tile and chunk in flight)
