@@ -979,6 +979,16 @@ struct Workspace {
 static std::vector<Workspace> g_ws;
 static std::mutex *g_ws_mu = new std::mutex;
 
+// Growing the scratch needs a stream sync and a hipMalloc, neither of which may happen while the stream is being
+// captured into a hipGraph: the first call of a given size must run eagerly (every driver here warms up that way).
+static bool stream_is_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (st == hipStreamCaptureStatusNone) return false;
+    set_error("the split / merge scratch of this stream must grow, which is not possible during hipGraph capture: run the same call once eagerly first");
+    return true;
+}
+
 void *workspace(hipStream_t stream, size_t bytes) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -986,6 +996,7 @@ void *workspace(hipStream_t stream, size_t bytes) {
     for (auto &w : g_ws)
         if (w.device == dev && w.stream == stream) {
             if (w.bytes >= bytes) return w.ptr;
+            if (stream_is_capturing(stream)) return nullptr;
             (void)hipStreamSynchronize(stream);
             (void)hipFree(w.ptr);
             w.ptr = nullptr;
@@ -994,6 +1005,7 @@ void *workspace(hipStream_t stream, size_t bytes) {
             w.bytes = bytes;
             return w.ptr;
         }
+    if (stream_is_capturing(stream)) return nullptr;
     Workspace w{dev, stream, nullptr, 0};
     if (!check_hip(hipMalloc(&w.ptr, bytes), "workspace hipMalloc")) return nullptr;
     w.bytes = bytes;

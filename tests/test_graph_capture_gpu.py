@@ -66,3 +66,39 @@ def test_decode_step_ops_capture_and_replay(gpu):
         ref = A.flash_attn_kv_cache(q2, caches[l][0], caches[l][1], d ** -0.5, BF16, bts, lens)
         assert_close(outs[l].numpy(np.uint16, q.shape), ref, BF16, atol=ATOL_VS_F32[BF16], what=f"graph replay, layer {l}")
     assert np.array_equal(didx.numpy(np.int32, (B,)), logits2.argmax(1))
+
+
+def test_capture_without_warm_up_fails_loudly(gpu):
+    """The split scratch of a stream cannot grow during capture: the call reports it instead of launching on freed memory."""
+    rng = np.random.default_rng(5)
+    B, h, hk, d, page, L = 2, 8, 2, 128, 16, 700
+    from util import rand_half, make_paged_cache
+    lens = np.full(B, L, np.int32)
+    nb = B * ((L + page - 1) // page) + 1
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, 1, lens)
+    q = rand_half(rng, (B, 1, h, d), 1)
+    dq, dk, dv, dbt, dl = (gpu.DeviceBuffer.from_numpy(a) for a in (q, kc, vc, bt, lens))
+    do = gpu.DeviceBuffer(q.nbytes)
+    st = gpu.Stream()                                   # a fresh stream: no scratch yet
+
+    def call():
+        gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bt.shape[1] * page, softmax_scale=d ** -0.5, is_bf16=1,
+                    q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                    v_strides=(page * hk * d, hk * d, d), cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt,
+                    block_table_batch_stride=bt.shape[1], page_block_size=page, force_split_kernel=True, unpadded_lse=False, stream=st.s)
+    # Stream handles are recycled, so this stream may inherit a scratch that is already large enough; if it is not, the
+    # call must say so (RuntimeError from atoma_last_error) instead of launching on memory it could not grow.
+    try:
+        with gpu.Graph.capture(st):
+            call()
+    except RuntimeError as e:
+        assert "hipGraph capture" in str(e)
+    call()                                              # eagerly: allocates the scratch
+    st.synchronize()
+    want = do.numpy(np.uint16, q.shape).copy()
+    do.fill_bytes(0)
+    with gpu.Graph.capture(st) as g:
+        call()
+    g.launch()
+    st.synchronize()
+    assert np.array_equal(do.numpy(np.uint16, q.shape), want)
