@@ -187,12 +187,16 @@ def main():
 
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk_l, h_l)
-    if rank == 0:
-        print(json.dumps(out))
     if comm is not None:
         ah.lib.atoma_comm_destroy(comm)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # the one JSON line goes out LAST: RCCL's version banner sits in the C stdio buffer until it is flushed
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
