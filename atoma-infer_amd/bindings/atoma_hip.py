@@ -85,6 +85,7 @@ def _opt(name, argtypes, restype=_int):
 
 
 _opt("atoma_rms_norm", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _int, _vp])
+_opt("atoma_add_rms_norm", [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _int, _vp])
 _opt("atoma_rope", [_vp, _vp, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp])
 _opt("atoma_rope_qk", [_vp, _vp, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp])
 _opt("atoma_rope_qk_cache", [_vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,

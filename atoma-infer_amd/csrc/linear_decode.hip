@@ -272,6 +272,7 @@ __global__ void __launch_bounds__(64 * NW) linear_wg_kernel(const LinearParams p
 }
 
 static const int linear_wg = getenv("ATOMA_LINEAR_WG") ? atoi(getenv("ATOMA_LINEAR_WG")) : 1;
+static const int linear_wg_max_batch = getenv("ATOMA_LINEAR_WG_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_WG_MAX_BATCH")) : 4;
 // wavefronts per workgroup: as many as keep ~8 wavefronts per CU streaming, each with at least 4 chunks (512 inputs)
 template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t stream) {
     const bool pair = p.epilogue == 2;
@@ -295,7 +296,7 @@ template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t s
 // 512 bytes per weight-row visit (two 128-input chunks per pipeline stage) when the split allows: +2-5 % over 256
 static const int linear_ch = getenv("ATOMA_LINEAR_CH") ? atoi(getenv("ATOMA_LINEAR_CH")) : 2;
 template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
-    if (linear_wg && p.batch <= 4) {
+    if (linear_wg && p.batch <= std::min(linear_wg_max_batch, 16)) {
         const int rc = launch_linear_wg<T>(p, stream);
         if (rc <= 0) return rc;
     }

@@ -35,10 +35,13 @@ template <typename T> __device__ __forceinline__ uint4 pack8(const float (&f)[8]
 // ------------------------------------------------------------------------------------------
 constexpr int NORM_THREADS = 256;
 
-template <typename T, int ITERS>
+// ADD: x = round(a + b) first (the residual add that precedes every RMSNorm of a decoder layer, llama.rs:404,409 -> 402,408),
+// written to `sum` as the separate add kernel would and normalised from the rounded values: bit-identical to the two ops.
+template <typename T, int ITERS, bool ADD = false>
 __global__ void __launch_bounds__(NORM_THREADS)
 rms_norm_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w, uint16_t *__restrict__ y,
-                int hidden, int64_t x_row_stride, int64_t y_row_stride, float eps) {
+                int hidden, int64_t x_row_stride, int64_t y_row_stride, float eps, const uint16_t *__restrict__ b = nullptr,
+                uint16_t *__restrict__ sum = nullptr, int64_t b_row_stride = 0, int64_t sum_row_stride = 0) {
     __shared__ float red[NORM_THREADS / 64];
     const int64_t row = blockIdx.x;
     const uint16_t *xr = x + row * x_row_stride;
@@ -51,6 +54,17 @@ rms_norm_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w, 
         const int i = it * NORM_THREADS + threadIdx.x;
         xv[it] = make_uint4(0, 0, 0, 0);
         if (i < nvec) xv[it] = reinterpret_cast<const uint4 *>(xr)[i];
+        if constexpr (ADD) {
+            if (i < nvec) {
+                float fa[8], fb[8];
+                unpack8<T>(xv[it], fa);
+                unpack8<T>(reinterpret_cast<const uint4 *>(b + row * b_row_stride)[i], fb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+                xv[it] = pack8<T>(fa);
+                reinterpret_cast<uint4 *>(sum + row * sum_row_stride)[i] = xv[it];
+            }
+        }
         float f[8];
         unpack8<T>(xv[it], f);
 #pragma unroll
@@ -280,6 +294,30 @@ int atoma_rms_norm(const void *x, const void *weight, void *y, int64_t rows, int
     if (dtype == ATOMA_BF16) atoma::launch_rms_norm<atoma::bf16_t>(x, weight, y, rows, hidden, x_row_stride, y_row_stride, eps, s);
     else atoma::launch_rms_norm<atoma::f16_t>(x, weight, y, rows, hidden, x_row_stride, y_row_stride, eps, s);
     return atoma::has_error() ? -1 : 0;
+}
+
+int atoma_add_rms_norm(const void *a, const void *b, const void *weight, void *sum, void *y, int64_t rows, int64_t hidden,
+                       int64_t a_row_stride, int64_t b_row_stride, int64_t sum_row_stride, int64_t y_row_stride, float eps, int dtype,
+                       void *stream) {
+    using namespace atoma;
+    clear_error();
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("add_rms_norm: dtype must be f16 or bf16"); return -1; }
+    if (hidden <= 0 || hidden % 8 || hidden > 8 * 8 * NORM_THREADS) { set_error("add_rms_norm: hidden must be a multiple of 8, at most 16384"); return -1; }
+    if (a_row_stride % 8 || b_row_stride % 8 || sum_row_stride % 8 || y_row_stride % 8) { set_error("add_rms_norm: row strides must be multiples of 8 elements"); return -1; }
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(sum) |
+         reinterpret_cast<uintptr_t>(y)) & 15u) { set_error("add_rms_norm: tensors must be 16-byte aligned"); return -1; }
+    if (rows <= 0) return 0;
+    auto s = static_cast<hipStream_t>(stream);
+    auto a16 = static_cast<const uint16_t *>(a), b16 = static_cast<const uint16_t *>(b), w16 = static_cast<const uint16_t *>(weight);
+    auto s16 = static_cast<uint16_t *>(sum), y16 = static_cast<uint16_t *>(y);
+    const int64_t iters = cdiv(hidden / 8, NORM_THREADS);
+    const dim3 grid((unsigned)rows), block(NORM_THREADS);
+#define ATOMA_ARN(T_, IT_) hipLaunchKernelGGL((rms_norm_kernel<T_, IT_, true>), grid, block, 0, s, a16, w16, y16, (int)hidden, a_row_stride, y_row_stride, eps, b16, s16, b_row_stride, sum_row_stride)
+#define ATOMA_ARN_T(T_) do { if (iters <= 1) ATOMA_ARN(T_, 1); else if (iters <= 2) ATOMA_ARN(T_, 2); else if (iters <= 4) ATOMA_ARN(T_, 4); else ATOMA_ARN(T_, 8); } while (0)
+    if (dtype == ATOMA_BF16) ATOMA_ARN_T(bf16_t); else ATOMA_ARN_T(f16_t);
+#undef ATOMA_ARN_T
+#undef ATOMA_ARN
+    return ATOMA_CHECK_LAUNCH("add_rms_norm") ? 0 : -1;
 }
 
 int atoma_rope(const void *x, void *y, const void *cos_table, const void *sin_table, const int64_t *positions,

@@ -136,6 +136,12 @@ void atoma_host_free(void *p);
  * y = T(rsqrt(mean(x^2) + eps) * x * w), f32 arithmetic, one rounding. */
 int atoma_rms_norm(const void *x, const void *weight, void *y, int64_t rows, int64_t hidden,
                    int64_t x_row_stride, int64_t y_row_stride, float eps, int dtype, void *stream);
+/* The residual add that precedes every RMSNorm of a decoder layer, fused (llama.rs:404,409 then 402,408,474):
+ * sum = round(a + b), y = rms_norm(sum) * weight -- bit-identical to atoma_add followed by atoma_rms_norm.
+ * hidden a multiple of 8 (<= 16384), row strides multiples of 8 elements, 16-byte aligned tensors. */
+int atoma_add_rms_norm(const void *a, const void *b, const void *weight, void *sum, void *y, int64_t rows, int64_t hidden,
+                       int64_t a_row_stride, int64_t b_row_stride, int64_t sum_row_stride, int64_t y_row_stride, float eps, int dtype,
+                       void *stream);
 
 /* RoPE, rotate-half (models/src/llama.rs:218-251 -> candle_nn::rotary_emb::rope), with the
  * reference's index_select of the cos/sin rows fused in: x,y [T, heads, d] (token / head

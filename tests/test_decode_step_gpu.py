@@ -161,8 +161,8 @@ def test_llama_decode_step_fused_epilogues_are_bit_identical(gpu):
     ids = rng.integers(0, cfg.vocab, B)
     slots = np.array([CO.slot_mapping_for(bt[i], int(ctx[i]), int(ctx[i]) + 1, cfg.page)[0] for i in range(B)], np.int64)
     res = []
-    for fused in (False, True):
-        step = DS.DecodeStep(cfg, B, num_pages, bt.shape[1], w, st, fused_epilogues=fused)
+    for fused, fuse_norm in ((False, False), (True, False), (False, True)):   # op by op / fused projection epilogues / fused add + RMSNorm
+        step = DS.DecodeStep(cfg, B, num_pages, bt.shape[1], w, st, fused_epilogues=fused, fuse_norm=fuse_norm)
         for l in range(cfg.layers):
             step.kc[l].upload(kc0[l])
             step.vc[l].upload(vc0[l])
@@ -171,8 +171,9 @@ def test_llama_decode_step_fused_epilogues_are_bit_identical(gpu):
         st.synchronize()
         res.append((step.logits.numpy(np.uint16, (B, cfg.vocab)), step.next_ids.numpy(np.int32, (B,)),
                     [step.kc[l].numpy(np.uint16) for l in range(cfg.layers)]))
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
-    assert all(np.array_equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1])
+        assert all(np.array_equal(a, b) for a, b in zip(res[0][2], other[2]))
 
 
 def test_prefill_step_matches_token_by_token_decode(gpu):

@@ -140,3 +140,21 @@ def test_fused_rope_qk_cache_rejects_bad_arguments(gpu):
     assert gpu.lib.atoma_rope_qk_cache(*args(page=0)) == -1 and "page_size" in gpu.last_error()
     assert gpu.lib.atoma_rope_qk_cache(*args(dtype=7)) == -1 and "dtype" in gpu.last_error()
     assert gpu.lib.atoma_rope_qk_cache(*args(bs=1021)) == -1 and "strides" in gpu.last_error()
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("rows,hidden", [(1, 4096), (7, 2048), (256, 4096), (3, 8192), (5, 520)])
+def test_add_rms_norm_is_bit_identical_to_the_two_ops(gpu, dtype, rows, hidden):
+    """atoma_add_rms_norm = atoma_add then atoma_rms_norm, same rounding points (the sum is rounded before it is normalised)."""
+    rng = np.random.default_rng(rows + hidden)
+    a, b = rand_half(rng, (rows, hidden), dtype), rand_half(rng, (rows, hidden), dtype)
+    w = rand_half(rng, (hidden,), dtype)
+    da, db, dw = (gpu.DeviceBuffer.from_numpy(t) for t in (a, b, w))
+    s1, y1, s2, y2 = (gpu.DeviceBuffer(a.nbytes) for _ in range(4))
+    assert gpu.lib.atoma_add(da.ptr, db.ptr, s1.ptr, rows * hidden, dtype, None) == 0, gpu.last_error()
+    assert gpu.lib.atoma_rms_norm(s1.ptr, dw.ptr, y1.ptr, rows, hidden, hidden, hidden, 1e-5, dtype, None) == 0, gpu.last_error()
+    assert gpu.lib.atoma_add_rms_norm(da.ptr, db.ptr, dw.ptr, s2.ptr, y2.ptr, rows, hidden, hidden, hidden, hidden, hidden, 1e-5, dtype, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    assert np.array_equal(s1.numpy(np.uint16, a.shape), s2.numpy(np.uint16, a.shape))
+    assert np.array_equal(y1.numpy(np.uint16, a.shape), y2.numpy(np.uint16, a.shape))
+    assert gpu.lib.atoma_add_rms_norm(da.ptr, db.ptr, dw.ptr, s2.ptr, y2.ptr, rows, 4100, 4100, 4100, 4100, 4100, 1e-5, dtype, None) == -1

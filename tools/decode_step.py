@@ -33,10 +33,11 @@ LLAMA_3_1_8B = Config(32, 4096, 32, 8, 128, 14336, 128256)
 class DecodeStep:
     """Device-resident weights, caches and activations of a model + `run()` = one decode step for `batch` sequences."""
 
-    def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False, fused_epilogues=False):
+    def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False, fused_epilogues=False, fuse_norm=True):
         c = self.cfg = cfg
         self.B, self.stream, self.keep = batch, stream, keep_intermediates
         self.fused = fused_epilogues and not keep_intermediates and batch <= 4   # residual adds and SiLU.up inside the projections' split merge (weight-streaming kernel: batches it serves)
+        self.fuse_norm = fuse_norm and not keep_intermediates and not self.fused   # residual add + the RMSNorm that follows it in one kernel
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
         page_elems = c.page * c.hk * c.d
         self.kc = [ah.DeviceBuffer.zeros((num_pages * page_elems,), np.uint16) for _ in range(c.layers)]
@@ -91,9 +92,11 @@ class DecodeStep:
         self._ok(L.atoma_embedding(self.ids.ptr, 0, self.w["emb"].ptr, x.ptr, B, H, c.vocab, H, BF16, s), "embedding")
         if self.keep:
             self.trace.append(("embedding", 0, dict(out=x)))
+        xf = self._buf("xf", 0, B * H * 2)
         for l in range(c.layers):
             xn = self._buf("xn1", l, B * H * 2)
-            self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+            if not (self.fuse_norm and l > 0):             # with fuse_norm the previous layer's last add produced xn already
+                self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
             qkv = self._buf("qkv", l, B * qkvw * 2)
             self._ok(L.atoma_linear(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, B, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
             qkv_pre = None
@@ -124,19 +127,27 @@ class DecodeStep:
             else:
                 o = self._buf("o", l, B * H * 2)
                 self._ok(L.atoma_linear(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
-                self._ok(L.atoma_add(x.ptr, o.ptr, x1.ptr, B * H, BF16, s), "residual add")
-                self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+                if self.fuse_norm:
+                    self._ok(L.atoma_add_rms_norm(x.ptr, o.ptr, self.w["norm2"][l].ptr, x1.ptr, xn2.ptr, B, H, H, H, H, H, c.eps, BF16, s), "residual add + rms_norm")
+                else:
+                    self._ok(L.atoma_add(x.ptr, o.ptr, x1.ptr, B * H, BF16, s), "residual add")
+                    self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
                 gu = self._buf("gu", l, B * 2 * c.inter * 2)
                 self._ok(L.atoma_linear(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
                 self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
                 dn = self._buf("dn", l, B * H * 2)
                 self._ok(L.atoma_linear(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
-                self._ok(L.atoma_add(x1.ptr, dn.ptr, x2.ptr, B * H, BF16, s), "residual add")
+                if self.fuse_norm:                       # ... + the next layer's input norm (or the final norm)
+                    last = l == c.layers - 1
+                    nw, nout = (self.w["norm_f"], xf) if last else (self.w["norm1"][l + 1], self._buf("xn1", l + 1, B * H * 2))
+                    self._ok(L.atoma_add_rms_norm(x1.ptr, dn.ptr, nw.ptr, x2.ptr, nout.ptr, B, H, H, H, H, H, c.eps, BF16, s), "residual add + rms_norm")
+                else:
+                    self._ok(L.atoma_add(x1.ptr, dn.ptr, x2.ptr, B * H, BF16, s), "residual add")
             if self.keep:
                 self.trace.append(("layer", l, dict(x=x, xn1=xn, qkv_pre=qkv_pre, qkv=qkv, att=att, o=o, x1=x1, xn2=xn2, gu=gu, act=act, dn=dn, x2=x2)))
             x = x2
-        xf = self._buf("xf", 0, B * H * 2)
-        self._ok(L.atoma_rms_norm(x.ptr, self.w["norm_f"].ptr, xf.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+        if not self.fuse_norm:
+            self._ok(L.atoma_rms_norm(x.ptr, self.w["norm_f"].ptr, xf.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
         self._ok(L.atoma_linear(xf.ptr, self.w["lm_head"].ptr, self.logits.ptr, B, H, c.vocab, H, H, c.vocab, BF16, s), "lm_head")
         self._ok(L.atoma_argmax_rows(self.logits.ptr, B, c.vocab, c.vocab, BF16, self.next_ids.ptr, self.next_val.ptr, s), "argmax")
         if self.keep:
