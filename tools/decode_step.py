@@ -192,7 +192,8 @@ class PrefillStep:
         x, x1, x2 = self.x, self.x1, self.x2
         self._ok(L.atoma_embedding(self.ids.ptr, 0, self.w["emb"].ptr, x.ptr, T, H, c.vocab, H, BF16, s), "embedding")
         for l in range(c.layers):
-            self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, self.xn.ptr, T, H, H, H, c.eps, BF16, s), "rms_norm")
+            if l == 0:                                      # later layers: the previous layer's last add produced xn already
+                self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, self.xn.ptr, T, H, H, H, c.eps, BF16, s), "rms_norm")
             self._ok(L.atoma_linear(self.xn.ptr, self.w["wqkv"][l].ptr, self.qkv.ptr, T, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
             kptr, vptr = self.qkv.ptr + hd * 2, self.qkv.ptr + (hd + c.hk * c.d) * 2
             self._ok(L.atoma_rope_qk_cache(self.qkv.ptr, kptr, vptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr, self.w["cos"].ptr,
@@ -202,12 +203,14 @@ class PrefillStep:
                        is_bf16=BF16, q_strides=(0, qkvw, c.d), k_strides=(0, qkvw, c.d), v_strides=(0, qkvw, c.d), o_strides=(0, hd, c.d),
                        is_causal=1, cu_seqlens_q=self.cu, cu_seqlens_k=self.cu, stream=s)
             self._ok(L.atoma_linear(self.att.ptr, self.w["wo"][l].ptr, self.o.ptr, T, hd, H, hd, hd, H, BF16, s), "o projection")
-            self._ok(L.atoma_add(x.ptr, self.o.ptr, x1.ptr, T * H, BF16, s), "residual add")
-            self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, self.xn.ptr, T, H, H, H, c.eps, BF16, s), "rms_norm")
+            self._ok(L.atoma_add_rms_norm(x.ptr, self.o.ptr, self.w["norm2"][l].ptr, x1.ptr, self.xn.ptr, T, H, H, H, H, H, c.eps, BF16, s), "residual add + rms_norm")
             self._ok(L.atoma_linear(self.xn.ptr, self.w["wgu"][l].ptr, self.gu.ptr, T, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
             self._ok(L.atoma_silu_mul(self.gu.ptr, self.gu.ptr + c.inter * 2, self.act.ptr, T, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
             self._ok(L.atoma_linear(self.act.ptr, self.w["wdown"][l].ptr, self.o.ptr, T, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
-            self._ok(L.atoma_add(x1.ptr, self.o.ptr, x2.ptr, T * H, BF16, s), "residual add")
+            if l + 1 < c.layers:
+                self._ok(L.atoma_add_rms_norm(x1.ptr, self.o.ptr, self.w["norm1"][l + 1].ptr, x2.ptr, self.xn.ptr, T, H, H, H, H, H, c.eps, BF16, s), "residual add + rms_norm")
+            else:                                           # the final norm only touches the last token of every prompt
+                self._ok(L.atoma_add(x1.ptr, self.o.ptr, x2.ptr, T * H, BF16, s), "residual add")
             x, x2 = x2, x
         Ts, n = T // self.n, self.n
         last = x.ptr + (Ts - 1) * H * 2                      # the last token of every prompt: rows Ts - 1, 2 Ts - 1, ...
