@@ -271,6 +271,146 @@ __global__ void __launch_bounds__(64 * NW) linear_wg_kernel(const LinearParams p
     *reinterpret_cast<uint2 *>(p.y + (int64_t)col * p.y_row_stride + n) = o;
 }
 
+// Batches of 1..4 rows, loads laid out for the memory system instead of the matrix cores.  tools/probes/weight_stream_probe.hip:
+// with no arithmetic at all, 16 rows x 64 bytes per load instruction (the MFMA A-operand layout used above) streams lm_head at
+// 5.7 TB/s, 4 rows x 256 bytes per instruction at 6.7 TB/s (the whole 128 KiB block front to back: 6.85).  At 1..4 batch rows
+// the arithmetic is tiny (2.B flop per byte), so it moves to the VALU: lane = 16.g + c loads 16 bytes (8 inputs, chunk c of a
+// 128-input slab) of row 4.rg + g, multiplies them with the matching 8 inputs of every batch row (v_dot2c, fp32) and the 16
+// lanes of a row are summed once at the end (DPP).  Workgroup structure, split of K over NW wavefronts, LDS merge and the
+// epilogues are those of linear_wg_kernel.
+__device__ __forceinline__ float lin_row16_sum(float x) {   // sum over the 16 lanes of a DPP row
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0.f, x, 0x140, 0xf, 0xf, true);   // row_mirror
+    return x;
+}
+template <typename T, int NW, bool PAIR, int NB, int P>
+__global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams p) {
+    constexpr int RT = PAIR ? 2 : 1;
+    __shared__ float red[NW][RT][16][4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
+    const int n0 = blockIdx.x * 16;
+    const int out_n = PAIR ? p.n / 2 : p.n;
+    const int chunks = p.k >> 7, per = (chunks + NW - 1) / NW;
+    const int c0 = wave * per, c1 = min(c0 + per, chunks);
+    const int64_t row_bytes = p.w_row_stride * 2;
+
+    const char *wrow = reinterpret_cast<const char *>(p.w + (int64_t)n0 * p.w_row_stride);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wrow), 0, 0x7fffffff, 0x00020000);
+    uint32_t w_lane[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) w_lane[r] = (uint32_t)(((int64_t)r * out_n + g) * row_bytes + c * 16);
+    const uint16_t *xrow[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) xrow[b] = p.x + (int64_t)min(b, p.batch - 1) * p.x_row_stride + c * 8;   // rows beyond the batch: recomputed, never stored
+
+    lu32x4 wb[P][RT][4], xb[P][NB];
+    auto issue = [&](int s, int chunk) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                wb[s][r][rg] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], (int)(rg * 4 * row_bytes + chunk * 256), 2 /* nt */);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) xb[s][b] = *reinterpret_cast<const lu32x4 *>(xrow[b] + chunk * 128);
+    };
+    float acc[RT][4][NB];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[r][rg][b] = 0.f;
+    auto compute = [&](int s) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    float a = acc[r][rg][b];
+                    a = dot2<T>(wb[s][r][rg][0], xb[s][b][0], a);
+                    a = dot2<T>(wb[s][r][rg][1], xb[s][b][1], a);
+                    a = dot2<T>(wb[s][r][rg][2], xb[s][b][2], a);
+                    a = dot2<T>(wb[s][r][rg][3], xb[s][b][3], a);
+                    acc[r][rg][b] = a;
+                }
+    };
+    int ch = c0;
+    if (c0 + 2 * P <= c1) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) issue(s, c0 + s);
+        for (; ch + 2 * P <= c1; ch += P) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                compute(s);
+                issue(s, ch + s + P);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < P; ++s)
+            if (c0 + s < c1) issue(s, c0 + s);
+    }
+    for (; ch < c1; ch += P) {
+#pragma unroll
+        for (int s = 0; s < P; ++s)
+            if (ch + s < c1) {
+                compute(s);
+                if (ch + s + P < c1) issue(s, ch + s + P);
+            }
+    }
+    // sum the 16 lanes of every row; lane c == 0 of group g then holds row 4.rg + g
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float v = lin_row16_sum(acc[r][rg][b]);
+                if (c == 0) red[wave][r][rg * 4 + g][b] = v;
+            }
+    __syncthreads();
+    if (wave > 0) return;
+    const int row = lane & 15, b = lane >> 4;         // 16 rows x 4 batch rows = the 64 lanes of wavefront 0
+    if (b >= p.batch || b >= NB) return;
+    float v[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        float t = red[0][r][row][b];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) t += red[w][r][row][b];   // fixed order: deterministic
+        v[r] = round_through<T>(t);
+    }
+    const int n = n0 + row;
+    float out = v[0];
+    if (p.epilogue == 1) out += lo_to_f32<T>((uint32_t)p.aux[(int64_t)b * p.aux_row_stride + n]);
+    if constexpr (PAIR) out = round_through<T>(out / (1.f + __expf(-out))) * v[1];
+    p.y[(int64_t)b * p.y_row_stride + n] = (uint16_t)f32_to_bits<T>(out);
+}
+
+static const int linear_gemv = getenv("ATOMA_LINEAR_GEMV") ? atoi(getenv("ATOMA_LINEAR_GEMV")) : 1;
+template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t stream) {
+    const bool pair = p.epilogue == 2;
+    const int64_t tiles = (pair ? p.n / 2 : p.n) / 16, chunks = p.k / 128;
+    int nw = 1;
+    while (nw < 8 && tiles * nw * 2 <= (int64_t)device_num_cus() * 8 && chunks / (nw * 2) >= 4) nw *= 2;
+    const dim3 grid((unsigned)tiles), block(64 * nw);
+#define ATOMA_GV3(NW_, NB_) do { if (pair) hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, true, NB_, 2>), grid, block, 0, stream, p); \
+                                 else hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, false, NB_, 3>), grid, block, 0, stream, p); } while (0)
+#define ATOMA_GV2(NW_) do { if (p.batch == 1) ATOMA_GV3(NW_, 1); else if (p.batch == 2) ATOMA_GV3(NW_, 2); else ATOMA_GV3(NW_, 4); } while (0)
+    switch (nw) {
+        case 1: ATOMA_GV2(1); break;
+        case 2: ATOMA_GV2(2); break;
+        case 4: ATOMA_GV2(4); break;
+        default: ATOMA_GV2(8); break;
+    }
+#undef ATOMA_GV2
+#undef ATOMA_GV3
+    return ATOMA_CHECK_LAUNCH("linear_gemv_kernel") ? 0 : -1;
+}
+
 static const int linear_wg = getenv("ATOMA_LINEAR_WG") ? atoi(getenv("ATOMA_LINEAR_WG")) : 1;
 static const int linear_wg_max_batch = getenv("ATOMA_LINEAR_WG_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_WG_MAX_BATCH")) : 4;
 // wavefronts per workgroup: as many as keep ~8 wavefronts per CU streaming, each with at least 4 chunks (512 inputs)
@@ -296,6 +436,7 @@ template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t s
 // 512 bytes per weight-row visit (two 128-input chunks per pipeline stage) when the split allows: +2-5 % over 256
 static const int linear_ch = getenv("ATOMA_LINEAR_CH") ? atoi(getenv("ATOMA_LINEAR_CH")) : 2;
 template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
+    if (linear_gemv && p.batch <= 4) return launch_linear_gemv<T>(p, stream);
     if (linear_wg && p.batch <= std::min(linear_wg_max_batch, 16)) {
         const int rc = launch_linear_wg<T>(p, stream);
         if (rc <= 0) return rc;
