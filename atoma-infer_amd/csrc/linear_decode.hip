@@ -10,6 +10,8 @@
 //   * W: non-temporal buffer loads (read once); x: ordinary loads (128 KiB at most, L2-resident, shared by every wave);
 //   * the K range is split until ~8 wavefronts per CU exist; partial sums go to an fp32 workspace [split][B][N] and a
 //     second small kernel adds them and rounds once -- fp32 accumulation throughout, one rounding to the storage dtype.
+// Batches of 1..4 rows (the ones atoma_linear sends here) run linear_gemv_kernel below: loads of 256 contiguous bytes per row and
+// v_dot2c instead of the MFMA operand layout, one launch; the MFMA kernels serve 5..64 rows.
 // Parity: unpinned (Candle / cuBLAS are not in the tree); the oracle is the f64-accumulated product rounded once,
 // the kernel differs from it by at most one unit in the last place (accumulation order).
 #include "common.h"
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(64 * NW) linear_wg_kernel(const LinearParams p
     *reinterpret_cast<uint2 *>(p.y + (int64_t)col * p.y_row_stride + n) = o;
 }
 
-// Batches of 1..4 rows, loads laid out for the memory system instead of the matrix cores.  tools/probes/weight_stream_probe.hip:
+// Batches of 1..8 rows, loads laid out for the memory system instead of the matrix cores.  tools/probes/weight_stream_probe.hip:
 // with no arithmetic at all, 16 rows x 64 bytes per load instruction (the MFMA A-operand layout used above) streams lm_head at
 // 5.7 TB/s, 4 rows x 256 bytes per instruction at 6.7 TB/s (the whole 128 KiB block front to back: 6.85).  At 1..4 batch rows
 // the arithmetic is tiny (2.B flop per byte), so it moves to the VALU: lane = 16.g + c loads 16 bytes (8 inputs, chunk c of a
@@ -288,7 +290,7 @@ __device__ __forceinline__ float lin_row16_sum(float x) {   // sum over the 16 l
 template <typename T, int NW, bool PAIR, int NB, int P>
 __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams p) {
     constexpr int RT = PAIR ? 2 : 1;
-    __shared__ float red[NW][RT][16][4];
+    __shared__ float red[NW][RT][16][NB < 4 ? 4 : NB];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, c = lane & 15;
     const int n0 = blockIdx.x * 16;
     const int out_n = PAIR ? p.n / 2 : p.n;
@@ -373,24 +375,25 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
             }
     __syncthreads();
     if (wave > 0) return;
-    const int row = lane & 15, b = lane >> 4;         // 16 rows x 4 batch rows = the 64 lanes of wavefront 0
-    if (b >= p.batch || b >= NB) return;
-    float v[RT];
+    const int row = lane & 15, n = n0 + row;          // 16 rows x 4 batch rows per pass over the 64 lanes of wavefront 0
+    for (int b = lane >> 4; b < NB && b < p.batch; b += 4) {
+        float v[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        float t = red[0][r][row][b];
+        for (int r = 0; r < RT; ++r) {
+            float t = red[0][r][row][b];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) t += red[w][r][row][b];   // fixed order: deterministic
-        v[r] = round_through<T>(t);
+            for (int w = 1; w < NW; ++w) t += red[w][r][row][b];   // fixed order: deterministic
+            v[r] = round_through<T>(t);
+        }
+        float out = v[0];
+        if (p.epilogue == 1) out += lo_to_f32<T>((uint32_t)p.aux[(int64_t)b * p.aux_row_stride + n]);
+        if constexpr (PAIR) out = round_through<T>(out / (1.f + __expf(-out))) * v[1];
+        p.y[(int64_t)b * p.y_row_stride + n] = (uint16_t)f32_to_bits<T>(out);
     }
-    const int n = n0 + row;
-    float out = v[0];
-    if (p.epilogue == 1) out += lo_to_f32<T>((uint32_t)p.aux[(int64_t)b * p.aux_row_stride + n]);
-    if constexpr (PAIR) out = round_through<T>(out / (1.f + __expf(-out))) * v[1];
-    p.y[(int64_t)b * p.y_row_stride + n] = (uint16_t)f32_to_bits<T>(out);
 }
 
 static const int linear_gemv = getenv("ATOMA_LINEAR_GEMV") ? atoi(getenv("ATOMA_LINEAR_GEMV")) : 1;
+static const int linear_gemv_max_batch = getenv("ATOMA_LINEAR_GEMV_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_GEMV_MAX_BATCH")) : 8;
 template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t stream) {
     const bool pair = p.epilogue == 2;
     const int64_t tiles = (pair ? p.n / 2 : p.n) / 16, chunks = p.k / 128;
@@ -398,8 +401,8 @@ template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t
     while (nw < 8 && tiles * nw * 2 <= (int64_t)device_num_cus() * 8 && chunks / (nw * 2) >= 4) nw *= 2;
     const dim3 grid((unsigned)tiles), block(64 * nw);
 #define ATOMA_GV3(NW_, NB_) do { if (pair) hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, true, NB_, 2>), grid, block, 0, stream, p); \
-                                 else hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, false, NB_, 3>), grid, block, 0, stream, p); } while (0)
-#define ATOMA_GV2(NW_) do { if (p.batch == 1) ATOMA_GV3(NW_, 1); else if (p.batch == 2) ATOMA_GV3(NW_, 2); else ATOMA_GV3(NW_, 4); } while (0)
+                                 else hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, false, NB_, (NB_ > 4 ? 2 : 3)>), grid, block, 0, stream, p); } while (0)
+#define ATOMA_GV2(NW_) do { if (p.batch == 1) ATOMA_GV3(NW_, 1); else if (p.batch == 2) ATOMA_GV3(NW_, 2); else if (p.batch <= 4) ATOMA_GV3(NW_, 4); else ATOMA_GV3(NW_, 8); } while (0)
     switch (nw) {
         case 1: ATOMA_GV2(1); break;
         case 2: ATOMA_GV2(2); break;
@@ -436,7 +439,7 @@ template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t s
 // 512 bytes per weight-row visit (two 128-input chunks per pipeline stage) when the split allows: +2-5 % over 256
 static const int linear_ch = getenv("ATOMA_LINEAR_CH") ? atoi(getenv("ATOMA_LINEAR_CH")) : 2;
 template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
-    if (linear_gemv && p.batch <= 4) return launch_linear_gemv<T>(p, stream);
+    if (linear_gemv && p.batch <= std::min(linear_gemv_max_batch, 8)) return launch_linear_gemv<T>(p, stream);
     if (linear_wg && p.batch <= std::min(linear_wg_max_batch, 16)) {
         const int rc = launch_linear_wg<T>(p, stream);
         if (rc <= 0) return rc;

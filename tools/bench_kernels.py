@@ -275,12 +275,12 @@ def bench_linear():
     rng = np.random.default_rng(8)
     for name, N, K in (("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336), ("lm_head", 128256, 4096)):
         w = rand_dev(rng, N * K * 2)
-        for B in (1, 16, 64):
+        for B in (1, 4, 8, 16, 64):
             x, y = rand_dev(rng, B * K * 2), ah.DeviceBuffer(B * N * 2)
             ms = timeit(lambda: ah.lib.atoma_linear_decode(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
             emit(f"L1 linear_decode {name} [{N} x {K}] batch={B}", ms, nbytes=N * K * 2 + B * K * 2 + B * N * 2)
         smax = int(os.environ.get("ATOMA_LINEAR_STREAM_MAX_BATCH", "4"))
-        for B in (1, 16, 32, 64, 128, 256, 2048):        # atoma_linear: streaming kernel up to smax rows, vendor GEMM above; 2048 = a prefill chunk
+        for B in (1, 4, 8, 16, 32, 64, 128, 256, 2048):        # atoma_linear: streaming kernel up to smax rows, vendor GEMM above; 2048 = a prefill chunk
             if B <= min(smax, 64):
                 continue                                  # measured above
             x, y = rand_dev(rng, B * K * 2), ah.DeviceBuffer(B * N * 2)
