@@ -11,7 +11,8 @@
 //   * the K range is split until ~8 wavefronts per CU exist; partial sums go to an fp32 workspace [split][B][N] and a
 //     second small kernel adds them and rounds once -- fp32 accumulation throughout, one rounding to the storage dtype.
 // Batches of 1..4 rows (the ones atoma_linear sends here) run linear_gemv_kernel below: loads of 256 contiguous bytes per row and
-// v_dot2c instead of the MFMA operand layout, one launch; the MFMA kernels serve 5..64 rows.
+// v_dot2c instead of the MFMA operand layout, one launch; 5..16 rows run linear_wg_kernel<RELAY> (the same loads, re-laid into
+// the MFMA operand order through LDS, one launch); the two-launch MFMA-layout kernel at the top serves 17..64 rows.
 // Parity: unpinned (Candle / cuBLAS are not in the tree); the oracle is the f64-accumulated product rounded once,
 // the kernel differs from it by at most one unit in the last place (accumulation order).
 #include "common.h"
@@ -177,10 +178,15 @@ template <typename T> __global__ void __launch_bounds__(256) linear_reduce_kerne
 // up features of a stacked gate / up matrix); wavefront w streams the w-th part of K, the NW accumulator tiles are added
 // through LDS and the epilogue (none / + residual / silu(gate).up) runs in the workgroup -- no fp32 partials in HBM and no
 // second kernel, which on the 33-120 MB projections of one layer is 3-5 us of a 11-30 us op.
-template <typename T, int NW, bool PAIR, int P>
+// RELAY: the weights are loaded 4 rows x 256 contiguous bytes per instruction (the pattern that streams at 6.7 TB/s instead
+// of 5.7, see linear_gemv_kernel) and re-laid into the MFMA A-operand order through a 4 KiB LDS tile per wavefront: lane
+// 16.g + c writes its 16 bytes of row 4.rg + g to [row][chunk c ^ row], lane 16.kg + i reads [row i][chunk (4q + kg) ^ i] --
+// both conflict-free; LDS serves one wavefront's accesses in order, the compiler is kept from reordering them by fences.
+template <typename T, int NW, bool PAIR, int P, bool RELAY = false>
 __global__ void __launch_bounds__(64 * NW) linear_wg_kernel(const LinearParams p) {
     constexpr int RT = PAIR ? 2 : 1;
     __shared__ float red[NW > 1 ? NW - 1 : 1][RT][64][4];
+    __shared__ __attribute__((aligned(16))) char relay[RELAY ? NW : 1][RELAY ? RT : 1][RELAY ? 4096 : 16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), grp = lane >> 4, col = lane & 15;
     const int n0 = blockIdx.x * 16;
     const int out_n = PAIR ? p.n / 2 : p.n;
@@ -191,7 +197,10 @@ __global__ void __launch_bounds__(64 * NW) linear_wg_kernel(const LinearParams p
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wrow), 0, 0x7fffffff, 0x00020000);
     uint32_t w_lane[RT];
 #pragma unroll
-    for (int r = 0; r < RT; ++r) w_lane[r] = (uint32_t)(((int64_t)r * out_n + col) * p.w_row_stride * 2 + grp * 16);
+    for (int r = 0; r < RT; ++r)
+        w_lane[r] = RELAY ? (uint32_t)(((int64_t)r * out_n + grp) * p.w_row_stride * 2 + col * 16)     // row 4.q + grp, chunk col
+                          : (uint32_t)(((int64_t)r * out_n + col) * p.w_row_stride * 2 + grp * 16);
+    const int64_t row_bytes = p.w_row_stride * 2;
     const bool has_x = col < p.batch;
     const uint16_t *xrow = p.x + (int64_t)(has_x ? col : 0) * p.x_row_stride + grp * 8;
 
@@ -200,7 +209,9 @@ __global__ void __launch_bounds__(64 * NW) linear_wg_kernel(const LinearParams p
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) wb[s][r][q] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], chunk * 256 + q * 64, 2 /* nt */);
+            for (int q = 0; q < 4; ++q)
+                wb[s][r][q] = RELAY ? __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], (int)(q * 4 * row_bytes + chunk * 256), 2 /* nt */)
+                                    : __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], chunk * 256 + q * 64, 2 /* nt */);
 #pragma unroll
         for (int q = 0; q < 4; ++q) xb[s][q] = has_x ? *reinterpret_cast<const lu32x4 *>(xrow + chunk * 128 + q * 32) : lu32x4{0, 0, 0, 0};
     };
@@ -208,10 +219,36 @@ __global__ void __launch_bounds__(64 * NW) linear_wg_kernel(const LinearParams p
 #pragma unroll
     for (int r = 0; r < RT; ++r) acc[r] = lf32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int s) {
+        if constexpr (RELAY) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < RT; ++r) {
+                char *tile = relay[wave][r];
 #pragma unroll
-            for (int r = 0; r < RT; ++r) acc[r] = lin_mfma<T>(wb[s][r][q], xb[s][q], acc[r]);
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 4 * q + grp;
+                    *reinterpret_cast<lu32x4 *>(tile + row * 256 + ((col ^ row) & 15) * 16) = wb[s][r][q];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const char *tile = relay[wave][r];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const lu32x4 a = *reinterpret_cast<const lu32x4 *>(tile + col * 256 + (((4 * q + grp) ^ col) & 15) * 16);
+                    acc[r] = lin_mfma<T>(a, xb[s][q], acc[r]);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r] = lin_mfma<T>(wb[s][r][q], xb[s][q], acc[r]);
+        }
     };
     int c = c0;
     if (c0 + 2 * P <= c1) {
@@ -393,7 +430,7 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
 }
 
 static const int linear_gemv = getenv("ATOMA_LINEAR_GEMV") ? atoi(getenv("ATOMA_LINEAR_GEMV")) : 1;
-static const int linear_gemv_max_batch = getenv("ATOMA_LINEAR_GEMV_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_GEMV_MAX_BATCH")) : 8;
+static const int linear_gemv_max_batch = getenv("ATOMA_LINEAR_GEMV_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_GEMV_MAX_BATCH")) : 4;
 template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t stream) {
     const bool pair = p.epilogue == 2;
     const int64_t tiles = (pair ? p.n / 2 : p.n) / 16, chunks = p.k / 128;
@@ -415,17 +452,21 @@ template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t
 }
 
 static const int linear_wg = getenv("ATOMA_LINEAR_WG") ? atoi(getenv("ATOMA_LINEAR_WG")) : 1;
-static const int linear_wg_max_batch = getenv("ATOMA_LINEAR_WG_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_WG_MAX_BATCH")) : 4;
+static const int linear_wg_max_batch = getenv("ATOMA_LINEAR_WG_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_WG_MAX_BATCH")) : 16;
 // wavefronts per workgroup: as many as keep ~8 wavefronts per CU streaming, each with at least 4 chunks (512 inputs)
 template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t stream) {
     const bool pair = p.epilogue == 2;
     const int64_t tiles = (pair ? p.n / 2 : p.n) / 16, chunks = p.k / 128;
     int nw = 1;
     while (nw < 8 && tiles * nw * 2 <= (int64_t)device_num_cus() * 8 && chunks / (nw * 2) >= 4) nw *= 2;
-    if (nw == 1 && p.epilogue == 0) return 1;   // already one launch on the split-free path, which visits 512 bytes per row: 3-5 % faster
+    static const int relay_on = getenv("ATOMA_LINEAR_RELAY") ? atoi(getenv("ATOMA_LINEAR_RELAY")) : 1;
+    if (!relay_on && nw == 1 && p.epilogue == 0) return 1;   // MFMA-layout loads: the split-free path visits 512 bytes per row and is 3-5 % faster
     const dim3 grid((unsigned)tiles), block(64 * nw);
-#define ATOMA_LWG(NW_) do { if (pair) hipLaunchKernelGGL((linear_wg_kernel<T, NW_, true, 2>), grid, block, 0, stream, p); \
-                            else hipLaunchKernelGGL((linear_wg_kernel<T, NW_, false, 3>), grid, block, 0, stream, p); } while (0)
+    static const int relay = getenv("ATOMA_LINEAR_RELAY") ? atoi(getenv("ATOMA_LINEAR_RELAY")) : 1;
+#define ATOMA_LWG(NW_) do { if (relay) { if (pair) hipLaunchKernelGGL((linear_wg_kernel<T, NW_, true, 2, true>), grid, block, 0, stream, p); \
+                                         else hipLaunchKernelGGL((linear_wg_kernel<T, NW_, false, 3, true>), grid, block, 0, stream, p); } \
+                            else { if (pair) hipLaunchKernelGGL((linear_wg_kernel<T, NW_, true, 2>), grid, block, 0, stream, p); \
+                                   else hipLaunchKernelGGL((linear_wg_kernel<T, NW_, false, 3>), grid, block, 0, stream, p); } } while (0)
     switch (nw) {
         case 1: ATOMA_LWG(1); break;
         case 2: ATOMA_LWG(2); break;
