@@ -432,10 +432,11 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
 static const int linear_gemv = getenv("ATOMA_LINEAR_GEMV") ? atoi(getenv("ATOMA_LINEAR_GEMV")) : 1;
 static const int linear_gemv_max_batch = getenv("ATOMA_LINEAR_GEMV_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_GEMV_MAX_BATCH")) : 4;
 template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t stream) {
+    static const int gemv_wpc = getenv("ATOMA_LINEAR_GEMV_WAVES_PER_CU") ? atoi(getenv("ATOMA_LINEAR_GEMV_WAVES_PER_CU")) : 8;
     const bool pair = p.epilogue == 2;
     const int64_t tiles = (pair ? p.n / 2 : p.n) / 16, chunks = p.k / 128;
     int nw = 1;
-    while (nw < 8 && tiles * nw * 2 <= (int64_t)device_num_cus() * 8 && chunks / (nw * 2) >= 4) nw *= 2;
+    while (nw < 8 && tiles * nw * 2 <= (int64_t)device_num_cus() * gemv_wpc && chunks / (nw * 2) >= 4) nw *= 2;
     const dim3 grid((unsigned)tiles), block(64 * nw);
 #define ATOMA_GV3(NW_, NB_) do { if (pair) hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, true, NB_, 2>), grid, block, 0, stream, p); \
                                  else hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, false, NB_, (NB_ > 4 ? 2 : 3)>), grid, block, 0, stream, p); } while (0)
