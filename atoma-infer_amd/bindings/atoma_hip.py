@@ -100,6 +100,9 @@ _opt("atoma_linear", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _
 _opt("atoma_topk_rows", [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp])
 _opt("atoma_argmax_rows", [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp])
 _opt("atoma_rope_table", [_vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _int])
+_opt("atoma_warmup", [_vp, _i64, _i64, _i64, _i64, _i64, _i64])
+_opt("atoma_reserve_workspace", [_vp, _i64])
+_opt("atoma_release_workspaces", [])
 _opt("atoma_comm_unique_id", [_vp])
 _opt("atoma_comm_init", [C.POINTER(_vp), _int, _int, _vp, _int])
 _opt("atoma_allreduce_sum", [_vp, _vp, _vp, _i64, _int, _vp])

@@ -553,6 +553,11 @@ static int linear_decode_entry(const void *x, const void *w, void *y, int64_t ba
         set_error("linear_decode: x and w must be 16-byte aligned, y 8-byte aligned");
         return -1;
     }
+    // the stacked gate / up kernels reach the up rows through a 32-bit buffer offset from the gate tile's base
+    if (epilogue == 2 && (out_features / 2 + 16) * w_row_stride * 2 >= ((int64_t)1 << 31)) {
+        set_error("linear_decode: the silu.up epilogue needs the gate block [intermediate, in_features] to stay below 2 GiB (32-bit buffer offsets)");
+        return -1;
+    }
     if (batch == 0) return 0;
     LinearParams p{};
     p.x = static_cast<const uint16_t *>(x);

@@ -69,7 +69,7 @@ struct GemmPlan {
 };
 struct LtDevice {
     hipblasLtHandle_t handle = nullptr;
-    void *workspace = nullptr;
+    std::map<hipStream_t, void *> workspaces;   // one per stream: two GEMMs on different streams may run concurrently
     std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t>, GemmPlan> plans;
 };
 static const size_t LT_WORKSPACE_BYTES = 64u << 20;
@@ -96,7 +96,16 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
     LtDevice &d = (*g_lt_devices)[dev];
     if (!d.handle) {
         if (!lt_ok(api.create(&d.handle), "hipblasLtCreate")) { d.handle = nullptr; return -1; }
-        if (!check_hip(hipMalloc(&d.workspace, LT_WORKSPACE_BYTES), "linear: workspace hipMalloc")) return -1;
+    }
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &capturing);
+    void *&lt_ws = d.workspaces[stream];
+    if (!lt_ws) {
+        if (capturing != hipStreamCaptureStatusNone) {
+            set_error("linear: the hipBLASLt workspace of this stream cannot be allocated during hipGraph capture: run the same call once eagerly first");
+            return -1;
+        }
+        if (!check_hip(hipMalloc(&lt_ws, LT_WORKSPACE_BYTES), "linear: workspace hipMalloc")) { lt_ws = nullptr; return -1; }
     }
     const auto key = std::make_tuple(dtype, batch, k, n, ldx, ldw, ldy);
     auto it = d.plans.find(key);
@@ -127,8 +136,6 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
         if (!ok) return -1;
         if (found < 1) { set_error("linear: hipBLASLt has no algorithm for this problem"); return -1; }
         int best = 0;
-        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(stream, &capturing);
         if (found > 1 && capturing == hipStreamCaptureStatusNone) {
             const float alpha = 1.f, beta = 0.f;
             hipEvent_t e0, e1;
@@ -138,7 +145,7 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
                 bool good = true;
                 (void)hipEventRecord(e0, stream);
                 for (int rep = 0; rep < reps && good; ++rep)
-                    good = api.matmul(d.handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &res[c].algo, d.workspace,
+                    good = api.matmul(d.handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &res[c].algo, lt_ws,
                                       LT_WORKSPACE_BYTES, stream) == HIPBLAS_STATUS_SUCCESS;
                 (void)hipEventRecord(e1, stream);
                 if (hipEventSynchronize(e1) != hipSuccess || !good) { (void)hipGetLastError(); return false; }
@@ -172,11 +179,18 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
         }
         pl.algo = res[best].algo;
         pl.workspace = res[best].workspaceSize;
+        if (found > 1 && capturing != hipStreamCaptureStatusNone) {
+            // first seen during capture: the candidates could not be timed -- use the heuristic's choice for this launch only,
+            // so that a later eager call still tunes the problem
+            const float alpha1 = 1.f, beta0 = 0.f;
+            return lt_ok(api.matmul(d.handle, pl.desc, &alpha1, w, pl.a, x, pl.b, &beta0, y, pl.c, y, pl.c, &pl.algo, lt_ws,
+                                    LT_WORKSPACE_BYTES, stream), "Matmul") ? 0 : -1;
+        }
         it = d.plans.emplace(key, pl).first;
     }
     const GemmPlan &pl = it->second;
     const float alpha = 1.f, beta = 0.f;
-    if (!lt_ok(api.matmul(d.handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &pl.algo, d.workspace,
+    if (!lt_ok(api.matmul(d.handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &pl.algo, lt_ws,
                           LT_WORKSPACE_BYTES, stream), "Matmul"))
         return -1;
     return 0;

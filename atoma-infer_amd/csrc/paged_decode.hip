@@ -32,7 +32,7 @@
 #include "attn_params.h"
 #include <type_traits>
 
-#include <mutex>
+#include <atomic>
 #include <stdlib.h>
 
 #ifndef DECODE_DEFAULT_P
@@ -66,7 +66,7 @@ struct DecodeParams {
     int num_splits;        // KV splits per sequence (grid slots)
     int stream_waves;      // > 0: balanced mode available -- this many wavefronts share the batch's tiles evenly (decode_run_items)
     int group_tile;        // q heads per wavefront (the kernel's G)
-    int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence
+    int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
     float scale, scale_log2;
 };
 
@@ -967,51 +967,7 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-// Grow-only fp32 workspace for split partials, one per (device, stream).  The reference hands
-// caller scratch to the kernel and may drop it right after the async launch
-// (/root/reference/csrc/src/lib.rs:1023-1042,1100); owning the scratch here removes that race.
-struct Workspace {
-    int device;
-    hipStream_t stream;
-    void *ptr;
-    size_t bytes;
-};
-static std::vector<Workspace> g_ws;
-static std::mutex *g_ws_mu = new std::mutex;
-
-// Growing the scratch needs a stream sync and a hipMalloc, neither of which may happen while the stream is being
-// captured into a hipGraph: the first call of a given size must run eagerly (every driver here warms up that way).
-static bool stream_is_capturing(hipStream_t stream) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (st == hipStreamCaptureStatusNone) return false;
-    set_error("the split / merge scratch of this stream must grow, which is not possible during hipGraph capture: run the same call once eagerly first");
-    return true;
-}
-
-void *workspace(hipStream_t stream, size_t bytes) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(*g_ws_mu);
-    for (auto &w : g_ws)
-        if (w.device == dev && w.stream == stream) {
-            if (w.bytes >= bytes) return w.ptr;
-            if (stream_is_capturing(stream)) return nullptr;
-            (void)hipStreamSynchronize(stream);
-            (void)hipFree(w.ptr);
-            w.ptr = nullptr;
-            w.bytes = 0;
-            if (!check_hip(hipMalloc(&w.ptr, bytes), "workspace hipMalloc")) return nullptr;
-            w.bytes = bytes;
-            return w.ptr;
-        }
-    if (stream_is_capturing(stream)) return nullptr;
-    Workspace w{dev, stream, nullptr, 0};
-    if (!check_hip(hipMalloc(&w.ptr, bytes), "workspace hipMalloc")) return nullptr;
-    w.bytes = bytes;
-    g_ws.push_back(w);
-    return w.ptr;
-}
+void *workspace(hipStream_t stream, size_t bytes);   // runtime.hip: grow-only scratch per (device, stream), never freed under a graph
 
 // Split count for THIS kernel: enough wavefronts to fill the resident slots of every CU (8, or 4 for the
 // 512-register G = 8 / d = 128 variant), never fewer than `min_tiles` 16-token tiles per split.  (The reference's heuristic, lib.rs:2122-2199,
@@ -1040,20 +996,23 @@ static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
 }
+// One OS thread per GPU calls into the library (model_executor.rs:428): the knobs are relaxed atomics, initialised once
+// (function-local static), so a set_option from one thread never tears a read on another.
+typedef std::atomic<int> opt_int;
 struct DecodeOptions {
-    int p = env_int("ATOMA_DECODE_P", DECODE_DEFAULT_P);
-    int nt = env_int("ATOMA_DECODE_NT", DECODE_DEFAULT_NT);
-    int stream = env_int("ATOMA_DECODE_STREAM", 1);
-    int stream_waves_per_cu = env_int("ATOMA_DECODE_STREAM_WAVES_PER_CU", 0);   // 0 = resident capacity
-    int waves_per_cu = env_int("ATOMA_DECODE_WAVES_PER_CU", 0);   // 0 = resident capacity
-    int min_tiles = env_int("ATOMA_DECODE_MIN_TILES", 8);
-    int mqk = env_int("ATOMA_DECODE_MQK", 5);   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches
+    opt_int p{env_int("ATOMA_DECODE_P", DECODE_DEFAULT_P)};
+    opt_int nt{env_int("ATOMA_DECODE_NT", DECODE_DEFAULT_NT)};
+    opt_int stream{env_int("ATOMA_DECODE_STREAM", 1)};
+    opt_int stream_waves_per_cu{env_int("ATOMA_DECODE_STREAM_WAVES_PER_CU", 0)};   // 0 = resident capacity
+    opt_int waves_per_cu{env_int("ATOMA_DECODE_WAVES_PER_CU", 0)};   // 0 = resident capacity
+    opt_int min_tiles{env_int("ATOMA_DECODE_MIN_TILES", 8)};
+    opt_int mqk{env_int("ATOMA_DECODE_MQK", 5)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches
 };
 static DecodeOptions &decode_options() {
     static DecodeOptions o;
     return o;
 }
-extern int prefill_cfg;  // prefill_mfma.hip
+extern std::atomic<int> prefill_cfg;  // prefill_mfma.hip
 bool set_decode_option(const std::string &name, int value) {
     DecodeOptions &o = decode_options();
     if (name == "prefill_cfg") { prefill_cfg = value; return true; }
@@ -1135,8 +1094,15 @@ static void launch_decode_tdg(DecodeParams &p, hipStream_t stream) {
     }
 }
 
-template <typename T, int D>
-static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
+// The launch decisions that do not depend on the element type: q heads per wavefront (G), matrix-core scores or not,
+// KV splits, balanced mode, and the fp32 scratch rows they need.  Shared by the launcher and by atoma_warmup's sizing.
+struct DecodeLaunchPlan {
+    int G;
+    bool use_mqk;
+    size_t rows;          // fp32 partial rows of D floats (+ 1 LSE each); 0 = no scratch
+    size_t bytes;         // scratch bytes including the plan ints
+};
+static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D) {
     const int g = p.g;
     // matrix-core scores: d = 128, selected groups (option decode_mqk: bit 0 = groups of 5..8+ q heads, bit 1 = smaller ones, bit 2 below)
     const int mqk_opt = decode_options().mqk;
@@ -1150,8 +1116,9 @@ static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
     if (p.num_splits <= 0) {
         const int64_t waves = (int64_t)p.b * p.h_k * p.gchunks;
         const int cap = (G >= 8 && D >= 128 && !use_mqk) ? 4 : 8;   // resident wavefronts per CU of the variant that will run
-        const int wpc = decode_options().waves_per_cu > 0 ? decode_options().waves_per_cu : cap;
-        p.num_splits = decode_num_splits(waves, p.seqlen_k, wpc, std::max(1, decode_options().min_tiles));
+        const int wpc_opt = decode_options().waves_per_cu;
+        const int wpc = wpc_opt > 0 ? wpc_opt : cap;
+        p.num_splits = decode_num_splits(waves, p.seqlen_k, wpc, std::max(1, decode_options().min_tiles.load()));
     }
     p.group_tile = G;
     p.stream_waves = 0;
@@ -1161,13 +1128,43 @@ static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
         // enough wavefronts without splitting and the lengths are on the device: the kernel balances ragged batches itself
         p.stream_waves = (int)std::min<int64_t>(p.b * hk_chunks, (int64_t)device_num_cus() * DECODE_STREAM_MAX_WAVES_PER_CU);   // upper bound, set per kernel at launch
     }
+    DecodeLaunchPlan lp{G, use_mqk, 0, 0};
     if (p.num_splits > 1 || p.stream_waves > 0) {
-        const size_t rows = p.stream_waves > 0 ? (size_t)p.stream_waves * 2 * G : (size_t)p.num_splits * p.b * p.h;
-        float *ws = static_cast<float *>(workspace(stream, rows * (D + 1) * sizeof(float) + (p.b + 2) * sizeof(int)));
+        lp.rows = p.stream_waves > 0 ? (size_t)p.stream_waves * 2 * G : (size_t)p.num_splits * p.b * p.h;
+        // plan: [0], [1], then b + 1 prefix entries (decode_run_items writes plan[2 + i] for i = 0..b, the combine kernel reads plan[3 + b])
+        lp.bytes = lp.rows * (D + 1) * sizeof(float) + ((size_t)p.b + 3) * sizeof(int);
+    }
+    return lp;
+}
+
+// Largest scratch any decode call with batch <= max_b, these head counts and contexts <= max_seqlen_k can ask for
+// (atoma_warmup reserves it up front, so that a hipGraph capture never meets a growing workspace).
+size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k) {
+    size_t worst = 0;
+    if (h_k <= 0 || h % h_k) return 0;
+    const int dummy = 0;
+    for (int b = 1; b <= max_b; ++b) {
+        DecodeParams p{};
+        p.b = b; p.h = h; p.h_k = h_k; p.g = h / h_k;
+        p.seqlen_k = max_seqlen_k;
+        p.cu_seqlens_k = &dummy;   // lengths on the device: the balanced mode is reachable
+        p.num_splits = 0;
+        worst = std::max(worst, decode_plan_launch(p, d).bytes);
+    }
+    return worst;
+}
+
+template <typename T, int D>
+static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
+    const DecodeLaunchPlan lp = decode_plan_launch(p, D);
+    const int G = lp.G;
+    const bool use_mqk = lp.use_mqk;
+    if (lp.rows) {
+        float *ws = static_cast<float *>(workspace(stream, lp.bytes));
         if (!ws) return;
         p.o_accum = ws;
-        p.lse_accum = ws + rows * D;
-        p.plan = reinterpret_cast<int *>(ws + rows * (D + 1));
+        p.lse_accum = ws + lp.rows * D;
+        p.plan = reinterpret_cast<int *>(ws + lp.rows * (D + 1));
     }
     if (D == 128 && use_mqk) {
         switch (G) {

@@ -27,6 +27,7 @@
 //    workgroups that share a kv head's K/V are steered to the same XCD (L2 reuse).
 // MFMA-bound: 4*Lq*Lk*d flops per (sequence, head) (half of it when causal).
 #include "attn_params.h"
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1083,10 +1084,10 @@ static void launch_pf_pipe(const AttnParams &p, hipStream_t stream) {
 // un-overlapped barrier / LDS-DMA issue time makes it slower than 0 -- DESIGN.md).  RB = 1 of the pipelined
 // kernel is not instantiated: hipcc splits a 256-register budget 128 / 128 between the two register files
 // and the arch half spills.  The environment variable ATOMA_PREFILL_CFG overrides the option.
-int prefill_cfg = PREFILL_DEFAULT_CFG;
+std::atomic<int> prefill_cfg{PREFILL_DEFAULT_CFG};
 static int prefill_cfg_effective() {
     static const int env = [] { const char *e = getenv("ATOMA_PREFILL_CFG"); return e ? atoi(e) : -1; }();
-    return env >= 0 ? env : prefill_cfg;   // the environment wins (lets the test suite run against a variant)
+    return env >= 0 ? env : prefill_cfg.load();   // the environment wins (lets the test suite run against a variant)
 }
 
 template <typename T, int D, bool CAUSAL>

@@ -1,6 +1,7 @@
 // Error slot, device queries and the reference's host-side split heuristic.
 #include "common.h"
 
+#include <algorithm>
 #include <math.h>
 #include <mutex>
 
@@ -29,6 +30,63 @@ int device_num_cus() {
     }
     return cached[dev];
 }
+
+// ---- library-owned scratch: one grow-only block per (device, stream) ---------------------------------------------
+// Split-KV / balanced-mode partials of the decode kernel, the K-split partials of the projections.  The reference hands
+// caller scratch to the kernel and may drop it right after the async launch (/root/reference/csrc/src/lib.rs:1023-1042,
+// 1100); owning the scratch here removes that race.  Rules that make it safe for the reference's one-thread-per-GPU
+// callers and for hipGraphs (SURVEY 8b says "callee is stateless"; this is the one piece of state, so it is explicit):
+//   * a block that was ever handed out is NEVER freed behind the caller's back: when a later call needs more, a new block
+//     of at least twice the size is allocated and the old one is RETIRED (kept alive), because a captured hipGraph may
+//     have its address baked into kernel arguments;
+//   * growth cannot happen during stream capture (hipMalloc is illegal there): the call fails with a message that names
+//     atoma_warmup / atoma_reserve_workspace, which size the block up front;
+//   * atoma_release_workspaces() frees everything (live and retired) when the caller knows no graph and no in-flight
+//     work refers to them (engine shutdown, or after destroying its graphs).
+struct Workspace {
+    int device;
+    hipStream_t stream;
+    void *ptr;
+    size_t bytes;
+};
+static std::vector<Workspace> g_ws;
+static std::vector<void *> g_ws_retired;
+static std::mutex *g_ws_mu = new std::mutex;
+
+static bool stream_is_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+void *workspace(hipStream_t stream, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(*g_ws_mu);
+    Workspace *slot = nullptr;
+    for (auto &w : g_ws)
+        if (w.device == dev && w.stream == stream) { slot = &w; break; }
+    if (slot && slot->bytes >= bytes) return slot->ptr;
+    if (stream_is_capturing(stream)) {
+        set_error("the split / merge scratch of this stream must grow, which is not possible during hipGraph capture: call "
+                  "atoma_warmup (or atoma_reserve_workspace) for this stream before capturing, or run the same call once eagerly first");
+        return nullptr;
+    }
+    const size_t want = std::max(bytes, slot ? slot->bytes * 2 : (size_t)0);
+    void *fresh = nullptr;
+    if (!check_hip(hipMalloc(&fresh, want), "workspace hipMalloc")) return nullptr;
+    if (!slot) {
+        g_ws.push_back(Workspace{dev, stream, nullptr, 0});
+        slot = &g_ws.back();
+    } else if (slot->ptr) {
+        g_ws_retired.push_back(slot->ptr);   // a captured graph may still point at it
+    }
+    slot->ptr = fresh;
+    slot->bytes = want;
+    return fresh;
+}
+
+size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k);   // paged_decode.hip
 
 // /root/reference/csrc/src/lib.rs:2122-2167, f32 arithmetic as there.
 int num_splits_heuristic(int64_t batch_nheads_mblocks, int64_t num_sms, int64_t num_n_blocks, int64_t max_splits) {
@@ -77,6 +135,42 @@ int atoma_set_option(const char *name, int value) {
     if (name && atoma::set_decode_option(name, value)) return 0;
     atoma::set_error(std::string("atoma_set_option: unknown option ") + (name ? name : "(null)"));
     return -1;
+}
+
+int atoma_reserve_workspace(void *stream, int64_t bytes) {
+    atoma::clear_error();
+    if (bytes < 0) { atoma::set_error("atoma_reserve_workspace: negative size"); return -1; }
+    if (bytes == 0) return 0;
+    return atoma::workspace(static_cast<hipStream_t>(stream), (size_t)bytes) ? 0 : -1;
+}
+
+int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, int64_t max_seqlen_k,
+                 int64_t extra_bytes) {
+    atoma::clear_error();
+    if (max_batch <= 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads || max_seqlen_k <= 0 || extra_bytes < 0) {
+        atoma::set_error("atoma_warmup: invalid shape");
+        return -1;
+    }
+    (void)atoma::device_num_cus();
+    const size_t need = std::max(atoma::decode_workspace_bound((int)std::min<int64_t>(max_batch, 1 << 20), (int)num_heads, (int)num_kv_heads,
+                                                               (int)head_dim, (int)std::min<int64_t>(max_seqlen_k, 1 << 30)),
+                                 (size_t)extra_bytes);
+    if (need == 0) return 0;
+    return atoma::workspace(static_cast<hipStream_t>(stream), need) ? 0 : -1;
+}
+
+int atoma_release_workspaces(void) {
+    atoma::clear_error();
+    std::lock_guard<std::mutex> lock(*atoma::g_ws_mu);
+    int rc = 0;
+    for (auto &w : atoma::g_ws)
+        if (w.ptr && hipFree(w.ptr) != hipSuccess) { (void)hipGetLastError(); rc = -1; }
+    for (void *p : atoma::g_ws_retired)
+        if (hipFree(p) != hipSuccess) { (void)hipGetLastError(); rc = -1; }
+    atoma::g_ws.clear();
+    atoma::g_ws_retired.clear();
+    if (rc) atoma::set_error("atoma_release_workspaces: hipFree failed");
+    return rc;
 }
 
 int atoma_device_count(void) {

@@ -10,14 +10,27 @@
 
 namespace atoma {
 
+// Every comparison below is an INTEGER comparison of an order-preserving key made from the float's bit pattern:
+// this translation unit is built with -fno-honor-nans (Makefile), under which the compiler may fold `v != v` to false
+// and give `v > b` any value for a NaN operand.  Larger float <=> larger key; -0.0 == +0.0; NaN (either sign) -> 0,
+// below the key of -inf (0x007fffff), so a NaN is never selected and sorts last.
+__device__ __forceinline__ uint32_t order_key(float v) {
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0u;   // NaN, from the bits
+    if ((u & 0x7fffffffu) == 0u) u = 0u;              // -0.0 and +0.0 compare equal
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+constexpr uint32_t KEY_NEG_INF = 0x007fffffu;
+
 struct Best {
-    float v;
+    uint32_t v;   // order_key of the value
     int i;
 };
 // larger value wins; equal values: smaller index (so the result does not depend on the work split)
 __device__ __forceinline__ Best better(Best a, Best b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
 __device__ __forceinline__ void take(Best &b, float v, int i) {
-    if (v > b.v) { b.v = v; b.i = i; }   // strict: keeps the first occurrence inside a thread's ascending scan; NaN never wins
+    const uint32_t k = order_key(v);
+    if (k > b.v) { b.v = k; b.i = i; }   // strict: keeps the first occurrence inside a thread's ascending scan; NaN never wins
 }
 
 template <typename T> __device__ __forceinline__ float load1(const void *row, int64_t i);
@@ -35,7 +48,7 @@ __global__ void __launch_bounds__(1024) argmax_rows_kernel(const void *__restric
                                                            int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
     constexpr int EPV = std::is_same<T, float>::value ? 4 : 8;   // elements per 16-byte load
     const char *row = static_cast<const char *>(logits) + (int64_t)blockIdx.x * row_stride_bytes;
-    Best best{-INFINITY, 0x7fffffff};
+    Best best{KEY_NEG_INF, 0x7fffffff};
     if (VEC) {
         const int nvec = vocab / EPV;
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_v;
@@ -60,19 +73,19 @@ __global__ void __launch_bounds__(1024) argmax_rows_kernel(const void *__restric
     // wave reduction, then across the waves through LDS
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        Best o{__shfl_xor(best.v, off, 64), __shfl_xor(best.i, off, 64)};
+        Best o{(uint32_t)__shfl_xor((int)best.v, off, 64), __shfl_xor(best.i, off, 64)};
         best = better(best, o);
     }
-    __shared__ float sv[16];
+    __shared__ uint32_t sv[16];
     __shared__ int si[16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
     if (lane == 0) { sv[wave] = best.v; si[wave] = best.i; }
     __syncthreads();
     if (wave == 0) {
-        Best b = lane < nw ? Best{sv[lane], si[lane]} : Best{-INFINITY, 0x7fffffff};
+        Best b = lane < nw ? Best{sv[lane], si[lane]} : Best{KEY_NEG_INF, 0x7fffffff};
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
-            Best o{__shfl_xor(b.v, off, 64), __shfl_xor(b.i, off, 64)};
+            Best o{(uint32_t)__shfl_xor((int)b.v, off, 64), __shfl_xor(b.i, off, 64)};
             b = better(b, o);
         }
         if (lane == 0) {
@@ -128,11 +141,6 @@ namespace atoma {
 
 constexpr int TOPK_MAX = 1024, TOPK_CAP = 4096, TOPK_THREADS = 1024;
 
-__device__ __forceinline__ uint32_t order_key(float v) {   // larger float <=> larger key; NaN lowest
-    if (v != v) return 0u;
-    const uint32_t u = v == 0.f ? 0u : __float_as_uint(v);   // -0.0 and +0.0 compare equal
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
 // sort key of a candidate: value key in the high word, inverted index in the low word -> plain descending order
 __device__ __forceinline__ unsigned long long cand(uint32_t key, int idx) { return ((unsigned long long)key << 32) | (uint32_t)(0x7fffffff - idx); }
 

@@ -147,7 +147,8 @@ int atoma_add_rms_norm(const void *a, const void *b, const void *weight, void *s
  * reference's index_select of the cos/sin rows fused in: x,y [T, heads, d] (token / head
  * strides in elements, d contiguous), tables [max_pos, d/2] in the tensor dtype, positions
  * int64 [T].  per_op_rounding != 0 reproduces Candle's arithmetic in the tensor dtype
- * (every product and the sum rounded); 0 = f32 round-once.  y may alias x. */
+ * (every product and the sum rounded); 0 = f32 round-once.  y may alias x.  positions[t] must lie in [0, max_pos) of
+ * the tables: they are device data and are not checked (Candle's index_select on CUDA does not check either). */
 int atoma_rope(const void *x, void *y, const void *cos_table, const void *sin_table,
                const int64_t *positions, int64_t num_tokens, int64_t num_heads, int64_t head_dim,
                int64_t x_token_stride, int64_t x_head_stride, int64_t y_token_stride,
@@ -274,6 +275,22 @@ int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int6
  * software-pipelined one-wave-per-SIMD kernel).  Defaults also come from ATOMA_DECODE_{P,NT,STREAM,WAVES_PER_CU,
  * MIN_TILES,MQK}; ATOMA_PREFILL_CFG overrides "prefill_cfg". */
 int atoma_set_option(const char *name, int value);
+
+/* Library-owned scratch (the one piece of state behind the "stateless callee" of csrc/src/lib.rs -- the reference passes
+ * caller scratch, lib.rs:1023-1042, and may drop it while the kernel still runs).  One grow-only block per (device, stream)
+ * holds the split-KV / balanced-mode partials of the decode kernel and the K-split partials of the projections.
+ *   - A block that was handed out is never freed behind the caller: growth allocates a larger block and RETIRES the old one
+ *     (a captured hipGraph may have its address in kernel arguments).
+ *   - Growth is impossible during stream capture; atoma_warmup sizes the block for every decode call with
+ *     batch <= max_batch, these head counts, contexts <= max_seqlen_k, and at least extra_bytes (projection partials:
+ *     splits * batch * out_features * 4) -- call it once per stream before capturing, instead of relying on an eager call.
+ *   - atoma_release_workspaces frees live and retired blocks of ALL streams: only when no graph that used them will be
+ *     replayed and the streams are idle.
+ * The device is the calling thread's current device (hipSetDevice), as for every entry point. */
+int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, int64_t max_seqlen_k,
+                 int64_t extra_bytes);
+int atoma_reserve_workspace(void *stream, int64_t bytes);
+int atoma_release_workspaces(void);
 
 /* Device helpers used by the host layer, tests and bench (plain HIP runtime, no torch). */
 int atoma_device_count(void);

@@ -102,3 +102,67 @@ def test_capture_without_warm_up_fails_loudly(gpu):
     g.launch()
     st.synchronize()
     assert np.array_equal(do.numpy(np.uint16, q.shape), want)
+
+
+def _decode_case(gpu, rng, B, L, h=8, hk=2, d=128, page=16):
+    lens = np.full(B, L, np.int32)
+    nb = B * ((L + page - 1) // page) + 1
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    dq, dk, dv, dbt, dl = (gpu.DeviceBuffer.from_numpy(a) for a in (q, kc, vc, bt, lens))
+    do = gpu.DeviceBuffer(q.nbytes)
+
+    def call(st):
+        gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bt.shape[1] * page, softmax_scale=d ** -0.5, is_bf16=1,
+                    q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                    v_strides=(page * hk * d, hk * d, d), cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt,
+                    block_table_batch_stride=bt.shape[1], page_block_size=page, force_split_kernel=True, unpadded_lse=False, stream=st.s)
+    ref = A.flash_attn_kv_cache(q, kc, vc, d ** -0.5, BF16, bt, lens)
+    keep = (dq, dk, dv, dbt, dl)
+    return call, do, q.shape, ref, keep
+
+
+def test_warmup_makes_first_call_capturable(gpu):
+    """atoma_warmup sizes the stream's scratch for every decode call up to the given shape, so a capture needs no eager call first
+    (the Rust caller believes the callee is stateless: SURVEY 8b)."""
+    assert gpu.lib.atoma_release_workspaces() == 0        # forget whatever earlier tests left behind
+    rng = np.random.default_rng(11)
+    st = gpu.Stream()
+    assert gpu.lib.atoma_warmup(st.s, 4, 8, 2, 128, 4096, 0) == 0, gpu.last_error()
+    for B, L in ((1, 4096), (3, 1000), (4, 70)):          # split-KV, split-KV, tiny
+        call, do, shape, ref, keep = _decode_case(gpu, rng, B, L)
+        with gpu.Graph.capture(st) as g:
+            call(st)
+        g.launch()
+        st.synchronize()
+        assert_close(do.numpy(np.uint16, shape), ref, BF16, atol=ATOL_VS_F32[BF16], what=f"captured without an eager call, B={B} L={L}")
+    assert gpu.lib.atoma_warmup(st.s, 0, 8, 2, 128, 4096, 0) == -1 and "invalid" in gpu.last_error()
+
+
+def test_scratch_growth_keeps_captured_graphs_valid(gpu):
+    """A graph captured against a small scratch block must stay valid after a later, larger eager call grew the scratch:
+    the old block is retired, not freed (replaying used freed memory)."""
+    assert gpu.lib.atoma_release_workspaces() == 0
+    rng = np.random.default_rng(12)
+    st = gpu.Stream()
+    small_call, small_o, small_shape, small_ref, k1 = _decode_case(gpu, rng, 1, 2048)
+    small_call(st)                                        # eager: allocates a small block
+    st.synchronize()
+    with gpu.Graph.capture(st) as g:
+        small_call(st)
+    big_call, big_o, big_shape, big_ref, k2 = _decode_case(gpu, rng, 16, 3000, h=32, hk=8)
+    big_call(st)                                          # needs (much) more scratch: grows
+    st.synchronize()
+    assert_close(big_o.numpy(np.uint16, big_shape), big_ref, BF16, atol=ATOL_VS_F32[BF16], what="call that grew the scratch")
+    # churn the allocator so that a freed block would be reused and overwritten
+    junk = [gpu.DeviceBuffer(1 << 20) for _ in range(8)]
+    for j in junk:
+        j.fill_bytes(0xff)
+    small_o.fill_bytes(0)
+    g.launch()
+    big_call(st)
+    g.launch()
+    st.synchronize()
+    assert_close(small_o.numpy(np.uint16, small_shape), small_ref, BF16, atol=ATOL_VS_F32[BF16], what="replay after the scratch grew")
+    del g
+    assert gpu.lib.atoma_release_workspaces() == 0

@@ -129,3 +129,35 @@ def test_topk_rows_k1_equals_argmax_and_rejects_bad_arguments(gpu):
     assert gpu.lib.atoma_topk_rows(d.ptr, 1, 16, 16, F32, 17, d.ptr, d.ptr, None) == -1
     assert gpu.lib.atoma_topk_rows(d.ptr, 1, 16, 16, 9, 4, d.ptr, d.ptr, None) == -1 and "dtype" in gpu.last_error()
     assert gpu.lib.atoma_topk_rows(d.ptr, 1, 16, 16, F32, 4, None, d.ptr, None) == -1
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16])
+def test_topk_and_argmax_with_nans(gpu, dtype):
+    """NaNs (both signs, quiet and signalling patterns) are never selected by argmax and sort LAST in top-k -- decided from
+    the bit pattern, because the library is built with -fno-honor-nans."""
+    rng = np.random.default_rng(5)
+    rows, vocab, k = 5, 9000, 40
+    if dtype == F32:
+        x = (rng.standard_normal((rows, vocab)) * 3).astype(np.float32)
+        bits = x.view(np.uint32)
+        nan_patterns = [0x7fc00000, 0xffc00000, 0x7f800001, 0xff812345]
+    else:
+        x = rand_half(rng, (rows, vocab), dtype, 3.0)
+        bits = x
+        nan_patterns = [0x7fc0, 0xffc0, 0x7f81, 0xff85] if dtype == BF16 else [0x7e00, 0xfe00, 0x7c01, 0xfd55]
+    for r in range(rows - 1):
+        pos = rng.choice(vocab, 300, replace=False)
+        bits[r, pos] = np.array(nan_patterns, bits.dtype)[np.arange(300) % 4]
+    bits[0, 0] = nan_patterns[0]                        # a NaN in front of the row
+    bits[rows - 1, :] = nan_patterns[1]                 # an all-NaN row ...
+    bits[rows - 1, 17] = 0                              # ... but for one finite value
+    x32 = x if dtype == F32 else to_f32(x, dtype)
+    clean = np.where(np.isnan(x32), -np.inf, x32)       # NaN ranks below -inf; no -inf in this data
+    idx, val = gpu_argmax(gpu, x, dtype)
+    assert np.array_equal(idx, clean.argmax(1)) and idx[rows - 1] == 17
+    assert np.array_equal(val, clean[np.arange(rows), idx])
+    tv, ti = gpu_topk(gpu, x, dtype, k)
+    rv, ri = np_topk(clean[: rows - 1], k)
+    assert np.array_equal(ti[: rows - 1], ri) and np.array_equal(tv[: rows - 1], rv)
+    assert ti[rows - 1, 0] == 17 and np.isnan(tv[rows - 1, 1:]).all()      # after the one finite value: NaNs, index order
+    assert ti[rows - 1, 1:].tolist() == [i for i in range(k + 1) if i != 17][: k - 1]
