@@ -74,7 +74,7 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import atoma_hip as ah
-    from oracle.halfs import BF16, from_f32
+    from halfs import BF16, from_f32          # bindings/halfs.py (product-side plumbing; oracle/ is only used by cpu_baseline)
 
     ah.set_device(local_rank)
     B, S, h, hk, d, page = args.batch, args.seq, args.heads, args.kv_heads, args.head_dim, args.block_size

@@ -199,3 +199,59 @@ def test_swap_blocks_multi_all_layers(gpu):
     for i in range(2 * L):
         CO.swap_blocks(srcs[i], dsts[i], mapping)
         assert np.array_equal(dd[i].numpy(), dsts[i])
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_swap_blocks_multi_cpu_gpu_config4_shape(gpu, pinned):
+    """BASELINE configs[4]: every layer's K and V of Llama-3.1-8B fp16 -- 64 tensors -- 256 random distinct
+    pages each way, through atoma_swap_blocks_multi kinds 2 (gpu -> cpu) and 1 (cpu -> gpu), pinned (one gather/scatter
+    kernel over PCIe) and pageable (per-page memcpy).  Bit-exact against the oracle per tensor, untouched pages stay
+    untouched, and swap-out followed by swap-in restores the GPU cache (worker.rs:602-632 loops the layers)."""
+    rng = np.random.default_rng(40 + pinned)
+    n_t, nb, npairs = 64, 288, 256
+    shape = (nb, 16, 8, 128)                                    # 32 KiB pages
+    page_bytes = int(np.prod(shape[1:])) * 2
+    nbytes = nb * page_bytes
+    base = rand_half(rng, (n_t // 8,) + shape, F16)             # 8 distinct tensors' worth of data, re-used with a per-tensor tag
+    gpu_np = [np.ascontiguousarray(base[i % len(base)] ^ np.uint16(i)) for i in range(n_t)]
+    dgs = [gpu.DeviceBuffer.from_numpy(a) for a in gpu_np]
+    hosts, hptrs = [], []
+    for i in range(n_t):
+        if pinned:
+            p = gpu.lib.atoma_host_alloc(nbytes)
+            assert p
+            a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint16)), shape=(nbytes // 2,)).reshape(shape)
+        else:
+            a = np.empty(shape, np.uint16)
+            p = a.ctypes.data
+        a[...] = np.uint16(0x1111 + i)                          # recognisable background
+        hosts.append(a)
+        hptrs.append(p)
+    src_pages, dst_pages = rng.permutation(nb)[:npairs], rng.permutation(nb)[:npairs]
+    out_map = np.stack([src_pages, dst_pages], 1).astype(np.int64)
+    gp = (C.c_void_p * n_t)(*[b.ptr for b in dgs])
+    hp = (C.c_void_p * n_t)(*hptrs)
+    rc = gpu.lib.atoma_swap_blocks_multi(gp, hp, n_t, out_map.ctypes.data, npairs, page_bytes, 2, None)     # gpu -> cpu
+    assert rc == 0, gpu.last_error()
+    gpu.synchronize()
+    mapping = {int(s): int(d) for s, d in out_map}
+    for i in range(n_t):
+        want = np.full(shape, np.uint16(0x1111 + i), np.uint16)
+        CO.swap_blocks(gpu_np[i], want, mapping)
+        assert np.array_equal(hosts[i], want), f"gpu->cpu tensor {i}"
+    # wipe the GPU side, swap back in through the inverse map
+    for b in dgs:
+        b.fill_bytes(0)
+    in_map = np.ascontiguousarray(out_map[:, ::-1])
+    rc = gpu.lib.atoma_swap_blocks_multi(hp, gp, n_t, in_map.ctypes.data, npairs, page_bytes, 1, None)      # cpu -> gpu
+    assert rc == 0, gpu.last_error()
+    gpu.synchronize()
+    touched = np.zeros(nb, bool)
+    touched[src_pages] = True
+    for i in range(n_t):
+        back = dgs[i].numpy(np.uint16, shape)
+        assert np.array_equal(back[touched], gpu_np[i][touched]), f"cpu->gpu tensor {i}"
+        assert not back[~touched].any(), f"cpu->gpu tensor {i}: a page outside the map was written"
+    if pinned:
+        for p in hptrs:
+            gpu.lib.atoma_host_free(p)

@@ -158,3 +158,21 @@ def test_add_rms_norm_is_bit_identical_to_the_two_ops(gpu, dtype, rows, hidden):
     assert np.array_equal(s1.numpy(np.uint16, a.shape), s2.numpy(np.uint16, a.shape))
     assert np.array_equal(y1.numpy(np.uint16, a.shape), y2.numpy(np.uint16, a.shape))
     assert gpu.lib.atoma_add_rms_norm(da.ptr, db.ptr, dw.ptr, s2.ptr, y2.ptr, rows, 4100, 4100, 4100, 4100, 4100, 1e-5, dtype, None) == -1
+
+
+TORCH_FX = np.load(os.path.join(os.path.dirname(__file__), "golden", "norm_rope_torch.npz"))
+
+
+@pytest.mark.parametrize("tag,dtype", [("bf16", BF16), ("f16", F16)])
+def test_kernels_against_torch_fixtures(gpu, tag, dtype):
+    """The device kernels against values torch produced in the build container (tests/golden/gen_norm_rope_torch.py): a
+    third implementation beside the kernel and the numpy restatement (Candle's source is absent: parity unpinned)."""
+    fx = TORCH_FX
+    got = gpu_rms_norm(gpu, fx[f"rms_{tag}_x"], fx[f"rms_{tag}_w"], float(fx[f"rms_{tag}_eps"]), dtype)
+    d = ulps_apart(got, fx[f"rms_{tag}_y"], dtype)
+    assert d.max() <= 1 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
+    x, pos, cos, sin = fx[f"rope_{tag}_x"], fx[f"rope_{tag}_pos"], fx[f"tab_{tag}_cos"], fx[f"tab_{tag}_sin"]
+    assert np.array_equal(gpu_rope(gpu, x, cos, sin, pos, dtype, per_op=1), fx[f"rope_{tag}_per_op"])
+    fused = gpu_rope(gpu, x, cos, sin, pos, dtype, per_op=0)
+    d = ulps_apart(fused, fx[f"rope_{tag}_fused"], dtype)
+    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())     # fma contraction: a boundary flip at most

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "atoma-infer_amd", "bindings"))
 import atoma_hip as ah  # noqa: E402
-from oracle.halfs import BF16, from_f32  # noqa: E402
+from halfs import BF16, from_f32  # noqa: E402  (atoma-infer_amd/bindings/halfs.py)
 
 HBM, MFMA_BF16 = 8000.0, 2500.0  # GB/s, TFLOP/s dense (MI355X_MICROARCH.md)
 

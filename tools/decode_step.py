@@ -220,8 +220,13 @@ class PrefillStep:
 
 
 def rope_tables(cfg):
-    from oracle import norm_rope_oracle as NR
-    return NR.rope_table(cfg.max_pos, cfg.d, cfg.theta, BF16)
+    """cos / sin [max_pos, d/2] from the library's own table builder (atoma_rope_table = `Cache::new`, llama.rs:154-200)."""
+    cos = np.zeros((cfg.max_pos, cfg.d // 2), np.uint16)
+    sin = np.zeros_like(cos)
+    rc = ah.lib.atoma_rope_table(cos.ctypes.data, sin.ctypes.data, cfg.max_pos, cfg.d, float(cfg.theta), 0.0, 0.0, 0.0, 0, BF16)
+    if rc != 0:
+        raise RuntimeError(ah.last_error())
+    return cos, sin
 
 
 def upload_weights(cfg, host):
