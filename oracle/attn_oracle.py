@@ -83,6 +83,81 @@ def attend_rows(qf, kf, vf, scale, causal=False, alibi_slopes=None, mode="f32", 
     return out, lse
 
 
+def attend_decode_online(qf, kf, vf, scale, dtype, tile=16, ngroups=4, group_of=None, alibi_slopes=None):
+    """One decode row per head (``qf [h,d]``) over ``kf,vf [L,hk,d]`` with the reference kernel's arithmetic -- exp2 domain,
+    f32 row sum of the unrounded p, p rounded to the storage dtype before P.V, f32 accumulation, one division at the end
+    (softmax.h:65-91,135-185) -- evaluated under an explicit ONLINE-softmax schedule: keys arrive in tiles of ``tile``;
+    key j of a tile belongs to accumulator group ``group_of(j)`` (``ngroups`` independent (max, sum, O) states, each
+    rescaled when its running max rises: softmax.h:135-160), and the groups are merged at the end with the LSE rule.
+
+    Why it exists: rounding p = exp2(s - m) to bf16 depends on WHICH running max m it is taken against, so two correct
+    kernels with different schedules differ by up to 2^-9 * |v| on rows with few keys (tests/test_oracle_golden.py shows
+    it on the CPU).  ``mode="kernel"`` of attend_rows is the one-tile / one-group schedule (global max); the reference's
+    split-KV kernel is (tile = 128 or 64, one group); libatoma_hip's decode kernels are (16, 4 groups, j % 4) for d = 128,
+    (16, 8 groups, j % 8) for d = 64 and (16, 4 groups, j // 4) for the matrix-core variant.  Given the kernel's own
+    schedule the comparison is tight (1e-3 + 1 ulp at every row length).  Returns out f32 [h,d] (not yet rounded)."""
+    h, d = qf.shape
+    L, hk, _ = kf.shape
+    g = h // hk
+    group_of = group_of or (lambda j: j % ngroups)
+    sl2 = np.float32(np.float32(scale) * LOG2E)
+    m = np.full((ngroups, h), -np.inf, np.float32)
+    l = np.zeros((ngroups, h), np.float32)
+    o = np.zeros((ngroups, h, d), np.float32)
+    head_kv = np.arange(h) // g
+    for t0 in range(0, L, tile):
+        rows = np.arange(t0, min(t0 + tile, L))
+        kt = kf[rows][:, head_kv]                                   # [n, h, d]
+        vt = vf[rows][:, head_kv]
+        s = np.einsum("hd,nhd->nh", qf, kt, dtype=np.float32).astype(np.float32) * sl2
+        if alibi_slopes is not None:                                # mask.h:183 with one query row at position L - 1
+            s = s - (np.asarray(alibi_slopes, np.float32) * LOG2E)[None, :] * (L - 1 - rows)[:, None].astype(np.float32)
+        grp = np.array([group_of(int(j - t0)) for j in rows])
+        for gi in range(ngroups):
+            sel = grp == gi
+            if not sel.any():
+                continue
+            sg = s[sel]
+            mnew = np.maximum(m[gi], sg.max(0))
+            with np.errstate(invalid="ignore"):
+                alpha = np.where(np.isfinite(m[gi]), np.exp2(m[gi] - mnew), np.float32(0)).astype(np.float32)
+            l[gi] *= alpha
+            o[gi] *= alpha[:, None]
+            m[gi] = mnew
+            p = np.exp2(sg - mnew[None, :]).astype(np.float32)
+            l[gi] += p.sum(0, dtype=np.float32)
+            o[gi] += np.einsum("nh,nhd->hd", round_through(p, dtype), vt[sel], dtype=np.float32)
+    mt = m.max(0)
+    with np.errstate(invalid="ignore"):
+        w = np.where(np.isfinite(m), np.exp2(m - np.where(np.isfinite(mt), mt, np.float32(0))[None, :]), np.float32(0)).astype(np.float32)
+    lt = (l * w).sum(0, dtype=np.float32)
+    ot = (o * w[:, :, None]).sum(0, dtype=np.float32)
+    return np.where(lt[:, None] > 0, ot / np.where(lt > 0, lt, np.float32(1))[:, None], np.float32(0)).astype(np.float32)
+
+
+DECODE_SCHEDULES = {            # (head_dim, variant) -> (ngroups, group_of): row ownership of libatoma_hip's decode kernels
+    (128, "dot2"): (4, lambda j: j % 4),      # paged_decode_item: 16 lanes per row, lane group `sub` loads rows sub + 4r
+    (64, "dot2"): (8, lambda j: j % 8),       # 8 lanes per row, 8 rows per load instruction
+    (128, "mqk"): (4, lambda j: j // 4),      # paged_decode_mqk_item: lane group grp holds S^T[token 4.grp + i]
+}
+
+
+def flash_attn_kv_cache_online(q, kc, vc, scale, dtype, block_table, seqlens_k, variant="dot2", alibi_slopes=None):
+    """flash_attn_kv_cache for seqlen_q = 1 under the decode kernel's own schedule (see attend_decode_online)."""
+    qf, kf, vf = to_f32(q, dtype), to_f32(kc, dtype), to_f32(vc, dtype)
+    B, _, h, d = qf.shape
+    ngroups, group_of = DECODE_SCHEDULES[(d, variant)]
+    out = np.zeros(qf.shape, np.float32)
+    for b in range(B):
+        L = int(seqlens_k[b])
+        if L == 0:
+            continue
+        ps = kf.shape[1]
+        kb, vb = gather_paged(kf, block_table[b], L, ps), gather_paged(vf, block_table[b], L, ps)
+        out[b, 0] = attend_decode_online(qf[b, 0], kb, vb, scale, dtype, 16, ngroups, group_of, alibi_slopes)
+    return from_f32(out, dtype)
+
+
 def combine_splits(o_parts, lse_parts):
     """LSE-weighted merge of split-KV partials (flash_fwd_kernel.h:1204-1236).
 
