@@ -107,6 +107,16 @@ _opt("atoma_comm_unique_id", [_vp])
 _opt("atoma_comm_init", [C.POINTER(_vp), _int, _int, _vp, _int])
 _opt("atoma_allreduce_sum", [_vp, _vp, _vp, _i64, _int, _vp])
 _opt("atoma_comm_destroy", [_vp])
+_opt("atoma_comm_set_mode", [_vp, _int])
+_opt("atoma_comm_info", [_vp], C.c_char_p)
+_opt("atoma_xgmi_create", [C.POINTER(_vp), _int, _int, _int, _i64])
+_opt("atoma_xgmi_handle", [_vp, _vp])
+_opt("atoma_xgmi_connect", [_vp, _vp])
+_opt("atoma_xgmi_allreduce_sum", [_vp, _vp, _vp, _i64, _int, _vp])
+_opt("atoma_xgmi_allreduce_sum_mode", [_vp, _vp, _vp, _i64, _int, _int, _vp])
+_opt("atoma_xgmi_status", [_vp])
+_opt("atoma_xgmi_capacity", [_vp], _i64)
+_opt("atoma_xgmi_destroy", [_vp])
 
 
 def last_error():

@@ -1,4 +1,5 @@
-// Tensor-parallel sum all-reduce over RCCL / xGMI.
+// Tensor-parallel sum all-reduce: the communicator (RCCL bootstrap, as the reference's NCCL one) and the dispatch between
+// RCCL's ncclAllReduce and the direct xGMI kernels of allreduce_xgmi.hip.
 //
 // Replaces /root/reference/models/src/multi_gpu.rs:141-179 (`AllReduce::cuda_fwd` ->
 // cudarc `ncclAllReduce(sum)`, out-of-place, bf16/f16/f32) and the communicator bootstrap of
@@ -27,6 +28,7 @@ struct Rccl {
     int (*GetUniqueId)(nccl_unique_id *) = nullptr;
     int (*CommInitRank)(nccl_comm_t *, int, nccl_unique_id, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -44,6 +46,7 @@ static Rccl *rccl() {
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
     });
@@ -60,9 +63,18 @@ static bool check_nccl(Rccl *r, int code, const char *what) {
     return false;
 }
 
+// Which engine atoma_allreduce_sum uses.  The direct xGMI kernels (allreduce_xgmi.hip) are bootstrapped over the RCCL
+// communicator itself (an all-gather of the 128-byte staging handles), so the caller's bootstrap stays the reference's:
+// one unique id, one Comm::from_rank per GPU.  Default: RCCL -- the direct path has only run with all ranks on ONE device
+// so far (no multi-GPU box in the build pool); ATOMA_ALLREDUCE=auto|xgmi or atoma_comm_set_mode opt in.
+enum { AR_RCCL = 0, AR_XGMI = 1, AR_AUTO = 2 };
 struct Comm {
     nccl_comm_t comm;
     int rank, world, device;
+    void *xgmi = nullptr;        // connected atoma_xgmi communicator, or null (see xgmi_note)
+    int mode = AR_RCCL;
+    int64_t xgmi_auto_max = 8 << 20;
+    std::string xgmi_note;       // why the direct path is unavailable, if it is
 };
 
 }  // namespace atoma
@@ -79,6 +91,60 @@ int atoma_comm_unique_id(void *id128_out) {
     return 0;
 }
 
+int atoma_xgmi_create(void **out, int rank, int world_size, int device, int64_t max_bytes);
+int atoma_xgmi_handle(void *xg, void *handle128_out);
+int atoma_xgmi_connect(void *xg, const void *handles);
+int atoma_xgmi_allreduce_sum(void *xg, const void *in, void *out, int64_t count, int dtype, void *stream);
+int64_t atoma_xgmi_capacity(void *xg);
+int atoma_xgmi_destroy(void *xg);
+
+// Bring up the direct xGMI path of a communicator: staging region, handle all-gather over RCCL, peer mapping, and an
+// agreement round (the path is used only if EVERY rank mapped every peer).  Never fails the communicator: the reason
+// lands in atoma_comm_info().
+static void comm_setup_xgmi(atoma::Rccl *r, atoma::Comm *c) {
+    using namespace atoma;
+    const char *mb = getenv("ATOMA_XGMI_MAX_BYTES");
+    const int64_t cap = mb ? atoll(mb) : (int64_t)(8 << 20);
+    c->xgmi_auto_max = cap;
+    if (c->world > 8) { c->xgmi_note = "direct path supports up to 8 ranks"; return; }
+    if (!r->AllGather) { c->xgmi_note = "ncclAllGather not found"; return; }
+    void *xg = nullptr;
+    int ok = atoma_xgmi_create(&xg, c->rank, c->world, c->device, cap) == 0;
+    std::string why = ok ? "" : atoma_last_error();
+    unsigned char mine[128] = {0};
+    if (ok && atoma_xgmi_handle(xg, mine) != 0) { ok = 0; why = atoma_last_error(); }
+    // exchange the handles (and, in byte 127, whether this rank is still healthy) through RCCL
+    mine[127] = ok ? 1 : 0;
+    unsigned char *dsend = nullptr, *drecv = nullptr;
+    std::vector<unsigned char> all((size_t)c->world * 128, 0);
+    bool xok = hipMalloc(reinterpret_cast<void **>(&dsend), 128) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&drecv), all.size()) == hipSuccess &&
+               hipMemcpy(dsend, mine, 128, hipMemcpyHostToDevice) == hipSuccess &&
+               r->AllGather(dsend, drecv, 128, 0 /* ncclInt8 */, c->comm, nullptr) == 0 && hipStreamSynchronize(nullptr) == hipSuccess &&
+               hipMemcpy(all.data(), drecv, all.size(), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!xok) { (void)hipGetLastError(); ok = 0; if (why.empty()) why = "handle all-gather over RCCL failed"; }
+    for (int q = 0; q < c->world && xok; ++q)
+        if (!all[(size_t)q * 128 + 127]) { ok = 0; if (why.empty()) why = "rank " + std::to_string(q) + " could not create its staging region"; }
+    for (int q = 0; q < c->world; ++q) all[(size_t)q * 128 + 127] = 0;
+    if (ok && atoma_xgmi_connect(xg, all.data()) != 0) { ok = 0; why = atoma_last_error(); }
+    // agreement: sum of the ranks' ok flags must equal the world size
+    float flag = ok ? 1.f : 0.f, total = 0.f;
+    bool aok = xok && hipMemcpy(dsend, &flag, 4, hipMemcpyHostToDevice) == hipSuccess &&
+               r->AllReduce(dsend, drecv, 1, NCCL_FLOAT32, NCCL_SUM, c->comm, nullptr) == 0 && hipStreamSynchronize(nullptr) == hipSuccess &&
+               hipMemcpy(&total, drecv, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    if (dsend) (void)hipFree(dsend);
+    if (drecv) (void)hipFree(drecv);
+    (void)hipGetLastError();
+    if (!aok || (int)(total + 0.5f) != c->world) {
+        if (why.empty()) why = "another rank could not map its peers";
+        if (xg) atoma_xgmi_destroy(xg);
+        c->xgmi_note = why;
+        clear_error();
+        return;
+    }
+    c->xgmi = xg;
+    clear_error();
+}
+
 int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128, int device) {
     atoma::clear_error();
     atoma::Rccl *r = atoma::rccl();
@@ -92,8 +158,32 @@ int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128
         delete c;
         return -1;
     }
+    const char *m = getenv("ATOMA_ALLREDUCE");
+    c->mode = (m && !strcmp(m, "xgmi")) ? atoma::AR_XGMI : ((m && !strcmp(m, "auto")) ? atoma::AR_AUTO : atoma::AR_RCCL);
+    const char *setup = getenv("ATOMA_XGMI_SETUP");       // 0: never build the direct path (saves the staging memory)
+    if (!(setup && atoi(setup) == 0)) comm_setup_xgmi(r, c);
     *comm_out = c;
     return 0;
+}
+
+// 0 = RCCL, 1 = direct xGMI kernels (error when unavailable), 2 = auto: direct for messages up to ATOMA_XGMI_MAX_BYTES
+// that meet its alignment rules, RCCL otherwise.  All ranks must choose the same mode.
+int atoma_comm_set_mode(void *comm, int mode) {
+    atoma::clear_error();
+    auto *c = static_cast<atoma::Comm *>(comm);
+    if (!c || mode < 0 || mode > 2) { atoma::set_error("atoma_comm_set_mode: bad argument"); return -1; }
+    if (mode == atoma::AR_XGMI && !c->xgmi) { atoma::set_error("atoma_comm_set_mode: the direct xGMI path is unavailable: " + c->xgmi_note); return -1; }
+    c->mode = mode;
+    return 0;
+}
+
+// "xgmi: ready" or "xgmi: unavailable (<reason>)"; valid until the communicator is destroyed
+const char *atoma_comm_info(void *comm) {
+    auto *c = static_cast<atoma::Comm *>(comm);
+    if (!c) return "";
+    if (c->xgmi) c->xgmi_note = "xgmi: ready";
+    else if (c->xgmi_note.rfind("xgmi:", 0) != 0) c->xgmi_note = "xgmi: unavailable (" + c->xgmi_note + ")";
+    return c->xgmi_note.c_str();
 }
 
 // multi_gpu.rs:141-179: out-of-place sum over the tensor-parallel ranks, input contiguous.
@@ -111,6 +201,14 @@ int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, in
     }
     if (count <= 0) return 0;
     auto *c = static_cast<atoma::Comm *>(comm);
+    if (c->mode != atoma::AR_RCCL) {
+        const int64_t bytes = count * (dtype == ATOMA_F32 ? 4 : 2);
+        const bool fits = c->xgmi && bytes % 16 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+        if (c->mode == atoma::AR_XGMI || (fits && bytes <= c->xgmi_auto_max)) {
+            if (!c->xgmi) { atoma::set_error("atoma_allreduce_sum: the direct xGMI path is unavailable: " + c->xgmi_note); return -1; }
+            return atoma_xgmi_allreduce_sum(c->xgmi, in, out, count, dtype, stream);
+        }
+    }
     return atoma::check_nccl(r, r->AllReduce(in, out, (size_t)count, nd, atoma::NCCL_SUM, c->comm,
                                              static_cast<hipStream_t>(stream)), "ncclAllReduce") ? 0 : -1;
 }
@@ -121,6 +219,7 @@ int atoma_comm_destroy(void *comm) {
     atoma::Rccl *r = atoma::rccl();
     auto *c = static_cast<atoma::Comm *>(comm);
     int rc = 0;
+    if (c->xgmi) atoma_xgmi_destroy(c->xgmi);
     if (r && !atoma::check_nccl(r, r->CommDestroy(c->comm), "ncclCommDestroy")) rc = -1;
     delete c;
     return rc;

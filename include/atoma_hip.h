@@ -230,6 +230,38 @@ int atoma_comm_unique_id(void *id128_out);
 int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128, int device);
 int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, int dtype, void *stream);
 int atoma_comm_destroy(void *comm);
+/* Engine behind atoma_allreduce_sum: 0 = RCCL's ncclAllReduce (default), 1 = the direct xGMI kernels below (error when
+ * they could not be brought up), 2 = auto (direct up to ATOMA_XGMI_MAX_BYTES, default 8 MiB, when the message is a
+ * multiple of 16 bytes and 16-byte aligned; RCCL otherwise).  Initial value from ATOMA_ALLREDUCE=rccl|xgmi|auto.  All
+ * ranks must choose the same mode.  atoma_comm_init builds the direct path over the RCCL communicator (all-gather of the
+ * staging handles + an agreement round) unless ATOMA_XGMI_SETUP=0; atoma_comm_info says "xgmi: ready" or why not. */
+int atoma_comm_set_mode(void *comm, int mode);
+const char *atoma_comm_info(void *comm);
+
+/* Direct sum all-reduce over peer-mapped staging memory (xGMI inside a node; same arithmetic contract as above:
+ * models/src/multi_gpu.rs:141-179, out-of-place or in-place, f16 / bf16 / f32): one-shot push for messages up to
+ * ATOMA_XGMI_ONESHOT_MAX (default 512 KiB), reduce-scatter + all-gather (two one-hop stages) above; fp32 accumulation in
+ * RANK ORDER and one rounding, so every rank holds bit-identical results.  Usable without RCCL:
+ *   atoma_xgmi_create   this rank's staging region (uncached device memory, sized for messages up to max_bytes per launch;
+ *                       larger messages are cut into pieces), world_size <= 8;
+ *   atoma_xgmi_handle   128 bytes to hand to every other rank out of band (like the ncclUniqueId of
+ *                       backends/vllm/src/model_executor.rs:413, but one per rank: all-gather them);
+ *   atoma_xgmi_connect  handles of ALL ranks in rank order [world_size][128]: peers in the same process (one thread per
+ *                       GPU, as the reference runs) are reached through peer access, other processes through HIP IPC;
+ *   atoma_xgmi_allreduce_sum  enqueue on `stream` (one stream per communicator; every rank issues the same calls with the
+ *                       same counts); count * element size must be a multiple of 16, in / out 16-byte aligned; capturable in
+ *                       a hipGraph (the call counter lives in device memory);
+ *   atoma_xgmi_status   0, or 1 + the rank a wait timed out on (ATOMA_XGMI_TIMEOUT_MS, default 30 s): never a hung GPU;
+ *   atoma_xgmi_destroy  after all ranks drained their streams. */
+int atoma_xgmi_create(void **xgmi_out, int rank, int world_size, int device, int64_t max_bytes);
+int atoma_xgmi_handle(void *xgmi, void *handle128_out);
+int atoma_xgmi_connect(void *xgmi, const void *handles);
+int atoma_xgmi_allreduce_sum(void *xgmi, const void *in, void *out, int64_t count, int dtype, void *stream);
+/* mode: 0 = by size, 1 = one-shot (message must fit a staging slot), 2 = two-shot -- for A/B measurements and tests */
+int atoma_xgmi_allreduce_sum_mode(void *xgmi, const void *in, void *out, int64_t count, int dtype, int mode, void *stream);
+int atoma_xgmi_status(void *xgmi);
+int64_t atoma_xgmi_capacity(void *xgmi);
+int atoma_xgmi_destroy(void *xgmi);
 
 /* ---- host-side batch preparation (backends/vllm/src/worker.rs:224-460, ModelWorker::prepare_input_tensors) ----
  * One sequence of the step as the scheduler describes it (SequenceGroupMetadata / SequenceData): is_prompt,
