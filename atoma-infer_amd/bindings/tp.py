@@ -40,3 +40,37 @@ def rccl_comm(ah, dist, rank, world, device):
     if ah.lib.atoma_comm_init(C.byref(comm), rank, world, raw, device) != 0:
         raise RuntimeError(ah.last_error())
     return comm
+
+
+def shard_config(cfg, world):
+    """The model dimensions ONE rank of a `world`-way tensor-parallel job works with (llama_nccl.rs:165-166: heads and kv
+    heads divided by the world size; the MLP width is split by TensorParallelColumnLinear / RowLinear).  hidden, vocab,
+    layers stay whole: embedding, norms and lm_head are replicated (llama_nccl.rs:270,321)."""
+    if cfg.h % world or cfg.hk % world or cfg.inter % world:
+        raise ValueError(f"heads {cfg.h} / kv heads {cfg.hk} / intermediate {cfg.inter} must divide over {world} ranks")
+    return type(cfg)(cfg.layers, cfg.hidden, cfg.h // world, cfg.hk // world, cfg.d, cfg.inter // world, cfg.vocab, cfg.page, cfg.eps,
+                     cfg.theta, cfg.max_pos)
+
+
+def shard_weights(host, cfg, rank, world):
+    """This rank's slice of a full set of host weights (numpy uint16, the layout tools/decode_step.py uses:
+    wqkv [(h + 2 h_k) d, H] = q rows, k rows, v rows; wo [H, h d]; wgu [2 inter, H] = gate rows, up rows; wdown [H, inter]).
+    Column-parallel layers (q, k, v, gate, up: multi_gpu.rs:20-35 `shard(0, rank, size)`) keep a block of OUTPUT rows,
+    row-parallel layers (o, down: multi_gpu.rs:52-57 `shard(1, ...)`) a block of INPUT columns; their outputs are partial
+    sums that the all-reduce completes."""
+    import numpy as np
+    c, d = cfg, cfg.d
+    hq, hk, it = c.h // world, c.hk // world, c.inter // world
+    out = {k: v for k, v in host.items() if not isinstance(v, list)}       # emb, norm_f, lm_head: replicated
+    out["norm1"], out["norm2"] = list(host["norm1"]), list(host["norm2"])
+    out["wqkv"], out["wo"], out["wgu"], out["wdown"] = [], [], [], []
+    for l in range(c.layers):
+        wqkv = host["wqkv"][l].reshape((c.h + 2 * c.hk) * d, c.hidden)
+        q, k, v = wqkv[:c.h * d], wqkv[c.h * d:(c.h + c.hk) * d], wqkv[(c.h + c.hk) * d:]
+        out["wqkv"].append(np.ascontiguousarray(np.concatenate([q[rank * hq * d:(rank + 1) * hq * d], k[rank * hk * d:(rank + 1) * hk * d],
+                                                                v[rank * hk * d:(rank + 1) * hk * d]])))
+        out["wo"].append(np.ascontiguousarray(host["wo"][l].reshape(c.hidden, c.h * d)[:, rank * hq * d:(rank + 1) * hq * d]))
+        wgu = host["wgu"][l].reshape(2 * c.inter, c.hidden)
+        out["wgu"].append(np.ascontiguousarray(np.concatenate([wgu[rank * it:(rank + 1) * it], wgu[c.inter + rank * it:c.inter + (rank + 1) * it]])))
+        out["wdown"].append(np.ascontiguousarray(host["wdown"][l].reshape(c.hidden, c.inter)[:, rank * it:(rank + 1) * it]))
+    return out

@@ -1,0 +1,119 @@
+"""A tensor-parallel decode step on the device: two ranks, each a DecodeStep over its weight / head / cache shard with the
+direct xGMI all-reduce after the o and the down projection (llama_nccl.rs:139,195; multi_gpu.rs:48-50,141-179), both
+placed on device 0 (own streams, own staging regions -- everything but the physical link), against the UNSHARDED step
+on the same device, which tests/test_decode_step_gpu.py pins op by op to the oracle."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from oracle import allreduce_oracle as AO
+from oracle import cache_oracle as CO
+from oracle.halfs import BF16, to_f32
+from util import rand_half
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, monkeypatch):
+    monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "8000")
+    import decode_step as DS
+    import tp
+    from test_allreduce_xgmi_gpu import make_ranks
+    rng = np.random.default_rng(21)
+    cfg = DS.Config(layers=3, hidden=512, heads=8, kv_heads=2, head_dim=128, intermediate=1024, vocab=1008, page=16, max_pos=256)
+    B = 6
+    ctx = np.array([0, 17, 40, 64, 100, 130])
+    lens = (ctx + 1).astype(np.int32)
+    blocks = [(int(L) + cfg.page - 1) // cfg.page for L in lens]
+    num_pages = sum(blocks) + 3
+    perm = rng.permutation(num_pages)
+    bt = np.zeros((B, max(blocks)), np.int32)
+    p0 = 0
+    for i, n in enumerate(blocks):
+        bt[i, :n] = perm[p0:p0 + n]
+        p0 += n
+    host = DS.random_host_weights(rng, cfg)
+    kc0 = [rand_half(rng, (num_pages, cfg.page, cfg.hk, cfg.d), BF16) for _ in range(cfg.layers)]
+    vc0 = [rand_half(rng, (num_pages, cfg.page, cfg.hk, cfg.d), BF16) for _ in range(cfg.layers)]
+    ids = rng.integers(0, cfg.vocab, B)
+    slots = np.array([CO.slot_mapping_for(bt[i], int(ctx[i]), int(ctx[i]) + 1, cfg.page)[0] for i in range(B)], np.int64)
+
+    # ---- the unsharded step ----
+    st = gpu.Stream()
+    full = DS.DecodeStep(cfg, B, num_pages, bt.shape[1], DS.upload_weights(cfg, host), st, keep_intermediates=True)
+    for l in range(cfg.layers):
+        full.kc[l].upload(kc0[l])
+        full.vc[l].upload(vc0[l])
+    full.set_inputs(ids, ctx, slots, lens, bt)
+    full.run()
+    st.synchronize()
+    H = cfg.hidden
+    logits_full = to_f32(full.logits.numpy(np.uint16, (B, cfg.vocab)), BF16)
+    o_full = [t["o"].numpy(np.uint16, (B, H)) for (n, l, t) in full.trace[1:-1]]
+    dn_full = [t["dn"].numpy(np.uint16, (B, H)) for (n, l, t) in full.trace[1:-1]]
+
+    # ---- two ranks ----
+    xs = make_ranks(gpu, world, 1 << 20)
+    streams = [gpu.Stream() for _ in range(world)]
+    scfg = tp.shard_config(cfg, world)
+    steps = []
+    try:
+        for r in range(world):
+            def allreduce(ptr, count, r=r):
+                assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], ptr, ptr, count, BF16, streams[r].s) == 0, gpu.last_error()
+            w = DS.upload_weights(scfg, tp.shard_weights(host, cfg, r, world))
+            s = DS.DecodeStep(scfg, B, num_pages, bt.shape[1], w, streams[r], keep_intermediates=not graph, allreduce=allreduce)
+            _, ks = tp.head_shard(cfg.h, cfg.hk, r, world)
+            for l in range(cfg.layers):                        # the rank's KV cache holds its kv heads (worker.rs:584-591)
+                s.kc[l].upload(np.ascontiguousarray(kc0[l][:, :, ks]))
+                s.vc[l].upload(np.ascontiguousarray(vc0[l][:, :, ks]))
+            s.set_inputs(ids, ctx, slots, lens, bt)            # identical metadata on every rank (model_executor.rs:531-542)
+            steps.append(s)
+        if graph:
+            # scratch of each stream sized explicitly (atoma_warmup); one eager step so that the vendor GEMM behind the
+            # 6-row projections has its plan and workspace (it cannot create them during capture) -- it rewrites the same
+            # cache slots with the same values
+            graphs = []
+            for r in range(world):
+                assert gpu.lib.atoma_warmup(streams[r].s, B, scfg.h, scfg.hk, scfg.d, bt.shape[1] * cfg.page, 64 << 20) == 0, gpu.last_error()
+            for s in steps:
+                s.run()
+            for r in range(world):
+                streams[r].synchronize()
+            for r in range(world):
+                with gpu.Graph.capture(streams[r]) as g:
+                    steps[r].run()
+                graphs.append(g)
+            for g in graphs:
+                g.launch()
+        else:
+            for s in steps:                                    # rank 0's kernels wait on the device for rank 1's
+                s.run()
+        for r in range(world):
+            streams[r].synchronize()
+            assert gpu.lib.atoma_xgmi_status(xs[r]) == 0, f"rank {r}: an all-reduce wait timed out"
+        logits = [s.logits.numpy(np.uint16, (B, cfg.vocab)) for s in steps]
+        assert np.array_equal(logits[0], logits[1]), "ranks disagree: the all-reduce must leave bit-identical activations everywhere"
+        l32 = to_f32(logits[0], BF16)
+        # sharding moves rounding points (partial projections are rounded before they are summed): a few bf16 ulps on O(1) logits
+        assert np.abs(l32 - logits_full).max() < 0.08, np.abs(l32 - logits_full).max()
+        ids_tp, ids_full = steps[0].next_ids.numpy(np.int32, (B,)), full.next_ids.numpy(np.int32, (B,))
+        top2 = np.sort(logits_full, 1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 0.1                  # rows whose winner is not a near tie
+        assert clear.any() and np.array_equal(ids_tp[clear], ids_full[clear])
+        if not graph:
+            for li, (n, l, t) in enumerate(steps[0].trace[1:-1]):
+                # the summed projection outputs against the unsharded projection (same inputs up to earlier rounding)
+                for key, ref in (("o", o_full[li]), ("dn", dn_full[li])):
+                    got = to_f32(t[key].numpy(np.uint16, (B, H)), BF16)
+                    r32 = to_f32(ref, BF16)
+                    assert (np.abs(got - r32) <= 0.02 + 2.0 ** -5 * np.abs(r32)).all(), f"layer {l} {key}"
+    finally:
+        for x in xs:
+            gpu.lib.atoma_xgmi_destroy(x)

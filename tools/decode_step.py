@@ -33,10 +33,15 @@ LLAMA_3_1_8B = Config(32, 4096, 32, 8, 128, 14336, 128256)
 class DecodeStep:
     """Device-resident weights, caches and activations of a model + `run()` = one decode step for `batch` sequences."""
 
-    def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False, fused_epilogues=False, fuse_norm=True):
+    def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False, fused_epilogues=False, fuse_norm=True,
+                 allreduce=None):
+        """allreduce(ptr, count): in-place sum of a [batch, hidden] bf16 tensor over the tensor-parallel ranks, enqueued on
+        `stream` -- called after the o and the down projection when `cfg` / `weights` are ONE rank's shard
+        (llama_nccl.rs:139,195 via TensorParallelRowLinear, multi_gpu.rs:48-50); None = not tensor parallel."""
         c = self.cfg = cfg
         self.B, self.stream, self.keep = batch, stream, keep_intermediates
-        self.fused = fused_epilogues and not keep_intermediates and batch <= 4   # residual adds and SiLU.up inside the projections' split merge (weight-streaming kernel: batches it serves)
+        self.allreduce = allreduce
+        self.fused = fused_epilogues and not keep_intermediates and batch <= 4 and allreduce is None   # residual adds and SiLU.up inside the projections' split merge (weight-streaming kernel: batches it serves); a TP rank must all-reduce before the residual
         self.fuse_norm = fuse_norm and not keep_intermediates and not self.fused   # residual add + the RMSNorm that follows it in one kernel
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
         page_elems = c.page * c.hk * c.d
@@ -127,6 +132,8 @@ class DecodeStep:
             else:
                 o = self._buf("o", l, B * H * 2)
                 self._ok(L.atoma_linear(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
+                if self.allreduce:
+                    self.allreduce(o.ptr, B * H)
                 if self.fuse_norm:
                     self._ok(L.atoma_add_rms_norm(x.ptr, o.ptr, self.w["norm2"][l].ptr, x1.ptr, xn2.ptr, B, H, H, H, H, H, c.eps, BF16, s), "residual add + rms_norm")
                 else:
@@ -137,6 +144,8 @@ class DecodeStep:
                 self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
                 dn = self._buf("dn", l, B * H * 2)
                 self._ok(L.atoma_linear(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
+                if self.allreduce:
+                    self.allreduce(dn.ptr, B * H)
                 if self.fuse_norm:                       # ... + the next layer's input norm (or the final norm)
                     last = l == c.layers - 1
                     nw, nout = (self.w["norm_f"], xf) if last else (self.w["norm1"][l + 1], self._buf("xn1", l + 1, B * H * 2))
@@ -227,6 +236,20 @@ def rope_tables(cfg):
     if rc != 0:
         raise RuntimeError(ah.last_error())
     return cos, sin
+
+
+def random_host_weights(rng, cfg):
+    """Synthetic bf16 weights of a whole model on the host (numpy uint16), scaled so that activations stay O(1):
+    the dict layout `upload_weights` and `tp.shard_weights` take."""
+    from halfs import from_f32
+    H, I = cfg.hidden, cfg.inter
+    r = lambda shape, scale: from_f32((rng.standard_normal(shape) * scale).astype(np.float32), BF16)
+    near1 = lambda: from_f32((1 + 0.1 * rng.standard_normal(H)).astype(np.float32), BF16)
+    return dict(emb=r((cfg.vocab, H), 1.0), norm1=[near1() for _ in range(cfg.layers)],
+                wqkv=[r((cfg.qkv, H), H ** -0.5) for _ in range(cfg.layers)],
+                wo=[r((H, cfg.h * cfg.d), (cfg.h * cfg.d) ** -0.5) for _ in range(cfg.layers)],
+                norm2=[near1() for _ in range(cfg.layers)], wgu=[r((2 * I, H), H ** -0.5) for _ in range(cfg.layers)],
+                wdown=[r((H, I), I ** -0.5) for _ in range(cfg.layers)], norm_f=near1(), lm_head=r((cfg.vocab, H), H ** -0.5))
 
 
 def upload_weights(cfg, host):
