@@ -53,7 +53,7 @@ struct XgmiParams {
     char *peer[XGMI_MAX_WORLD];   // base of every rank's staging region as mapped in THIS process (peer[rank] = own)
     const char *in;
     char *out;
-    uint32_t *seq;                // device: [0] = sequence number of the last completed call, [1] = blocks that left the current one
+    uint32_t *seq;                // device: [0] = sequence number of the last completed call, [1] = blocks that left the current one, [2] = a wait timed out
     uint32_t *status;             // host-mapped: != 0 after a timed-out wait
     int64_t nvec;                 // 16-byte vectors in the message
     int64_t chunk_vec;            // two-shot: vectors per rank chunk (ceil(nvec / world))
@@ -126,10 +126,14 @@ __device__ __forceinline__ void xgmi_signal_and_wait(const XgmiParams &p, int pa
         __hip_atomic_store(xgmi_flag(p.peer[t], p, parity, stage, p.rank, blockIdx.x), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         uint32_t *mine = xgmi_flag(p.peer[p.rank], p, parity, stage, t, blockIdx.x);
         const long long t0 = wall_clock64();
+        // once a wait has timed out (device-side copy of the status in seq[2]) the communicator is broken: later waits give
+        // up at once, so a captured graph of 160 calls costs one timeout, not 160
+        const long long limit = __hip_atomic_load(p.seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : p.timeout_ticks;
         while ((int)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > p.timeout_ticks) {
+            if (wall_clock64() - t0 > limit) {
                 __hip_atomic_store(p.status, 1u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // which peer never arrived
+                __hip_atomic_store(p.seq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
@@ -295,8 +299,8 @@ int atoma_xgmi_create(void **out, int rank, int world_size, int device, int64_t 
     if (!check_hip(hipExtMallocWithFlags(&mem, x->region_bytes, hipDeviceMallocUncached), "xgmi staging region (hipExtMallocWithFlags uncached)")) { delete x; return -1; }
     x->region = static_cast<char *>(mem);
     bool ok = check_hip(hipMemset(x->region, 0, x->region_bytes), "xgmi region memset");
-    ok = ok && check_hip(hipMalloc(reinterpret_cast<void **>(&x->seq), 2 * sizeof(uint32_t)), "xgmi sequence word");
-    ok = ok && check_hip(hipMemset(x->seq, 0, 2 * sizeof(uint32_t)), "xgmi sequence memset");
+    ok = ok && check_hip(hipMalloc(reinterpret_cast<void **>(&x->seq), 4 * sizeof(uint32_t)), "xgmi sequence word");
+    ok = ok && check_hip(hipMemset(x->seq, 0, 4 * sizeof(uint32_t)), "xgmi sequence memset");
     ok = ok && check_hip(hipHostMalloc(reinterpret_cast<void **>(&x->status), sizeof(uint32_t), hipHostMallocMapped), "xgmi status word");
     ok = ok && check_hip(hipDeviceSynchronize(), "xgmi create sync");
     if (!ok) { if (x->seq) (void)hipFree(x->seq); (void)hipFree(x->region); delete x; return -1; }

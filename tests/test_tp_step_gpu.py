@@ -63,10 +63,12 @@ def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, monkeypatch):
     streams = [gpu.Stream() for _ in range(world)]
     scfg = tp.shard_config(cfg, world)
     steps = []
+    live = [False]
     try:
         for r in range(world):
             def allreduce(ptr, count, r=r):
-                assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], ptr, ptr, count, BF16, streams[r].s) == 0, gpu.last_error()
+                if live[0]:
+                    assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], ptr, ptr, count, BF16, streams[r].s) == 0, gpu.last_error()
             w = DS.upload_weights(scfg, tp.shard_weights(host, cfg, r, world))
             s = DS.DecodeStep(scfg, B, num_pages, bt.shape[1], w, streams[r], keep_intermediates=not graph, allreduce=allreduce)
             _, ks = tp.head_shard(cfg.h, cfg.hk, r, world)
@@ -75,6 +77,16 @@ def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, monkeypatch):
                 s.vc[l].upload(np.ascontiguousarray(vc0[l][:, :, ks]))
             s.set_inputs(ids, ctx, slots, lens, bt)            # identical metadata on every rank (model_executor.rs:531-542)
             steps.append(s)
+        # Both ranks are driven from this one host thread.  The vendor GEMM behind the 6-row projections synchronises with
+        # the stream the first time it sees a shape; that must not happen while rank 0's all-reduce waits on the device for
+        # kernels of rank 1 that this thread has not enqueued yet: a first pass with the exchange switched off.
+        for s in steps:
+            s.run()
+        for r in range(world):
+            streams[r].synchronize()
+        live[0] = True
+        for r in range(world):                                 # the warm pass wrote the step's K/V rows already (same values); intermediates are rebuilt
+            steps[r].trace = []
         if graph:
             # scratch of each stream sized explicitly (atoma_warmup); one eager step so that the vendor GEMM behind the
             # 6-row projections has its plan and workspace (it cannot create them during capture) -- it rewrites the same
