@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--block-size", type=int, default=16)
     ap.add_argument("--identity-table", action="store_true", help="physical page i = logical page i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="only the headline (profiling runs): skip the end-to-end extras")
+    ap.add_argument("--tp-step", action="store_true", help="N = 1: also time the whole 70B-shaped decode step on this GPU (226 GB)")
     ap.add_argument("--cpu-sample-seqs", type=int, default=64)
     args = ap.parse_args()
 
@@ -66,6 +68,7 @@ def main():
     # all-reduce) even with one rank -- lets a single-GPU box exercise what the 8-GPU run will execute.
     force_comm = os.environ.get("ATOMA_BENCH_FORCE_COMM") == "1"
     dist = None
+    os.environ.setdefault("ATOMA_XGMI_TIMEOUT_MS", "5000")   # read when the communicator builds its direct path: a lost peer costs 5 s, not a hang
     if world > 1 or force_comm:
         import torch  # only for the rendezvous / barrier / max-over-ranks (gloo, CPU tensors)
         import torch.distributed as dist
@@ -185,9 +188,33 @@ def main():
                     out["roofline"]["traffic"] = int(e["hbm_traffic_bytes_per_launch"])
                     out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT)
 
+    # ---- end-to-end numbers beside the headline, each timed with HIP events in this same run (tools/bench_extra.py) ----
+    # N = 1: the 8B decode step of configs[2], the prefill kernel, the configs[4] swap.  N > 1: the tensor-parallel decode step
+    # of configs[3] (70B-shaped shard per rank, 2 all-reduces of [64, 8192] per layer) with RCCL and with the direct xGMI kernels.
+    if not args.no_extra:
+        for b_ in (dkc, dvc, dq, do):
+            b_.free()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        extra = {}
+        try:
+            if world == 1 and not force_comm:
+                import bench_extra
+                extra.update(bench_extra.collect())
+                if args.tp_step:
+                    import tp_step
+                    extra["tp_step"] = tp_step.run(steps=10)
+            elif world > 1:
+                import tp_step
+                extra["tp_step"] = tp_step.run(steps=10, dist=dist, rank=rank, world=world, local_rank=local_rank, comm=comm)
+        except Exception as e:              # never lose the headline to an extra
+            extra["error"] = repr(e)
+        out["extra"] = extra
+
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk_l, h_l)
     if comm is not None:
+        if dist is not None:
+            dist.barrier()
         ah.lib.atoma_comm_destroy(comm)
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,117 @@
+"""The end-to-end numbers bench.py carries beside its headline, each timed with HIP events in the SAME run:
+
+  c3_decode_step   one whole Llama-3.1-8B decode step on the device (BASELINE configs[2] mid-trace: batch 256, contexts
+                   U[2048, 2560), block 16, hipGraph replay) -> ms, decode tokens/s/GPU, fraction of the byte roofline;
+  prefill          causal varlen FlashAttention-2 prefill, 16 prompts of 2048 tokens, 32 q / 8 kv heads, d = 128
+                   -> TFLOP/s and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak;
+  swap             CPU<->GPU KV swap of BASELINE configs[4]: 64 tensors (32 layers x K, V), 256 pages of 32 KiB, pinned host
+                   memory, both directions -> GB/s over PCIe.
+Bench plumbing over the C ABI; synthetic data; nothing here imports oracle/."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "tools"), os.path.join(ROOT, "atoma-infer_amd", "bindings")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import atoma_hip as ah  # noqa: E402
+import decode_step as DS  # noqa: E402
+import tp_step as TS  # noqa: E402
+
+HBM_PEAK, MFMA_PEAK_BF16 = 8e12, 2.5e15
+
+
+def _timed(stream, fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    stream.synchronize()
+    a, b = ah.Event(), ah.Event()
+    a.record(stream.s)
+    for _ in range(iters):
+        fn()
+    b.record(stream.s)
+    b.synchronize()
+    return a.elapsed_ms(b) / iters
+
+
+def c3_decode_step(iters=10, batch=256, seed=9):
+    rng = np.random.default_rng(seed)
+    c = DS.LLAMA_3_1_8B
+    w = TS.random_shard_weights(rng, c)
+    st = ah.Stream()
+    S = 2560
+    pps = S // c.page + 1
+    step = DS.DecodeStep(c, batch, batch * pps + 2, pps, w, st, fused_epilogues=True)
+    bt = rng.permutation(batch * pps).astype(np.int32).reshape(batch, pps)
+    ctx = rng.integers(2048, 2560, batch)
+    slots = bt[np.arange(batch), ctx // c.page].astype(np.int64) * c.page + ctx % c.page
+    step.set_inputs(rng.integers(0, c.vocab, batch), ctx, slots, ctx + 1, bt)
+    step.run()
+    st.synchronize()
+    with ah.Graph.capture(st) as g:
+        step.run()
+    ms = _timed(st, g.launch, iters)
+    weight_bytes = 2 * (c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden)) + 2 * batch * c.hidden
+    nbytes = weight_bytes + 2 * int((ctx + 1).sum()) * c.hk * c.d * 2 * c.layers
+    out = {"workload": f"Llama-3.1-8B decode step (BASELINE configs[2] mid-trace), batch {batch}, contexts U[2048,2560), block {c.page}, bf16, hipGraph replay",
+           "ms_per_step": round(ms, 3), "decode_tokens_per_s_per_gpu": round(batch / (ms * 1e-3), 1), "algorithmic_bytes": int(nbytes),
+           "roofline_tokens_per_s": round(batch / (nbytes / HBM_PEAK), 1), "frac_of_hbm_roofline": round(nbytes / HBM_PEAK / (ms * 1e-3), 4)}
+    del g, step, w
+    return out
+
+
+def prefill(iters=10, S=2048, nseq=16, h=32, hk=8, d=128, seed=1):
+    rng = np.random.default_rng(seed)
+    T = S * nseq
+    q, k, v = (TS.rand_dev(rng, T * n * d * 2) for n in (h, hk, hk))
+    o = ah.DeviceBuffer(T * h * d * 2)
+    cu = ah.DeviceBuffer.from_numpy((np.arange(nseq + 1) * S).astype(np.int32))
+    st = ah.Stream()
+
+    def run():
+        ah.run_mha(q, k, v, o, b=nseq, h=h, h_k=hk, d=d, seqlen_q=S, seqlen_k=S, softmax_scale=d ** -0.5, is_bf16=1,
+                   q_strides=(0, h * d, d), o_strides=(0, h * d, d), k_strides=(0, hk * d, d), v_strides=(0, hk * d, d),
+                   is_causal=1, cu_seqlens_q=cu, cu_seqlens_k=cu, stream=st.s)
+    ms = _timed(st, run, iters)
+    flops = 4 * S * S * h * d / 2 * nseq
+    return {"workload": f"FlashAttention-2 prefill, causal varlen, {nseq} x {S} tokens, {h} q / {hk} kv heads, d = {d}, bf16", "ms": round(ms, 4),
+            "flops": int(flops), "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1), "frac_mfma": round(flops / (ms * 1e-3) / MFMA_PEAK_BF16, 4),
+            "prompt_tokens_per_s_attention_only": round(T / (ms * 1e-3))}
+
+
+def swap(iters=3, tensors=64, pages=256, nb=512, page_bytes=16 * 8 * 128 * 2, seed=4):
+    rng = np.random.default_rng(seed)
+    gpu = [ah.DeviceBuffer(nb * page_bytes) for _ in range(tensors)]
+    host = [ah.lib.atoma_host_alloc(nb * page_bytes) for _ in range(tensors)]
+    gp, hp = (C.c_void_p * tensors)(*[b.ptr for b in gpu]), (C.c_void_p * tensors)(*host)
+    m = np.stack([rng.permutation(nb)[:pages], rng.permutation(nb)[:pages]], 1).astype(np.int64)
+    st = ah.Stream()
+    res = {"workload": f"swap_blocks (BASELINE configs[4]): {tensors} tensors x {pages} pages x {page_bytes // 1024} KiB fp16, pinned host memory, one gather/scatter launch per direction",
+           "bytes_one_way": tensors * pages * page_bytes}
+    for kind, s, d_, label in ((2, gp, hp, "gpu_to_cpu"), (1, hp, gp, "cpu_to_gpu")):
+        def run():
+            assert ah.lib.atoma_swap_blocks_multi(s, d_, tensors, m.ctypes.data, pages, page_bytes, kind, st.s) == 0, ah.last_error()
+        ms = _timed(st, run, iters, warm=1)
+        res[label + "_GBps"] = round(tensors * pages * page_bytes / (ms * 1e-3) / 1e9, 1)
+    for p in host:
+        ah.lib.atoma_host_free(p)
+    return res
+
+
+def collect(which=("c3_decode_step", "prefill", "swap")):
+    out = {}
+    for name in which:
+        try:
+            out[name] = globals()[name]()
+        except Exception as e:          # an extra must never take the headline down with it
+            out[name] = {"error": repr(e)}
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    ah.set_device(0)
+    print(json.dumps(collect(tuple(sys.argv[1:]) or ("c3_decode_step", "prefill", "swap"))))

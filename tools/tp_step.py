@@ -213,6 +213,7 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
         for r, rk in enumerate(ranks):                        # a virtual rank is a TP=8 shard whose communicator has `virtual_ranks` members
             Rank.__init__(rk, full_cfg, r, tp_world, B, ctx, 0)
             rk.world = virtual_ranks
+        os.environ["ATOMA_XGMI_ONESHOT_MAX"] = str(max(msg, 1 << 20))   # so that both kernels can be forced on the 1 MiB message
         for r in range(virtual_ranks):
             h = C.c_void_p()
             assert ah.lib.atoma_xgmi_create(C.byref(h), r, virtual_ranks, 0, max(msg, 1 << 20)) == 0, ah.last_error()
