@@ -66,6 +66,7 @@ struct DecodeParams {
     int num_splits;        // KV splits per sequence (grid slots)
     int stream_waves;      // > 0: balanced mode available -- this many wavefronts share the batch's tiles evenly (decode_run_items)
     int group_tile;        // q heads per wavefront (the kernel's G)
+    const float *k_scale, *v_scale;   // fp8 (e4m3fn) KV cache: per-kv-head dequantisation scales [h_k]; null for 16-bit caches
     int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
     float scale, scale_log2;
 };
@@ -576,6 +577,272 @@ __device__ __forceinline__ void paged_decode_item(const DecodeParams &p, const D
 template <typename T, int D, int G, int P, int MINW, bool NT, bool STREAM>
 __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodeParams p) {
     decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_item<T, D, G, P, NT>(pp, wk); });
+}
+
+// ------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3fn) KV cache, d = 128 (/root/reference/README.md:35 roadmap "quantization").  The cache
+// keeps the reference's layout [nb, page, h_k, d] with ONE byte per element and a per-kv-head dequantisation scale
+// (value = e4m3 * scale[hk]); q and o stay bf16 / f16.  Decode is HBM-bound, so halving the K/V bytes is the lever:
+//   * a token row of one kv head is 128 bytes: 8 adjacent lanes read it with one 16-byte load each, a wave instruction
+//     covers 8 rows = 8 full 128-byte lines (1 KiB, as in the 16-bit kernel); a 16-token tile is 2 + 2 load instructions;
+//   * fp8 -> bf16 is exact: v_cvt_scalef32_pk_bf16_fp8 with scale 1.0 turns two bytes into one packed bf16 pair (8 per
+//     16-byte load), after which q.k and P.V are the same v_dot2c streams as in the 16-bit kernel;
+//   * the K scale folds into the softmax scale (scores = k_scale * q.k_q), the V scale into the final 1/l -- nothing per element.
+// Same work mapping, split-KV / balanced modes and combine kernel as the 16-bit path.  Groups of more than 4 q heads run
+// in chunks of 4 (K/V re-read per chunk).
+// ------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ uint32_t fp8x2_to_pair(uint32_t word, bool hi);
+template <> __device__ __forceinline__ uint32_t fp8x2_to_pair<bf16_t>(uint32_t word, bool hi) {
+    return hi ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(word, 1.0f, true))
+              : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(word, 1.0f, false));
+}
+template <> __device__ __forceinline__ uint32_t fp8x2_to_pair<f16_t>(uint32_t word, bool hi) {
+    return hi ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(word, 1.0f, true))
+              : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(word, 1.0f, false));
+}
+// 16 fp8 bytes -> 8 packed 16-bit pairs, element order preserved
+template <typename T> __device__ __forceinline__ void fp8x16_to_pairs(const u32x4 &v, uint32_t (&out)[8]) {
+    out[0] = fp8x2_to_pair<T>(v.x, false); out[1] = fp8x2_to_pair<T>(v.x, true);
+    out[2] = fp8x2_to_pair<T>(v.y, false); out[3] = fp8x2_to_pair<T>(v.y, true);
+    out[4] = fp8x2_to_pair<T>(v.z, false); out[5] = fp8x2_to_pair<T>(v.z, true);
+    out[6] = fp8x2_to_pair<T>(v.w, false); out[7] = fp8x2_to_pair<T>(v.w, true);
+}
+
+template <typename T, int G, int P, bool NT>
+__device__ __forceinline__ void paged_decode_fp8_item(const DecodeParams &p, const DecodeWork &wk) {
+    constexpr int D = 128;
+    constexpr int LPR = 8;         // lanes per 128-byte row
+    constexpr int RPI = 8;         // rows per load instruction
+    const int lane = threadIdx.x;
+    const int sub = lane / LPR, dc = lane % LPR;   // row of the 8-row slab, 16-element chunk of the row
+
+    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
+    const bool partial = wk.partial;
+    const int hq0 = hk * p.g + gc * G;
+    const int nq = min(G, p.g - gc * G);
+
+    const float sl2 = p.scale_log2 * load_ro(p.k_scale + hk);   // scores = k_scale * (q . k_q)
+    float m[G], l[G], o[G][16];
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+        m[gq] = -INFINITY;
+        l[gq] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[gq][e] = 0.f;
+    }
+
+    if (t0 < t1) {
+        uint32_t qv[G][8];   // q[head][16.dc ..+15] as 8 packed pairs, replicated over the 8 row groups
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) {
+            uint4 a = make_uint4(0, 0, 0, 0), c = a;
+            if (gq < nq) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(p.q + (int64_t)b * p.q_batch_stride + (int64_t)(hq0 + gq) * p.q_head_stride + dc * 16);
+                a = src[0];
+                c = src[1];
+            }
+            qv[gq][0] = a.x; qv[gq][1] = a.y; qv[gq][2] = a.z; qv[gq][3] = a.w;
+            qv[gq][4] = c.x; qv[gq][5] = c.y; qv[gq][6] = c.z; qv[gq][7] = c.w;
+        }
+        // ---- loader: as paged_decode_item, strides in BYTES (one byte per element) ----
+        const uint32_t tpp = (uint32_t)(p.page_size >> 4);
+        const uint32_t tpp_magic = tpp > 1 ? (uint32_t)((0x100000000ull + tpp - 1) / tpp) : 0u;
+        const int last_pg = (L + p.page_size - 1) / p.page_size - 1;
+        const int *bt_row = p.block_table + (int64_t)b * p.block_table_batch_stride;
+        const char *kbase = reinterpret_cast<const char *>(p.k) + (int64_t)hk * p.k_head_stride;
+        const char *vbase = reinterpret_cast<const char *>(p.v) + (int64_t)hk * p.v_head_stride;
+        const int64_t k_row_bytes = p.k_row_stride, v_row_bytes = p.v_row_stride;
+        const int64_t k_page_bytes = p.k_batch_stride, v_page_bytes = p.v_batch_stride;
+        const uint32_t k_lane_off = (uint32_t)(sub * k_row_bytes + dc * 16);
+        const uint32_t v_lane_off = (uint32_t)(sub * v_row_bytes + dc * 16);
+        auto page_of = [&](int tile, uint32_t &tip) -> int {
+            if (tpp == 1) { tip = 0; return tile; }
+            const uint32_t pg = __umulhi((uint32_t)tile, tpp_magic);
+            tip = (uint32_t)tile - pg * tpp;
+            return (int)pg;
+        };
+        auto fetch_pid = [&](int tile) -> int {
+            uint32_t tip;
+            const int pg = min(page_of(tile, tip), last_pg);
+            return load_ro(bt_row + pg);
+        };
+        constexpr int AUX = NT ? 2 : 0;
+        auto issue = [&](u32x4 (&kb)[2], u32x4 (&vb)[2], int tile, int pid) {   // paged tiles always own their 16 rows
+            uint32_t tip;
+            (void)page_of(tile, tip);
+            const char *kt = kbase + (int64_t)pid * k_page_bytes + (int64_t)(tip << 4) * k_row_bytes;
+            const char *vt = vbase + (int64_t)pid * v_page_bytes + (int64_t)(tip << 4) * v_row_bytes;
+            const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(kt), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vt), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) kb[r] = __builtin_amdgcn_raw_buffer_load_b128(kr, k_lane_off, (int)(r * RPI * k_row_bytes), AUX);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) vb[r] = __builtin_amdgcn_raw_buffer_load_b128(vr, v_lane_off, (int)(r * RPI * v_row_bytes), AUX);
+        };
+        auto compute = [&](const u32x4 (&kb)[2], const u32x4 (&vb)[2], int tile) {
+            float s[2][G];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                uint32_t kk[8];
+                fp8x16_to_pairs<T>(kb[r], kk);
+#pragma unroll
+                for (int gq = 0; gq < G; ++gq) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a = dot2<T>(kk[i], qv[gq][i], a);
+                    s[r][gq] = row_allreduce<LPR>(a) * sl2;   // log2 domain
+                }
+            }
+            const int tok0 = (tile << 4) + sub;
+            if ((tile << 4) + 16 > L) {   // wave-uniform: ragged last tile
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+                    if (tok0 + r * RPI >= L) {
+#pragma unroll
+                        for (int gq = 0; gq < G; ++gq) s[r][gq] = -INFINITY;
+                    }
+            }
+            float mnew[G];
+            bool changed = false;
+#pragma unroll
+            for (int gq = 0; gq < G; ++gq) {
+                mnew[gq] = fmaxf(m[gq], fmaxf(s[0][gq], s[1][gq]));
+                changed |= mnew[gq] > m[gq];
+            }
+            if (__any(changed)) {
+#pragma unroll
+                for (int gq = 0; gq < G; ++gq) {
+                    const float ms = mnew[gq] == -INFINITY ? 0.f : mnew[gq];
+                    const float alpha = __builtin_amdgcn_exp2f(m[gq] - ms);
+                    l[gq] *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[gq][e] *= alpha;
+                    m[gq] = mnew[gq];
+                }
+            }
+            uint32_t pp[G];
+#pragma unroll
+            for (int gq = 0; gq < G; ++gq) {
+                const float ms = m[gq] == -INFINITY ? 0.f : m[gq];
+                const float p0 = __builtin_amdgcn_exp2f(s[0][gq] - ms), p1 = __builtin_amdgcn_exp2f(s[1][gq] - ms);
+                l[gq] += p0 + p1;
+                pp[gq] = pack_pair<T>(p0, p1);   // tokens (sub, 8 + sub)
+            }
+            uint32_t va[8], vc[8];
+            fp8x16_to_pairs<T>(vb[0], va);
+            fp8x16_to_pairs<T>(vb[1], vc);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const uint32_t lo = __builtin_amdgcn_perm(vc[w], va[w], 0x05040100u);  // (row sub, row 8 + sub) of element 2w
+                const uint32_t hi = __builtin_amdgcn_perm(vc[w], va[w], 0x07060302u);  // ... of element 2w + 1
+#pragma unroll
+                for (int gq = 0; gq < G; ++gq) {
+                    o[gq][2 * w] = dot2<T>(lo, pp[gq], o[gq][2 * w]);
+                    o[gq][2 * w + 1] = dot2<T>(hi, pp[gq], o[gq][2 * w + 1]);
+                }
+            }
+        };
+        // ---- software pipeline: P tiles in flight (every paged tile is complete: one code path, unconditional steady state) ----
+        u32x4 kb[P][2], vb[P][2];
+        int pid[P];
+        int t = t0;
+        if (t0 + 2 * P <= t1) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                issue(kb[s], vb[s], t0 + s, pid[s]);
+                pid[s] = fetch_pid(t0 + s + P);
+            }
+            for (; t + 2 * P <= t1; t += P) {
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    compute(kb[s], vb[s], t + s);
+                    issue(kb[s], vb[s], t + s + P, pid[s]);
+                    pid[s] = fetch_pid(t + s + 2 * P);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
+#pragma unroll
+            for (int s = 0; s < P; ++s)
+                if (t0 + s < t1) {
+                    issue(kb[s], vb[s], t0 + s, pid[s]);
+                    pid[s] = fetch_pid(t0 + s + P);
+                }
+        }
+        for (; t < t1; t += P) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                if (t + s < t1) {
+                    compute(kb[s], vb[s], t + s);
+                    if (t + s + P < t1) {
+                        issue(kb[s], vb[s], t + s + P, pid[s]);
+                        pid[s] = fetch_pid(t + s + 2 * P);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- merge the 8 row groups ----
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+        float mt = m[gq];
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) mt = fmaxf(mt, __shfl_xor(mt, off, 64));
+        const float ms = mt == -INFINITY ? 0.f : mt;
+        const float w = __builtin_amdgcn_exp2f(m[gq] - ms);
+        float lt = l[gq] * w;
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) lt += __shfl_xor(lt, off, 64);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float x = o[gq][e] * w;
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1) x += __shfl_xor(x, off, 64);
+            o[gq][e] = x;
+        }
+        m[gq] = mt;
+        l[gq] = lt;
+    }
+    if (sub != 0) return;
+    const float vs = load_ro(p.v_scale + hk);
+#pragma unroll
+    for (int gq = 0; gq < G; ++gq) {
+        if (gq >= nq) continue;
+        const int hq = hq0 + gq;
+        const bool empty = !(l[gq] > 0.f);
+        const float inv = empty ? 0.f : vs / l[gq];      // O = v_scale * sum(p v_q) / sum(p)
+        const float lse = empty ? INFINITY : (m[gq] + __builtin_amdgcn_logf(l[gq])) * 0.6931471805599453f;
+        if (!partial) {
+            uint4 w4[2];
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                w4[hlf].x = pack2<T>(o[gq][8 * hlf + 0] * inv, o[gq][8 * hlf + 1] * inv);
+                w4[hlf].y = pack2<T>(o[gq][8 * hlf + 2] * inv, o[gq][8 * hlf + 3] * inv);
+                w4[hlf].z = pack2<T>(o[gq][8 * hlf + 4] * inv, o[gq][8 * hlf + 5] * inv);
+                w4[hlf].w = pack2<T>(o[gq][8 * hlf + 6] * inv, o[gq][8 * hlf + 7] * inv);
+            }
+            uint4 *dst = reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + dc * 16);
+            dst[0] = w4[0];
+            dst[1] = w4[1];
+            if (p.lse && dc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
+        } else {
+            const int64_t row = wk.prow + gq;
+            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + dc * 16);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                dst[q4] = make_float4(o[gq][4 * q4] * inv, o[gq][4 * q4 + 1] * inv, o[gq][4 * q4 + 2] * inv, o[gq][4 * q4 + 3] * inv);
+            if (dc == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
+        }
+    }
+}
+
+template <typename T, int G, int P, bool NT, bool STREAM>
+__global__ void __launch_bounds__(64, 2) paged_decode_fp8_kernel(const DecodeParams p) {
+    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_item<T, G, P, NT>(pp, wk); });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1102,7 +1369,7 @@ struct DecodeLaunchPlan {
     size_t rows;          // fp32 partial rows of D floats (+ 1 LSE each); 0 = no scratch
     size_t bytes;         // scratch bytes including the plan ints
 };
-static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D) {
+static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = false) {
     const int g = p.g;
     // matrix-core scores: d = 128, selected groups (option decode_mqk: bit 0 = groups of 5..8+ q heads, bit 1 = smaller ones, bit 2 below)
     const int mqk_opt = decode_options().mqk;
@@ -1110,8 +1377,8 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D) {
     // matrix-core kernel's instruction stream per tile is 1.5x shorter (B=1: 32 -> 27 us, 70B TP=8 shard B=64: -6 %);
     // at larger batches the two kernels tie or the dot2 kernel wins by 2-3 %, and MHA always prefers dot2.
     const bool tiny = g >= 2 && g <= 4 && (int64_t)p.b * p.h_k <= 64;
-    const bool use_mqk = D == 128 && ((g > 4 && (mqk_opt & 1)) || (g <= 4 && (mqk_opt & 2)) || (tiny && (mqk_opt & 4)));
-    const int G = g >= 8 ? 8 : (g > 4 && use_mqk ? 8 : (g > 2 ? 4 : (g == 2 ? 2 : 1)));
+    const bool use_mqk = !fp8 && D == 128 && ((g > 4 && (mqk_opt & 1)) || (g <= 4 && (mqk_opt & 2)) || (tiny && (mqk_opt & 4)));
+    const int G = fp8 ? (g > 2 ? 4 : (g == 2 ? 2 : 1)) : (g >= 8 ? 8 : (g > 4 && use_mqk ? 8 : (g > 2 ? 4 : (g == 2 ? 2 : 1))));
     p.gchunks = (int)cdiv(g, G);
     if (p.num_splits <= 0) {
         const int64_t waves = (int64_t)p.b * p.h_k * p.gchunks;
@@ -1183,6 +1450,43 @@ static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
     }
 }
 
+// fp8 KV cache (d = 128): same planning (splits / balanced mode / scratch) as the 16-bit path, G <= 4 heads per wavefront
+template <typename T, int G>
+static void launch_decode_fp8_g(DecodeParams &p, hipStream_t stream) {
+    const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
+    if (p.stream_waves > 0) set_stream_waves(p, 8);   // __launch_bounds__(64, 2)
+    const bool nt = decode_options().nt != 0;
+#define ATOMA_F8(NT_, S_) hipLaunchKernelGGL((paged_decode_fp8_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p)
+    if (nt) { if (p.stream_waves > 0) ATOMA_F8(true, true); else ATOMA_F8(true, false); }
+    else { if (p.stream_waves > 0) ATOMA_F8(false, true); else ATOMA_F8(false, false); }
+#undef ATOMA_F8
+    if (!ATOMA_CHECK_LAUNCH("paged_decode_fp8_kernel")) return;
+    if (p.num_splits > 1 || p.stream_waves > 0) {
+        hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, 4 * device_num_cus())), dim3(64), 0, stream, p);
+        ATOMA_CHECK_LAUNCH("decode_combine_kernel");
+    }
+}
+template <typename T>
+static void launch_decode_fp8(DecodeParams &p, hipStream_t stream) {
+    const DecodeLaunchPlan lp = decode_plan_launch(p, 128, true);
+    if (lp.rows) {
+        float *ws = static_cast<float *>(workspace(stream, lp.bytes));
+        if (!ws) return;
+        p.o_accum = ws;
+        p.lse_accum = ws + lp.rows * 128;
+        p.plan = reinterpret_cast<int *>(ws + lp.rows * 129);
+    }
+    switch (lp.G) {
+        case 1: launch_decode_fp8_g<T, 1>(p, stream); break;
+        case 2: launch_decode_fp8_g<T, 2>(p, stream); break;
+        default: launch_decode_fp8_g<T, 4>(p, stream); break;
+    }
+}
+void launch_paged_decode_fp8(DecodeParams &p, bool is_bf16, hipStream_t stream) {
+    if (is_bf16) launch_decode_fp8<bf16_t>(p, stream);
+    else launch_decode_fp8<f16_t>(p, stream);
+}
+
 bool decode_supported(int d) { return d == 64 || d == 128; }
 
 void launch_paged_decode(DecodeParams &p, int d, bool is_bf16, hipStream_t stream) {
@@ -1221,3 +1525,51 @@ void launch_paged_decode_from_attn(const AttnParams &a, bool is_bf16, int num_sp
 }
 
 }  // namespace atoma
+
+// Paged decode attention (seqlen_q = 1) over an fp8 e4m3fn KV cache [nb, page, h_k, 128] with per-kv-head scales; the
+// 16-bit path's semantics otherwise (flash_attn_kv_cache_full, csrc/src/lib.rs:1521-1855: per-sequence lengths, block table,
+// empty sequence -> zeros).  Strides in elements (= bytes for the caches).
+extern "C" int atoma_paged_decode_fp8(const void *q, const void *k_cache, const void *v_cache, void *o, const float *k_scale, const float *v_scale,
+                                      const int32_t *block_table, const int32_t *seqlens_k, int64_t batch, int64_t num_heads, int64_t num_kv_heads,
+                                      int64_t head_dim, int64_t block_table_batch_stride, int64_t page_size, int64_t q_batch_stride,
+                                      int64_t q_head_stride, int64_t o_batch_stride, int64_t o_head_stride, int64_t cache_block_stride,
+                                      int64_t cache_row_stride, int64_t cache_head_stride, float softmax_scale, int dtype, void *stream) {
+    using namespace atoma;
+    clear_error();
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("paged_decode_fp8: q / o dtype must be f16 or bf16"); return -1; }
+    if (head_dim != 128) { set_error("paged_decode_fp8: head_dim must be 128"); return -1; }
+    if (batch < 0 || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads) { set_error("paged_decode_fp8: invalid head counts"); return -1; }
+    if (page_size <= 0 || page_size % 16) { set_error("paged_decode_fp8: page_size must be a positive multiple of 16"); return -1; }
+    if (!q || !k_cache || !v_cache || !o || !k_scale || !v_scale || !block_table || !seqlens_k) { set_error("paged_decode_fp8: null tensor"); return -1; }
+    if (q_batch_stride % 8 || q_head_stride % 8 || o_batch_stride % 8 || o_head_stride % 8 || cache_block_stride % 16 || cache_row_stride % 16 || cache_head_stride % 16) {
+        set_error("paged_decode_fp8: q / o strides must be multiples of 8 elements, cache strides multiples of 16 bytes");
+        return -1;
+    }
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(k_cache) | reinterpret_cast<uintptr_t>(v_cache)) & 15u) {
+        set_error("paged_decode_fp8: tensors must be 16-byte aligned");
+        return -1;
+    }
+    if (batch == 0) return 0;
+    DecodeParams p{};
+    p.q = static_cast<const uint16_t *>(q);
+    p.k = static_cast<const uint16_t *>(k_cache);
+    p.v = static_cast<const uint16_t *>(v_cache);
+    p.o = static_cast<uint16_t *>(o);
+    p.k_scale = k_scale; p.v_scale = v_scale;
+    p.block_table = block_table;
+    p.cu_seqlens_k = seqlens_k;
+    p.is_seqlens_k_cumulative = 0;
+    p.q_batch_stride = q_batch_stride; p.q_head_stride = q_head_stride;
+    p.o_batch_stride = o_batch_stride; p.o_head_stride = o_head_stride;
+    p.k_batch_stride = p.v_batch_stride = cache_block_stride;
+    p.k_row_stride = p.v_row_stride = cache_row_stride;
+    p.k_head_stride = p.v_head_stride = cache_head_stride;
+    p.block_table_batch_stride = block_table_batch_stride;
+    p.page_size = (int)page_size;
+    p.b = (int)batch; p.h = (int)num_heads; p.h_k = (int)num_kv_heads; p.g = (int)(num_heads / num_kv_heads);
+    p.seqlen_k = (int)(block_table_batch_stride * page_size);
+    p.num_splits = 0;
+    p.scale = softmax_scale; p.scale_log2 = softmax_scale * 1.4426950408889634f;
+    launch_paged_decode_fp8(p, dtype == ATOMA_BF16, static_cast<hipStream_t>(stream));
+    return has_error() ? -1 : 0;
+}

@@ -168,6 +168,31 @@ int atoma_rope_qk_cache(void *q, void *k, const void *v, void *k_cache, void *v_
                         int64_t k_token_stride, int64_t v_token_stride, int64_t block_stride, int64_t page_size, int dtype,
                         int per_op_rounding, void *stream);
 
+/* ---- fp8 (OCP e4m3fn) KV cache (the reference's roadmap "quantization", README.md:35) ----
+ * The cache keeps the reference's layout [num_blocks, block_size, h_k, d] with ONE byte per element; k_scale / v_scale are
+ * DEVICE arrays f32[h_k] of per-kv-head dequantisation scales (value = e4m3 * scale).  copy_blocks_* / atoma_swap_blocks*
+ * move bytes and serve these caches unchanged (sizes in bytes; copy_blocks: numel_per_block = page bytes / 2).
+ * atoma_reshape_and_cache_flash_fp8: reshape_and_cache_flash (csrc/kernels/cache_manager.cu:139-170, same slot rule) with
+ *   byte = e4m3fn(clamp(f32(x) * (1 / scale[head]), -448, 448)), round-to-nearest-even; src_dtype f16 / bf16; block_stride
+ *   and key / value strides in elements (multiples of 8).
+ * atoma_rope_qk_cache_fp8: atoma_rope_qk_cache for such a cache (q, k rotated in place; rotated k and v quantised).
+ * atoma_paged_decode_fp8: flash_attn_kv_cache_full (csrc/src/lib.rs:1521-1855) for seqlen_q = 1 over such a cache:
+ *   q [batch, h, 128] / o in f16 / bf16 (strides in elements), block_table int32 [batch, max_blocks], seqlens_k int32 [batch]
+ *   on the device; cache strides in bytes; scores = softmax_scale * k_scale[hk] * (q . k_q), O = v_scale[hk] * softmax . v_q.
+ *   head_dim 128 only; groups of more than 4 q heads per kv head run in chunks of 4. */
+int atoma_reshape_and_cache_flash_fp8(const void *key, const void *value, void *key_cache, void *value_cache, const int64_t *slot_mapping,
+                                      const float *k_scale, const float *v_scale, int64_t block_stride, int64_t num_tokens, int64_t num_heads,
+                                      int64_t head_size, int64_t block_size, int64_t key_stride, int64_t value_stride, int src_dtype, void *stream);
+int atoma_rope_qk_cache_fp8(void *q, void *k, const void *v, void *k_cache, void *v_cache, const int64_t *slot_mapping, const float *k_scale,
+                            const float *v_scale, const void *cos_table, const void *sin_table, const int64_t *positions, int64_t num_tokens,
+                            int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t q_token_stride, int64_t k_token_stride,
+                            int64_t v_token_stride, int64_t block_stride, int64_t page_size, int dtype, int per_op_rounding, void *stream);
+int atoma_paged_decode_fp8(const void *q, const void *k_cache, const void *v_cache, void *o, const float *k_scale, const float *v_scale,
+                           const int32_t *block_table, const int32_t *seqlens_k, int64_t batch, int64_t num_heads, int64_t num_kv_heads,
+                           int64_t head_dim, int64_t block_table_batch_stride, int64_t page_size, int64_t q_batch_stride,
+                           int64_t q_head_stride, int64_t o_batch_stride, int64_t o_head_stride, int64_t cache_block_stride,
+                           int64_t cache_row_stride, int64_t cache_head_stride, float softmax_scale, int dtype, void *stream);
+
 /* cos/sin table of `Cache::new` (models/src/llama.rs:154-200) built on the HOST into
  * cos_out/sin_out [max_pos, head_dim/2] (storage dtype).  rope_factor <= 0: no Llama-3 scaling. */
 int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head_dim,

@@ -111,6 +111,46 @@ def bench_decode():
     decode_case("decode Llama-3.2-1B shape d=64 B=256 S=4096", 256, 4096, 32, 8, d=64)
 
 
+def bench_decode_fp8():
+    """f4: the C2a workload over an fp8 (e4m3fn) KV cache -- same B, heads, contexts, random block table; half the K/V bytes.
+    Bytes = the fp8 cache read once + q in + o out + table + lengths (+ the 2 x h_k scales)."""
+    rng = np.random.default_rng(0)
+    for name, B, S, h, hk, ragged in (("C2a over fp8 KV: B=256 h=32 hk=8 S=4096", 256, 4096, 32, 8, False),
+                                      ("C2c over fp8 KV: ragged U[2048,4096]", 256, 4096, 32, 8, True),
+                                      ("fp8 KV, 70B TP=8 shard: B=64 h=8 hk=1 S=4096 (two chunks of 4 heads)", 64, 4096, 8, 1, False),
+                                      ("fp8 KV, B=16 S=8192", 16, 8192, 32, 8, False)):
+        d, page = 128, 16
+        pps = S // page
+        n_pages = int(B * pps * 1.125)
+        lens = rng.integers(2048, S + 1, B).astype(np.int32) if ragged else np.full(B, S, np.int32)
+        bt = rng.permutation(n_pages)[:B * pps].astype(np.int32).reshape(B, pps)
+        kc = ah.DeviceBuffer(n_pages * page * hk * d)
+        vc = ah.DeviceBuffer(n_pages * page * hk * d)
+        slab = rng.integers(0, 0x78, 32 << 20, dtype=np.uint8) | (rng.integers(0, 2, 32 << 20, dtype=np.uint8) << 7)   # finite e4m3 codes, both signs
+        for buf in (kc, vc):
+            off = 0
+            while off < buf.nbytes:
+                n = min(slab.nbytes, buf.nbytes - off)
+                ah.hip_check(ah.hip.hipMemcpy(buf.ptr + off, slab.ctypes.data, n, ah.H2D), "upload")
+                off += n
+        q = rand_dev(rng, B * h * d * 2)
+        o = ah.DeviceBuffer(B * h * d * 2)
+        ks = ah.DeviceBuffer.from_numpy(np.full(hk, 0.02, np.float32))
+        vs = ah.DeviceBuffer.from_numpy(np.full(hk, 0.02, np.float32))
+        dbt, dl = ah.DeviceBuffer.from_numpy(bt), ah.DeviceBuffer.from_numpy(lens)
+
+        def run():
+            rc = ah.lib.atoma_paged_decode_fp8(q.ptr, kc.ptr, vc.ptr, o.ptr, ks.ptr, vs.ptr, dbt.ptr, dl.ptr, B, h, hk, d, pps, page, h * d, d, h * d, d,
+                                               page * hk * d, hk * d, d, d ** -0.5, 1, None)
+            assert rc == 0, ah.last_error()
+        ms = timeit(run, iters=20)
+        tok = int(lens.sum())
+        nbytes = 2 * tok * hk * d + 2 * B * h * d * 2 + 4 * int(((lens + page - 1) // page).sum()) + 4 * B + 8 * hk
+        emit(name, ms, nbytes=nbytes, decode_tokens_per_s=round(B / (ms * 1e-3)), bf16_cache_bytes=2 * tok * hk * d * 2)
+        for b_ in (kc, vc, q, o):
+            b_.free()
+
+
 def bench_prefill():
     cfg = int(os.environ.get("ATOMA_PREFILL_CFG", "0"))
     ah.lib.atoma_set_option(b"prefill_cfg", cfg)
