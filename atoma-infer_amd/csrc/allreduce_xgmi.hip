@@ -18,8 +18,8 @@
 // Protocol (no grid-wide barrier, no host involvement, capturable in a hipGraph):
 //   * staging regions are allocated uncached (hipDeviceMallocUncached: fine-grained, never resident in a non-coherent
 //     L2) and additionally accessed with system-scope (sc0 sc1) loads / stores;
-//   * a call's sequence number lives in DEVICE memory (read by every block at kernel start, advanced by the last block
-//     to leave), so a captured graph replays correctly; its parity selects one of two staging halves: a rank can only
+//   * a call's sequence number lives in device memory -- in the uncached region itself -- (read by every block at kernel
+//     start, advanced by the last block to leave), so a captured graph replays correctly; its parity selects one of two staging halves: a rank can only
 //     start call n + 1 after every peer's flags of call n arrived, i.e. after every peer finished READING the staging
 //     half of call n - 1, which is the half call n + 1 overwrites -- no end-of-call barrier is needed;
 //   * block b of every rank works on the same element ranges and talks only to block b of its peers (flag per
@@ -128,12 +128,12 @@ __device__ __forceinline__ void xgmi_signal_and_wait(const XgmiParams &p, int pa
         const long long t0 = wall_clock64();
         // once a wait has timed out (device-side copy of the status in seq[2]) the communicator is broken: later waits give
         // up at once, so a captured graph of 160 calls costs one timeout, not 160
-        const long long limit = __hip_atomic_load(p.seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : p.timeout_ticks;
+        const long long limit = __hip_atomic_load(p.seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 0 : p.timeout_ticks;
         while ((int)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > limit) {
                 __hip_atomic_store(p.status, 1u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // which peer never arrived
-                __hip_atomic_store(p.seq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.seq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
@@ -145,17 +145,17 @@ __device__ __forceinline__ void xgmi_signal_and_wait(const XgmiParams &p, int pa
 __device__ __forceinline__ void xgmi_leave(const XgmiParams &p, uint32_t seq) {
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t n = __hip_atomic_fetch_add(p.seq + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t n = __hip_atomic_fetch_add(p.seq + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (n == gridDim.x - 1) {
-            __hip_atomic_store(p.seq + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.seq + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p.seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(XGMI_THREADS) xgmi_oneshot_kernel(const XgmiParams p) {
-    const uint32_t seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const uint32_t seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
     const int parity = (int)(seq & 1u);
     const int64_t half = (int64_t)parity * p.half_bytes;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(XGMI_THREADS) xgmi_oneshot_kernel(const XgmiPa
 
 template <typename T>
 __global__ void __launch_bounds__(XGMI_THREADS) xgmi_twoshot_kernel(const XgmiParams p) {
-    const uint32_t seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const uint32_t seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
     const int parity = (int)(seq & 1u);
     const int64_t half = (int64_t)parity * p.half_bytes;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,12 +246,12 @@ struct Xgmi {
     int rank, world, device;
     size_t capacity;             // largest message served by one launch (bytes)
     size_t oneshot_max;
-    size_t region_bytes, half_bytes, off_flags, off_scatter, off_gather, slot_bytes;
+    size_t region_bytes, half_bytes, off_flags, off_scatter, off_gather, slot_bytes, off_seq;
     char *region = nullptr;
     char *peer[XGMI_MAX_WORLD] = {};
     bool ipc_opened[XGMI_MAX_WORLD] = {};
     bool connected = false;
-    uint32_t *seq = nullptr;      // device
+    uint32_t *seq = nullptr;      // inside the uncached region (off_seq)
     uint32_t *status = nullptr;   // host-mapped
     uint32_t *status_dev = nullptr;
     long long timeout_ticks;
@@ -265,7 +265,12 @@ static void xgmi_layout(Xgmi &x) {
     const size_t chunk = round_up((x.capacity + x.world - 1) / x.world, 16);
     x.slot_bytes = round_up(std::max(chunk, std::min(x.oneshot_max, x.capacity)), 256);
     x.off_flags = 0;
-    const size_t flags_bytes = round_up((size_t)2 * 2 * XGMI_MAX_WORLD * XGMI_MAX_BLOCKS * sizeof(uint32_t), 4096);
+    // the flag words, then this rank's own call counter / ticket / broken marker (x.off_seq): they live in the UNCACHED region
+    // too -- consecutive kernels of a stream (and of a replayed graph) read and advance the counter from different XCDs, and an
+    // L2-served load of ordinary device memory can return the previous call's value (seen as ranks drifting apart by one call)
+    const size_t flag_words = (size_t)2 * 2 * XGMI_MAX_WORLD * XGMI_MAX_BLOCKS * sizeof(uint32_t);
+    x.off_seq = flag_words;
+    const size_t flags_bytes = round_up(flag_words + 256, 4096);
     x.off_scatter = 0;                                  // offsets inside a half
     x.off_gather = x.slot_bytes * x.world;
     x.half_bytes = 2 * x.slot_bytes * x.world;
@@ -299,11 +304,10 @@ int atoma_xgmi_create(void **out, int rank, int world_size, int device, int64_t 
     if (!check_hip(hipExtMallocWithFlags(&mem, x->region_bytes, hipDeviceMallocUncached), "xgmi staging region (hipExtMallocWithFlags uncached)")) { delete x; return -1; }
     x->region = static_cast<char *>(mem);
     bool ok = check_hip(hipMemset(x->region, 0, x->region_bytes), "xgmi region memset");
-    ok = ok && check_hip(hipMalloc(reinterpret_cast<void **>(&x->seq), 4 * sizeof(uint32_t)), "xgmi sequence word");
-    ok = ok && check_hip(hipMemset(x->seq, 0, 4 * sizeof(uint32_t)), "xgmi sequence memset");
+    x->seq = reinterpret_cast<uint32_t *>(x->region + x->off_seq);
     ok = ok && check_hip(hipHostMalloc(reinterpret_cast<void **>(&x->status), sizeof(uint32_t), hipHostMallocMapped), "xgmi status word");
     ok = ok && check_hip(hipDeviceSynchronize(), "xgmi create sync");
-    if (!ok) { if (x->seq) (void)hipFree(x->seq); (void)hipFree(x->region); delete x; return -1; }
+    if (!ok) { (void)hipFree(x->region); delete x; return -1; }
     *x->status = 0;
     x->status_dev = x->status;
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&x->status_dev), x->status, 0) != hipSuccess) { (void)hipGetLastError(); x->status_dev = x->status; }
@@ -440,7 +444,6 @@ int atoma_xgmi_destroy(void *xg) {
     (void)hipSetDevice(x->device);
     for (int q = 0; q < x->world; ++q)
         if (x->ipc_opened[q]) (void)hipIpcCloseMemHandle(x->peer[q]);
-    if (x->seq) (void)hipFree(x->seq);
     if (x->status) (void)hipHostFree(x->status);
     if (x->region) (void)hipFree(x->region);
     (void)hipGetLastError();

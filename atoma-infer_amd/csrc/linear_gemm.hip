@@ -79,6 +79,8 @@ static const int linear_autotune = getenv("ATOMA_LINEAR_AUTOTUNE") ? atoi(getenv
 static std::mutex *g_lt_mu = new std::mutex;
 static std::map<int, LtDevice> *g_lt_devices = new std::map<int, LtDevice>;
 
+static const int lt_debug = getenv("ATOMA_LINEAR_DEBUG") ? atoi(getenv("ATOMA_LINEAR_DEBUG")) : 0;
+#define LT_DBG(...) do { if (lt_debug) { fprintf(stderr, "[lt] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 static bool lt_ok(hipblasStatus_t st, const char *what) {
     if (st == HIPBLAS_STATUS_SUCCESS) return true;
     set_error(std::string("linear: hipBLASLt ") + what + " failed with status " + std::to_string((int)st));
@@ -106,9 +108,14 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
             return -1;
         }
         if (!check_hip(hipMalloc(&lt_ws, LT_WORKSPACE_BYTES), "linear: workspace hipMalloc")) { lt_ws = nullptr; return -1; }
+        // Zero it: recycled device memory holds other buffers' bytes, and some of the library's algorithms (stream-K style
+        // split accumulation) keep synchronisation words in the workspace -- observed as a GEMM that never finishes when
+        // the per-stream workspace came out of recycled memory.
+        if (!check_hip(hipMemsetAsync(lt_ws, 0, LT_WORKSPACE_BYTES, stream), "linear: workspace memset")) return -1;
     }
     const auto key = std::make_tuple(dtype, batch, k, n, ldx, ldw, ldy);
     auto it = d.plans.find(key);
+    LT_DBG("gemm batch=%lld k=%lld n=%lld stream=%p plan %s", (long long)batch, (long long)k, (long long)n, (void *)stream, it == d.plans.end() ? "MISS" : "hit");
     if (it == d.plans.end()) {
         GemmPlan pl;
         const hipDataType t = dtype == ATOMA_BF16 ? HIP_R_16BF : HIP_R_16F;
@@ -142,6 +149,7 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
             (void)hipEventCreate(&e0);
             (void)hipEventCreate(&e1);
             auto run = [&](int c, int reps, float *ms) -> bool {          // `reps` back-to-back launches of candidate c
+                LT_DBG("  time candidate %d of %d x %d", c, found, reps);
                 bool good = true;
                 (void)hipEventRecord(e0, stream);
                 for (int rep = 0; rep < reps && good; ++rep)

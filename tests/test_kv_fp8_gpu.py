@@ -149,8 +149,11 @@ def test_decode_fp8_split_kv_balanced_and_invariants(gpu):
     out2 = gpu_decode_fp8(gpu, q, kc8[inv], vc8[inv], ks, vs, perm[bt].astype(np.int32), lens, sc, BF16)
     assert np.array_equal(out, out2)
     # (d) scaling the V scale by 2 doubles the output exactly (power of two), scaling K's scale equals scaling softmax_scale
+    base8 = gpu_decode_fp8(gpu, q[:8], kc8, vc8, ks, vs, bt[:8], lens[:8], sc, BF16)          # same launch shape as the scaled runs below
     out3 = gpu_decode_fp8(gpu, q[:8], kc8, vc8, ks, vs * 2, bt[:8], lens[:8], sc, BF16)
-    assert np.array_equal(to_f32(out3, BF16), 2 * to_f32(out[:8], BF16))
+    assert np.array_equal(to_f32(out3, BF16), 2 * to_f32(base8, BF16))
+    out4 = gpu_decode_fp8(gpu, q[:8], kc8, vc8, ks * 4, vs, bt[:8], lens[:8], sc / 4, BF16)
+    assert np.array_equal(out4, base8)
 
 
 def test_decode_fp8_rejects_bad_arguments(gpu):

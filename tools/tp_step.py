@@ -9,7 +9,12 @@ metadata and completes the two row-parallel projections of every layer with a su
 
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/tp_step.py [--steps 20]
     python tools/tp_step.py                      # N = 1: the whole model on one GPU (140 GB of weights), no exchange
-    python tools/tp_step.py --virtual-ranks 2    # 2 ranks of a TP=8 job on ONE device (direct all-reduce only): protocol cost without the link
+    python tools/tp_step.py --virtual-ranks 2 --batch 16   # EXPERIMENTAL: 2 ranks of a TP=8 job on ONE device (direct all-reduce only)
+        Two ranks sharing one GPU is a functional check, not a benchmark: a rank's all-reduce spins on the device until its peer
+        arrives, and the peer's kernels must become resident beside it.  Small shapes do (tests/test_tp_step_gpu.py, batch <= 16
+        here); at batch 64 the peer's vendor GEMMs (whole-chip grids) and the spinning blocks starve each other and the run
+        stalls (observed; each rank on its own GPU cannot get there: a stream is in order, nothing of the rank runs beside its
+        own all-reduce).
 
 Measured per engine (RCCL's ncclAllReduce, the direct xGMI kernels): ms per step (max over ranks), and the all-reduce alone
 (graph of 160 back-to-back calls).  Prints one JSON line on rank 0; `run()` returns the same dict for bench.py.
@@ -289,6 +294,10 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
 
 
 def main():
+    import faulthandler
+    faulthandler.enable()
+    if os.environ.get("ATOMA_TP_STEP_WATCHDOG_S"):       # debugging aid: dump every thread's Python stack and exit if the run takes longer
+        faulthandler.dump_traceback_later(int(os.environ["ATOMA_TP_STEP_WATCHDOG_S"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--ctx", type=int, default=4096)
