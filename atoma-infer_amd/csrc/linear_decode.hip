@@ -18,6 +18,7 @@
 #include "common.h"
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace atoma {
 
@@ -310,6 +311,155 @@ __global__ void __launch_bounds__(64 * NW) linear_wg_kernel(const LinearParams p
     *reinterpret_cast<uint2 *>(p.y + (int64_t)col * p.y_row_stride + n) = o;
 }
 
+// Batches of 17..64 rows (the continuous-batching and tensor-parallel decode regimes: config[2] tails, config[3] at bs = 64):
+// one workgroup of 4 wavefronts owns 64 output features (PAIR: 64 gate + the 64 matching up features) x ALL batch rows over a
+// K range.  What the two kernels above get wrong at these sizes is the x operand: every wavefront re-read its own K slice of
+// x from L2 in fragment-shaped 64-byte pieces, 4 x the weight traffic at 64 rows.  Here
+//   * x is staged ONCE per workgroup and 128-input chunk, in full 256-byte row pieces (a wave instruction = 4 rows x 256 B),
+//     into an XOR-swizzled LDS tile [row][chunk ^ row] that all four wavefronts read as MFMA B operands (conflict-free);
+//     x traffic = (N / 64) x |x| -- about the size of W itself at 64 rows;
+//   * W keeps the 4 rows x 256 B streaming pattern (6.7 TB/s in the probe) and is re-laid into the A-operand order through
+//     a private 4 KiB LDS tile per wavefront, as in linear_wg_kernel<RELAY>;
+//   * global loads of chunk c + 1 are issued before the MFMAs of chunk c and written to LDS after them (x double-buffered,
+//     one workgroup barrier per chunk); 4.CT MFMAs (16x16x32) per wavefront and chunk against 4 + 4.CT LDS reads;
+//   * K is split over workgroups only as far as needed to put ~2 workgroups on every CU; the fp32 partials and the
+//     epilogues then go through linear_reduce_kernel, otherwise the epilogue runs here (one launch).
+template <typename T, int CT, bool PAIR>
+__global__ void __launch_bounds__(256, 2) linear_mid_kernel(const LinearParams p) {
+    constexpr int RT = PAIR ? 2 : 1;
+    constexpr int XT = CT * 4096;                              // one x tile: 16.CT rows x 256 B
+    __shared__ __attribute__((aligned(16))) char smem[2 * XT + 4 * RT * 4096];   // ONE LDS object: x tiles [2], then the relay tiles [wave][r]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = lane >> 4, col = lane & 15;
+    const int out_n = PAIR ? p.n / 2 : p.n;
+    const int tiles_n = out_n >> 6;
+    const int tile = blockIdx.x % tiles_n, split = blockIdx.x / tiles_n;
+    const int n0 = tile * 64 + wave * 16;
+    const int chunks = p.k >> 7;
+    const int c0 = split * p.chunks_per_split, c1 = min(c0 + p.chunks_per_split, chunks);
+    char *relay = smem + 2 * XT + wave * RT * 4096;
+
+    const int64_t row_bytes = p.w_row_stride * 2;
+    const char *wrow = reinterpret_cast<const char *>(p.w + (int64_t)n0 * p.w_row_stride);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wrow), 0, 0x7fffffff, 0x00020000);
+    uint32_t w_lane[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) w_lane[r] = (uint32_t)(((int64_t)r * out_n + grp) * row_bytes + col * 16);   // row 4.q + grp, chunk col
+    // x staging: thread -> (row xr of a 16-row slab, 16-byte chunk xc); rows beyond the batch re-read the last row (never stored)
+    const int xr = tid >> 4, xc = tid & 15;
+    const uint16_t *xsrc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) xsrc[c] = p.x + (int64_t)min(16 * c + xr, p.batch - 1) * p.x_row_stride + xc * 8;
+    const int x_st = xr * 256 + ((xc ^ xr) & 15) * 16;         // + c * 4096 inside a tile
+
+    // two register stages: chunk c + 2 is requested while chunk c is multiplied and chunk c + 1 (requested one step earlier)
+    // moves from its stage into LDS -- two chunks (2 x 16 KiB of W per workgroup) are always in flight, which is what the HBM
+    // latency needs at two workgroups per CU (one chunk in flight: 3.9-4.8 TB/s, the loop ran at the latency of a load)
+    lu32x4 wst[2][RT][4], xst[2][CT];
+    auto gload = [&](auto ST, int chunk) {
+        constexpr int st = decltype(ST)::value;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wst[st][r][q] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], (int)(q * 4 * row_bytes + chunk * 256), 2 /* nt */);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) xst[st][c] = *reinterpret_cast<const lu32x4 *>(xsrc[c] + chunk * 128);
+    };
+    auto lds_store = [&](auto ST, int buf) {
+        constexpr int st = decltype(ST)::value;
+        char *xt = smem + buf * XT;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) *reinterpret_cast<lu32x4 *>(xt + c * 4096 + x_st) = xst[st][c];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 4 * q + grp;
+                *reinterpret_cast<lu32x4 *>(relay + r * 4096 + row * 256 + ((col ^ row) & 15) * 16) = wst[st][r][q];
+            }
+    };
+    lf32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = lf32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        const char *xt = smem + buf * XT;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sw = (((4 * q + grp) ^ col) & 15) * 16;
+            lu32x4 a[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const lu32x4 *>(relay + r * 4096 + col * 256 + sw);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const lu32x4 b = *reinterpret_cast<const lu32x4 *>(xt + c * 4096 + col * 256 + sw);
+#pragma unroll
+                for (int r = 0; r < RT; ++r) acc[r][c] = lin_mfma<T>(a[r], b, acc[r][c]);
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    // one chunk: PAR = parity of (chunk - c0) = LDS buffer and register stage of this chunk; FULL = no bounds checks
+    auto step = [&](auto PAR, auto FULL, int c) {
+        constexpr int par = decltype(PAR)::value;
+        constexpr bool full = decltype(FULL)::value;
+        if (full || c + 2 < c1) gload(std::integral_constant<int, par>{}, c + 2);       // this chunk's stage is free: it sits in LDS already
+        compute(par);
+        if (full || c + 1 < c1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // this wavefront's relay reads above stay ahead of the stores below
+            __builtin_amdgcn_wave_barrier();
+            lds_store(std::integral_constant<int, par ^ 1>{}, par ^ 1);
+        }
+        __syncthreads();
+    };
+    if (c0 < c1) {
+        gload(S0{}, c0);
+        if (c0 + 1 < c1) gload(S1{}, c0 + 1);
+        lds_store(S0{}, 0);
+        __syncthreads();
+        int c = c0;
+        for (; c + 3 < c1; c += 2) {
+            step(S0{}, std::true_type{}, c);
+            step(S1{}, std::true_type{}, c + 1);
+        }
+        for (; c < c1; c += 2) {
+            step(S0{}, std::false_type{}, c);
+            if (c + 1 < c1) step(S1{}, std::false_type{}, c + 1);
+        }
+    }
+    // lane holds y^T[n0 + 4.grp + i][batch row 16.c + col]
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int brow = 16 * c + col;
+        if (brow >= p.batch) continue;
+        const int n = n0 + 4 * grp;
+        if (p.partial) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const lf32x4 a = acc[r][c];
+                *reinterpret_cast<float4 *>(p.partial + ((int64_t)split * p.batch + brow) * p.n + (int64_t)r * out_n + n) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+        } else {                                               // rounding points as in linear_reduce_kernel
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = round_through<T>(acc[0][c][i]);
+            if (p.epilogue == 1) {
+                const uint2 rr = *reinterpret_cast<const uint2 *>(p.aux + (int64_t)brow * p.aux_row_stride + n);
+                v[0] += lo_to_f32<T>(rr.x); v[1] += hi_to_f32<T>(rr.x); v[2] += lo_to_f32<T>(rr.y); v[3] += hi_to_f32<T>(rr.y);
+            }
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = round_through<T>(v[i] / (1.f + __expf(-v[i]))) * round_through<T>(acc[1][c][i]);
+            }
+            uint2 o;
+            o.x = pack2<T>(v[0], v[1]);
+            o.y = pack2<T>(v[2], v[3]);
+            *reinterpret_cast<uint2 *>(p.y + (int64_t)brow * p.y_row_stride + n) = o;
+        }
+    }
+}
+
 // Batches of 1..8 rows, loads laid out for the memory system instead of the matrix cores.  tools/probes/weight_stream_probe.hip:
 // with no arithmetic at all, 16 rows x 64 bytes per load instruction (the MFMA A-operand layout used above) streams lm_head at
 // 5.7 TB/s, 4 rows x 256 bytes per instruction at 6.7 TB/s (the whole 128 KiB block front to back: 6.85).  At 1..4 batch rows
@@ -478,12 +628,56 @@ template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t s
     return ATOMA_CHECK_LAUNCH("linear_wg_kernel") ? 0 : -1;
 }
 
+// 17..64 rows: linear_mid_kernel (x staged through LDS once per workgroup).  Needs 64 output features per workgroup.
+static const int linear_mid = getenv("ATOMA_LINEAR_MID") ? atoi(getenv("ATOMA_LINEAR_MID")) : 1;
+static const int linear_mid_wg_per_cu = getenv("ATOMA_LINEAR_MID_WG_PER_CU") ? atoi(getenv("ATOMA_LINEAR_MID_WG_PER_CU")) : 2;
+template <typename T> static int launch_linear_mid(LinearParams &p, hipStream_t stream) {
+    const bool pair = p.epilogue == 2;
+    const int out_n = pair ? p.n / 2 : p.n;
+    if (out_n % 64) return 1;                                  // not served: the caller falls through to linear_decode_kernel
+    const int64_t tiles_n = out_n / 64, chunks = p.k / 128;
+    const int ct = (p.batch + 15) / 16;
+    // Split K so that the workgroups fill the resident slots (2 per CU) in whole rounds: the largest split count whose
+    // workgroups still fit one round, never below 4 chunks (512 inputs) per split.  The count is derived from the W ROWS
+    // (p.n / 64), not from the workgroups, so that the stacked gate / up launch with its SiLU.up epilogue splits K exactly like
+    // the plain projection of the same matrix and stays bit-identical to projection + atoma_silu_mul.
+    const int64_t target = (int64_t)device_num_cus() * linear_mid_wg_per_cu, row_tiles = p.n / 64;
+    int64_t splits = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(row_tiles, 1), chunks / 4));
+    p.chunks_per_split = (int)cdiv(chunks, splits);
+    p.splits = (int)cdiv(chunks, p.chunks_per_split);
+    p.partial = nullptr;
+    if (p.splits > 1) {
+        p.partial = static_cast<float *>(workspace(stream, (size_t)p.splits * p.batch * p.n * sizeof(float)));
+        if (!p.partial) return -1;
+    }
+    const dim3 grid((unsigned)(tiles_n * p.splits)), block(256);
+#define ATOMA_MID(CT_) do { if (pair) hipLaunchKernelGGL((linear_mid_kernel<T, CT_, true>), grid, block, 0, stream, p); \
+                            else hipLaunchKernelGGL((linear_mid_kernel<T, CT_, false>), grid, block, 0, stream, p); } while (0)
+    switch (ct) {
+        case 1: ATOMA_MID(1); break;
+        case 2: ATOMA_MID(2); break;
+        case 3: ATOMA_MID(3); break;
+        default: ATOMA_MID(4); break;
+    }
+#undef ATOMA_MID
+    if (!ATOMA_CHECK_LAUNCH("linear_mid_kernel")) return -1;
+    if (p.partial) {
+        hipLaunchKernelGGL((linear_reduce_kernel<T>), dim3((unsigned)cdiv((int64_t)p.batch * out_n, 1024)), dim3(256), 0, stream, p);
+        if (!ATOMA_CHECK_LAUNCH("linear_reduce_kernel")) return -1;
+    }
+    return 0;
+}
+
 // 512 bytes per weight-row visit (two 128-input chunks per pipeline stage) when the split allows: +2-5 % over 256
 static const int linear_ch = getenv("ATOMA_LINEAR_CH") ? atoi(getenv("ATOMA_LINEAR_CH")) : 2;
 template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
     if (linear_gemv && p.batch <= std::min(linear_gemv_max_batch, 8)) return launch_linear_gemv<T>(p, stream);
     if (linear_wg && p.batch <= std::min(linear_wg_max_batch, 16)) {
         const int rc = launch_linear_wg<T>(p, stream);
+        if (rc <= 0) return rc;
+    }
+    if (linear_mid && p.batch > 16) {
+        const int rc = launch_linear_mid<T>(p, stream);
         if (rc <= 0) return rc;
     }
     const int64_t chunks = p.k / 128;

@@ -117,6 +117,31 @@ def test_linear_decode_fused_epilogues_match_the_separate_ops(gpu):
     assert d.max() <= 1 and (d > 0).mean() < 0.01
 
 
+@pytest.mark.parametrize("B,K,N,I", [(17, 1024, 512, 768), (40, 4096, 1024, 1024), (64, 1024, 256, 128), (33, 8192, 512, 3584), (64, 2048, 4096, 2048)])
+def test_linear_mid_batch_epilogues_match_the_separate_ops(gpu, B, K, N, I):
+    """17..64 rows (linear_mid_kernel: one workgroup per 64 features, with and without K splitting): the fused epilogues keep the
+    rounding points of projection + atoma_add / atoma_silu_mul -- bit for bit -- and the plain projection meets the oracle bound."""
+    rng = np.random.default_rng(B + K + N)
+    x = rand_half(rng, (B, K), BF16)
+    w = rand_half(rng, (N, K), BF16, K ** -0.5)
+    res = rand_half(rng, (B, N), BF16)
+    wgu = rand_half(rng, (2 * I, K), BF16, K ** -0.5)
+    dx, dw, dr, dwgu = (gpu.DeviceBuffer.from_numpy(a) for a in (x, w, res, wgu))
+    y, y2, gu, act, act2 = (gpu.DeviceBuffer(n * 2) for n in (B * N, B * N, B * 2 * I, B * I, B * I))
+    L = gpu.lib
+    assert L.atoma_linear_decode(dx.ptr, dw.ptr, y.ptr, B, K, N, K, K, N, BF16, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    check(y.numpy(np.uint16, (B, N)), LO.linear(x, w, BF16), BF16)
+    assert L.atoma_add(y.ptr, dr.ptr, y.ptr, B * N, BF16, None) == 0
+    assert L.atoma_linear_decode_residual(dx.ptr, dw.ptr, dr.ptr, y2.ptr, B, K, N, K, K, N, N, BF16, None) == 0, gpu.last_error()
+    assert L.atoma_linear_decode(dx.ptr, dwgu.ptr, gu.ptr, B, K, 2 * I, K, K, 2 * I, BF16, None) == 0
+    assert L.atoma_silu_mul(gu.ptr, gu.ptr + I * 2, act.ptr, B, I, 2 * I, 2 * I, I, BF16, None) == 0
+    assert L.atoma_linear_decode_silu_mul(dx.ptr, dwgu.ptr, act2.ptr, B, K, I, K, K, I, BF16, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    assert np.array_equal(y.numpy(np.uint16, (B, N)), y2.numpy(np.uint16, (B, N)))
+    assert np.array_equal(act.numpy(np.uint16, (B, I)), act2.numpy(np.uint16, (B, I)))
+
+
 def gpu_linear_any(gpu, x, w, dtype, x_stride=None, y_stride=None):
     B, K, N = x.shape[0], w.shape[1], w.shape[0]
     dx, dw = gpu.DeviceBuffer.from_numpy(x), gpu.DeviceBuffer.from_numpy(w)

@@ -333,6 +333,34 @@ def bench_linear():
         w.free()
 
 
+def bench_linear_mid():
+    """f.1 at 17..64 rows: atoma_linear_decode (linear_mid_kernel: x staged through LDS once per workgroup) against the vendor
+    GEMM (atoma_linear above ATOMA_LINEAR_STREAM_MAX_BATCH) on the Llama-3.1-8B layer shapes and on the shapes of one rank of a
+    Llama-3.1-70B TP = 8 job; also the fused epilogues (residual / SiLU.up) against projection + separate op."""
+    rng = np.random.default_rng(8)
+    shapes = (("8B qkv", 6144, 4096), ("8B o", 4096, 4096), ("8B gate_up", 28672, 4096), ("8B down", 4096, 14336),
+              ("70B/8 qkv", 1280, 8192), ("70B/8 o", 8192, 1024), ("70B/8 gate_up", 7168, 8192), ("70B/8 down", 8192, 3584))
+    for name, N, K in shapes:
+        w = rand_dev(rng, N * K * 2)
+        for B in (32, 64):
+            x, y, r = rand_dev(rng, B * K * 2), ah.DeviceBuffer(B * N * 2), rand_dev(rng, B * N * 2)
+            nbytes = N * K * 2 + B * K * 2 + B * N * 2
+            ms = timeit(lambda: ah.lib.atoma_linear_decode(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
+            emit(f"L3 linear_mid {name} [{N} x {K}] batch={B}", ms, nbytes=nbytes)
+            ah.lib.atoma_linear(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None)
+            ah.synchronize()
+            time.sleep(0.1)
+            ms_lt = timeit(lambda: ah.lib.atoma_linear(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
+            emit(f"L3 vendor GEMM {name} [{N} x {K}] batch={B}", ms_lt, nbytes=nbytes)
+            if "gate_up" in name:
+                ms_f = timeit(lambda: ah.lib.atoma_linear_decode_silu_mul(x.ptr, w.ptr, y.ptr, B, K, N // 2, K, K, N // 2, 1, None))
+                emit(f"L3 linear_mid + SiLU.up epilogue {name} batch={B}", ms_f, nbytes=N * K * 2 + B * K * 2 + B * N)
+            elif "qkv" not in name:
+                ms_f = timeit(lambda: ah.lib.atoma_linear_decode_residual(x.ptr, w.ptr, r.ptr, y.ptr, B, K, N, K, K, N, N, 1, None))
+                emit(f"L3 linear_mid + residual epilogue {name} batch={B}", ms_f, nbytes=nbytes + B * N * 2)
+        w.free()
+
+
 def bench_step():
     """C3-lite: one whole Llama-3.1-8B decode step on the device (tools/decode_step.py) at batch 1 and 16, context 4096,
     synthetic bf16 weights, eager and replayed from a hipGraph.  Bytes = weights read once + the KV cache of the batch."""
