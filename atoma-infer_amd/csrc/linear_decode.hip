@@ -460,6 +460,175 @@ __global__ void __launch_bounds__(256, 2) linear_mid_kernel(const LinearParams p
     }
 }
 
+// Batches of 65..256 rows (continuous batching at bs <= 256, config[2]): 2.B flop per weight byte reaches the machine balance
+// here, so this is a real GEMM tile -- one workgroup of 4 wavefronts (one per SIMD, 512 registers) owns 128 weight rows
+// (PAIR: 64 gate + the 64 matching up rows) x BM = 128 or 256 batch rows over a K range, v_mfma_f32_32x32x16:
+//   * wavefront (wm, wn) of a 2 x 2 grid: BM / 2 batch rows x 64 weight rows = 2 A fragments x BM / 64 B fragments; every
+//     fragment read from LDS feeds 2-4 MFMAs (6 KiB of LDS reads per 8 MFMAs = 75 % of the LDS pipe at the MFMA rate);
+//   * K advances in chunks of 64 inputs: W tile 128 x 128 B and x tile BM x 128 B, staged through registers in full
+//     128-byte lines (a wave instruction = 8 rows x 128 B), two chunks in flight, LDS double-buffered, one barrier per chunk;
+//     LDS image [row][chunk ^ ((row >> 1) & 7)]: a 16-lane group reading 16 consecutive rows at one k-chunk hits all 64 banks;
+//   * weights are read once per workgroup (x is re-read N / 128 times from L2: 2 MB at 256 rows, K = 4096);
+//   * K is split over workgroups for the layers with few row tiles (q/k/v, o, down); partials + epilogues then go through
+//     linear_reduce_kernel; otherwise the epilogue runs here with the reference's rounding points.
+typedef __attribute__((ext_vector_type(16))) float lf32x16;
+template <typename T> __device__ __forceinline__ lf32x16 lin_mfma32(const lu32x4 &a, const lu32x4 &b, lf32x16 c);
+template <> __device__ __forceinline__ lf32x16 lin_mfma32<bf16_t>(const lu32x4 &a, const lu32x4 &b, lf32x16 c) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ lf32x16 lin_mfma32<f16_t>(const lu32x4 &a, const lu32x4 &b, lf32x16 c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 v8;
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+
+template <typename T, int BM, bool PAIR>
+__global__ void __launch_bounds__(256, 1) linear_big_kernel(const LinearParams p) {
+    constexpr int WT = 128 * 128;                              // W tile bytes: 128 rows x 64 inputs
+    constexpr int XT = BM * 128;                               // x tile bytes
+    constexpr int NB = BM / 64;                                // B fragments (32 batch rows each) per wavefront
+    constexpr int XL = BM / 32;                                // x staging loads per thread and chunk
+    __shared__ __attribute__((aligned(16))) char smem[2 * (WT + XT)];   // [buffer][W tile | x tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, kh = lane >> 5;
+    const int out_n = PAIR ? p.n / 2 : p.n;
+    const int tiles_n = PAIR ? out_n >> 6 : out_n >> 7;
+    const int tile = blockIdx.x % tiles_n, split = blockIdx.x / tiles_n;
+    const int n0 = PAIR ? tile * 64 : tile * 128;              // first output feature of the workgroup
+    const int chunks = p.k >> 6;                               // 64-input chunks
+    const int cps = p.chunks_per_split * 2;                    // chunks_per_split counts 128-input chunks
+    const int c0 = split * cps, c1 = min(c0 + cps, chunks);
+
+    // staging: thread -> row (tid >> 3) of a 32-row slab, 16-byte chunk (tid & 7)
+    const int sr = tid >> 3, sc = tid & 7;
+    const uint16_t *wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 32 * i + sr;                             // W tile row: PAIR rows 0..63 gate, 64..127 up
+        const int64_t wrow = PAIR ? (r < 64 ? n0 + r : out_n + n0 + (r - 64)) : n0 + r;
+        wsrc[i] = p.w + wrow * p.w_row_stride + sc * 8;
+    }
+    const uint16_t *xsrc[XL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) xsrc[i] = p.x + (int64_t)min(32 * i + sr, p.batch - 1) * p.x_row_stride + sc * 8;
+    const int st_off = sr * 128 + ((sc ^ ((sr >> 1) & 7)) & 7) * 16;    // + 32-row slab * 4096 (rows 32 i + sr: (row >> 1) & 7 == (sr >> 1) & 7)
+
+    lu32x4 wst[2][4], xst[2][XL];
+    auto gload = [&](auto ST, int chunk) {
+        constexpr int st = decltype(ST)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wst[st][i] = __builtin_nontemporal_load(reinterpret_cast<const lu32x4 *>(wsrc[i] + chunk * 64));
+#pragma unroll
+        for (int i = 0; i < XL; ++i) xst[st][i] = *reinterpret_cast<const lu32x4 *>(xsrc[i] + chunk * 64);
+    };
+    auto lds_store = [&](auto ST, int buf) {
+        constexpr int st = decltype(ST)::value;
+        char *wt = smem + buf * (WT + XT), *xt = wt + WT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<lu32x4 *>(wt + i * 4096 + st_off) = wst[st][i];
+#pragma unroll
+        for (int i = 0; i < XL; ++i) *reinterpret_cast<lu32x4 *>(xt + i * 4096 + st_off) = xst[st][i];
+    };
+    lf32x16 acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // fragment rows of this lane inside the tiles
+    int a_row[2], b_row[NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) a_row[a] = (PAIR ? 64 * a + 32 * wn : 64 * wn + 32 * a) + l32;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) b_row[b] = (BM / 2) * wm + 32 * b + l32;
+    auto compute = [&](int buf) {
+        const char *wt = smem + buf * (WT + XT), *xt = wt + WT;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                          // k16 steps of the 64-input chunk: lane's 16-byte chunk 2 s + kh
+            lu32x4 af[2], bf[NB];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const lu32x4 *>(wt + a_row[a] * 128 + (((2 * s + kh) ^ ((a_row[a] >> 1) & 7)) & 7) * 16);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bf[b] = *reinterpret_cast<const lu32x4 *>(xt + b_row[b] * 128 + (((2 * s + kh) ^ ((b_row[b] >> 1) & 7)) & 7) * 16);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) acc[a][b] = lin_mfma32<T>(af[a], bf[b], acc[a][b]);
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    auto step = [&](auto PAR, auto FULL, int c) {
+        constexpr int par = decltype(PAR)::value;
+        constexpr bool full = decltype(FULL)::value;
+        if (full || c + 2 < c1) gload(std::integral_constant<int, par>{}, c + 2);
+        compute(par);
+        if (full || c + 1 < c1) lds_store(std::integral_constant<int, par ^ 1>{}, par ^ 1);
+        __syncthreads();
+    };
+    if (c0 < c1) {
+        gload(S0{}, c0);
+        if (c0 + 1 < c1) gload(S1{}, c0 + 1);
+        lds_store(S0{}, 0);
+        __syncthreads();
+        int c = c0;
+        for (; c + 3 < c1; c += 2) {
+            step(S0{}, std::true_type{}, c);
+            step(S1{}, std::true_type{}, c + 1);
+        }
+        for (; c < c1; c += 2) {
+            step(S0{}, std::false_type{}, c);
+            if (c + 1 < c1) step(S1{}, std::false_type{}, c + 1);
+        }
+    }
+    // C layout of 32x32: lane holds, for batch row (lane & 31) of the B fragment, weight rows 8 j + 4 kh + i of the A fragment (reg 4 j + i)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int brow = (BM / 2) * wm + 32 * b + l32;
+        if (brow >= p.batch) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (p.partial) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int64_t col = PAIR ? (int64_t)a * out_n + n0 + 32 * wn + 8 * j + 4 * kh : (int64_t)n0 + 64 * wn + 32 * a + 8 * j + 4 * kh;
+                    *reinterpret_cast<float4 *>(p.partial + ((int64_t)split * p.batch + brow) * p.n + col) =
+                        make_float4(acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]);
+                }
+            } else if constexpr (PAIR) {
+                const int n = n0 + 32 * wn + 8 * j + 4 * kh;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float g = round_through<T>(acc[0][b][4 * j + i]);
+                    v[i] = round_through<T>(g / (1.f + __expf(-g))) * round_through<T>(acc[1][b][4 * j + i]);
+                }
+                uint2 o;
+                o.x = pack2<T>(v[0], v[1]);
+                o.y = pack2<T>(v[2], v[3]);
+                *reinterpret_cast<uint2 *>(p.y + (int64_t)brow * p.y_row_stride + n) = o;
+            } else {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int n = n0 + 64 * wn + 32 * a + 8 * j + 4 * kh;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = round_through<T>(acc[a][b][4 * j + i]);
+                    if (p.epilogue == 1) {
+                        const uint2 rr = *reinterpret_cast<const uint2 *>(p.aux + (int64_t)brow * p.aux_row_stride + n);
+                        v[0] += lo_to_f32<T>(rr.x); v[1] += hi_to_f32<T>(rr.x); v[2] += lo_to_f32<T>(rr.y); v[3] += hi_to_f32<T>(rr.y);
+                    }
+                    uint2 o;
+                    o.x = pack2<T>(v[0], v[1]);
+                    o.y = pack2<T>(v[2], v[3]);
+                    *reinterpret_cast<uint2 *>(p.y + (int64_t)brow * p.y_row_stride + n) = o;
+                }
+            }
+        }
+    }
+}
+
 // Batches of 1..8 rows, loads laid out for the memory system instead of the matrix cores.  tools/probes/weight_stream_probe.hip:
 // with no arithmetic at all, 16 rows x 64 bytes per load instruction (the MFMA A-operand layout used above) streams lm_head at
 // 5.7 TB/s, 4 rows x 256 bytes per instruction at 6.7 TB/s (the whole 128 KiB block front to back: 6.85).  At 1..4 batch rows
@@ -668,6 +837,37 @@ template <typename T> static int launch_linear_mid(LinearParams &p, hipStream_t 
     return 0;
 }
 
+// 65..256 rows: linear_big_kernel.  128 weight rows per workgroup (PAIR: 64 gate + 64 up), one workgroup per CU.
+template <typename T> static int launch_linear_big(LinearParams &p, hipStream_t stream) {
+    const bool pair = p.epilogue == 2;
+    const int out_n = pair ? p.n / 2 : p.n;
+    if (p.n % 128 || p.k % 128) return 1;
+    const int64_t row_tiles = p.n / 128, chunks = p.k / 128;
+    // split K (in units of 128 inputs) until the workgroups fill one round of the CUs; derived from the W rows, so that the
+    // stacked gate / up launch with its epilogue splits exactly like the plain projection (bit-identical results)
+    const int64_t target = device_num_cus();
+    int64_t splits = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(row_tiles, 1), chunks / 4));
+    p.chunks_per_split = (int)cdiv(chunks, splits);
+    p.splits = (int)cdiv(chunks, p.chunks_per_split);
+    p.partial = nullptr;
+    if (p.splits > 1) {
+        p.partial = static_cast<float *>(workspace(stream, (size_t)p.splits * p.batch * p.n * sizeof(float)));
+        if (!p.partial) return -1;
+    }
+    const int64_t tiles_n = pair ? out_n / 64 : out_n / 128;
+    const dim3 grid((unsigned)(tiles_n * p.splits)), block(256);
+#define ATOMA_BIG(BM_) do { if (pair) hipLaunchKernelGGL((linear_big_kernel<T, BM_, true>), grid, block, 0, stream, p); \
+                            else hipLaunchKernelGGL((linear_big_kernel<T, BM_, false>), grid, block, 0, stream, p); } while (0)
+    if (p.batch <= 128) ATOMA_BIG(128); else ATOMA_BIG(256);
+#undef ATOMA_BIG
+    if (!ATOMA_CHECK_LAUNCH("linear_big_kernel")) return -1;
+    if (p.partial) {
+        hipLaunchKernelGGL((linear_reduce_kernel<T>), dim3((unsigned)cdiv((int64_t)p.batch * out_n, 1024)), dim3(256), 0, stream, p);
+        if (!ATOMA_CHECK_LAUNCH("linear_reduce_kernel")) return -1;
+    }
+    return 0;
+}
+
 // 512 bytes per weight-row visit (two 128-input chunks per pipeline stage) when the split allows: +2-5 % over 256
 static const int linear_ch = getenv("ATOMA_LINEAR_CH") ? atoi(getenv("ATOMA_LINEAR_CH")) : 2;
 template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
@@ -675,6 +875,12 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
     if (linear_wg && p.batch <= std::min(linear_wg_max_batch, 16)) {
         const int rc = launch_linear_wg<T>(p, stream);
         if (rc <= 0) return rc;
+    }
+    if (p.batch > 64) {
+        const int rc = launch_linear_big<T>(p, stream);
+        if (rc <= 0) return rc;
+        set_error("linear_decode: more than 64 rows need out_features and in_features to be multiples of 128");
+        return -1;
     }
     if (linear_mid && p.batch > 16) {
         const int rc = launch_linear_mid<T>(p, stream);
@@ -728,7 +934,7 @@ static int linear_decode_entry(const void *x, const void *w, void *y, int64_t ba
     using namespace atoma;
     clear_error();
     if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("linear_decode: dtype must be f16 or bf16"); return -1; }
-    if (batch < 0 || batch > 64) { set_error("linear_decode: batch must be in [0, 64] (larger batches are a GEMM, not a weight stream)"); return -1; }
+    if (batch < 0 || batch > 256) { set_error("linear_decode: batch must be in [0, 256]"); return -1; }
     if (in_features <= 0 || in_features % 128 != 0) { set_error("linear_decode: in_features must be a positive multiple of 128"); return -1; }
     if (out_features <= 0 || out_features % 16 != 0) { set_error("linear_decode: out_features must be a positive multiple of 16"); return -1; }
     const int64_t y_width = epilogue == 2 ? out_features / 2 : out_features;

@@ -81,7 +81,8 @@ def test_linear_decode_exact_cases_and_linearity(gpu):
 def test_linear_decode_rejects_bad_arguments(gpu):
     d = gpu.DeviceBuffer(1 << 16)
     call = lambda B=1, K=128, N=16, xs=None, dt=BF16: gpu.lib.atoma_linear_decode(d.ptr, d.ptr, d.ptr, B, K, N, xs or K, K, N, dt, None)
-    assert call(B=65) == -1 and "batch" in gpu.last_error()
+    assert call(B=257) == -1 and "batch" in gpu.last_error()
+    assert call(B=65) == -1 and "multiples of 128" in gpu.last_error()      # 65..256 rows: the GEMM tile needs 128 | N, K
     assert call(K=100) == -1 and "in_features" in gpu.last_error()
     assert call(N=24) == -1 and "out_features" in gpu.last_error()
     assert call(xs=64) == -1 and "strides" in gpu.last_error()
@@ -117,10 +118,46 @@ def test_linear_decode_fused_epilogues_match_the_separate_ops(gpu):
     assert d.max() <= 1 and (d > 0).mean() < 0.01
 
 
-@pytest.mark.parametrize("B,K,N,I", [(17, 1024, 512, 768), (40, 4096, 1024, 1024), (64, 1024, 256, 128), (33, 8192, 512, 3584), (64, 2048, 4096, 2048)])
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("B,K,N", [(65, 1024, 256), (100, 4096, 1024), (128, 4096, 4096), (129, 2048, 6144), (200, 14336, 512), (256, 4096, 4096), (256, 1024, 28672),
+                                   (256, 8192, 1280)])
+def test_linear_decode_65_to_256_rows(gpu, dtype, B, K, N):
+    """linear_big_kernel (32x32x16 MFMA tile of 128 weight rows x 128 / 256 batch rows, with and without K splitting)."""
+    rng = np.random.default_rng(B + K + N)
+    x = rand_half(rng, (B, K), dtype)
+    w = rand_half(rng, (N, K), dtype, K ** -0.5)
+    check(gpu_linear(gpu, x, w, dtype), LO.linear(x, w, dtype), dtype)
+
+
+def test_linear_decode_big_exact_cases(gpu):
+    """Integer-valued inputs (every partial sum exact in fp32): bit-exact whatever the tiling / split; W = I reproduces x; a
+    strided x and a padded y."""
+    rng = np.random.default_rng(41)
+    from oracle.halfs import from_f32
+    B, K, N = 200, 2048, 1024
+    x = from_f32(rng.integers(-4, 5, (B, K)).astype(np.float32), BF16)
+    w = from_f32(rng.integers(-2, 3, (N, K)).astype(np.float32), BF16)
+    assert np.array_equal(gpu_linear(gpu, x, w, BF16), LO.linear(x, w, BF16))
+    eye = from_f32(np.eye(1024, dtype=np.float32), BF16)
+    xr = rand_half(rng, (256, 1024), BF16)
+    assert np.array_equal(gpu_linear(gpu, xr, eye, BF16), xr)
+    wide = from_f32(rng.integers(-4, 5, (B, K + 64)).astype(np.float32), BF16)
+    dx, dw = gpu.DeviceBuffer.from_numpy(wide), gpu.DeviceBuffer.from_numpy(w)
+    ys = N + 64
+    dy = gpu.DeviceBuffer(B * ys * 2)
+    dy.fill_bytes(0xAB)
+    assert gpu.lib.atoma_linear_decode(dx.ptr + 32 * 2, dw.ptr, dy.ptr, B, K, N, K + 64, K, ys, BF16, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    out = dy.numpy(np.uint16, (B, ys))
+    assert np.array_equal(out[:, :N], LO.linear(np.ascontiguousarray(wide[:, 32:32 + K]), w, BF16)) and (out[:, N:] == 0xABAB).all()
+
+
+@pytest.mark.parametrize("B,K,N,I", [(17, 1024, 512, 768), (40, 4096, 1024, 1024), (64, 1024, 256, 128), (33, 8192, 512, 3584), (64, 2048, 4096, 2048),
+                                     (65, 1024, 256, 128), (130, 4096, 1024, 1024), (256, 2048, 4096, 14336), (256, 14336, 512, 256)])
 def test_linear_mid_batch_epilogues_match_the_separate_ops(gpu, B, K, N, I):
-    """17..64 rows (linear_mid_kernel: one workgroup per 64 features, with and without K splitting): the fused epilogues keep the
-    rounding points of projection + atoma_add / atoma_silu_mul -- bit for bit -- and the plain projection meets the oracle bound."""
+    """17..64 rows (linear_mid_kernel: one workgroup per 64 features) and 65..256 rows (linear_big_kernel), with and without K
+    splitting: the fused epilogues keep the rounding points of projection + atoma_add / atoma_silu_mul -- bit for bit -- and the
+    plain projection meets the oracle bound."""
     rng = np.random.default_rng(B + K + N)
     x = rand_half(rng, (B, K), BF16)
     w = rand_half(rng, (N, K), BF16, K ** -0.5)

@@ -361,6 +361,27 @@ def bench_linear_mid():
         w.free()
 
 
+def bench_linear_big():
+    """f.1 at 65..256 rows: atoma_linear_decode (linear_big_kernel) against the vendor GEMM on the Llama-3.1-8B layer shapes."""
+    rng = np.random.default_rng(8)
+    for name, N, K in (("8B qkv", 6144, 4096), ("8B o", 4096, 4096), ("8B gate_up", 28672, 4096), ("8B down", 4096, 14336), ("8B lm_head", 128256, 4096)):
+        w = rand_dev(rng, N * K * 2)
+        for B in (128, 256):
+            x, y, r = rand_dev(rng, B * K * 2), ah.DeviceBuffer(B * N * 2), rand_dev(rng, B * N * 2)
+            nbytes, flops = N * K * 2 + B * K * 2 + B * N * 2, 2 * B * N * K
+            ms = timeit(lambda: ah.lib.atoma_linear_decode(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
+            emit(f"L4 linear_big {name} [{N} x {K}] batch={B}", ms, nbytes=nbytes, flops=flops)
+            ah.lib.atoma_linear(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None)
+            ah.synchronize()
+            time.sleep(0.1)
+            ms_lt = timeit(lambda: ah.lib.atoma_linear(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
+            emit(f"L4 vendor GEMM {name} [{N} x {K}] batch={B}", ms_lt, nbytes=nbytes, flops=flops)
+            if "gate_up" in name:
+                ms_f = timeit(lambda: ah.lib.atoma_linear_decode_silu_mul(x.ptr, w.ptr, y.ptr, B, K, N // 2, K, K, N // 2, 1, None))
+                emit(f"L4 linear_big + SiLU.up epilogue {name} batch={B}", ms_f, nbytes=N * K * 2 + B * K * 2 + B * N, flops=flops)
+        w.free()
+
+
 def bench_step():
     """C3-lite: one whole Llama-3.1-8B decode step on the device (tools/decode_step.py) at batch 1 and 16, context 4096,
     synthetic bf16 weights, eager and replayed from a hipGraph.  Bytes = weights read once + the KV cache of the batch."""
