@@ -221,3 +221,56 @@ def test_prefill_step_matches_token_by_token_decode(gpu):
             assert (np.abs(a[slots] - b2[slots]) <= 2.0 ** -6 * np.abs(b2[slots]) + 1e-2).mean() > 0.99, f"layer {l} {name} cache"
     assert np.abs(logits_prefill - logits_decode).max() < 0.1
     assert tok_prefill == int(step2.next_ids.numpy(np.int32, (1,))[0]) or np.sort(logits_decode)[-1] - np.sort(logits_decode)[-2] < 0.1
+
+
+def test_decode_step_with_fp8_kv_cache_tracks_the_bf16_step(gpu):
+    """DecodeStep(kv_fp8=True): RoPE + quantised cache write + decode over the fp8 cache inside a whole step.  With caches that
+    hold the SAME values (the bf16 cache = the dequantised fp8 cache) the two steps differ only by the quantisation of the one
+    new K/V row per sequence: logits agree closely and the newly written cache rows are the oracle's bytes."""
+    import decode_step as DS
+    from oracle import fp8_oracle as F8
+    rng = np.random.default_rng(31)
+    cfg = DS.Config(layers=2, hidden=512, heads=4, kv_heads=2, head_dim=128, intermediate=1024, vocab=1008, page=16, max_pos=256)
+    B = 4
+    ctx = np.array([3, 17, 40, 100])
+    lens = (ctx + 1).astype(np.int32)
+    blocks = [(int(L) + cfg.page - 1) // cfg.page for L in lens]
+    num_pages = sum(blocks) + 2
+    perm = rng.permutation(num_pages)
+    bt = np.zeros((B, max(blocks)), np.int32)
+    p0 = 0
+    for i, n in enumerate(blocks):
+        bt[i, :n] = perm[p0:p0 + n]
+        p0 += n
+    host = DS.random_host_weights(rng, cfg)
+    w = DS.upload_weights(cfg, host)
+    scale = 0.02
+    shape = (num_pages, cfg.page, cfg.hk, cfg.d)
+    k8 = [rng.integers(0, 0x70, shape, dtype=np.uint8) | (rng.integers(0, 2, shape, dtype=np.uint8) << 7) for _ in range(cfg.layers)]
+    v8 = [rng.integers(0, 0x70, shape, dtype=np.uint8) | (rng.integers(0, 2, shape, dtype=np.uint8) << 7) for _ in range(cfg.layers)]
+    from oracle.halfs import from_f32
+    ids = rng.integers(0, cfg.vocab, B)
+    slots = np.array([CO.slot_mapping_for(bt[i], int(ctx[i]), int(ctx[i]) + 1, cfg.page)[0] for i in range(B)], np.int64)
+    st = gpu.Stream()
+    s8 = DS.DecodeStep(cfg, B, num_pages, bt.shape[1], w, st, kv_fp8=True, kv_scale=scale, keep_intermediates=True)
+    s16 = DS.DecodeStep(cfg, B, num_pages, bt.shape[1], w, st)
+    for l in range(cfg.layers):
+        s8.kc[l].upload(k8[l]); s8.vc[l].upload(v8[l])
+        s16.kc[l].upload(from_f32(F8.decode(k8[l]) * np.float32(scale), BF16))       # exactly representable: 4 significant bits x a scale
+        s16.vc[l].upload(from_f32(F8.decode(v8[l]) * np.float32(scale), BF16))
+    for s in (s8, s16):
+        s.set_inputs(ids, ctx, slots, lens, bt)
+        s.run()
+    st.synchronize()
+    l8 = to_f32(s8.logits.numpy(np.uint16, (B, cfg.vocab)), BF16)
+    l16 = to_f32(s16.logits.numpy(np.uint16, (B, cfg.vocab)), BF16)
+    assert np.isfinite(l8).all() and np.abs(l8 - l16).max() < 0.25 and np.abs(l8 - l16).mean() < 0.02
+    # the rows this step wrote: layer 0's rotated k / v (kept by the trace) quantised by the oracle
+    _, _, t = s8.trace[1]
+    qkv = t["qkv"].numpy(np.uint16, (B, cfg.qkv))
+    hd = cfg.h * cfg.d
+    k_rot = np.ascontiguousarray(qkv[:, hd:hd + cfg.hk * cfg.d]).reshape(B, cfg.hk, cfg.d)
+    v_new = np.ascontiguousarray(qkv[:, hd + cfg.hk * cfg.d:]).reshape(B, cfg.hk, cfg.d)
+    kc, vc = k8[0].copy(), v8[0].copy()
+    F8.reshape_and_cache_flash_fp8(k_rot, v_new, kc, vc, slots, np.full(cfg.hk, scale, np.float32), np.full(cfg.hk, scale, np.float32), BF16)
+    assert np.array_equal(s8.kc[0].numpy(np.uint8, shape), kc) and np.array_equal(s8.vc[0].numpy(np.uint8, shape), vc)

@@ -37,14 +37,14 @@ def _timed(stream, fn, iters, warm=2):
     return a.elapsed_ms(b) / iters
 
 
-def c3_decode_step(iters=10, batch=256, seed=9):
+def c3_decode_step(iters=10, batch=256, seed=9, kv_fp8=False, weights=None):
     rng = np.random.default_rng(seed)
     c = DS.LLAMA_3_1_8B
-    w = TS.random_shard_weights(rng, c)
+    w = weights or TS.random_shard_weights(rng, c)
     st = ah.Stream()
     S = 2560
     pps = S // c.page + 1
-    step = DS.DecodeStep(c, batch, batch * pps + 2, pps, w, st, fused_epilogues=True)
+    step = DS.DecodeStep(c, batch, batch * pps + 2, pps, w, st, fused_epilogues=True, kv_fp8=kv_fp8)
     bt = rng.permutation(batch * pps).astype(np.int32).reshape(batch, pps)
     ctx = rng.integers(2048, 2560, batch)
     slots = bt[np.arange(batch), ctx // c.page].astype(np.int64) * c.page + ctx % c.page
@@ -55,12 +55,21 @@ def c3_decode_step(iters=10, batch=256, seed=9):
         step.run()
     ms = _timed(st, g.launch, iters)
     weight_bytes = 2 * (c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden)) + 2 * batch * c.hidden
-    nbytes = weight_bytes + 2 * int((ctx + 1).sum()) * c.hk * c.d * 2 * c.layers
-    out = {"workload": f"Llama-3.1-8B decode step (BASELINE configs[2] mid-trace), batch {batch}, contexts U[2048,2560), block {c.page}, bf16, hipGraph replay",
+    nbytes = weight_bytes + 2 * int((ctx + 1).sum()) * c.hk * c.d * (1 if kv_fp8 else 2) * c.layers
+    out = {"workload": f"Llama-3.1-8B decode step (BASELINE configs[2] mid-trace), batch {batch}, contexts U[2048,2560), block {c.page}, bf16 weights and activations, "
+                       + ("fp8 e4m3fn KV cache" if kv_fp8 else "bf16 KV cache") + ", hipGraph replay",
            "ms_per_step": round(ms, 3), "decode_tokens_per_s_per_gpu": round(batch / (ms * 1e-3), 1), "algorithmic_bytes": int(nbytes),
            "roofline_tokens_per_s": round(batch / (nbytes / HBM_PEAK), 1), "frac_of_hbm_roofline": round(nbytes / HBM_PEAK / (ms * 1e-3), 4)}
-    del g, step, w
+    del g, step
+    if weights is None:
+        del w
     return out
+
+
+def c3_decode_step_fp8_kv(iters=10):
+    """The same step over an fp8 (e4m3fn) KV cache: the attention bytes halve; a VARIANT, not the headline --
+    the reference's cache is 16-bit."""
+    return c3_decode_step(iters=iters, kv_fp8=True)
 
 
 def prefill(iters=10, S=2048, nseq=16, h=32, hk=8, d=128, seed=1):
@@ -101,7 +110,7 @@ def swap(iters=3, tensors=64, pages=256, nb=512, page_bytes=16 * 8 * 128 * 2, se
     return res
 
 
-def collect(which=("c3_decode_step", "prefill", "swap")):
+def collect(which=("c3_decode_step", "c3_decode_step_fp8_kv", "prefill", "swap")):
     out = {}
     for name in which:
         try:
@@ -114,4 +123,4 @@ def collect(which=("c3_decode_step", "prefill", "swap")):
 if __name__ == "__main__":
     import json
     ah.set_device(0)
-    print(json.dumps(collect(tuple(sys.argv[1:]) or ("c3_decode_step", "prefill", "swap"))))
+    print(json.dumps(collect(tuple(sys.argv[1:]) or ("c3_decode_step", "c3_decode_step_fp8_kv", "prefill", "swap"))))

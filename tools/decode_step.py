@@ -34,7 +34,7 @@ class DecodeStep:
     """Device-resident weights, caches and activations of a model + `run()` = one decode step for `batch` sequences."""
 
     def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False, fused_epilogues=False, fuse_norm=True,
-                 allreduce=None):
+                 allreduce=None, kv_fp8=False, kv_scale=0.05):
         """allreduce(ptr, count): in-place sum of a [batch, hidden] bf16 tensor over the tensor-parallel ranks, enqueued on
         `stream` -- called after the o and the down projection when `cfg` / `weights` are ONE rank's shard
         (llama_nccl.rs:139,195 via TensorParallelRowLinear, multi_gpu.rs:48-50); None = not tensor parallel."""
@@ -45,8 +45,14 @@ class DecodeStep:
         self.fuse_norm = fuse_norm and not keep_intermediates and not self.fused   # residual add + the RMSNorm that follows it in one kernel
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
         page_elems = c.page * c.hk * c.d
-        self.kc = [ah.DeviceBuffer.zeros((num_pages * page_elems,), np.uint16) for _ in range(c.layers)]
-        self.vc = [ah.DeviceBuffer.zeros((num_pages * page_elems,), np.uint16) for _ in range(c.layers)]
+        # kv_fp8: the KV cache holds e4m3fn bytes with one dequantisation scale per kv head (atoma_rope_qk_cache_fp8 /
+        # atoma_paged_decode_fp8); everything else of the step is unchanged
+        self.kv_fp8 = kv_fp8
+        cache_dt = np.uint8 if kv_fp8 else np.uint16
+        self.kc = [ah.DeviceBuffer.zeros((num_pages * page_elems,), cache_dt) for _ in range(c.layers)]
+        self.vc = [ah.DeviceBuffer.zeros((num_pages * page_elems,), cache_dt) for _ in range(c.layers)]
+        self.k_scale = ah.DeviceBuffer.from_numpy(np.full(c.hk, kv_scale, np.float32))
+        self.v_scale = ah.DeviceBuffer.from_numpy(np.full(c.hk, kv_scale, np.float32))
         self.max_blocks = max_blocks
         B = batch
         self.ids = ah.DeviceBuffer.zeros((B,), np.int32)
@@ -109,15 +115,23 @@ class DecodeStep:
                 qkv_pre = self._buf("qkv_pre", l, B * qkvw * 2)
                 ah.hip_check(ah.hip.hipMemcpyAsync(qkv_pre.ptr, qkv.ptr, B * qkvw * 2, 3, s), "copy")
             kptr, vptr = qkv.ptr + hd * 2, qkv.ptr + (hd + c.hk * c.d) * 2
-            self._ok(L.atoma_rope_qk_cache(qkv.ptr, kptr, vptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr, self.w["cos"].ptr,
-                                           self.w["sin"].ptr, self.pos.ptr, B, c.h, c.hk, c.d, qkvw, qkvw, qkvw, c.page * c.hk * c.d,
-                                           c.page, BF16, 1, s), "rope + cache write")
             att = self._buf("att", l, B * hd * 2)
-            ah.run_mha(qkv, self.kc[l], self.vc[l], att, b=B, h=c.h, h_k=c.hk, d=c.d, seqlen_q=1, seqlen_k=self.max_blocks * c.page,
-                       softmax_scale=c.d ** -0.5, is_bf16=BF16, q_strides=(qkvw, qkvw, c.d), o_strides=(hd, hd, c.d),
-                       k_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d), v_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d),
-                       cu_seqlens_k=self.lens.ptr, is_seqlens_k_cumulative=False, block_table=self.bt.ptr, block_table_batch_stride=self.max_blocks,
-                       page_block_size=c.page, force_split_kernel=True, unpadded_lse=False, stream=s)
+            if self.kv_fp8:
+                self._ok(L.atoma_rope_qk_cache_fp8(qkv.ptr, kptr, vptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr, self.k_scale.ptr, self.v_scale.ptr,
+                                                   self.w["cos"].ptr, self.w["sin"].ptr, self.pos.ptr, B, c.h, c.hk, c.d, qkvw, qkvw, qkvw,
+                                                   c.page * c.hk * c.d, c.page, BF16, 1, s), "rope + fp8 cache write")
+                self._ok(L.atoma_paged_decode_fp8(qkv.ptr, self.kc[l].ptr, self.vc[l].ptr, att.ptr, self.k_scale.ptr, self.v_scale.ptr, self.bt.ptr,
+                                                  self.lens.ptr, B, c.h, c.hk, c.d, self.max_blocks, c.page, qkvw, c.d, hd, c.d, c.page * c.hk * c.d,
+                                                  c.hk * c.d, c.d, c.d ** -0.5, BF16, s), "paged decode over the fp8 cache")
+            else:
+                self._ok(L.atoma_rope_qk_cache(qkv.ptr, kptr, vptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr, self.w["cos"].ptr,
+                                               self.w["sin"].ptr, self.pos.ptr, B, c.h, c.hk, c.d, qkvw, qkvw, qkvw, c.page * c.hk * c.d,
+                                               c.page, BF16, 1, s), "rope + cache write")
+                ah.run_mha(qkv, self.kc[l], self.vc[l], att, b=B, h=c.h, h_k=c.hk, d=c.d, seqlen_q=1, seqlen_k=self.max_blocks * c.page,
+                           softmax_scale=c.d ** -0.5, is_bf16=BF16, q_strides=(qkvw, qkvw, c.d), o_strides=(hd, hd, c.d),
+                           k_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d), v_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d),
+                           cu_seqlens_k=self.lens.ptr, is_seqlens_k_cumulative=False, block_table=self.bt.ptr, block_table_batch_stride=self.max_blocks,
+                           page_block_size=c.page, force_split_kernel=True, unpadded_lse=False, stream=s)
             x1 = self._buf("x1", l, B * H * 2)
             xn2 = self._buf("xn2", l, B * H * 2)
             act = self._buf("act", l, B * c.inter * 2)
