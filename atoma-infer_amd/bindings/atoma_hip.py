@@ -103,6 +103,10 @@ _opt("atoma_rope_table", [_vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _i
 _opt("atoma_reshape_and_cache_flash_fp8", [_vp, _vp, _vp, _vp, _i64p, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_rope_qk_cache_fp8", [_vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp])
 _opt("atoma_paged_decode_fp8", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _int, _vp])
+_opt("atoma_kv_blocks_packed_size", [_i64, _i64, _i64, _i64, _i64, _int], _i64)
+_opt("atoma_kv_pack_blocks", [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _int, _vp, _vp, _vp, _i64, _vp])
+_opt("atoma_kv_read_header", [_vp, _i64, _vp])
+_opt("atoma_kv_unpack_blocks", [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _vp])
 _opt("atoma_warmup", [_vp, _i64, _i64, _i64, _i64, _i64, _i64])
 _opt("atoma_reserve_workspace", [_vp, _i64])
 _opt("atoma_release_workspaces", [])

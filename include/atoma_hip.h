@@ -193,6 +193,29 @@ int atoma_paged_decode_fp8(const void *q, const void *k_cache, const void *v_cac
                            int64_t q_head_stride, int64_t o_batch_stride, int64_t o_head_stride, int64_t cache_block_stride,
                            int64_t cache_row_stride, int64_t cache_head_stride, float softmax_scale, int dtype, void *stream);
 
+/* ---- KV block container: a checksummed, self-describing image of a set of pages of EVERY layer, for
+ * handing KV blocks to another engine or to disk.  The reference only swaps raw pages between two caches of one process
+ * (csrc/src/cache_manager.rs:18-128, worker.rs:602-632); this is that swap with one contiguous destination.  Image =
+ * header | int64 block ids [n] | (fp8 only) f32 scales [2][layers][h_k] | payload [layer][K|V][block][page bytes].
+ * k_caches / v_caches: HOST arrays of per-layer DEVICE pointers [nb, block_size, h_k, d]; ids on the HOST; dtype f16 / bf16 /
+ * ATOMA_U8 (= fp8 e4m3fn cache).  pack synchronises the stream (it checksums the bytes); unpack is stream-ordered and
+ * verifies magic, version, geometry and checksum first.  Pinned host memory (atoma_host_alloc) moves with one gather /
+ * scatter launch, pageable memory page by page. */
+typedef struct atoma_kv_block_header {
+    char magic[8];                 /* "ATOMAKV1" */
+    uint32_t version, dtype, num_layers, num_kv_heads, head_dim, block_size;
+    uint64_t num_blocks, page_bytes, payload_offset, total_bytes, checksum;
+    uint8_t reserved[56];
+} atoma_kv_block_header;           /* 128 bytes */
+int64_t atoma_kv_blocks_packed_size(int64_t num_layers, int64_t num_kv_heads, int64_t head_dim, int64_t block_size, int64_t num_blocks, int dtype);
+int atoma_kv_pack_blocks(const void *const *k_caches, const void *const *v_caches, int64_t num_layers, int64_t num_kv_heads, int64_t head_dim,
+                         int64_t block_size, const int64_t *block_ids, int64_t num_blocks, int dtype, const float *k_scales, const float *v_scales,
+                         void *out, int64_t out_capacity, void *stream);
+int atoma_kv_read_header(const void *packed, int64_t bytes, atoma_kv_block_header *header);
+int atoma_kv_unpack_blocks(const void *packed, int64_t bytes, void *const *k_caches, void *const *v_caches, int64_t num_layers, int64_t num_kv_heads,
+                           int64_t head_dim, int64_t block_size, int dtype, const int64_t *dst_block_ids, int64_t num_blocks, float *k_scales_out,
+                           float *v_scales_out, void *stream);
+
 /* cos/sin table of `Cache::new` (models/src/llama.rs:154-200) built on the HOST into
  * cos_out/sin_out [max_pos, head_dim/2] (storage dtype).  rope_factor <= 0: no Llama-3 scaling. */
 int atoma_rope_table(void *cos_out, void *sin_out, int64_t max_pos, int64_t head_dim,
