@@ -98,6 +98,7 @@ _opt("atoma_linear_decode_silu_mul", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i6
 _opt("atoma_linear_decode", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_linear", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_topk_rows", [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp])
+_opt("atoma_sample_rows", [_vp, _i64, _i64, _i64, _int, _f32, _i64, _f32, _vp, _vp, _vp, _vp])
 _opt("atoma_argmax_rows", [_vp, _i64, _i64, _i64, _int, _vp, _vp, _vp])
 _opt("atoma_rope_table", [_vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _i64, _int])
 _opt("atoma_reshape_and_cache_flash_fp8", [_vp, _vp, _vp, _vp, _i64p, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])

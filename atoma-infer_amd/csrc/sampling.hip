@@ -269,3 +269,238 @@ extern "C" int atoma_topk_rows(const void *logits, int64_t rows, int64_t vocab, 
         hipLaunchKernelGGL((topk_rows_kernel<f16_t>), dim3((unsigned)rows), dim3(TOPK_THREADS), 0, s, logits, stride_bytes, (int)vocab, (int)k, out_val, out_idx);
     return ATOMA_CHECK_LAUNCH("topk_rows") ? 0 : -1;
 }
+
+// ------------------------------------------------------------------------------------------
+// Stochastic token selection on the device: the non-ArgMax branches of candle_transformers' LogitsProcessor::sample, which
+// /root/reference/backends/vllm/src/llm_service.rs:348-372 configures (All / TopK / TopP / TopKThenTopP with a temperature)
+// and model_executor.rs:230-249 calls once per sequence on a logits row copied to the host.  Per row, in f32:
+//   w_i = exp((x_i - max x) / temperature)            (softmax numerators; the denominator cancels in a weighted draw)
+//   top_k > 0: only the k largest logits keep their weight; top_p < 1: in descending order, tokens keep their weight until the
+//   cumulative probability reaches top_p (the token that crosses it is kept, as in Candle's sample_topp);
+//   draw = u * sum(kept w); the token is the first kept one whose running sum exceeds draw.
+// The order of the running sum is vocabulary order for plain multinomial sampling and (logit descending, index ascending) for
+// top-k / top-p -- any fixed order gives the same distribution (Candle's own top-k order is unspecified: select_nth_unstable).
+// The random stream stays with the caller: u[row] in [0, 1), one uniform per row (rand's WeightedIndex draws one uniform in
+// [0, total)).  Two passes over the row for plain sampling (max, then 512-element chunk sums and a rescan of ONE chunk); the
+// restricted variants run atoma_topk_rows first and then touch k values (+ one pass for the full-row denominator of top_p).
+// ------------------------------------------------------------------------------------------
+namespace atoma {
+
+void *workspace(hipStream_t stream, size_t bytes);   // runtime.hip
+
+constexpr int SAMPLE_THREADS = 1024, SAMPLE_CHUNK = 512, SAMPLE_MAX_CHUNKS = 4096;   // vocab <= 2 M
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+// finite-or-minus-infinity view of a logit: NaN never takes part (weight 0), from the bits (-fno-honor-nans)
+__device__ __forceinline__ float sample_clean(float v) {
+    return (__float_as_uint(v) & 0x7fffffffu) > 0x7f800000u ? -INFINITY : v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(SAMPLE_THREADS) sample_full_kernel(const void *__restrict__ logits, int64_t row_stride_bytes, int vocab, float inv_temp,
+                                                                     const float *__restrict__ u, int32_t *__restrict__ out_idx, float *__restrict__ out_logit) {
+    __shared__ float csum[SAMPLE_MAX_CHUNKS];
+    __shared__ float red[16];
+    const char *row = static_cast<const char *>(logits) + (int64_t)blockIdx.x * row_stride_bytes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // pass 1: row max
+    float mx = -INFINITY;
+    for (int i = tid; i < vocab; i += SAMPLE_THREADS) mx = fmaxf(mx, sample_clean(load1<T>(row, i)));
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+    const float m = mx == -INFINITY ? 0.f : mx;
+    // pass 2: weight sum of every 512-element chunk (lane: 8 consecutive elements, then a wave reduction)
+    const int n_chunks = (vocab + SAMPLE_CHUNK - 1) / SAMPLE_CHUNK;
+    auto weight = [&](int i) { return i < vocab ? __expf((sample_clean(load1<T>(row, i)) - m) * inv_temp) : 0.f; };
+    for (int c = wave; c < n_chunks; c += 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += weight(c * SAMPLE_CHUNK + lane * 8 + e);
+        s = wave_sum(s);
+        if (lane == 0) csum[c] = s;
+    }
+    __syncthreads();
+    // wave 0: total, draw, the chunk in which the running sum crosses the draw
+    if (wave == 0) {
+        float part = 0.f;
+        for (int c = lane; c < n_chunks; c += 64) part += csum[c];
+        const float total = wave_sum(part);
+        const float draw = u[blockIdx.x] * total;
+        // running sum over chunks in order, 64 at a time (inclusive scan over the lanes)
+        float base = 0.f;
+        int found = -1;
+        float found_base = 0.f;
+        for (int c0 = 0; c0 < n_chunks && found < 0; c0 += 64) {
+            const float v = c0 + lane < n_chunks ? csum[c0 + lane] : 0.f;
+            float inc = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float y = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += y;
+            }
+            const bool hit = c0 + lane < n_chunks && base + inc > draw;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                const int l0 = __builtin_ctzll(mask);
+                found = c0 + l0;
+                found_base = base + __shfl(inc - v, l0, 64);
+            }
+            base += __shfl(inc, 63, 64);
+        }
+        if (found < 0) { found = n_chunks - 1; found_base = base - csum[n_chunks - 1]; }   // draw == total after rounding: the last chunk
+        // rescan that chunk: lane's 8 elements, inclusive scan over lanes, first element whose running sum exceeds the draw
+        float wv[8], s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { wv[e] = weight(found * SAMPLE_CHUNK + lane * 8 + e); s += wv[e]; }
+        float inc = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float y = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += y;
+        }
+        float run = found_base + inc - s;
+        int idx = -1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            run += wv[e];
+            if (idx < 0 && wv[e] > 0.f && run > draw) idx = found * SAMPLE_CHUNK + lane * 8 + e;
+        }
+        const unsigned long long mask = __ballot(idx >= 0);
+        int chosen;
+        if (mask) chosen = __shfl(idx, __builtin_ctzll(mask), 64);
+        else {   // rounding left the draw beyond the last weight: the last token of the chunk that has any weight
+            int last = -1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (wv[e] > 0.f) last = found * SAMPLE_CHUNK + lane * 8 + e;
+            const unsigned long long m2 = __ballot(last >= 0);
+            chosen = m2 ? __shfl(last, 63 - __builtin_clzll(m2), 64) : 0;
+        }
+        if (lane == 0) {
+            out_idx[blockIdx.x] = chosen;
+            if (out_logit) out_logit[blockIdx.x] = load1<T>(row, chosen);
+        }
+    }
+}
+
+// top-k / top-p: `vals`, `idxs` [rows][k] from atoma_topk_rows (value descending, index ascending); one wave per row
+template <typename T>
+__global__ void __launch_bounds__(256) sample_topk_kernel(const void *__restrict__ logits, int64_t row_stride_bytes, int vocab, const float *__restrict__ vals,
+                                                          const int32_t *__restrict__ idxs, int k, float inv_temp, float top_p, const float *__restrict__ u,
+                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_logit) {
+    __shared__ float red[4];
+    const char *row = static_cast<const char *>(logits) + (int64_t)blockIdx.x * row_stride_bytes;
+    const float *v = vals + (int64_t)blockIdx.x * k;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float m = sample_clean(v[0]) == -INFINITY ? 0.f : v[0];
+    float denom = 0.f;      // full-row softmax denominator, needed only by top_p
+    if (top_p < 1.f) {
+        float s = 0.f;
+        for (int i = tid; i < vocab; i += 256) s += __expf((sample_clean(load1<T>(row, i)) - m) * inv_temp);
+        s = wave_sum(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        denom = red[0] + red[1] + red[2] + red[3];
+    }
+    if (wave != 0) return;
+    // kept prefix of the sorted list: all k, or up to (and including) the token whose cumulative probability reaches top_p
+    int keep = k;
+    float total = 0.f;
+    {
+        float base = 0.f;
+        bool cut = false;
+        for (int c0 = 0; c0 < k && !cut; c0 += 64) {
+            const float w = c0 + lane < k ? __expf((sample_clean(v[c0 + lane]) - m) * inv_temp) : 0.f;
+            float inc = w;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float y = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += y;
+            }
+            if (top_p < 1.f) {
+                const bool reach = c0 + lane < k && (base + inc) >= top_p * denom;
+                const unsigned long long mask = __ballot(reach);
+                if (mask) {
+                    const int l0 = __builtin_ctzll(mask);
+                    keep = c0 + l0 + 1;
+                    total = base + __shfl(inc, l0, 64);
+                    cut = true;
+                    break;
+                }
+            }
+            base += __shfl(inc, 63, 64);
+            total = base;
+        }
+    }
+    const float draw = u[blockIdx.x] * total;
+    float base = 0.f;
+    int chosen = -1;
+    for (int c0 = 0; c0 < keep && chosen < 0; c0 += 64) {
+        const float w = c0 + lane < keep ? __expf((sample_clean(v[c0 + lane]) - m) * inv_temp) : 0.f;
+        float inc = w;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float y = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += y;
+        }
+        const unsigned long long mask = __ballot(c0 + lane < keep && w > 0.f && base + inc > draw);
+        if (mask) chosen = c0 + __builtin_ctzll(mask);
+        base += __shfl(inc, 63, 64);
+    }
+    if (chosen < 0) chosen = keep - 1;
+    if (lane == 0) {
+        const int tok = idxs[(int64_t)blockIdx.x * k + chosen];
+        out_idx[blockIdx.x] = tok;
+        if (out_logit) out_logit[blockIdx.x] = load1<T>(row, tok);
+    }
+}
+
+}  // namespace atoma
+
+extern "C" int atoma_sample_rows(const void *logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype, float temperature, int64_t top_k,
+                                 float top_p, const float *u, int32_t *out_idx, float *out_logit, void *stream) {
+    using namespace atoma;
+    clear_error();
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16 && dtype != ATOMA_F32) { set_error("sample_rows: dtype must be f16, bf16 or f32"); return -1; }
+    if (rows < 0 || vocab <= 0 || vocab > (int64_t)SAMPLE_CHUNK * SAMPLE_MAX_CHUNKS) { set_error("sample_rows: invalid shape"); return -1; }
+    if (row_stride < vocab) { set_error("sample_rows: row_stride must be >= vocab"); return -1; }
+    if (!(temperature > 0.f)) { set_error("sample_rows: temperature must be positive (greedy selection is atoma_argmax_rows)"); return -1; }
+    if (top_k < 0 || top_k > TOPK_MAX) { set_error("sample_rows: top_k must be in [0, 1024] (0 = no top-k)"); return -1; }
+    if (!(top_p > 0.f)) { set_error("sample_rows: top_p must be in (0, 1] (1 = no top-p)"); return -1; }
+    if (!u || !out_idx) { set_error("sample_rows: u and out_idx are required"); return -1; }
+    if (rows == 0) return 0;
+    const int64_t stride_bytes = row_stride * (dtype == ATOMA_F32 ? 4 : 2);
+    const auto s = static_cast<hipStream_t>(stream);
+    const float inv_temp = 1.f / temperature;
+    const bool restricted = (top_k > 0 && top_k < vocab) || top_p < 1.f;
+    if (!restricted) {
+#define ATOMA_SF(TT) hipLaunchKernelGGL((sample_full_kernel<TT>), dim3((unsigned)rows), dim3(SAMPLE_THREADS), 0, s, logits, stride_bytes, (int)vocab, inv_temp, u, out_idx, out_logit)
+        if (dtype == ATOMA_F32) ATOMA_SF(float); else if (dtype == ATOMA_BF16) ATOMA_SF(bf16_t); else ATOMA_SF(f16_t);
+#undef ATOMA_SF
+        return ATOMA_CHECK_LAUNCH("sample_rows") ? 0 : -1;
+    }
+    // top-p without top-k: the nucleus is searched among the 1024 most probable tokens (it ends there for any real distribution)
+    const int64_t k = std::min<int64_t>((top_k > 0 && top_k < vocab) ? top_k : TOPK_MAX, vocab);
+    char *ws = static_cast<char *>(workspace(s, (size_t)rows * k * 8));
+    if (!ws) return -1;
+    float *vals = reinterpret_cast<float *>(ws);
+    int32_t *idxs = reinterpret_cast<int32_t *>(ws + (size_t)rows * k * 4);
+    if (atoma_topk_rows(logits, rows, vocab, row_stride, dtype, k, vals, idxs, stream) != 0) return -1;
+#define ATOMA_ST(TT) hipLaunchKernelGGL((sample_topk_kernel<TT>), dim3((unsigned)rows), dim3(256), 0, s, logits, stride_bytes, (int)vocab, vals, idxs, (int)k, inv_temp, top_p, u, out_idx, out_logit)
+    if (dtype == ATOMA_F32) ATOMA_ST(float); else if (dtype == ATOMA_BF16) ATOMA_ST(bf16_t); else ATOMA_ST(f16_t);
+#undef ATOMA_ST
+    return ATOMA_CHECK_LAUNCH("sample_rows (top-k / top-p)") ? 0 : -1;
+}

@@ -271,6 +271,18 @@ int atoma_argmax_rows(const void *logits, int64_t rows, int64_t vocab, int64_t r
 int atoma_topk_rows(const void *logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype, int64_t k, float *out_val,
                     int32_t *out_idx, void *stream);
 
+/* Stochastic token selection on the device: the All / TopK / TopP / TopKThenTopP branches of candle_transformers'
+ * LogitsProcessor::sample (configured at backends/vllm/src/llm_service.rs:348-372, called per sequence at model_executor.rs:
+ * 230-235 on a row copied to the host).  Weights w_i = exp((x_i - max) / temperature) in f32; top_k in [1, 1024] keeps the k
+ * largest logits (0 = off); top_p in (0, 1) keeps, in descending order, the tokens up to and including the one whose
+ * cumulative probability reaches top_p (1 = off; without top_k the nucleus is searched among the 1024 most probable tokens);
+ * the token is the first kept one whose running weight sum exceeds u[row] * (sum of kept weights), in vocabulary order for
+ * plain sampling and in (logit descending, index ascending) order otherwise.  The random stream stays with the caller:
+ * u f32 [rows] on the device, uniform in [0, 1).  out_logit (optional) = the chosen token's logit (the reference's log-prob
+ * read-back, model_executor.rs:249).  NaN logits have weight 0.  Greedy selection is atoma_argmax_rows. */
+int atoma_sample_rows(const void *logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype, float temperature, int64_t top_k,
+                      float top_p, const float *u, int32_t *out_idx, float *out_logit, void *stream);
+
 /* Tensor-parallel sum all-reduce (models/src/multi_gpu.rs:141-179 `AllReduce::cuda_fwd`,
  * bootstrap backends/vllm/src/model_executor.rs:413,436-439 `Id::new` / `Comm::from_rank`).
  * One process (or thread) per GPU over RCCL/xGMI.  id128: 128-byte ncclUniqueId. */

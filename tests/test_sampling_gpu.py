@@ -161,3 +161,80 @@ def test_topk_and_argmax_with_nans(gpu, dtype):
     assert np.array_equal(ti[: rows - 1], ri) and np.array_equal(tv[: rows - 1], rv)
     assert ti[rows - 1, 0] == 17 and np.isnan(tv[rows - 1, 1:]).all()      # after the one finite value: NaNs, index order
     assert ti[rows - 1, 1:].tolist() == [i for i in range(k + 1) if i != 17][: k - 1]
+
+
+# ---- stochastic selection (atoma_sample_rows) ----
+from oracle import sampling_oracle as SO
+
+
+def gpu_sample(gpu, logits, dtype, u, temperature, top_k=0, top_p=1.0, stride=None, vocab=None):
+    rows = logits.shape[0]
+    vocab = vocab or logits.shape[1]
+    stride = stride or logits.shape[1]
+    dl, du = gpu.DeviceBuffer.from_numpy(logits), gpu.DeviceBuffer.from_numpy(np.asarray(u, np.float32))
+    di, dv = gpu.DeviceBuffer.zeros((rows,), np.int32), gpu.DeviceBuffer.zeros((rows,), np.float32)
+    rc = gpu.lib.atoma_sample_rows(dl.ptr, rows, vocab, stride, dtype, temperature, top_k, top_p, du.ptr, di.ptr, dv.ptr, None)
+    assert rc == 0, gpu.last_error()
+    gpu.synchronize()
+    return di.numpy(np.int32, (rows,)), dv.numpy(np.float32, (rows,))
+
+
+def check_draws(x32, idx, u, temperature, top_k=0, top_p=1.0, slack=2e-5):
+    """Every answer must be the oracle's token for this u, up to f32 rounding of the running sums: u lies inside the token's
+    interval widened by `slack` (relative to a total of 1)."""
+    exact = 0
+    for r in range(x32.shape[0]):
+        lo, hi = SO.bracket(x32[r], int(idx[r]), temperature, top_k, top_p)
+        assert lo - slack <= u[r] < hi + slack, (r, int(idx[r]), float(u[r]), lo, hi)
+        exact += int(idx[r]) == SO.sample(x32[r], float(u[r]), temperature, top_k, top_p)
+    assert exact >= 0.98 * x32.shape[0]
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16])
+@pytest.mark.parametrize("rows,vocab,temperature,top_k,top_p", [(64, 128256, 1.0, 0, 1.0), (32, 32000, 0.7, 0, 1.0), (48, 128256, 0.8, 50, 1.0),
+                                                                (48, 128256, 1.0, 0, 0.9), (40, 50257, 1.3, 40, 0.95), (16, 97, 1.0, 0, 1.0), (8, 513, 0.5, 7, 0.5)])
+def test_sample_rows_matches_oracle(gpu, dtype, rows, vocab, temperature, top_k, top_p):
+    rng = np.random.default_rng(rows + vocab + top_k)
+    if dtype == F32:
+        logits = (rng.standard_normal((rows, vocab)) * 2.5).astype(np.float32)
+        x32 = logits
+    else:
+        logits = rand_half(rng, (rows, vocab), dtype, 2.5)
+        x32 = to_f32(logits, dtype)
+    u = rng.random(rows).astype(np.float32)
+    u[0], u[1 % rows] = 0.0, np.float32(1.0 - 2.0 ** -24)           # the two ends of [0, 1)
+    idx, val = gpu_sample(gpu, logits, dtype, u, temperature, top_k, top_p)
+    assert (idx >= 0).all() and (idx < vocab).all()
+    assert np.array_equal(val, x32[np.arange(rows), idx])
+    check_draws(x32, idx, u, temperature, top_k, top_p)
+
+
+def test_sample_rows_distribution_and_degenerate_rows(gpu):
+    """Equally spaced uniforms reproduce the distribution; -inf / NaN logits are never drawn; a one-hot row always returns its token;
+    padded rows ignore the padding."""
+    rng = np.random.default_rng(77)
+    vocab, stride, n = 1000, 1024, 4096
+    row = (rng.standard_normal(vocab) * 2).astype(np.float32)
+    row[[3, 500]] = -np.inf
+    row[7] = np.nan
+    x = np.full((n, stride), 50.0, np.float32)                      # padding columns hold a huge logit
+    x[:, :vocab] = row
+    u = ((np.arange(n) + 0.5) / n).astype(np.float32)
+    idx, _ = gpu_sample(gpu, x, F32, u, 1.0, vocab=vocab, stride=stride)
+    assert (idx < vocab).all() and not np.isin(idx, [3, 500, 7]).any()
+    order, w = SO.kept_weights(row, 1.0)
+    p = w / w.sum()
+    freq = np.bincount(idx, minlength=vocab) / n
+    assert np.abs(freq - p).max() < 2.0 / n + 1e-6                  # stratified uniforms: every frequency within 2 strata of its probability
+    onehot = np.full((5, vocab), -np.inf, np.float32)
+    onehot[np.arange(5), [0, 17, 511, 512, 999]] = 1.0
+    idx, _ = gpu_sample(gpu, onehot, F32, rng.random(5).astype(np.float32), 0.7)
+    assert idx.tolist() == [0, 17, 511, 512, 999]
+    idx, _ = gpu_sample(gpu, onehot, F32, rng.random(5).astype(np.float32), 0.7, top_k=5, top_p=0.9)
+    assert idx.tolist() == [0, 17, 511, 512, 999]
+    d = gpu.DeviceBuffer(4096)
+    L = gpu.lib
+    assert L.atoma_sample_rows(d.ptr, 1, 16, 16, F32, 0.0, 0, 1.0, d.ptr, d.ptr, None, None) == -1 and "temperature" in gpu.last_error()
+    assert L.atoma_sample_rows(d.ptr, 1, 16, 16, F32, 1.0, 2000, 1.0, d.ptr, d.ptr, None, None) == -1 and "top_k" in gpu.last_error()
+    assert L.atoma_sample_rows(d.ptr, 1, 16, 16, F32, 1.0, 0, 0.0, d.ptr, d.ptr, None, None) == -1 and "top_p" in gpu.last_error()
+    assert L.atoma_sample_rows(d.ptr, 1, 16, 16, F32, 1.0, 0, 1.0, None, d.ptr, None, None) == -1
