@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--block-size", type=int, default=16)
     ap.add_argument("--identity-table", action="store_true", help="physical page i = logical page i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure HBM traffic with rocprofv3 PMC passes inside this run")
     ap.add_argument("--no-extra", action="store_true", help="only the headline (profiling runs): skip the end-to-end extras")
     ap.add_argument("--tp-step", action="store_true", help="N = 1: also time the whole 70B-shaped decode step on this GPU (226 GB)")
     ap.add_argument("--cpu-sample-seqs", type=int, default=64)
@@ -180,7 +181,14 @@ def main():
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs of this same command, corrected as the MI355X guide prescribes:
     # tools/summarize_profiles.py); null when no profile of the default workload is present.
-    if world == 1 and (B, S, h, hk, d, page) == (256, 4096, 32, 8, 128, 16):
+    measured = None
+    if world == 1 and not args.no_traffic and not os.environ.get("ATOMA_BENCH_CHILD"):
+        measured = measure_traffic(sys.argv[1:])
+    if measured is not None:
+        out["roofline"]["traffic"] = int(measured)
+        out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes over 3 steps of this "
+                                             "same command), (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch -- the gfx950 correction of MI355X_MICROARCH.md")
+    elif world == 1 and (B, S, h, hk, d, page) == (256, 4096, 32, 8, 128, 16):
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
             for kern, e in json.load(open(f)).items():
@@ -226,6 +234,52 @@ def main():
         print(json.dumps(out), flush=True)
 
 
+def measure_traffic(argv):
+    """HBM bytes per launch of the decode kernel from the PMC counters, collected as the MI355X guide prescribes: one
+    rocprofv3 --pmc pass per counter (FETCH_SIZE, WRITE_SIZE; KiB; on gfx950 FETCH_SIZE tallies a wide coalesced stream at
+    half its bytes), each over a short child run of this same command.  None when rocprofv3 is missing or anything fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    keep = [a for a in argv if a not in ("--no-extra", "--no-cpu-baseline", "--no-traffic")]
+    drop_next = False
+    child_args = []
+    for a in keep:                       # strip --steps / --warmup (and their values): the child runs 3 + 1
+        if drop_next:
+            drop_next = False
+            continue
+        if a in ("--steps", "--warmup"):
+            drop_next = True
+            continue
+        if a.startswith("--steps=") or a.startswith("--warmup="):
+            continue
+        child_args.append(a)
+    means = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="atoma_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--no-traffic"] + child_args
+            env = dict(os.environ, TMPDIR="/tmp", ATOMA_BENCH_CHILD="1")
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "paged_decode_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        vals.append(float(r["Counter_Value"]))
+            shutil.rmtree(d, ignore_errors=True)
+            if not vals:
+                return None
+            means[counter] = sum(vals) / len(vals)
+        return (2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     """The oracle's C restatement (fa_acausal over the gathered pages, f32, OpenMP) on the first
     `--cpu-sample-seqs` sequences of the same workload; throughput is per byte, so the sample
@@ -243,22 +297,18 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     bts = np.ascontiguousarray(bt[:Bs])
     ls = np.ascontiguousarray(lens[:Bs])
     i64 = C.c_int64
-    lib.oracle_attention.argtypes = [C.c_void_p] * 6 + [C.c_int] + [i64] * 12 + [C.c_int] * 4 + [
-        C.c_float, C.c_void_p, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.oracle_decode_grouped.argtypes = [C.c_void_p] * 6 + [i64, C.c_int, i64, i64, i64] + [C.c_int] * 4 + [C.c_float, C.c_int]
     lib.oracle_max_threads.restype = C.c_int
     avail = len(os.sched_getaffinity(0)) or 1
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
 
-    def run(cores):
-        lib.oracle_attention(vp(qs), vp(kc), vp(vc), vp(o), None, vp(ls), 0,
-                             h * d, page * hk * d, page * hk * d, h * d,
-                             h * d, hk * d, hk * d, h * d, d, d, d, d,
-                             Bs, h, hk, d, float(d ** -0.5), vp(bts), bts.shape[1], page, 1, bts.shape[1] * page,
-                             1, 0, cores)
+    def run(cores):       # one task per (sequence, kv head): K / V rows converted once for the whole query group, vectorised inner loops
+        lib.oracle_decode_grouped(vp(qs), vp(kc), vp(vc), vp(o), vp(ls), vp(bts), bts.shape[1], page, page * hk * d, hk * d, d,
+                                  Bs, h, hk, d, float(d ** -0.5), cores)
     # OpenMP scaling of this memory-streaming loop saturates well below the box's hardware-thread
     # count (256 on the MI355X host): pick the fastest thread count, then time it for ~10 s.
     forced = int(os.environ.get("ATOMA_BENCH_CPU_THREADS", 0))
-    cands = [forced] if forced else sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)})
+    cands = [forced] if forced else sorted({min(avail, c) for c in (16, 32, 64, 128, avail)})
     best = None
     for c in cands:
         run(c)                                                      # warm the page cache / thread pool
@@ -278,7 +328,9 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     return {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
             "host_hw_threads": avail,
             "sample": "first %d of %d sequences of the same workload (same tensors), %d repetitions, %.3f s each; "
-                      "fa_acausal f32 restatement (oracle/c/oracle.c, gcc -O3 -fopenmp)" % (Bs, args.batch, reps_done, dt),
+                      "fa_acausal f32 restatement, one task per (sequence, kv head), K/V rows converted once per query group, "
+                      "vectorised inner loops (oracle/c/oracle.c oracle_decode_grouped, gcc -O3 -march=x86-64-v3 -fopenmp); thread count = the "
+                      "fastest of 16/32/64/128/all" % (Bs, args.batch, reps_done, dt),
             "decode_tokens_per_s": round(Bs / dt, 1)}
 
 

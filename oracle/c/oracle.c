@@ -156,6 +156,73 @@ void oracle_attention(const uint16_t *q, const uint16_t *k, const uint16_t *v, u
     }
 }
 
+/*
+ * The same result definition specialised for what bench.py times on the host cores ("cpu_baseline"): paged decode
+ * (seqlen_q = 1, per-sequence lengths, bf16), written the way a CPU implementation of the path would be -- one task per
+ * (sequence, KV head); a K / V row is converted to f32 ONCE and used by all h / h_k query heads of the group; the inner
+ * loops over d are contiguous f32 loops the compiler vectorises (omp simd).  Two passes (scores, then exp / accumulate):
+ * the arithmetic of fa_acausal, only the summation order inside a dot product differs from oracle_attention (checked by
+ * tests/test_oracle_golden.py: identical after the one rounding except for boundary cases, never more than one unit).
+ */
+void oracle_decode_grouped(const uint16_t *q, const uint16_t *k, const uint16_t *v, uint16_t *o, const int32_t *seqlens_k,
+                           const int32_t *block_table, int64_t block_table_batch_stride, int page_block_size, int64_t page_stride,
+                           int64_t row_stride, int64_t head_stride, int b, int h, int h_k, int d, float softmax_scale, int num_threads) {
+    const int g = h / h_k;
+#ifdef _OPENMP
+    if (num_threads > 0) omp_set_num_threads(num_threads);
+#endif
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (int ib = 0; ib < b; ++ib) {
+        for (int ihk = 0; ihk < h_k; ++ihk) {
+            const int L = seqlens_k[ib];
+            uint16_t *ob = o + ((int64_t)ib * h + (int64_t)ihk * g) * d;
+            if (L <= 0) {
+                for (int c = 0; c < g * d; ++c) ob[c] = 0;
+                continue;
+            }
+            float *qf = (float *)malloc(sizeof(float) * (size_t)g * d);
+            float *sc = (float *)malloc(sizeof(float) * (size_t)g * L);
+            float *acc = (float *)calloc((size_t)g * d, sizeof(float));
+            float *row = (float *)malloc(sizeof(float) * (size_t)d);
+            float m[64], l[64];
+            for (int c = 0; c < g * d; ++c) qf[c] = bf16_to_f32(q[((int64_t)ib * h + (int64_t)ihk * g) * d + c]);
+            for (int a = 0; a < g; ++a) { m[a] = -INFINITY; l[a] = 0.f; }
+            for (int j = 0; j < L; ++j) {
+                const uint16_t *kr = k + (int64_t)block_table[ib * block_table_batch_stride + j / page_block_size] * page_stride +
+                                     (int64_t)(j % page_block_size) * row_stride + (int64_t)ihk * head_stride;
+#pragma omp simd
+                for (int c = 0; c < d; ++c) row[c] = bf16_to_f32(kr[c]);
+                for (int a = 0; a < g; ++a) {
+                    float s = 0.f;
+#pragma omp simd reduction(+ : s)
+                    for (int c = 0; c < d; ++c) s += qf[a * d + c] * row[c];
+                    s *= softmax_scale;
+                    sc[(int64_t)a * L + j] = s;
+                    if (s > m[a]) m[a] = s;
+                }
+            }
+            for (int j = 0; j < L; ++j) {
+                const uint16_t *vr = v + (int64_t)block_table[ib * block_table_batch_stride + j / page_block_size] * page_stride +
+                                     (int64_t)(j % page_block_size) * row_stride + (int64_t)ihk * head_stride;
+#pragma omp simd
+                for (int c = 0; c < d; ++c) row[c] = bf16_to_f32(vr[c]);
+                for (int a = 0; a < g; ++a) {
+                    const float p = expf(sc[(int64_t)a * L + j] - m[a]);
+                    l[a] += p;
+                    float *ac = acc + a * d;
+#pragma omp simd
+                    for (int c = 0; c < d; ++c) ac[c] += p * row[c];
+                }
+            }
+            for (int a = 0; a < g; ++a) {
+                const float inv = 1.f / l[a];
+                for (int c = 0; c < d; ++c) ob[a * d + c] = f32_to_bf16(acc[a * d + c] * inv);
+            }
+            free(qf); free(sc); free(acc); free(row);
+        }
+    }
+}
+
 /* csrc/kernels/cache_manager.cu:139-170 */
 void oracle_reshape_and_cache_flash(const uint16_t *key, const uint16_t *value, uint16_t *key_cache,
                                     uint16_t *value_cache, const int64_t *slot_mapping,

@@ -212,3 +212,31 @@ def test_rope_table_llama3_scaling_monotone_and_bounded():
     fs = NR.inv_freq(128, 500000.0, dict(factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
                                          original_max_position_embeddings=8192))
     assert np.all(fs <= f) and np.allclose(fs[:16], f[:16]) and np.allclose(fs[-1], f[-1] / 8)
+
+
+def test_c_grouped_decode_equals_the_plain_restatement():
+    """oracle_decode_grouped (what bench.py times on the host cores: KV rows converted once per query group, vectorised
+    loops) computes the same fa_acausal result as oracle_attention; only the order of the sums inside a dot product differs,
+    so after the one rounding the two agree bit for bit except for boundary cases, never by more than one unit."""
+    import ctypes as C
+    from util import oracle_c, rand_half, make_paged_cache, c_attention
+    lib = oracle_c()
+    rng = np.random.default_rng(6)
+    B, h, hk, d, page = 5, 8, 2, 128, 16
+    lens = np.array([0, 1, 33, 200, 517], np.int32)
+    nb = int(sum((L + page - 1) // page for L in lens)) + 2
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    sc = float(d ** -0.5)
+    ref = c_attention(q, kc, vc, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bt.shape[1] * page, scale=sc, is_bf16=1,
+                      q_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d), v_strides=(page * hk * d, hk * d, d),
+                      o_shape=q.shape, o_strides=(h * d, h * d, d), cu_k=lens, k_cumulative=False, block_table=bt, page=page)
+    out = np.zeros_like(q)
+    i64 = C.c_int64
+    lib.oracle_decode_grouped.argtypes = [C.c_void_p] * 6 + [i64, C.c_int, i64, i64, i64] + [C.c_int] * 4 + [C.c_float, C.c_int]
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    btc, lc = np.ascontiguousarray(bt, np.int32), np.ascontiguousarray(lens, np.int32)
+    lib.oracle_decode_grouped(vp(q), vp(kc), vp(vc), vp(out), vp(lc), vp(btc), btc.shape[1], page, page * hk * d, hk * d, d, B, h, hk, d, sc, 2)
+    diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.01
+    assert not out[0].any()

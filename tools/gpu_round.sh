@@ -1,15 +1,21 @@
 #!/bin/bash
-# One GPU-box pass: gpu tests, bench, rocprofv3 kernel-trace stats, PMC passes.  Run through gpurun:
-#   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh r01'
-TAG=${1:-r01}
+# One GPU-box pass: gpu tests, bench (with its in-run extras and PMC traffic), rocprofv3 kernel-trace stats, PMC passes,
+# per-kernel measurements, the C3-lite trace and the 70B step.  Run through gpurun:
+#   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r02'
+# then: python tools/summarize_profiles.py r02   (copies the summaries into profiles/)
+TAG=${1:-r02}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
-(timeout 900 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -150) > $OUT/pytest_gpu.log
-(timeout 300 python bench.py --steps 50 --warmup 5 2>&1 | tail -3) > $OUT/bench_$TAG.log
+(timeout 1200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -60) > $OUT/pytest_gpu_$TAG.log
+(timeout 600 python bench.py 2>&1 | tail -2) > $OUT/bench_$TAG.log
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o decode -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -o decode -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch_$TAG.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -o decode -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_write_$TAG.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o decode -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --no-traffic > $OUT/prof_$TAG.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -o decode -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-traffic > $OUT/pmc_fetch_$TAG.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -o decode -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-traffic > $OUT/pmc_write_$TAG.log 2>&1
 cd $REPO
-find $OUT/prof_$TAG -name "*stats*" | head; ls -R $OUT | head -50
+(timeout 1500 python tools/bench_kernels.py decode decode_fp8 prefill prefill_paged cache norm sampling linear linear_mid linear_big graph step swap prep 2>&1) > $OUT/kernels_$TAG.jsonl
+(timeout 400 python tools/engine_trace.py 2>&1 | tail -1) > $OUT/trace_$TAG.json
+(timeout 400 python tools/engine_trace.py --model 70b-tp8-shard --requests 64 --prompt 4096 --decode-steps 256 2>&1 | tail -1) > $OUT/trace_70b_tp8_rank_$TAG.json
+(timeout 400 python tools/tp_step.py --steps 10 2>&1 | tail -1) > $OUT/tp_step_n1_$TAG.json
+find $OUT/prof_$TAG -name "*stats*" | head; tail -3 $OUT/pytest_gpu_$TAG.log; cat $OUT/bench_$TAG.log | cut -c1-600
