@@ -1137,6 +1137,236 @@ __global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodePar
     decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_mqk_item<T, G, P, NT>(pp, wk); });
 }
 
+// fp8 KV cache with q.K^T on the matrix cores (the VALU-bound dot2 variant above reaches 0.57 of HBM: the conversions and the
+// same dot products now fall on half the bytes).  Layout (lane = 16.grp + col), a 16-token tile = 2 + 2 loads of 16 bytes:
+//   * K load j: lane reads token `col`, bytes [64 j + 16 grp, + 16) of its 128-byte row -> 16 elements = the A operands of MFMA
+//     k-steps 2j and 2j + 1 (8 elements each); the k-slot <-> d mapping is a permutation of d, so Q^T is simply loaded with the
+//     same permutation: lane (grp, head col) holds q[d = 64 j + 16 grp + 8 u ..+7] for k-step 2j + u;
+//   * result: S^T[token 4.grp + i][head col], i = 0..3 -- one head per lane, softmax state two scalars per lane;
+//   * V load j: lane reads row 4.grp + 2j + (col >> 3), 16-byte chunk col & 7 (a wave instruction = 8 full 128-byte rows); the
+//     two rows a lane holds (j = 0, 1) form the token pair of the P.V dot2, and both belong to the lane's own 16-lane DPP row,
+//     where their probabilities live: head h's packed pair comes from lane (grp, h) by one row_newbcast.
+// ~140 VALU instructions per 4 KiB tile at 4 heads instead of ~250.
+template <typename T, int G, int P, bool NT>
+__device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p, const DecodeWork &wk) {
+    constexpr int D = 128;
+    const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15, vhalf = col >> 3, vc = col & 7;
+    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
+    const bool partial = wk.partial;
+    const int hq0 = hk * p.g + gc * G;
+    const int nq = min(G, p.g - gc * G);
+    const float sl2 = p.scale_log2 * load_ro(p.k_scale + hk);
+    float m = -INFINITY, l = 0.f;        // head `col`, this lane group's 4 tokens per tile
+    float o[G][16];                      // O[head][d = 16.vc ..+15] over this lane's two rows per tile
+#pragma unroll
+    for (int h = 0; h < G; ++h)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[h][e] = 0.f;
+
+    if (t0 < t1) {
+        u32x4 qb[4];                     // Q^T operand of k-step s = 2j + u: q[head col][64 j + 16 grp + 8 u ..+7]
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            qb[s4] = u32x4{0, 0, 0, 0};
+            if (col < nq)
+                qb[s4] = *reinterpret_cast<const u32x4 *>(p.q + (int64_t)b * p.q_batch_stride + (int64_t)(hq0 + col) * p.q_head_stride +
+                                                          64 * (s4 >> 1) + 16 * grp + 8 * (s4 & 1));
+        }
+        const uint32_t tpp = (uint32_t)(p.page_size >> 4);
+        const uint32_t tpp_magic = tpp > 1 ? (uint32_t)((0x100000000ull + tpp - 1) / tpp) : 0u;
+        const int last_pg = (L + p.page_size - 1) / p.page_size - 1;
+        const int *bt_row = p.block_table + (int64_t)b * p.block_table_batch_stride;
+        const char *kbase = reinterpret_cast<const char *>(p.k) + (int64_t)hk * p.k_head_stride;
+        const char *vbase = reinterpret_cast<const char *>(p.v) + (int64_t)hk * p.v_head_stride;
+        const int64_t k_row_bytes = p.k_row_stride, v_row_bytes = p.v_row_stride;
+        const int64_t k_page_bytes = p.k_batch_stride, v_page_bytes = p.v_batch_stride;
+        const uint32_t k_lane_off = (uint32_t)(col * k_row_bytes + grp * 16);                      // + 64 j
+        const uint32_t v_lane_off = (uint32_t)((4 * grp + vhalf) * v_row_bytes + vc * 16);         // + 2 j rows
+        auto page_of = [&](int tile, uint32_t &tip) -> int {
+            if (tpp == 1) { tip = 0; return tile; }
+            const uint32_t pg = __umulhi((uint32_t)tile, tpp_magic);
+            tip = (uint32_t)tile - pg * tpp;
+            return (int)pg;
+        };
+        auto fetch_pid = [&](int tile) -> int {
+            uint32_t tip;
+            const int pg = min(page_of(tile, tip), last_pg);
+            return load_ro(bt_row + pg);
+        };
+        constexpr int AUX = NT ? 2 : 0;
+        auto issue = [&](u32x4 (&kb)[2], u32x4 (&vb)[2], int tile, int pid) {
+            uint32_t tip;
+            (void)page_of(tile, tip);
+            const char *kt = kbase + (int64_t)pid * k_page_bytes + (int64_t)(tip << 4) * k_row_bytes;
+            const char *vt = vbase + (int64_t)pid * v_page_bytes + (int64_t)(tip << 4) * v_row_bytes;
+            const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(kt), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vt), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) kb[j] = __builtin_amdgcn_raw_buffer_load_b128(kr, k_lane_off, j * 64, AUX);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) vb[j] = __builtin_amdgcn_raw_buffer_load_b128(vr, v_lane_off, (int)(2 * j * v_row_bytes), AUX);
+        };
+        auto compute = [&](const u32x4 (&kb)[2], const u32x4 (&vb)[2], int tile) {
+            f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t kk[8];
+                fp8x16_to_pairs<T>(kb[j], kk);
+                acc = mfma16<T>(u32x4{kk[0], kk[1], kk[2], kk[3]}, qb[2 * j], acc);
+                acc = mfma16<T>(u32x4{kk[4], kk[5], kk[6], kk[7]}, qb[2 * j + 1], acc);
+            }
+            float s[4];
+            const int tok0 = (tile << 4) + 4 * grp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] = acc[i] * sl2;
+            if ((tile << 4) + 16 > L) {  // wave-uniform: ragged last tile
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (tok0 + i >= L) s[i] = -INFINITY;
+            }
+            const float mnew = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), m);
+            if (__any(mnew > m)) {
+                const float ms = mnew == -INFINITY ? 0.f : mnew;
+                const float alpha = __builtin_amdgcn_exp2f(m - ms);
+                l *= alpha;
+                m = mnew;
+                decode_static_for<0, G>([&](auto Hc) {
+                    constexpr int h = decltype(Hc)::value;
+                    const float ah = row_bcastf<h>(alpha);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[h][e] *= ah;
+                });
+            }
+            const float ms = m == -INFINITY ? 0.f : m;
+            float pr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pr[i] = __builtin_amdgcn_exp2f(s[i] - ms);
+            l += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+            // token pairs of the V rows a lane holds: (4 grp + vhalf, 4 grp + 2 + vhalf)
+            const uint32_t pk_even = pack_pair<T>(pr[0], pr[2]), pk_odd = pack_pair<T>(pr[1], pr[3]);
+            uint32_t ph[G];
+            decode_static_for<0, G>([&](auto Hc) {
+                constexpr int h = decltype(Hc)::value;
+                const uint32_t e0 = row_bcast<h>(pk_even), e1 = row_bcast<h>(pk_odd);
+                ph[h] = vhalf ? e1 : e0;
+            });
+            uint32_t va[8], vc2[8];
+            fp8x16_to_pairs<T>(vb[0], va);
+            fp8x16_to_pairs<T>(vb[1], vc2);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const uint32_t lo = __builtin_amdgcn_perm(vc2[w], va[w], 0x05040100u);
+                const uint32_t hi = __builtin_amdgcn_perm(vc2[w], va[w], 0x07060302u);
+#pragma unroll
+                for (int h = 0; h < G; ++h) {
+                    o[h][2 * w] = dot2<T>(lo, ph[h], o[h][2 * w]);
+                    o[h][2 * w + 1] = dot2<T>(hi, ph[h], o[h][2 * w + 1]);
+                }
+            }
+        };
+        u32x4 kb[P][2], vb[P][2];
+        int pid[P];
+        int t = t0;
+        if (t0 + 2 * P <= t1) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                issue(kb[s], vb[s], t0 + s, pid[s]);
+                pid[s] = fetch_pid(t0 + s + P);
+            }
+            for (; t + 2 * P <= t1; t += P) {
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    compute(kb[s], vb[s], t + s);
+                    issue(kb[s], vb[s], t + s + P, pid[s]);
+                    pid[s] = fetch_pid(t + s + 2 * P);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
+#pragma unroll
+            for (int s = 0; s < P; ++s)
+                if (t0 + s < t1) {
+                    issue(kb[s], vb[s], t0 + s, pid[s]);
+                    pid[s] = fetch_pid(t0 + s + P);
+                }
+        }
+        for (; t < t1; t += P) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                if (t + s < t1) {
+                    compute(kb[s], vb[s], t + s);
+                    if (t + s + P < t1) {
+                        issue(kb[s], vb[s], t + s + P, pid[s]);
+                        pid[s] = fetch_pid(t + s + 2 * P);
+                    }
+                }
+            }
+        }
+    }
+    // ---- merge: the 4 lane groups' (m, l) of head col; O over the 8 (grp, vhalf) row sets ----
+    float mt = m;
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float wgt = __builtin_amdgcn_exp2f(m - (mt == -INFINITY ? 0.f : mt));   // this lane group's weight for head col
+    float lt = l * wgt;
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    float mh[G], lh[G];
+    decode_static_for<0, G>([&](auto Hc) {
+        constexpr int h = decltype(Hc)::value;
+        const float wh = row_bcastf<h>(wgt);     // the group's weight for head h (same for both halves of the DPP row)
+        mh[h] = row_bcastf<h>(mt);
+        lh[h] = row_bcastf<h>(lt);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float x = o[h][e] * wh;
+            x += __shfl_xor(x, 8, 64);           // the other row of the pair set
+            x += __shfl_xor(x, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            o[h][e] = x;
+        }
+    });
+    if (lane >= 8) return;                       // lanes 0..7: d chunks 0..7
+    const float vs = load_ro(p.v_scale + hk);
+#pragma unroll
+    for (int h = 0; h < G; ++h) {
+        if (h >= nq) continue;
+        const int hq = hq0 + h;
+        const bool empty = !(lh[h] > 0.f);
+        const float inv = empty ? 0.f : vs / lh[h];
+        const float lse = empty ? INFINITY : (mh[h] + __builtin_amdgcn_logf(lh[h])) * 0.6931471805599453f;
+        if (!partial) {
+            uint4 w4[2];
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                w4[hlf].x = pack2<T>(o[h][8 * hlf + 0] * inv, o[h][8 * hlf + 1] * inv);
+                w4[hlf].y = pack2<T>(o[h][8 * hlf + 2] * inv, o[h][8 * hlf + 3] * inv);
+                w4[hlf].z = pack2<T>(o[h][8 * hlf + 4] * inv, o[h][8 * hlf + 5] * inv);
+                w4[hlf].w = pack2<T>(o[h][8 * hlf + 6] * inv, o[h][8 * hlf + 7] * inv);
+            }
+            uint4 *dst = reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + vc * 16);
+            dst[0] = w4[0];
+            dst[1] = w4[1];
+            if (p.lse && vc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
+        } else {
+            const int64_t row = wk.prow + h;
+            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + vc * 16);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                dst[q4] = make_float4(o[h][4 * q4] * inv, o[h][4 * q4 + 1] * inv, o[h][4 * q4 + 2] * inv, o[h][4 * q4 + 3] * inv);
+            if (vc == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
+        }
+    }
+}
+
+template <typename T, int G, int P, bool NT, bool STREAM>
+__global__ void __launch_bounds__(64, 2) paged_decode_fp8_mqk_kernel(const DecodeParams p) {
+    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_mqk_item<T, G, P, NT>(pp, wk); });
+}
+
 // LSE-weighted merge of the split partials: /root/reference/csrc/kernels/flash_fwd_kernel.h:1204-1236.
 // One wavefront per (b, q head); lane i owns D/64 output pairs.
 template <typename T, int D>
@@ -1273,6 +1503,7 @@ struct DecodeOptions {
     opt_int stream_waves_per_cu{env_int("ATOMA_DECODE_STREAM_WAVES_PER_CU", 0)};   // 0 = resident capacity
     opt_int waves_per_cu{env_int("ATOMA_DECODE_WAVES_PER_CU", 0)};   // 0 = resident capacity
     opt_int min_tiles{env_int("ATOMA_DECODE_MIN_TILES", 8)};
+    opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
     opt_int mqk{env_int("ATOMA_DECODE_MQK", 5)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches
 };
 static DecodeOptions &decode_options() {
@@ -1290,6 +1521,7 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_waves_per_cu") o.waves_per_cu = value;
     else if (name == "decode_min_tiles") o.min_tiles = value;
     else if (name == "decode_mqk") o.mqk = value;
+    else if (name == "decode_fp8_mqk") o.fp8_mqk = value;
     else return false;
     return true;
 }
@@ -1456,7 +1688,9 @@ static void launch_decode_fp8_g(DecodeParams &p, hipStream_t stream) {
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
     if (p.stream_waves > 0) set_stream_waves(p, 8);   // __launch_bounds__(64, 2)
     const bool nt = decode_options().nt != 0;
-#define ATOMA_F8(NT_, S_) hipLaunchKernelGGL((paged_decode_fp8_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p)
+    const bool mqk = decode_options().fp8_mqk != 0;
+#define ATOMA_F8(NT_, S_) do { if (mqk) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p); \
+                               else hipLaunchKernelGGL((paged_decode_fp8_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p); } while (0)
     if (nt) { if (p.stream_waves > 0) ATOMA_F8(true, true); else ATOMA_F8(true, false); }
     else { if (p.stream_waves > 0) ATOMA_F8(false, true); else ATOMA_F8(false, false); }
 #undef ATOMA_F8

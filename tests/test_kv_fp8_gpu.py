@@ -103,9 +103,17 @@ def oracle_decode(q, kc8, vc8, ks, vs, bt, lens, scale, dtype):
     return from_f32(out, dtype)
 
 
+@pytest.fixture(params=[1, 0], ids=["mfma-qk", "dot2-qk"])
+def qk_variant(gpu, request):
+    """both fp8 decode kernels: q.K^T on the matrix cores (default) and on v_dot2c"""
+    assert gpu.lib.atoma_set_option(b"decode_fp8_mqk", request.param) == 0
+    yield request.param
+    gpu.lib.atoma_set_option(b"decode_fp8_mqk", 1)
+
+
 @pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("h,hk,page", [(32, 8, 16), (8, 8, 16), (16, 8, 32), (6, 2, 16), (16, 2, 64)])
-def test_decode_fp8_matches_oracle_ragged(gpu, dtype, h, hk, page):
+def test_decode_fp8_matches_oracle_ragged(gpu, qk_variant, dtype, h, hk, page):
     """group sizes 1, 2, 3, 4 and 8 (two chunks of 4), pages of 16 / 32 / 64, ragged lengths incl. the empty sequence"""
     rng = np.random.default_rng(h * 3 + hk + page)
     d = 128
@@ -121,7 +129,7 @@ def test_decode_fp8_matches_oracle_ragged(gpu, dtype, h, hk, page):
     assert not out[0].any(), "empty sequence must produce exact zeros"
 
 
-def test_decode_fp8_split_kv_balanced_and_invariants(gpu):
+def test_decode_fp8_split_kv_balanced_and_invariants(gpu, qk_variant):
     rng = np.random.default_rng(9)
     h, hk, d, page = 32, 8, 128, 16
     # (a) one long sequence: split over many wavefronts + combine
