@@ -202,24 +202,34 @@ __device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, in
 // `item(p, wk)` is inlined exactly once.  In the balanced variant the kernel arguments are re-read through a pointer
 // the compiler cannot see through at the top of every segment: hoisting every field of DecodeParams out of the
 // segment loop costs ~20 SGPRs more than the 102 there are and the spills (v_readlane in the tile loop) cost 5 %.
-template <bool STREAM, typename F> __device__ __forceinline__ void decode_run_items(const DecodeParams &p0, F &&item) {
+// NWG wavefronts per workgroup (default 1): wavefront index = blockIdx.x * NWG + wave.  Consecutive indices are the kv heads
+// of ONE sequence, so a workgroup of NWG wavefronts reads NWG adjacent head slices of every token row from one CU at about
+// the same time -- with 128-byte slices (fp8 cache, or d = 64 at 16 bits) a lone wavefront fetches half of a 256-byte
+// DRAM granule and its neighbour, dispatched to another XCD (block index % 8), fetches the other half some time later.
+template <bool STREAM, int NWG = 1, typename F> __device__ __forceinline__ void decode_run_items(const DecodeParams &p0, F &&item) {
     DecodeWork wk;
+    const int wid = NWG == 1 ? (int)blockIdx.x : (int)blockIdx.x * NWG + (int)(threadIdx.x >> 6);
+    if (NWG > 1 && (int64_t)wid >= (int64_t)p0.b * p0.num_splits * p0.h_k * p0.gchunks) return;
     if constexpr (!STREAM) {
-        decode_map_work(p0, blockIdx.x, wk);
+        decode_map_work(p0, wid, wk);
         item(p0, wk);
     } else {
         __shared__ int cum[DECODE_STREAM_MAX_B + 1];
         const DecodePlan pl = decode_make_plan(p0, cum);
-        if (blockIdx.x == 0) {   // for the combine kernel
-            for (int i = threadIdx.x; i <= p0.b; i += 64) p0.plan[2 + i] = cum[i];
-            if (threadIdx.x == 0) { p0.plan[0] = pl.T; p0.plan[1] = pl.stream ? 1 : 0; }
+        if (wid == 0) {   // for the combine kernel
+            for (int i = threadIdx.x & 63; i <= p0.b; i += 64) p0.plan[2 + i] = cum[i];
+            if ((threadIdx.x & 63) == 0) { p0.plan[0] = pl.T; p0.plan[1] = pl.stream ? 1 : 0; }
         }
         const bool stream = pl.stream;
+        // position of this wavefront on the line.  The line is kv-head major, so wavefronts w and w + W / 8 walk the same
+        // sequences of adjacent heads: with 8 wavefronts per workgroup, give the 8 of a workgroup those ranges (W is a multiple of 8)
+        if (stream && wid >= p0.stream_waves) return;      // the line is shared by stream_waves wavefronts; the grid may hold more
+        const int lw = NWG == 1 ? wid : (wid % NWG) * (p0.stream_waves / NWG) + wid / NWG;
         int pos = 0, end = 1, hkc = 0, r = 0, b = 0;       // host guarantees total < 2^31
         bool first = true;
         if (stream) {
             const int64_t total = (int64_t)pl.T * p0.h_k * p0.gchunks;
-            const int64_t start = (int64_t)blockIdx.x * pl.share;
+            const int64_t start = (int64_t)lw * pl.share;
             if (start >= total) return;
             pos = (int)start;
             end = (int)min(start + pl.share, total);
@@ -251,9 +261,9 @@ template <bool STREAM, typename F> __device__ __forceinline__ void decode_run_it
                 wk.t1 = wk.t0 + seg;
                 wk.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + b) : 0;
                 wk.partial = seg != wk.n_tiles;
-                wk.prow = ((int64_t)blockIdx.x * 2 + (first ? 0 : 1)) * p.group_tile;
+                wk.prow = ((int64_t)lw * 2 + (first ? 0 : 1)) * p.group_tile;
             } else {
-                decode_map_work(p, blockIdx.x, wk);   // one wavefront per (sequence, kv head), final output
+                decode_map_work(p, wid, wk);   // one wavefront per (sequence, kv head), final output
             }
             item(p, wk);
             if (!stream) break;
@@ -613,7 +623,7 @@ __device__ __forceinline__ void paged_decode_fp8_item(const DecodeParams &p, con
     constexpr int D = 128;
     constexpr int LPR = 8;         // lanes per 128-byte row
     constexpr int RPI = 8;         // rows per load instruction
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, dc = lane % LPR;   // row of the 8-row slab, 16-element chunk of the row
 
     const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
@@ -1150,7 +1160,7 @@ __global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodePar
 template <typename T, int G, int P, bool NT>
 __device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p, const DecodeWork &wk) {
     constexpr int D = 128;
-    const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15, vhalf = col >> 3, vc = col & 7;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, col = lane & 15, vhalf = col >> 3, vc = col & 7;
     const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
     const bool partial = wk.partial;
     const int hq0 = hk * p.g + gc * G;
@@ -1362,9 +1372,9 @@ __device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p,
     }
 }
 
-template <typename T, int G, int P, bool NT, bool STREAM>
-__global__ void __launch_bounds__(64, 2) paged_decode_fp8_mqk_kernel(const DecodeParams p) {
-    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_mqk_item<T, G, P, NT>(pp, wk); });
+template <typename T, int G, int P, bool NT, bool STREAM, int NWG = 1>
+__global__ void __launch_bounds__(64 * NWG, 2) paged_decode_fp8_mqk_kernel(const DecodeParams p) {
+    decode_run_items<STREAM, NWG>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_mqk_item<T, G, P, NT>(pp, wk); });
 }
 
 // LSE-weighted merge of the split partials: /root/reference/csrc/kernels/flash_fwd_kernel.h:1204-1236.
@@ -1503,6 +1513,7 @@ struct DecodeOptions {
     opt_int stream_waves_per_cu{env_int("ATOMA_DECODE_STREAM_WAVES_PER_CU", 0)};   // 0 = resident capacity
     opt_int waves_per_cu{env_int("ATOMA_DECODE_WAVES_PER_CU", 0)};   // 0 = resident capacity
     opt_int min_tiles{env_int("ATOMA_DECODE_MIN_TILES", 8)};
+    opt_int fp8_wg{env_int("ATOMA_DECODE_FP8_WG", 1)};     // fp8 KV cache: 8 wavefronts (the kv heads of a sequence) per workgroup: 0 never, 1 split-KV launches, 2 always
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
     opt_int mqk{env_int("ATOMA_DECODE_MQK", 5)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches
 };
@@ -1522,6 +1533,7 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_min_tiles") o.min_tiles = value;
     else if (name == "decode_mqk") o.mqk = value;
     else if (name == "decode_fp8_mqk") o.fp8_mqk = value;
+    else if (name == "decode_fp8_wg") o.fp8_wg = value;
     else return false;
     return true;
 }
@@ -1689,7 +1701,13 @@ static void launch_decode_fp8_g(DecodeParams &p, hipStream_t stream) {
     if (p.stream_waves > 0) set_stream_waves(p, 8);   // __launch_bounds__(64, 2)
     const bool nt = decode_options().nt != 0;
     const bool mqk = decode_options().fp8_mqk != 0;
-#define ATOMA_F8(NT_, S_) do { if (mqk) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p); \
+    // 8 wavefronts per workgroup = the 8 kv-head slices (128 B each) of every token row read from one CU: whole 1 KiB rows
+    // (measured: uniform resident batches +7 %, split-KV batches +20 %; ragged batches in the balanced mode -15 %, where a
+    // workgroup's 8 wavefronts walk unrelated ranges -- so by default only launches that cannot take the balanced mode)
+    const int wg_opt = decode_options().fp8_wg;
+    const bool wg8 = mqk && ((int64_t)p.h_k * p.gchunks) % 8 == 0 && (wg_opt >= 2 || (wg_opt == 1 && p.stream_waves == 0));
+#define ATOMA_F8(NT_, S_) do { if (wg8) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, 3, NT_, S_, 8>), dim3((unsigned)cdiv(blocks, 8)), dim3(512), 0, stream, p); \
+                               else if (mqk) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p); \
                                else hipLaunchKernelGGL((paged_decode_fp8_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p); } while (0)
     if (nt) { if (p.stream_waves > 0) ATOMA_F8(true, true); else ATOMA_F8(true, false); }
     else { if (p.stream_waves > 0) ATOMA_F8(false, true); else ATOMA_F8(false, false); }

@@ -364,7 +364,8 @@ int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int6
  * (sequence, kv head)), "decode_stream_waves_per_cu", "decode_waves_per_cu" / "decode_min_tiles" (KV split
  * heuristic), "decode_mqk" (q.K^T on the matrix cores at head_dim 128: bit 0 = groups of more than 4 q heads per kv
  * head, bit 1 = smaller groups, bit 2 = groups of 2..4 when b * h_k <= 64; default 5), "decode_fp8_mqk" (fp8 KV cache: 1 = q.K^T of
- * the converted K on the matrix cores [default], 0 = v_dot2c).  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
+ * the converted K on the matrix cores [default], 0 = v_dot2c), "decode_fp8_wg" (fp8: the 8 kv-head wavefronts of a sequence in one
+ * workgroup: 0 never, 1 split-KV launches [default], 2 always).  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
  * software-pipelined one-wave-per-SIMD kernel).  Defaults also come from ATOMA_DECODE_{P,NT,STREAM,WAVES_PER_CU,
  * MIN_TILES,MQK}; ATOMA_PREFILL_CFG overrides "prefill_cfg". */
 int atoma_set_option(const char *name, int value);
