@@ -27,6 +27,7 @@ struct AttnParams {
     int is_seqlens_k_cumulative;
     int is_causal;
     int unpadded_lse;
+    int pp_pair;                     // prefill ping-pong variant: which wavefronts of a workgroup are treated as SIMD partners
     float scale, scale_log2;
 };
 

@@ -300,8 +300,9 @@ __device__ __forceinline__ bool pf_map_workgroup(const AttnParams &p, int block_
 }
 
 // W waves per workgroup (32 query rows each), NB LDS tile buffers (prefetch distance NB - 1).
-template <typename T, int D, bool CAUSAL, int W, int NB>
+template <typename T, int D, bool CAUSAL, int W, int NB, bool PP = false>
 __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParams p) {
+    const int pf_pp_pair = PP ? p.pp_pair : 0;
     constexpr int PF_BM = 32 * W;
     constexpr int NDMA2 = 2 * PfLoader<D, W>::NDMA;   // DMA instructions per wave per tile (K and V)
     constexpr int ROWB = D * 2;                     // bytes per tile row
@@ -522,6 +523,54 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
         }
     };
 
+    if constexpr (PP) {
+        // ---- ping-pong (W = 8, NB = 4): the two wavefronts of a SIMD (waves w and w + 4: rows 0..127 and 128..255 of the block)
+        // alternate -- while one issues the 32 MFMAs of a tile (P.V of the previous tile, then Q.K^T of this one), the other
+        // runs the softmax VALU stream of its tile; a workgroup barrier after every half step keeps them in opposite phases, so
+        // the matrix pipe of the SIMD sees the two wavefronts' MFMA bursts back to back instead of two wavefronts that
+        // drift into the same phase (measured on the 2 x 4-wave layout: MFMA time and VALU time of a SIMD add up).
+        //   half step hs:  set 0: even -> M(hs / 2), odd -> V((hs - 1) / 2);   set 1 one half step later.
+        //   M(t) = PV(t - 1) + QK(t);  V(t) = mask + online softmax of tile t (rescales O).
+        // K/V tile t lives in ring slot t % 4 from half step 2t to 2t + 3; tile hs / 2 + 2 is requested at even hs (its slot
+        // was released by the barrier of half step hs - 1), i.e. two tile times ahead of its first use.
+        static_assert(!PP || (W == 8 && NB == 4), "ping-pong layout");
+        // which two wavefronts share a SIMD depends on how the dispatcher deals a workgroup's wavefronts to the SIMDs:
+        // pp_pair 0 -> (w, w + 4), 1 -> (2k, 2k + 1) (measured: see DESIGN.md 4.2)
+        const int set = pf_pp_pair ? (wave & 1) : (wave >> 2);
+        f32x16_v s[2];
+        uint4 pp[2][2];
+        if (0 < n_tiles) ld.issue(0, smem);
+        if (1 < n_tiles) ld.issue(1, smem + 2 * TILEB);
+        if (n_tiles > 1) dma_wait_keep<NDMA2>(); else dma_wait_all();
+        __syncthreads();
+        const int last_hs = 2 * n_tiles + 1;
+        for (int hs = 0; hs <= last_hs; ++hs) {
+            if ((hs & 1) == 0) {
+                const int nt = (hs >> 1) + 2;
+                if (nt < n_tiles) ld.issue(nt, smem + (nt & 3) * 2 * TILEB);
+            }
+            const int my = hs - set;                         // this set's own half-step counter
+            if (my >= 0 && my <= 2 * n_tiles) {
+                const int t = my >> 1;
+                if ((my & 1) == 0) {                         // M phase of tile t
+                    if (t >= 1 && (t - 1) * PF_BN < n_end_w) pv_tile(smem_lds + ((t - 1) & 3) * 2 * TILEB + TILEB, pp);
+                    __builtin_amdgcn_sched_barrier(0);       // keep the K fragments of QK out of PV's register budget
+                    if (t < n_tiles && t * PF_BN < n_end_w) qk_tile(smem_lds + (t & 3) * 2 * TILEB, s);
+                } else if (t < n_tiles && t * PF_BN < n_end_w) {   // V phase of tile t
+                    softmax_tile(s, t * PF_BN, pp);
+                }
+            }
+            // tile (hs + 1) / 2 is first read in the next half step when that one is even: its DMAs (requested two tiles ago)
+            // must have landed; the one requested after it may stay in flight
+            if (hs & 1) {
+                const int need = (hs + 1) >> 1;
+                if (need < n_tiles) {
+                    if (need + 1 < n_tiles) dma_wait_keep<NDMA2>(); else dma_wait_all();
+                }
+            }
+            __syncthreads();
+        }
+    } else {
     // LDS ring of NB tiles, prefetch distance NB - 1, ONE barrier per tile:
     //   wait for this wave's pieces of tile t (later tiles may stay in flight) -> barrier (everyone's
     //   pieces of tile t are in LDS, and everyone is done reading tile t-1) -> issue tile t+NB-1 into the
@@ -564,6 +613,7 @@ __global__ void __launch_bounds__(64 * W, 2) prefill_mfma_kernel(const AttnParam
         buf = buf + 1 == NB ? 0 : buf + 1;
     }
 
+    }
 #ifdef PF_TIMING
     if (p.lse && tid == 0) {
         tacc[5] = (float)n_tiles;
@@ -1042,7 +1092,7 @@ bool prefill_mfma_supported(const AttnParams &p) {
     return (p.d == 64 || p.d == 128) && p.alibi_slopes == nullptr && p.seqlen_q > 1;
 }
 
-template <typename T, int D, bool CAUSAL, int W, int NB>
+template <typename T, int D, bool CAUSAL, int W, int NB, bool PP = false>
 static void launch_pf_cfg(const AttnParams &p, hipStream_t stream) {
 #ifdef PF_TIMING   // ATOMA_PF_ONE_WG=1: pad the LDS request so that only one workgroup fits a CU (occupancy experiment)
     static const int pad = getenv("ATOMA_PF_ONE_WG") ? 96 * 1024 - NB * 2 * PF_BN * D * 2 : 0;
@@ -1052,14 +1102,14 @@ static void launch_pf_cfg(const AttnParams &p, hipStream_t stream) {
 #endif
     static bool attr_set = false;  // up to 96 KiB: above the default dynamic-LDS limit
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL, W, NB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL, W, NB, PP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     const int64_t m_blocks = cdiv(p.seqlen_q, 32 * W), n_units = (int64_t)p.b * p.h;
     const int64_t nu_max = n_units / 8 + (n_units % 8 ? 1 : 0);
     dim3 grid((unsigned)(8 * nu_max * m_blocks));   // padded: see the mapping comment in the kernel
-    hipLaunchKernelGGL((prefill_mfma_kernel<T, D, CAUSAL, W, NB>), grid, dim3(64 * W), smem, stream, p);
+    hipLaunchKernelGGL((prefill_mfma_kernel<T, D, CAUSAL, W, NB, PP>), grid, dim3(64 * W), smem, stream, p);
     ATOMA_CHECK_LAUNCH("prefill_mfma_kernel");
 }
 
@@ -1094,6 +1144,13 @@ template <typename T, int D, bool CAUSAL>
 static void launch_pf(const AttnParams &p, hipStream_t stream) {
     switch (prefill_cfg_effective()) {
         case 2: launch_pf_pipe<T, D, CAUSAL, 2>(p, stream); break;
+        case 3: {                                                              // 8-wave ping-pong (see the kernel)
+            static const int pair = [] { const char *e = getenv("ATOMA_PREFILL_PP_PAIR"); return e ? atoi(e) : 0; }();
+            AttnParams q = p;
+            q.pp_pair = pair;
+            launch_pf_cfg<T, D, CAUSAL, 8, 4, true>(q, stream);
+            break;
+        }
         default: launch_pf_cfg<T, D, CAUSAL, 4, 2>(p, stream); break;
     }
 }
