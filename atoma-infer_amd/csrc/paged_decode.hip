@@ -1538,6 +1538,14 @@ bool set_decode_option(const std::string &name, int value) {
     return true;
 }
 
+// Combine grid: one wavefront merges the pieces of one (sequence, q head) -- a chain of dependent loads (plan -> LSEs -> partial rows,
+// ~3 us).  In a ragged batch nearly every (sequence, kv head) is cut once, so all b.h rows merge: with 4 workgroups per CU the
+// 8192 rows of the 8B step took 8 rounds = 25.6 us per layer (rocprofv3 on the decode step); 32 per CU take one or two.
+static int combine_grid_cap() {
+    static const int per_cu = env_int("ATOMA_DECODE_COMBINE_WG_PER_CU", 32);
+    return device_num_cus() * std::max(1, per_cu);
+}
+
 // Balanced mode: as many wavefronts share the batch as THIS kernel keeps resident (its register count decides: 8 per CU
 // for the 4-head variants, 12 for one head per wavefront); the workspace was sized for the upper bound of 16.
 #define DECODE_STREAM_MAX_WAVES_PER_CU 16
@@ -1577,7 +1585,7 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
 #undef ATOMA_MQK
     if (!ATOMA_CHECK_LAUNCH("paged_decode_mqk_kernel")) return;
     if (p.num_splits > 1 || p.stream_waves > 0) {
-        hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, 4 * device_num_cus())), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
 }
@@ -1600,7 +1608,7 @@ static void launch_decode_tdg(DecodeParams &p, hipStream_t stream) {
     }
     if (!ATOMA_CHECK_LAUNCH("paged_decode_kernel")) return;
     if (p.num_splits > 1 || p.stream_waves > 0) {
-        hipLaunchKernelGGL((decode_combine_kernel<T, D>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, 4 * device_num_cus())), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((decode_combine_kernel<T, D>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
 }
@@ -1714,7 +1722,7 @@ static void launch_decode_fp8_g(DecodeParams &p, hipStream_t stream) {
 #undef ATOMA_F8
     if (!ATOMA_CHECK_LAUNCH("paged_decode_fp8_kernel")) return;
     if (p.num_splits > 1 || p.stream_waves > 0) {
-        hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, 4 * device_num_cus())), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
 }
