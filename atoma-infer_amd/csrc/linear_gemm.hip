@@ -204,6 +204,20 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
     return 0;
 }
 
+// atoma_release_workspaces(): the per-stream 64 MiB workspaces of the vendor GEMM go with the library's own scratch
+// (stream handles are recycled by the runtime, so a long-lived process that creates and destroys streams would otherwise
+// accumulate one workspace per handle value ever seen)
+int release_gemm_workspaces() {
+    std::lock_guard<std::mutex> lock(*g_lt_mu);
+    int rc = 0;
+    for (auto &dev : *g_lt_devices) {
+        for (auto &ws : dev.second.workspaces)
+            if (ws.second && hipFree(ws.second) != hipSuccess) { (void)hipGetLastError(); rc = -1; }
+        dev.second.workspaces.clear();
+    }
+    return rc;
+}
+
 // batches up to this many rows take the weight-streaming kernel (measured crossover, tools/bench_kernels.py linear)
 static const int linear_stream_max_batch = getenv("ATOMA_LINEAR_STREAM_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_STREAM_MAX_BATCH")) : 4;
 

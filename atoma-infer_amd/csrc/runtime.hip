@@ -87,6 +87,7 @@ void *workspace(hipStream_t stream, size_t bytes) {
 }
 
 size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k);   // paged_decode.hip
+int release_gemm_workspaces();                                                       // linear_gemm.hip
 
 // /root/reference/csrc/src/lib.rs:2122-2167, f32 arithmetic as there.
 int num_splits_heuristic(int64_t batch_nheads_mblocks, int64_t num_sms, int64_t num_n_blocks, int64_t max_splits) {
@@ -169,6 +170,7 @@ int atoma_release_workspaces(void) {
         if (hipFree(p) != hipSuccess) { (void)hipGetLastError(); rc = -1; }
     atoma::g_ws.clear();
     atoma::g_ws_retired.clear();
+    if (atoma::release_gemm_workspaces() != 0) rc = -1;
     if (rc) atoma::set_error("atoma_release_workspaces: hipFree failed");
     return rc;
 }
