@@ -542,36 +542,59 @@ __global__ void __launch_bounds__(256, 1) linear_big_kernel(const LinearParams p
     for (int a = 0; a < 2; ++a) a_row[a] = (PAIR ? 64 * a + 32 * wn : 64 * wn + 32 * a) + l32;
 #pragma unroll
     for (int b = 0; b < NB; ++b) b_row[b] = (BM / 2) * wm + 32 * b + l32;
-    auto compute = [&](int buf) {
+    // Fragments are read from LDS ONE k16 step ahead of the MFMAs that use them (two register sets), also across the chunk
+    // boundary: the barrier sits in front of the LAST step's MFMAs, the first fragments of the next chunk are requested right
+    // behind it and their latency is covered by those 8 MFMAs; the ds_writes of the next chunk go out in the middle of the
+    // current one.  The order is pinned with sched_barrier(0): left alone, hipcc issues every ds_read right in front of its
+    // MFMA (seen in the ISA: two exposed LDS latencies per k16 step, ~3500 cycles per chunk for 1024 cycles of MFMA).
+    struct Frag { lu32x4 a[2], b[NB]; };
+    auto read_frags = [&](int buf, int s4, Frag &f) {          // k16 step s4 of the chunk in `buf`: lane's 16-byte chunk 2 s4 + kh
         const char *wt = smem + buf * (WT + XT), *xt = wt + WT;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {                          // k16 steps of the 64-input chunk: lane's 16-byte chunk 2 s + kh
-            lu32x4 af[2], bf[NB];
+        for (int a = 0; a < 2; ++a) f.a[a] = *reinterpret_cast<const lu32x4 *>(wt + a_row[a] * 128 + (((2 * s4 + kh) ^ ((a_row[a] >> 1) & 7)) & 7) * 16);
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const lu32x4 *>(wt + a_row[a] * 128 + (((2 * s + kh) ^ ((a_row[a] >> 1) & 7)) & 7) * 16);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) bf[b] = *reinterpret_cast<const lu32x4 *>(xt + b_row[b] * 128 + (((2 * s + kh) ^ ((b_row[b] >> 1) & 7)) & 7) * 16);
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int a = 0; a < 2; ++a) acc[a][b] = lin_mfma32<T>(af[a], bf[b], acc[a][b]);
-        }
+        for (int b = 0; b < NB; ++b) f.b[b] = *reinterpret_cast<const lu32x4 *>(xt + b_row[b] * 128 + (((2 * s4 + kh) ^ ((b_row[b] >> 1) & 7)) & 7) * 16);
     };
+    auto mfmas = [&](const Frag &f) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) acc[a][b] = lin_mfma32<T>(f.a[a], f.b[b], acc[a][b]);
+    };
+    Frag fA, fB;
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
+    // one chunk; on entry fA holds step 0 of chunk c (LDS buffer par); on exit fA holds step 0 of chunk c + 1 (if any)
     auto step = [&](auto PAR, auto FULL, int c) {
         constexpr int par = decltype(PAR)::value;
         constexpr bool full = decltype(FULL)::value;
+        const bool more1 = full || c + 1 < c1;
         if (full || c + 2 < c1) gload(std::integral_constant<int, par>{}, c + 2);
-        compute(par);
-        if (full || c + 1 < c1) lds_store(std::integral_constant<int, par ^ 1>{}, par ^ 1);
-        __syncthreads();
+        read_frags(par, 1, fB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fA);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(par, 2, fA);
+        if (more1) lds_store(std::integral_constant<int, par ^ 1>{}, par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fB);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(par, 3, fB);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fA);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                       // everybody's chunk c + 1 is in LDS; nobody reads chunk c from LDS any more
+        if (more1) read_frags(par ^ 1, 0, fA);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(fB);
+        __builtin_amdgcn_sched_barrier(0);
     };
     if (c0 < c1) {
         gload(S0{}, c0);
         if (c0 + 1 < c1) gload(S1{}, c0 + 1);
         lds_store(S0{}, 0);
         __syncthreads();
+        read_frags(0, 0, fA);
         int c = c0;
         for (; c + 3 < c1; c += 2) {
             step(S0{}, std::true_type{}, c);
