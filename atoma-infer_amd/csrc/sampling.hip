@@ -7,6 +7,7 @@
 // HBM-bound: rows * vocab * elt bytes read once.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace atoma {
 
@@ -144,24 +145,53 @@ constexpr int TOPK_MAX = 1024, TOPK_CAP = 4096, TOPK_THREADS = 1024;
 // sort key of a candidate: value key in the high word, inverted index in the low word -> plain descending order
 __device__ __forceinline__ unsigned long long cand(uint32_t key, int idx) { return ((unsigned long long)key << 32) | (uint32_t)(0x7fffffff - idx); }
 
+// sort the n <= TOPK_CAP candidates (bitonic, descending) and emit the first k; whole workgroup, n uniform
 template <typename T>
-__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const void *__restrict__ logits, int64_t row_stride_bytes, int vocab, int k,
-                                                                 float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
-    __shared__ unsigned int hist[4096];
-    __shared__ unsigned long long cands[TOPK_CAP];
-    __shared__ unsigned int n_cand, t_bucket;
-    const char *row = static_cast<const char *>(logits) + (int64_t)blockIdx.x * row_stride_bytes;
+__device__ __forceinline__ void topk_sort_emit(unsigned long long *cands, unsigned int n, int k, const char *row, float *ov, int32_t *oi) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < 4096; i += TOPK_THREADS) hist[i] = 0;
-    if (tid == 0) n_cand = 0;
+    int np2 = 1;
+    while (np2 < (int)n) np2 <<= 1;
+    for (int i = n + tid; i < np2; i += TOPK_THREADS) cands[i] = 0ull;   // padding sorts last
     __syncthreads();
-    for (int i = tid; i < vocab; i += TOPK_THREADS) atomicAdd(&hist[order_key(load1<T>(row, i)) >> 20], 1u);
+    for (int size = 2; size <= np2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < np2 / 2; i += TOPK_THREADS) {
+                const int lo = (i / stride) * 2 * stride + (i % stride), hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = cands[lo], b = cands[hi];
+                if ((a < b) == desc) { cands[lo] = b; cands[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int j = tid; j < k; j += TOPK_THREADS) {
+        const int idx = 0x7fffffff - (int)(uint32_t)cands[j];
+        oi[j] = idx;
+        ov[j] = load1<T>(row, idx);
+    }
+}
+
+struct TopkShared {
+    unsigned int hist[4096];
+    unsigned long long cands[TOPK_CAP];
+    unsigned long long red[TOPK_THREADS / 64];
+    unsigned int cnt[16];
+    unsigned int n_cand, t_bucket;
+};
+
+// the histogram route over a row in memory (two passes over the row; any vocabulary, any k <= TOPK_MAX)
+template <typename T>
+__device__ void topk_row_hist(TopkShared &sh, const char *row, int vocab, int k, float *ov, int32_t *oi) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += TOPK_THREADS) sh.hist[i] = 0;
+    if (tid == 0) sh.n_cand = 0;
+    __syncthreads();
+    for (int i = tid; i < vocab; i += TOPK_THREADS) atomicAdd(&sh.hist[order_key(load1<T>(row, i)) >> 20], 1u);
     __syncthreads();
     if (tid < 64) {   // one wavefront walks the histogram from the top: 64 buckets per step
         unsigned int above = 0;
         int found = -1;
         for (int base = 4096 - 64; base >= 0 && found < 0; base -= 64) {
-            const unsigned int c = hist[base + tid];
+            const unsigned int c = sh.hist[base + tid];
             // inclusive suffix sum over the 64 lanes (lane 63 = highest bucket)
             unsigned int suf = c;
 #pragma unroll
@@ -174,45 +204,21 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const void *__r
             if (m) found = base + 63 - __builtin_clzll(m);                  // highest bucket that reaches k
             above += __shfl(suf, 0, 64);
         }
-        if (tid == 0) t_bucket = found < 0 ? 0u : (unsigned)found;
+        if (tid == 0) sh.t_bucket = found < 0 ? 0u : (unsigned)found;
     }
     __syncthreads();
-    const unsigned int T0 = t_bucket;
+    const unsigned int T0 = sh.t_bucket;
     for (int i = tid; i < vocab; i += TOPK_THREADS) {
         const uint32_t key = order_key(load1<T>(row, i));
         if ((key >> 20) >= T0) {
-            const unsigned int pos = atomicAdd(&n_cand, 1u);
-            if (pos < TOPK_CAP) cands[pos] = cand(key, i);
+            const unsigned int pos = atomicAdd(&sh.n_cand, 1u);
+            if (pos < TOPK_CAP) sh.cands[pos] = cand(key, i);
         }
     }
     __syncthreads();
-    const unsigned int n = n_cand;
-    float *ov = out_val + (int64_t)blockIdx.x * k;
-    int32_t *oi = out_idx + (int64_t)blockIdx.x * k;
-    if (n <= TOPK_CAP) {
-        int np2 = 1;
-        while (np2 < (int)n) np2 <<= 1;
-        for (int i = n + tid; i < np2; i += TOPK_THREADS) cands[i] = 0ull;   // padding sorts last
-        __syncthreads();
-        for (int size = 2; size <= np2; size <<= 1)
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int i = tid; i < np2 / 2; i += TOPK_THREADS) {
-                    const int lo = (i / stride) * 2 * stride + (i % stride), hi = lo + stride;
-                    const bool desc = ((lo & size) == 0);
-                    const unsigned long long a = cands[lo], b = cands[hi];
-                    if ((a < b) == desc) { cands[lo] = b; cands[hi] = a; }
-                }
-                __syncthreads();
-            }
-        for (int j = tid; j < k; j += TOPK_THREADS) {
-            const int idx = 0x7fffffff - (int)(uint32_t)cands[j];
-            oi[j] = idx;
-            ov[j] = load1<T>(row, idx);
-        }
-        return;
-    }
+    const unsigned int n = sh.n_cand;
+    if (n <= TOPK_CAP) { topk_sort_emit<T>(sh.cands, n, k, row, ov, oi); return; }
     // fallback: k rounds of "largest candidate strictly below the previous pick" (lexicographic on (key, -index))
-    __shared__ unsigned long long red[TOPK_THREADS / 64];
     unsigned long long prev = ~0ull;
     for (int j = 0; j < k; ++j) {
         unsigned long long best = 0ull;
@@ -225,19 +231,19 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const void *__r
             const unsigned long long o = __shfl_xor(best, off, 64);
             best = o > best ? o : best;
         }
-        if ((tid & 63) == 0) red[tid >> 6] = best;
+        if ((tid & 63) == 0) sh.red[tid >> 6] = best;
         __syncthreads();
         if (tid < 64) {
-            unsigned long long b = tid < TOPK_THREADS / 64 ? red[tid] : 0ull;
+            unsigned long long b = tid < TOPK_THREADS / 64 ? sh.red[tid] : 0ull;
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) {
                 const unsigned long long o = __shfl_xor(b, off, 64);
                 b = o > b ? o : b;
             }
-            if (tid == 0) red[0] = b;
+            if (tid == 0) sh.red[0] = b;
         }
         __syncthreads();
-        prev = red[0];
+        prev = sh.red[0];
         __syncthreads();
         if (tid == 0) {
             const int idx = 0x7fffffff - (int)(uint32_t)prev;
@@ -247,7 +253,133 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const void *__r
     }
 }
 
+template <typename T>
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const void *__restrict__ logits, int64_t row_stride_bytes, int vocab, int k,
+                                                                 float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+    __shared__ TopkShared sh;
+    const char *row = static_cast<const char *>(logits) + (int64_t)blockIdx.x * row_stride_bytes;
+    topk_row_hist<T>(sh, row, vocab, k, out_val + (int64_t)blockIdx.x * k, out_idx + (int64_t)blockIdx.x * k);
+}
+
+// Rows of up to 131072 logits with k <= 256 (every real sampler setting): ONE pass over the row.  Each of the 1024 threads keeps
+// a 16-bit prefix of the order keys of its 128 elements in 64 registers (16-byte non-temporal loads, element (1024 j + tid) * EPV
+// + e).  Threshold: t = the k-th largest of the 1024 per-thread maxima (16 rounds of a ballot count, no sort): at least k
+// elements have a prefix >= t, so every member of the exact top k has one too -- and only a few more do (k = 50 of 128256 random
+// logits: 50-60 candidates).  Those are re-read with their full keys (a few hundred L2 hits), sorted and cut at k as before.
+// No histogram, no LDS atomics on hot buckets; a row with too many candidates (constant rows, NaN-filled rows) takes the
+// histogram route above.
+constexpr int TOPK_REG_MAX_VOCAB = 131072, TOPK_REG_MAX_K = 256;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_v;
+// 16-bit prefixes of the order, two at a time.  h = the top 16 bits of an f32 / the bf16 / the f16 pattern (sign, exponent,
+// leading mantissa bits); exact prefix: NaN -> 0, -0.0 == +0.0, negative -> ~h, positive -> h | 0x8000 (monotone in the exact
+// key).  The register kernel only needs an UPPER bound of it that is cheap on packed lanes: positive h + 0x8000, negative
+// -h = ~h + 1 (one too many except for -0.0, where it is exact), NaNs left as they fall (>= 0 = their exact prefix).  The
+// bound can only ADD candidates or raise the threshold; the latter is detected afterwards (fewer than k candidates whose exact
+// prefix reaches the threshold) and sent down the histogram route.
+typedef __attribute__((ext_vector_type(2))) short i16x2_v;
+__device__ __forceinline__ uint32_t prefix_approx2(uint32_t h2) {
+    const uint32_t m = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2_v, h2) >> (short)15);   // 0xffff in the negative halves
+    const uint32_t t = h2 ^ (m | 0x80008000u);                                                             // ~h or h | 0x8000
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2_v, t) + __builtin_bit_cast(u16x2_v, m & 0x00010001u));
+}
+template <typename T> __device__ __forceinline__ uint32_t prefix_exact(const void *row, int idx) {
+    if constexpr (std::is_same<T, f16_t>::value) {
+        const uint32_t h = static_cast<const uint16_t *>(row)[idx];
+        if ((h & 0x7fffu) > 0x7c00u) return 0u;
+        if ((h & 0x7fffu) == 0u) return 0x8000u;
+        return (h & 0x8000u) ? (~h & 0xffffu) : (h | 0x8000u);
+    } else {
+        return order_key(load1<T>(row, idx)) >> 16;
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_reg_kernel(const void *__restrict__ logits, int64_t row_stride_bytes, int vocab, int k,
+                                                                     float *__restrict__ out_val, int32_t *__restrict__ out_idx) {
+    constexpr bool F32IN = std::is_same<T, float>::value;
+    constexpr int EPV = F32IN ? 4 : 8, NV = TOPK_REG_MAX_VOCAB / TOPK_THREADS / EPV, PPV = EPV / 2, NP = NV * PPV;   // 64 packed registers
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_v;
+    __shared__ TopkShared sh;
+    const char *row = static_cast<const char *>(logits) + (int64_t)blockIdx.x * row_stride_bytes;
+    float *ov = out_val + (int64_t)blockIdx.x * k;
+    int32_t *oi = out_idx + (int64_t)blockIdx.x * k;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nvec = vocab / EPV;                                      // the launcher guarantees vocab % EPV == 0
+    if (tid < 16) sh.cnt[tid] = 0;
+    if (tid == 0) { sh.n_cand = 0; sh.t_bucket = 0; }
+    uint32_t pk[NP];
+    const u32x4_v *rv = reinterpret_cast<const u32x4_v *>(row);
+    constexpr uint32_t PAD = 0xffffffffu;                              // beyond the row: a negative NaN, whose prefix bound is 1 -- below every number
+    constexpr int BATCH = F32IN ? 4 : 8;                               // 16-byte loads in flight per thread (f32: 128 registers is the budget at 1024 threads)
+#pragma unroll
+    for (int j0 = 0; j0 < NV; j0 += BATCH) {
+        u32x4_v raw[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const int v = (j0 + j) * TOPK_THREADS + tid;
+            raw[j] = v < nvec ? __builtin_nontemporal_load(rv + v) : u32x4_v{PAD, PAD, PAD, PAD};   // beyond the row
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if constexpr (F32IN) {
+                pk[(j0 + j) * 2] = prefix_approx2(__builtin_amdgcn_perm(raw[j][1], raw[j][0], 0x07060302u));       // the top halves of two floats
+                pk[(j0 + j) * 2 + 1] = prefix_approx2(__builtin_amdgcn_perm(raw[j][3], raw[j][2], 0x07060302u));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[(j0 + j) * 4 + e] = prefix_approx2(raw[j][e]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                             // keep the batches apart: hoisting every load to the top spills
+    }
+    // per-thread maximum of the prefixes
+    u16x2_v m2 = __builtin_bit_cast(u16x2_v, pk[0]);
+#pragma unroll
+    for (int i = 1; i < NP; ++i) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2_v, pk[i]));
+    const uint32_t mx = m2[0] > m2[1] ? m2[0] : m2[1];
+    __syncthreads();                                                   // cnt / n_cand are zero
+    // t = the k-th largest of the 1024 maxima: the largest p with count(mx >= p) >= k
+    uint32_t t = 0;
+#pragma unroll 1
+    for (int bit = 15; bit >= 0; --bit) {
+        const uint32_t p = t | (1u << bit);
+        const unsigned int c = (unsigned)__builtin_popcountll(__ballot(mx >= p));
+        if (lane == 0 && c) atomicAdd(&sh.cnt[bit], c);
+        __syncthreads();
+        if (sh.cnt[bit] >= (unsigned)k) t = p;
+    }
+    // candidates: every element whose prefix is >= t (padding slots are beyond nvec and skipped)
+    const u16x2_v tm = u16x2_v{(unsigned short)(t ? t - 1 : 0), (unsigned short)(t ? t - 1 : 0)};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const u16x2_v kv = __builtin_bit_cast(u16x2_v, pk[i]);
+        const u16x2_v mm = __builtin_elementwise_max(kv, tm);
+        if (t == 0 || __builtin_bit_cast(uint32_t, mm) != __builtin_bit_cast(uint32_t, tm)) {   // some half is >= t
+            const int v = (i / PPV) * TOPK_THREADS + tid;
+            if (v < nvec) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (kv[h] >= t) {
+                        const int idx = v * EPV + (i % PPV) * 2 + h;
+                        const unsigned int pos = atomicAdd(&sh.n_cand, 1u);
+                        if (pos < TOPK_CAP) sh.cands[pos] = cand(order_key(load1<T>(row, idx)), idx);
+                        if (prefix_exact<T>(row, idx) >= t) atomicAdd(&sh.t_bucket, 1u);   // candidates the exact prefix would have admitted too
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned int n = sh.n_cand, n_exact = sh.t_bucket;
+    if (n <= TOPK_CAP && n_exact >= (unsigned)k) { topk_sort_emit<T>(sh.cands, n, k, row, ov, oi); return; }
+    __syncthreads();
+    topk_row_hist<T>(sh, row, vocab, k, ov, oi);
+}
+
 }  // namespace atoma
+
+static bool topk_reg_enabled() {   // ATOMA_TOPK_REG=0: always the two-pass histogram kernel (A/B runs)
+    static const bool on = [] { const char *e = getenv("ATOMA_TOPK_REG"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 extern "C" int atoma_topk_rows(const void *logits, int64_t rows, int64_t vocab, int64_t row_stride, int dtype, int64_t k, float *out_val,
                                int32_t *out_idx, void *stream) {
@@ -261,12 +393,18 @@ extern "C" int atoma_topk_rows(const void *logits, int64_t rows, int64_t vocab, 
     if (rows == 0) return 0;
     const int64_t stride_bytes = row_stride * (dtype == ATOMA_F32 ? 4 : 2);
     const auto s = static_cast<hipStream_t>(stream);
-    if (dtype == ATOMA_F32)
-        hipLaunchKernelGGL((topk_rows_kernel<float>), dim3((unsigned)rows), dim3(TOPK_THREADS), 0, s, logits, stride_bytes, (int)vocab, (int)k, out_val, out_idx);
-    else if (dtype == ATOMA_BF16)
-        hipLaunchKernelGGL((topk_rows_kernel<bf16_t>), dim3((unsigned)rows), dim3(TOPK_THREADS), 0, s, logits, stride_bytes, (int)vocab, (int)k, out_val, out_idx);
-    else
-        hipLaunchKernelGGL((topk_rows_kernel<f16_t>), dim3((unsigned)rows), dim3(TOPK_THREADS), 0, s, logits, stride_bytes, (int)vocab, (int)k, out_val, out_idx);
+    const int epv = dtype == ATOMA_F32 ? 4 : 8;
+    const bool reg = vocab <= TOPK_REG_MAX_VOCAB && k <= TOPK_REG_MAX_K && vocab % epv == 0 && vocab >= 4 * TOPK_THREADS &&
+                     (reinterpret_cast<uintptr_t>(logits) & 15u) == 0 && stride_bytes % 16 == 0 && topk_reg_enabled();
+#define ATOMA_TOPK(TT)                                                                                                                       \
+    do {                                                                                                                                     \
+        if (reg) hipLaunchKernelGGL((topk_rows_reg_kernel<TT>), dim3((unsigned)rows), dim3(TOPK_THREADS), 0, s, logits, stride_bytes, (int)vocab, (int)k, out_val, out_idx); \
+        else hipLaunchKernelGGL((topk_rows_kernel<TT>), dim3((unsigned)rows), dim3(TOPK_THREADS), 0, s, logits, stride_bytes, (int)vocab, (int)k, out_val, out_idx);       \
+    } while (0)
+    if (dtype == ATOMA_F32) ATOMA_TOPK(float);
+    else if (dtype == ATOMA_BF16) ATOMA_TOPK(bf16_t);
+    else ATOMA_TOPK(f16_t);
+#undef ATOMA_TOPK
     return ATOMA_CHECK_LAUNCH("topk_rows") ? 0 : -1;
 }
 

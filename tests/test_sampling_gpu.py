@@ -84,7 +84,8 @@ def np_topk(x32, k):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16, F16])
-@pytest.mark.parametrize("rows,vocab,k", [(256, 128256, 50), (3, 128256, 1), (2, 128256, 1024), (7, 32000, 40), (5, 97, 97), (4, 50257, 64)])
+@pytest.mark.parametrize("rows,vocab,k", [(256, 128256, 50), (3, 128256, 1), (2, 128256, 1024), (7, 32000, 40), (5, 97, 97), (4, 50257, 64),
+                                          (4, 131072, 256), (3, 4096, 100), (2, 128256, 256), (2, 131080, 50)])
 def test_topk_rows_matches_numpy(gpu, dtype, rows, vocab, k):
     rng = np.random.default_rng(rows + vocab + k)
     if dtype == F32:
