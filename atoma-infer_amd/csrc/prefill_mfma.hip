@@ -248,6 +248,54 @@ template <int D, int W> struct PfLoader {
             if (do_v) glds16(vsrc[u], v_lds + off);
         }
     }
+    // The same two fast routes, split into "bases now, pieces later": plan2() computes the wave-uniform source base of every
+    // piece of K tile `ktile` / V tile `vtile` (scalar work + block-table lookups) and says whether the tiles qualify;
+    // piece_k<U>() / piece_v<U>() then issue ONE DMA each, wherever the caller's instruction stream has room for it.
+    __device__ __forceinline__ bool plan2(int ktile, int vtile, uint64_t (&kb)[NDMA], uint64_t (&vb)[NDMA]) const {
+        const bool do_k = ktile >= 0, do_v = vtile >= 0;
+        const int kkey0 = ktile * PF_BN, vkey0 = vtile * PF_BN;
+        if ((do_k && kkey0 + PF_BN - 1 > last_key) || (do_v && vkey0 + PF_BN - 1 > last_key)) return false;
+        if (!bt) {
+            const uint64_t kb0 = uniform64((uint64_t)(kbase + (int64_t)kkey0 * k_row));
+            const uint64_t vb0 = uniform64((uint64_t)(vbase + (int64_t)vkey0 * v_row));
+#pragma unroll
+            for (int u = 0; u < NDMA; ++u) { kb[u] = kb0; vb[u] = vb0; }
+            return true;
+        }
+        if (page_shift < 0) return false;
+        constexpr int RPP = 64 / CPR;   // rows per piece
+        if (page_shift >= 6) {
+            const int kpi = max(kkey0, 0) >> page_shift, vpi = max(vkey0, 0) >> page_shift;
+            const int kpg = __builtin_amdgcn_readfirstlane(bt[kpi]), vpg = __builtin_amdgcn_readfirstlane(bt[vpi]);
+            const uint64_t kb0 = uniform64((uint64_t)(kbase + (int64_t)kpg * k_page + (int64_t)(kkey0 - (kpi << page_shift)) * k_row));
+            const uint64_t vb0 = uniform64((uint64_t)(vbase + (int64_t)vpg * v_page + (int64_t)(vkey0 - (vpi << page_shift)) * v_row));
+#pragma unroll
+            for (int u = 0; u < NDMA; ++u) { kb[u] = kb0; vb[u] = vb0; }
+            return true;
+        }
+#pragma unroll
+        for (int u = 0; u < NDMA; ++u) {
+            const int row0 = __builtin_amdgcn_readfirstlane((wave * NDMA + u) * RPP);
+            kb[u] = vb[u] = 0;
+            if (do_k) {
+                const int pi = (kkey0 + row0) >> page_shift;
+                const int pg = __builtin_amdgcn_readfirstlane(bt[pi]);
+                kb[u] = uniform64((uint64_t)(kbase + (int64_t)pg * k_page + (int64_t)(kkey0 - (pi << page_shift)) * k_row));
+            }
+            if (do_v) {
+                const int pi = (vkey0 + row0) >> page_shift;
+                const int pg = __builtin_amdgcn_readfirstlane(bt[pi]);
+                vb[u] = uniform64((uint64_t)(vbase + (int64_t)pg * v_page + (int64_t)(vkey0 - (pi << page_shift)) * v_row));
+            }
+        }
+        return true;
+    }
+    template <int U> __device__ __forceinline__ void piece_k(uint64_t base, uint32_t k_lds) const {
+        glds16_saddr(base, kfast[U], k_lds + __builtin_amdgcn_readfirstlane((uint32_t)((wave * NDMA + U) * 1024)));
+    }
+    template <int U> __device__ __forceinline__ void piece_v(uint64_t base, uint32_t v_lds) const {
+        glds16_saddr(base, vfast[U], v_lds + __builtin_amdgcn_readfirstlane((uint32_t)((wave * NDMA + U) * 1024)));
+    }
     // contiguous K / V tensor, tile fully inside the sequence: piece u of this wave's share, from a
     // wave-uniform tile base (no per-lane address arithmetic)
     __device__ __forceinline__ bool fast_tile(int tile) const { return !bt && tile * PF_BN + PF_BN - 1 <= last_key; }
@@ -749,6 +797,9 @@ ATOMA_PF_ACC(bf16_t, "v_mfma_f32_32x32x16_bf16", 192, PF_ACC_CLOBBERS_192);
 ATOMA_PF_ACC(f16_t, "v_mfma_f32_32x32x16_f16", 192, PF_ACC_CLOBBERS_192);
 #undef ATOMA_PF_ACC
 
+#ifndef PF_PIPE_VLA
+#define PF_PIPE_VLA 2
+#endif
 template <typename T, int D, bool CAUSAL, int RB>
 __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(const AttnParams p) {
     constexpr int W = 4, PF_BM = 32 * RB * W;
@@ -777,6 +828,7 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
     constexpr int RSTEP = PF_BM / RB;
     const int mw0 = m0 + wave * 32;                  // first query row of this wave's block 0
     const int my_q0 = mw0 + lq;                      // this lane's query row in row block 0 (+RSTEP per block)
+    const bool pf_ride = (p.pp_pair & 1) != 0;       // DMA pieces inside phase C (launch_pf)
 
     int n_end = si.len_k, n_end_w = si.len_k;
     if (CAUSAL) {
@@ -894,12 +946,16 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
                     const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s_in[erb][eblk][r], sl2, nms[erb]));
                     s_in[erb][eblk][r] = e;
                     ps[erb][r & 1] += e;
+                    asm volatile("" : "+v"(ps[erb][r & 1]));   // the sum is taken HERE, beside this MFMA (IR-level sinking: see below)
                 }
                 if constexpr (((m + 1) * EPM) % 8 == 0) {     // a group of 8 is complete: pack it
                     constexpr int g = ((m + 1) * EPM) / 8 - 1, grb = g >> 2, gblk = (g >> 1) & 1, kk = g & 1;
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         pp[grb][gblk][kk][c] = cvt_pk<T>(s_in[grb][gblk][8 * kk + 2 * c], s_in[grb][gblk][8 * kk + 2 * c + 1]);
+                    // materialise P HERE: LLVM's IR-level sinking otherwise moves the fma / exp / cvt chains of the later groups down
+                    // to their first use in phase C (sched_barrier only binds the machine scheduler), where nothing covers them
+                    asm volatile("" : "+v"(pp[grb][gblk][kk]));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -947,13 +1003,18 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
     };
 
     // ---- phase C: [O += V^T.P^T of the tile at vt]  ||  [row max of s_new] ----
-    auto phase_c = [&](auto with_max, uint32_t vt, f32x16_v (&s_new)[RB][2], float (&mx)[RB]) {
+    // Optional (ATOMA_PREFILL_RIDE=1): the DMA pieces of the NEXT ring slots ride in this phase (dma.on), one every NM / (2 NDMA)
+    // MFMAs, K and V alternating, instead of going out as a burst right behind the barrier.  Measured: the burst shrinks by 330
+    // cycles per tile and this phase grows by 410 -- a wave whose VMEM issue is held back (the LDS-DMA path moves about 1 KiB
+    // per 100 cycles per wave) cannot issue its next MFMA either, so the pieces cost the same wherever they stand.
+    struct DmaRide { bool on, do_k; uint64_t kb[NDMA], vb[NDMA]; uint32_t k_lds, v_lds; };
+    auto phase_c = [&](auto with_max, uint32_t vt, f32x16_v (&s_new)[RB][2], float (&mx)[RB], const DmaRide &dma) {
         constexpr bool MX = decltype(with_max)::value;
         constexpr int NA = 4 * NDB, EPM = 32 / NA;           // V^T operands per tile; score elements per MFMA
         uint32_t vb_[NDB];
 #pragma unroll
         for (int db = 0; db < NDB; ++db) { vb_[db] = vt + voff[db]; asm volatile("" : "+v"(vb_[db])); }
-        constexpr int VLA = 2;           // operands of lookahead (an LDS read takes 100+ cycles under load)
+        constexpr int VLA = PF_PIPE_VLA; // operands of lookahead (2 or 4 measure the same: the phase does not wait on these reads)
         auto vaddr = [&](int n) { const int q = n / NDB; return vb_[n % NDB] + ((q >> 1) * 32 + (q & 1) * 16) * ROWB; };
         u32x4_v vf[VLA + 1];
 #pragma unroll
@@ -975,6 +1036,15 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
                     constexpr int e0 = (n * RB + rb) * EPM;   // 0 .. 32.RB: elements of the flattened [rb][blk][r]
 #pragma unroll
                     for (int e = e0; e < e0 + EPM; ++e) mx[e >> 5] = fmaxf(mx[e >> 5], s_new[e >> 5][(e >> 4) & 1][e & 15]);
+                    asm volatile("" : "+v"(mx[e0 >> 5]));      // keep the max chain spread over the phase
+                }
+                constexpr int mi = n * RB + rb, STEP = NA * RB / (2 * NDMA);   // MFMA index in the phase; MFMAs per DMA piece
+                if constexpr (mi % STEP == STEP / 2) {
+                    constexpr int pi = mi / STEP, u = pi >> 1;
+                    if (dma.on) {
+                        if constexpr ((pi & 1) == 0) { if (dma.do_k) ld.template piece_k<u>(dma.kb[u], dma.k_lds); }
+                        else ld.template piece_v<u>(dma.vb[u], dma.v_lds);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -1005,22 +1075,29 @@ __global__ void __launch_bounds__(256, RB == 2 ? 1 : 2) prefill_pipe_kernel(cons
         else dma_wait_all();
         __syncthreads();
         PF_T(0);
-        if (t + NS - 1 < n_tiles) ld.issue2(t + NS < n_tiles ? t + NS : -1, k_slot(t + NS), t + NS - 1, v_slot(t + NS - 1));
-        PF_T(1);
         const int kv0 = t * PF_BN;
         const bool cur = kv0 < n_end_w, nxt = t + 1 < n_tiles && kv0 + PF_BN < n_end_w;   // wave-uniform; nxt implies cur
+        DmaRide dma;
+        dma.on = false;
+        if (t + NS - 1 < n_tiles) {
+            const int kti = t + NS < n_tiles ? t + NS : -1, vti = t + NS - 1;
+            dma.do_k = kti >= 0; dma.k_lds = k_slot(t + NS); dma.v_lds = v_slot(t + NS - 1);
+            if (pf_ride && nxt && ld.plan2(kti, vti, dma.kb, dma.vb)) dma.on = true;   // pieces go out inside phase C
+            else ld.issue2(kti, dma.k_lds, vti, dma.v_lds);
+        }
+        PF_T(1);
         float mx[RB];
         if (nxt) {
             phase_b(yes, yes, k_slot(t + 1), s_c, s_n);
             PF_T(2);
             if (need_mask(kv0 + PF_BN)) mask_tile(s_n, kv0 + PF_BN);
-            phase_c(yes, v_slot(t), s_n, mx);
+            phase_c(yes, v_slot(t), s_n, mx, dma);
             PF_T(3);
             raise_max(mx);
             PF_T(4);
         } else if (cur) {
             phase_b(no, yes, 0, s_c, s_n);
-            phase_c(no, v_slot(t), s_n, mx);
+            phase_c(no, v_slot(t), s_n, mx, dma);
         }
     };
 
@@ -1143,7 +1220,13 @@ static int prefill_cfg_effective() {
 template <typename T, int D, bool CAUSAL>
 static void launch_pf(const AttnParams &p, hipStream_t stream) {
     switch (prefill_cfg_effective()) {
-        case 2: launch_pf_pipe<T, D, CAUSAL, 2>(p, stream); break;
+        case 2: {
+            static const int ride = [] { const char *e = getenv("ATOMA_PREFILL_RIDE"); return e ? atoi(e) : 0; }();   // 1 = DMA pieces inside phase C instead of a burst behind the barrier (measured: no gain)
+            AttnParams q = p;
+            q.pp_pair = ride;
+            launch_pf_pipe<T, D, CAUSAL, 2>(q, stream);
+            break;
+        }
         case 3: {                                                              // 8-wave ping-pong (see the kernel)
             static const int pair = [] { const char *e = getenv("ATOMA_PREFILL_PP_PAIR"); return e ? atoi(e) : 0; }();
             AttnParams q = p;

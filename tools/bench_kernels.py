@@ -401,7 +401,10 @@ def bench_step():
     weight_bytes = 2 * (2 * c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden))
     st = ah.Stream()
     S = 4096
-    for B, ragged in ((1, False), (16, False), (64, False), (256, False), (256, True)):
+    cases = ((1, False), (16, False), (64, False), (256, False), (256, True))
+    if os.environ.get("ATOMA_BENCH_STEP_CASES"):      # e.g. "256r,64": a subset, for profiling one step shape
+        cases = tuple((int(t.rstrip("r")), t.endswith("r")) for t in os.environ["ATOMA_BENCH_STEP_CASES"].split(","))
+    for B, ragged in cases:
         pps = S // c.page + 1
         step = DS.DecodeStep(c, B, B * pps + 2, pps, w, st, fused_epilogues=True)
         bt = rng.permutation(B * pps).astype(np.int32).reshape(B, pps)
