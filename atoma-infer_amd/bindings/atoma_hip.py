@@ -95,6 +95,8 @@ _opt("atoma_add", [_vp, _vp, _vp, _i64, _int, _vp])
 _opt("atoma_silu_mul", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_linear_decode_residual", [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_linear_decode_silu_mul", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
+_opt("atoma_linear_decode_rmsnorm", [_vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
+_opt("atoma_linear_decode_rmsnorm_silu_mul", [_vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_linear_decode", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_linear", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_topk_rows", [_vp, _i64, _i64, _i64, _int, _i64, _vp, _vp, _vp])

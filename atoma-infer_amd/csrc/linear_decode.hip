@@ -16,6 +16,7 @@
 // Parity: unpinned (Candle / cuBLAS are not in the tree); the oracle is the f64-accumulated product rounded once,
 // the kernel differs from it by at most one unit in the last place (accumulation order).
 #include "common.h"
+#include "norm_shared.h"
 #include <algorithm>
 #include <stdlib.h>
 #include <type_traits>
@@ -46,6 +47,8 @@ struct LinearParams {
     int epilogue;                // 0 none; 1 out = round(y) + aux (residual add); 2 out[:, i] = silu(y[:, i]) * y[:, n/2 + i] (stacked gate / up)
     const uint16_t *aux;         // epilogue 1: the residual [batch, n]
     int64_t aux_row_stride;
+    const uint16_t *norm_w;      // non-null: x is RMS-normalised with this weight [k] on the way in (linear_gemv_kernel<.., NORM>)
+    float norm_eps;
 };
 
 // lane = 16.grp + col.  A operand: W[n0 + 16r + col][k0 + 32s + 8.grp ..+7] for the RT row tiles r of the wave;
@@ -666,7 +669,12 @@ __device__ __forceinline__ float lin_row16_sum(float x) {   // sum over the 16 l
     x += __builtin_amdgcn_update_dpp(0.f, x, 0x140, 0xf, 0xf, true);   // row_mirror
     return x;
 }
-template <typename T, int NW, bool PAIR, int NB, int P>
+// NORM: y = rms_norm(x; norm_w, eps) . W^T -- the RMSNorm in front of the q/k/v and the gate/up projections (llama.rs:402,408)
+// folded into the projection: every wavefront derives the row's scale itself, with the norm kernel's own arithmetic
+// (norm_shared.h: the lane plays the four wavefronts of that kernel's workgroup in turn; 8 KiB of x per batch row from L2, while
+// the first weight loads are in flight), and normalises + rounds its 16-byte pieces of x as they arrive -- the operand of the dot
+// products is bit for bit what the separate kernel would have written, so the results are identical and one launch per norm goes.
+template <typename T, int NW, bool PAIR, int NB, int P, bool NORM = false>
 __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams p) {
     constexpr int RT = PAIR ? 2 : 1;
     __shared__ float red[NW][RT][16][NB < 4 ? 4 : NB];
@@ -686,7 +694,7 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
 #pragma unroll
     for (int b = 0; b < NB; ++b) xrow[b] = p.x + (int64_t)min(b, p.batch - 1) * p.x_row_stride + c * 8;   // rows beyond the batch: recomputed, never stored
 
-    lu32x4 wb[P][RT][4], xb[P][NB];
+    lu32x4 wb[P][RT][4], xb[P][NB], gb[P];
     auto issue = [&](int s, int chunk) {
 #pragma unroll
         for (int r = 0; r < RT; ++r)
@@ -695,6 +703,7 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
                 wb[s][r][rg] = __builtin_amdgcn_raw_buffer_load_b128(wr, w_lane[r], (int)(rg * 4 * row_bytes + chunk * 256), 2 /* nt */);
 #pragma unroll
         for (int b = 0; b < NB; ++b) xb[s][b] = *reinterpret_cast<const lu32x4 *>(xrow[b] + chunk * 128);
+        if constexpr (NORM) gb[s] = *reinterpret_cast<const lu32x4 *>(p.norm_w + c * 8 + chunk * 128);
     };
     float acc[RT][4][NB];
 #pragma unroll
@@ -703,7 +712,16 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
         for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[r][rg][b] = 0.f;
+    float nscale[NB];
     auto compute = [&](int s) {
+        if constexpr (NORM) {
+            const uint4 gv = make_uint4(gb[s][0], gb[s][1], gb[s][2], gb[s][3]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const uint4 xn = norm_apply8<T>(make_uint4(xb[s][b][0], xb[s][b][1], xb[s][b][2], xb[s][b][3]), gv, nscale[b]);
+                xb[s][b] = lu32x4{xn.x, xn.y, xn.z, xn.w};
+            }
+        }
 #pragma unroll
         for (int r = 0; r < RT; ++r)
 #pragma unroll
@@ -718,10 +736,15 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
                     acc[r][rg][b] = a;
                 }
     };
+    // NORM: the scales are derived between the first issue and the first compute (the weight loads cover it)
+    auto scales = [&]() {
+        if constexpr (NORM) norm_scales_by_one_wave<T, NB>(p.x, p.x_row_stride, p.batch, p.k, p.norm_eps, lane, nscale);
+    };
     int ch = c0;
     if (c0 + 2 * P <= c1) {
 #pragma unroll
         for (int s = 0; s < P; ++s) issue(s, c0 + s);
+        scales();
         for (; ch + 2 * P <= c1; ch += P) {
 #pragma unroll
             for (int s = 0; s < P; ++s) {
@@ -733,6 +756,7 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
 #pragma unroll
         for (int s = 0; s < P; ++s)
             if (c0 + s < c1) issue(s, c0 + s);
+        scales();
     }
     for (; ch < c1; ch += P) {
 #pragma unroll
@@ -771,6 +795,7 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
     }
 }
 
+constexpr int LINEAR_NORM_MAX_BATCH = 2;
 static const int linear_gemv = getenv("ATOMA_LINEAR_GEMV") ? atoi(getenv("ATOMA_LINEAR_GEMV")) : 1;
 static const int linear_gemv_max_batch = getenv("ATOMA_LINEAR_GEMV_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_GEMV_MAX_BATCH")) : 4;
 template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t stream) {
@@ -780,9 +805,13 @@ template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t
     int nw = 1;
     while (nw < 8 && tiles * nw * 2 <= (int64_t)device_num_cus() * gemv_wpc && chunks / (nw * 2) >= 4) nw *= 2;
     const dim3 grid((unsigned)tiles), block(64 * nw);
+    const bool norm = p.norm_w != nullptr;
 #define ATOMA_GV3(NW_, NB_) do { if (pair) hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, true, NB_, 2>), grid, block, 0, stream, p); \
                                  else hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, false, NB_, (NB_ > 4 ? 2 : 3)>), grid, block, 0, stream, p); } while (0)
-#define ATOMA_GV2(NW_) do { if (p.batch == 1) ATOMA_GV3(NW_, 1); else if (p.batch == 2) ATOMA_GV3(NW_, 2); else if (p.batch <= 4) ATOMA_GV3(NW_, 4); else ATOMA_GV3(NW_, 8); } while (0)
+#define ATOMA_GV3N(NW_, NB_) do { if (!norm) ATOMA_GV3(NW_, NB_); \
+                                  else if (pair) hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, true, NB_, 2, true>), grid, block, 0, stream, p); \
+                                  else hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, false, NB_, 3, true>), grid, block, 0, stream, p); } while (0)
+#define ATOMA_GV2(NW_) do { if (p.batch == 1) ATOMA_GV3N(NW_, 1); else if (p.batch == 2) ATOMA_GV3N(NW_, 2); else if (p.batch <= 4) ATOMA_GV3(NW_, 4); else ATOMA_GV3(NW_, 8); } while (0)
     switch (nw) {
         case 1: ATOMA_GV2(1); break;
         case 2: ATOMA_GV2(2); break;
@@ -790,6 +819,7 @@ template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t
         default: ATOMA_GV2(8); break;
     }
 #undef ATOMA_GV2
+#undef ATOMA_GV3N
 #undef ATOMA_GV3
     return ATOMA_CHECK_LAUNCH("linear_gemv_kernel") ? 0 : -1;
 }
@@ -894,7 +924,10 @@ template <typename T> static int launch_linear_big(LinearParams &p, hipStream_t 
 // 512 bytes per weight-row visit (two 128-input chunks per pipeline stage) when the split allows: +2-5 % over 256
 static const int linear_ch = getenv("ATOMA_LINEAR_CH") ? atoi(getenv("ATOMA_LINEAR_CH")) : 2;
 template <typename T> static int launch_linear(LinearParams &p, hipStream_t stream) {
-    if (linear_gemv && p.batch <= std::min(linear_gemv_max_batch, 8)) return launch_linear_gemv<T>(p, stream);
+    // the self-normalising variant serves 1 and 2 rows: at 4 rows the normalisation of x (45 VALU instructions per row and 128-input
+    // chunk, repeated by every wavefront) makes the kernel VALU-bound -- measured 4.82 ms against 4.06 ms for the 8B step
+    if (linear_gemv && p.batch <= std::min(linear_gemv_max_batch, 8) && !(p.norm_w && p.batch > LINEAR_NORM_MAX_BATCH)) return launch_linear_gemv<T>(p, stream);
+    if (p.norm_w) return 2;                                                      // only the kernel above normalises its own input: the entry point runs the norm first
     if (linear_wg && p.batch <= std::min(linear_wg_max_batch, 16)) {
         const int rc = launch_linear_wg<T>(p, stream);
         if (rc <= 0) return rc;
@@ -951,11 +984,17 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
 
 }  // namespace atoma
 
+extern "C" int atoma_rms_norm(const void *x, const void *weight, void *y, int64_t rows, int64_t hidden, int64_t x_row_stride,
+                              int64_t y_row_stride, float eps, int dtype, void *stream);
+
 static int linear_decode_entry(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
                                int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int epilogue, const void *aux,
-                               int64_t aux_row_stride, int dtype, void *stream) {
+                               int64_t aux_row_stride, int dtype, void *stream, const void *norm_w = nullptr, float norm_eps = 0.f,
+                               void *xn_scratch = nullptr) {
     using namespace atoma;
     clear_error();
+    if (norm_w && (reinterpret_cast<uintptr_t>(norm_w) & 15u)) { set_error("linear_decode: the norm weight must be 16-byte aligned"); return -1; }
+    if (norm_w && in_features > 8 * 8 * NORM_THREADS) { set_error("linear_decode: the fused RMSNorm supports in_features <= 16384"); return -1; }
     if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("linear_decode: dtype must be f16 or bf16"); return -1; }
     if (batch < 0 || batch > 256) { set_error("linear_decode: batch must be in [0, 256]"); return -1; }
     if (in_features <= 0 || in_features % 128 != 0) { set_error("linear_decode: in_features must be a positive multiple of 128"); return -1; }
@@ -989,8 +1028,19 @@ static int linear_decode_entry(const void *x, const void *w, void *y, int64_t ba
     p.x_row_stride = x_row_stride; p.w_row_stride = w_row_stride; p.y_row_stride = y_row_stride;
     p.batch = (int)batch; p.n = (int)out_features; p.k = (int)in_features;
     p.epilogue = epilogue; p.aux = static_cast<const uint16_t *>(aux); p.aux_row_stride = aux_row_stride;
+    p.norm_w = static_cast<const uint16_t *>(norm_w); p.norm_eps = norm_eps;
     const auto s = static_cast<hipStream_t>(stream);
-    return dtype == ATOMA_BF16 ? launch_linear<bf16_t>(p, s) : launch_linear<f16_t>(p, s);
+    int rc = dtype == ATOMA_BF16 ? launch_linear<bf16_t>(p, s) : launch_linear<f16_t>(p, s);
+    if (rc == 2) {   // a batch the self-normalising kernel does not take: the two ops, through the caller's scratch rows
+        if (!xn_scratch || (reinterpret_cast<uintptr_t>(xn_scratch) & 15u)) {
+            set_error("linear_decode: this batch size needs a 16-byte aligned xn_scratch [batch, in_features] for the normalised rows");
+            return -1;
+        }
+        if (atoma_rms_norm(x, norm_w, xn_scratch, batch, in_features, x_row_stride, in_features, norm_eps, dtype, stream) != 0) return -1;
+        p.x = static_cast<const uint16_t *>(xn_scratch); p.x_row_stride = in_features; p.norm_w = nullptr;
+        rc = dtype == ATOMA_BF16 ? launch_linear<bf16_t>(p, s) : launch_linear<f16_t>(p, s);
+    }
+    return rc;
 }
 
 extern "C" int atoma_linear_decode(const void *x, const void *w, void *y, int64_t batch, int64_t in_features, int64_t out_features,
@@ -1002,6 +1052,20 @@ extern "C" int atoma_linear_decode_residual(const void *x, const void *w, const 
                                             int64_t y_row_stride, int dtype, void *stream) {
     return linear_decode_entry(x, w, y, batch, in_features, out_features, x_row_stride, w_row_stride, y_row_stride, 1, residual,
                                residual_row_stride, dtype, stream);
+}
+extern "C" int atoma_linear_decode_rmsnorm(const void *x, const void *norm_weight, float eps, const void *w, void *y, void *xn_scratch, int64_t batch,
+                                           int64_t in_features, int64_t out_features, int64_t x_row_stride, int64_t w_row_stride,
+                                           int64_t y_row_stride, int dtype, void *stream) {
+    if (!norm_weight) { atoma::clear_error(); atoma::set_error("linear_decode_rmsnorm: norm_weight is required"); return -1; }
+    return linear_decode_entry(x, w, y, batch, in_features, out_features, x_row_stride, w_row_stride, y_row_stride, 0, nullptr, 0, dtype, stream,
+                               norm_weight, eps, xn_scratch);
+}
+extern "C" int atoma_linear_decode_rmsnorm_silu_mul(const void *x, const void *norm_weight, float eps, const void *w_gate_up, void *y,
+                                                    void *xn_scratch, int64_t batch, int64_t in_features, int64_t intermediate,
+                                                    int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream) {
+    if (!norm_weight) { atoma::clear_error(); atoma::set_error("linear_decode_rmsnorm_silu_mul: norm_weight is required"); return -1; }
+    return linear_decode_entry(x, w_gate_up, y, batch, in_features, 2 * intermediate, x_row_stride, w_row_stride, y_row_stride, 2, nullptr, 0,
+                               dtype, stream, norm_weight, eps, xn_scratch);
 }
 extern "C" int atoma_linear_decode_silu_mul(const void *x, const void *w_gate_up, void *y, int64_t batch, int64_t in_features,
                                             int64_t intermediate, int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype,

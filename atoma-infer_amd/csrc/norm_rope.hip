@@ -10,30 +10,18 @@
 // (llama.rs:273-303) because Candle's kernel wants [1, h, T, d]; this kernel works on the
 // [T, h, d] layout the projections produce and fuses the cos/sin index_select.
 #include "common.h"
+#include "norm_shared.h"
 
 #include <math.h>
 #include <string.h>
 
 namespace atoma {
 
-template <typename T> __device__ __forceinline__ void unpack8(const uint4 &v, float (&f)[8]) {
-    f[0] = lo_to_f32<T>(v.x); f[1] = hi_to_f32<T>(v.x);
-    f[2] = lo_to_f32<T>(v.y); f[3] = hi_to_f32<T>(v.y);
-    f[4] = lo_to_f32<T>(v.z); f[5] = hi_to_f32<T>(v.z);
-    f[6] = lo_to_f32<T>(v.w); f[7] = hi_to_f32<T>(v.w);
-}
-template <typename T> __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
-    uint4 v;
-    v.x = pack2<T>(f[0], f[1]); v.y = pack2<T>(f[2], f[3]);
-    v.z = pack2<T>(f[4], f[5]); v.w = pack2<T>(f[6], f[7]);
-    return v;
-}
-
 // ------------------------------------------------------------------------------------------
 // RMSNorm: one 256-thread workgroup per row; the row stays in registers between the
-// sum-of-squares pass and the scale pass (ITERS x 8 elements per thread).
+// sum-of-squares pass and the scale pass (ITERS x 8 elements per thread).  The arithmetic itself
+// lives in norm_shared.h (shared with the projection kernel that normalises its own input).
 // ------------------------------------------------------------------------------------------
-constexpr int NORM_THREADS = 256;
 
 // ADD: x = round(a + b) first (the residual add that precedes every RMSNorm of a decoder layer, llama.rs:404,409 -> 402,408),
 // written to `sum` as the separate add kernel would and normalised from the rounded values: bit-identical to the two ops.
@@ -65,30 +53,19 @@ rms_norm_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w, 
                 reinterpret_cast<uint4 *>(sum + row * sum_row_stride)[i] = xv[it];
             }
         }
-        float f[8];
-        unpack8<T>(xv[it], f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+        ss = norm_sumsq8<T>(xv[it], ss);
     }
-#pragma unroll
-    for (int off = 32; off; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    ss = norm_wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
-    float tot = 0.f;
+    float redr[NORM_THREADS / 64];
 #pragma unroll
-    for (int i = 0; i < NORM_THREADS / 64; ++i) tot += red[i];
-    const float scale = 1.0f / sqrtf(tot / (float)hidden + eps);
+    for (int i = 0; i < NORM_THREADS / 64; ++i) redr[i] = red[i];
+    const float scale = norm_scale(redr, hidden, eps);
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int i = it * NORM_THREADS + threadIdx.x;
-        if (i < nvec) {
-            float f[8], g[8];
-            unpack8<T>(xv[it], f);
-            unpack8<T>(reinterpret_cast<const uint4 *>(w)[i], g);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = (scale * f[e]) * g[e];  // candle-kernels rmsnorm order
-            reinterpret_cast<uint4 *>(yr)[i] = pack8<T>(f);
-        }
+        if (i < nvec) reinterpret_cast<uint4 *>(yr)[i] = norm_apply8<T>(xv[it], reinterpret_cast<const uint4 *>(w)[i], scale);
     }
 }
 

@@ -240,6 +240,19 @@ int atoma_linear_decode_residual(const void *x, const void *w, const void *resid
 int atoma_linear_decode_silu_mul(const void *x, const void *w_gate_up, void *y, int64_t batch, int64_t in_features, int64_t intermediate,
                                  int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream);
 
+/* The RMSNorm in FRONT of a projection folded into it (llama.rs:402 -> 269-271 for q/k/v, :408 -> 364-365 for gate/up):
+ * y = rms_norm(x; norm_weight, eps) . w^T, and the _silu_mul form of the stacked gate/up projection on top of that.  At 1 and 2 rows
+ * the projection kernel derives each row's scale itself with atoma_rms_norm's own arithmetic and
+ * normalises its input on the way in: bit-identical to atoma_rms_norm followed by atoma_linear_decode[_silu_mul], one launch
+ * less per norm.  Larger batches run exactly those two calls, through xn_scratch [batch, in_features] (16-byte aligned; may be
+ * NULL when the batch never exceeds the limit).  norm_weight [in_features], 16-byte aligned; in_features <= 16384. */
+int atoma_linear_decode_rmsnorm(const void *x, const void *norm_weight, float eps, const void *w, void *y, void *xn_scratch, int64_t batch,
+                                int64_t in_features, int64_t out_features, int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride,
+                                int dtype, void *stream);
+int atoma_linear_decode_rmsnorm_silu_mul(const void *x, const void *norm_weight, float eps, const void *w_gate_up, void *y, void *xn_scratch,
+                                         int64_t batch, int64_t in_features, int64_t intermediate, int64_t x_row_stride, int64_t w_row_stride,
+                                         int64_t y_row_stride, int dtype, void *stream);
+
 /* The same product at any batch (candle_nn::Linear::forward = a cuBLAS GEMM in the reference, llama.rs:269-271,311,364-365):
  * up to 4 rows (ATOMA_LINEAR_STREAM_MAX_BATCH) it is atoma_linear_decode, above that a plain TN GEMM in the vendor
  * library (hipBLASLt, loaded on first use; bf16 / f16 inputs, fp32 accumulation, one rounding).  Sizes and strides in

@@ -119,6 +119,48 @@ def test_linear_decode_fused_epilogues_match_the_separate_ops(gpu):
 
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("B,K,N,I", [(1, 4096, 6144, 14336), (2, 4096, 512, 1024), (3, 8192, 1280, 3584), (4, 2048, 1024, 512), (1, 128, 16, 16),
+                                     (4, 16384, 256, 128), (7, 4096, 512, 768), (40, 1024, 256, 256)])
+def test_linear_decode_rmsnorm_is_the_two_ops_bit_for_bit(gpu, dtype, B, K, N, I):
+    """The RMSNorm folded into the projection (f1: fused RMSNorm -> QKV / gate-up): at 1 and 2 rows the projection kernel normalises
+    its own input with atoma_rms_norm's arithmetic, above that the entry point runs the two kernels through xn_scratch -- either way
+    the outputs must be the bits of atoma_rms_norm followed by atoma_linear_decode / atoma_linear_decode_silu_mul; x with a padded
+    row stride, rows of very different magnitude (the scale is per row)."""
+    rng = np.random.default_rng(B * 1000 + K + N)
+    xs = K + 64
+    x = rand_half(rng, (B, xs), dtype, 1.0)
+    x16 = x.view(np.uint16) if x.dtype != np.uint16 else x
+    if B > 1:   # one row 100x larger, one 100x smaller
+        from oracle.halfs import from_f32
+        f = to_f32(x, dtype)
+        f[0] *= 100.0
+        f[B - 1] *= 0.01
+        x = from_f32(f, dtype)
+    g = rand_half(rng, (K,), dtype, 1.0)
+    w = rand_half(rng, (N, K), dtype, K ** -0.5)
+    wgu = rand_half(rng, (2 * I, K), dtype, K ** -0.5)
+    eps = 1e-5
+    L = gpu.lib
+    dx, dg, dw, dwgu = (gpu.DeviceBuffer.from_numpy(a) for a in (x, g, w, wgu))
+    xn, scratch = gpu.DeviceBuffer(B * K * 2), gpu.DeviceBuffer(B * K * 2)
+    y, y2, act, act2 = (gpu.DeviceBuffer(n * 2) for n in (B * N, B * N, B * I, B * I))
+    assert L.atoma_rms_norm(dx.ptr, dg.ptr, xn.ptr, B, K, xs, K, eps, dtype, None) == 0, gpu.last_error()
+    assert L.atoma_linear_decode(xn.ptr, dw.ptr, y.ptr, B, K, N, K, K, N, dtype, None) == 0, gpu.last_error()
+    assert L.atoma_linear_decode_silu_mul(xn.ptr, dwgu.ptr, act.ptr, B, K, I, K, K, I, dtype, None) == 0, gpu.last_error()
+    sc = scratch.ptr if B > 2 else None
+    assert L.atoma_linear_decode_rmsnorm(dx.ptr, dg.ptr, eps, dw.ptr, y2.ptr, sc, B, K, N, xs, K, N, dtype, None) == 0, gpu.last_error()
+    assert L.atoma_linear_decode_rmsnorm_silu_mul(dx.ptr, dg.ptr, eps, dwgu.ptr, act2.ptr, sc, B, K, I, xs, K, I, dtype, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    assert np.array_equal(y.numpy(np.uint16, (B, N)), y2.numpy(np.uint16, (B, N)))
+    assert np.array_equal(act.numpy(np.uint16, (B, I)), act2.numpy(np.uint16, (B, I)))
+    assert np.isfinite(to_f32(y2.numpy(np.uint16, (B, N)), dtype)).all()
+    if B > 2:   # the larger batches need the scratch rows, and say so
+        assert L.atoma_linear_decode_rmsnorm(dx.ptr, dg.ptr, eps, dw.ptr, y2.ptr, None, B, K, N, xs, K, N, dtype, None) == -1
+        assert "xn_scratch" in gpu.last_error()
+    assert L.atoma_linear_decode_rmsnorm(dx.ptr, None, eps, dw.ptr, y2.ptr, None, B, K, N, xs, K, N, dtype, None) == -1
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("B,K,N", [(65, 1024, 256), (100, 4096, 1024), (128, 4096, 4096), (129, 2048, 6144), (200, 14336, 512), (256, 4096, 4096), (256, 1024, 28672),
                                    (256, 8192, 1280)])
 def test_linear_decode_65_to_256_rows(gpu, dtype, B, K, N):

@@ -42,6 +42,7 @@ class DecodeStep:
         self.B, self.stream, self.keep = batch, stream, keep_intermediates
         self.allreduce = allreduce
         self.fused = fused_epilogues and not keep_intermediates and batch <= 4 and allreduce is None   # residual adds and SiLU.up inside the projections' split merge (weight-streaming kernel: batches it serves); a TP rank must all-reduce before the residual
+        self.norm_in_proj = os.environ.get("ATOMA_STEP_NORM_IN_PROJ", "1") != "0"   # fused path: RMSNorm inside the q/k/v and gate/up projections (A/B switch)
         self.fuse_norm = fuse_norm and not keep_intermediates and not self.fused   # residual add + the RMSNorm that follows it in one kernel
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
         page_elems = c.page * c.hk * c.d
@@ -106,10 +107,14 @@ class DecodeStep:
         xf = self._buf("xf", 0, B * H * 2)
         for l in range(c.layers):
             xn = self._buf("xn1", l, B * H * 2)
-            if not (self.fuse_norm and l > 0):             # with fuse_norm the previous layer's last add produced xn already
-                self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
             qkv = self._buf("qkv", l, B * qkvw * 2)
-            self._ok(L.atoma_linear(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, B, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
+            if self.fused and self.norm_in_proj:            # the input norm inside the projection (batch <= 4: no launch of its own)
+                self._ok(L.atoma_linear_decode_rmsnorm(x.ptr, self.w["norm1"][l].ptr, c.eps, self.w["wqkv"][l].ptr, qkv.ptr, xn.ptr, B, H, qkvw, H, H, qkvw,
+                                                       BF16, s), "rms_norm + qkv projection")
+            else:
+                if not (self.fuse_norm and l > 0):         # with fuse_norm the previous layer's last add produced xn already
+                    self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+                self._ok(L.atoma_linear(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, B, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
             qkv_pre = None
             if self.keep:                                   # RoPE works in place: keep the projection's output for the checker
                 qkv_pre = self._buf("qkv_pre", l, B * qkvw * 2)
@@ -140,8 +145,12 @@ class DecodeStep:
             o = gu = dn = None
             if self.fused:
                 self._ok(L.atoma_linear_decode_residual(att.ptr, self.w["wo"][l].ptr, x.ptr, x1.ptr, B, hd, H, hd, hd, H, H, BF16, s), "o projection + residual")
-                self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
-                self._ok(L.atoma_linear_decode_silu_mul(xn2.ptr, self.w["wgu"][l].ptr, act.ptr, B, H, c.inter, H, H, c.inter, BF16, s), "gate/up projection + silu * up")
+                if self.norm_in_proj:
+                    self._ok(L.atoma_linear_decode_rmsnorm_silu_mul(x1.ptr, self.w["norm2"][l].ptr, c.eps, self.w["wgu"][l].ptr, act.ptr, xn2.ptr, B, H, c.inter,
+                                                                    H, H, c.inter, BF16, s), "rms_norm + gate/up projection + silu * up")
+                else:
+                    self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+                    self._ok(L.atoma_linear_decode_silu_mul(xn2.ptr, self.w["wgu"][l].ptr, act.ptr, B, H, c.inter, H, H, c.inter, BF16, s), "gate/up projection + silu * up")
                 self._ok(L.atoma_linear_decode_residual(act.ptr, self.w["wdown"][l].ptr, x1.ptr, x2.ptr, B, c.inter, H, c.inter, c.inter, H, H, BF16, s), "down projection + residual")
             else:
                 o = self._buf("o", l, B * H * 2)
