@@ -13,6 +13,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o decode -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --no-traffic > $OUT/prof_$TAG.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -o decode -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-traffic > $OUT/pmc_fetch_$TAG.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -o decode -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-traffic > $OUT/pmc_write_$TAG.log 2>&1
+ATOMA_BENCH_STEP_CASES=256r timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_step_$TAG -o step -- python $REPO/tools/bench_kernels.py step > $OUT/prof_step_$TAG.log 2>&1
+ATOMA_BENCH_STEP_CASES=1 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_step1_$TAG -o step -- python $REPO/tools/bench_kernels.py step > $OUT/prof_step1_$TAG.log 2>&1
 cd $REPO
 (timeout 1500 python tools/bench_kernels.py decode decode_fp8 prefill prefill_paged cache norm sampling linear linear_mid linear_big graph step swap prep 2>&1) > $OUT/kernels_$TAG.jsonl
 (timeout 400 python tools/engine_trace.py 2>&1 | tail -1) > $OUT/trace_$TAG.json
