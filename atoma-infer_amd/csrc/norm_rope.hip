@@ -12,6 +12,7 @@
 #include "common.h"
 #include "norm_shared.h"
 
+#include <atomic>
 #include <math.h>
 #include <string.h>
 
@@ -118,6 +119,15 @@ static void launch_rms_norm(const void *x, const void *w, void *y, int64_t rows,
     ATOMA_CHECK_LAUNCH("rms_norm");
 }
 
+// atoma_set_option("rope_table_rows", n): the number of rows of the cos / sin tables the caller built (atoma_rope_table's
+// max_pos).  The reference's index_select fails on a position beyond the table; these kernels cannot raise from the device,
+// so with the option set they read the table's LAST row for such a position instead of memory behind it (0 = unchecked,
+// the default: the FFI carries no table length).
+std::atomic<int64_t> rope_table_rows{0};
+__device__ __forceinline__ int64_t rope_pos(int64_t pos, int64_t table_rows) {
+    return table_rows > 0 ? (pos < 0 ? 0 : (pos >= table_rows ? table_rows - 1 : pos)) : pos;
+}
+
 // ------------------------------------------------------------------------------------------
 // RoPE (rotate-half): thread = (token, head, 8-element chunk of the first half).
 // PER_OP = Candle's arithmetic in the tensor dtype: every product and the sum are rounded.
@@ -159,11 +169,11 @@ __global__ void __launch_bounds__(256)
 rope_kernel(const uint16_t *__restrict__ xa, uint16_t *__restrict__ ya, int heads_a, int64_t xa_ts, int64_t xa_hs,
             int64_t ya_ts, int64_t ya_hs, const uint16_t *__restrict__ xb, uint16_t *__restrict__ yb, int heads_b,
             int64_t xb_ts, int64_t xb_hs, int64_t yb_ts, int64_t yb_hs, const uint16_t *__restrict__ cos_t,
-            const uint16_t *__restrict__ sin_t, const int64_t *__restrict__ positions, int head_dim) {
+            const uint16_t *__restrict__ sin_t, const int64_t *__restrict__ positions, int head_dim, int64_t table_rows) {
     const int64_t t = blockIdx.x;
     const int half = head_dim >> 1;
     const int cpr = half >> 3;  // chunks per (token, head)
-    const int64_t pos = positions[t];
+    const int64_t pos = rope_pos(positions[t], table_rows);
     const uint16_t *cosr = cos_t + pos * half, *sinr = sin_t + pos * half;
     const int total = (heads_a + heads_b) * cpr;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
@@ -197,7 +207,7 @@ static int launch_rope(const void *xa, void *ya, int64_t ha, int64_t xa_ts, int6
                        static_cast<const uint16_t *>(xa), static_cast<uint16_t *>(ya), (int)ha, xa_ts, xa_hs, ya_ts,  \
                        ya_hs, static_cast<const uint16_t *>(xb), static_cast<uint16_t *>(yb), (int)hb, xb_ts, xb_hs,  \
                        yb_ts, yb_hs, static_cast<const uint16_t *>(cos_t), static_cast<const uint16_t *>(sin_t),      \
-                       positions, (int)d)
+                       positions, (int)d, rope_table_rows.load())
     if (dtype == ATOMA_BF16) { if (per_op) ATOMA_ROPE_LAUNCH(bf16_t, true); else ATOMA_ROPE_LAUNCH(bf16_t, false); }
     else { if (per_op) ATOMA_ROPE_LAUNCH(f16_t, true); else ATOMA_ROPE_LAUNCH(f16_t, false); }
 #undef ATOMA_ROPE_LAUNCH
@@ -217,10 +227,10 @@ rope_cache_kernel(uint16_t *__restrict__ q, uint16_t *__restrict__ k, const uint
                   uint16_t *__restrict__ k_cache, uint16_t *__restrict__ v_cache, const int64_t *__restrict__ slot_mapping,
                   const uint16_t *__restrict__ cos_t, const uint16_t *__restrict__ sin_t,
                   const int64_t *__restrict__ positions, int heads_q, int heads_kv, int head_dim, int64_t q_ts, int64_t k_ts,
-                  int64_t v_ts, int64_t block_stride, int page_size) {
+                  int64_t v_ts, int64_t block_stride, int page_size, int64_t table_rows) {
     const int64_t t = blockIdx.x;
     const int half = head_dim >> 1, cpr = half >> 3, vpr = head_dim >> 3;
-    const int64_t pos = positions[t], slot = slot_mapping[t];
+    const int64_t pos = rope_pos(positions[t], table_rows), slot = slot_mapping[t];
     const uint16_t *cosr = cos_t + pos * half, *sinr = sin_t + pos * half;
     const int64_t row = slot >= 0 ? (slot / page_size) * block_stride + (slot % page_size) * (int64_t)heads_kv * head_dim : 0;
     const int n_rope = (heads_q + heads_kv) * cpr, total = n_rope + (slot >= 0 ? heads_kv * vpr : 0);
@@ -341,7 +351,7 @@ int atoma_rope_qk_cache(void *q, void *k, const void *v, void *k_cache, void *v_
                        static_cast<const uint16_t *>(v), static_cast<uint16_t *>(k_cache), static_cast<uint16_t *>(v_cache), \
                        slot_mapping, static_cast<const uint16_t *>(cos_table), static_cast<const uint16_t *>(sin_table), \
                        positions, (int)num_q_heads, (int)num_kv_heads, (int)head_dim, q_token_stride, k_token_stride,    \
-                       v_token_stride, block_stride, (int)page_size)
+                       v_token_stride, block_stride, (int)page_size, rope_table_rows.load())
     if (dtype == ATOMA_BF16) { if (per_op_rounding) ATOMA_RC_LAUNCH(bf16_t, true); else ATOMA_RC_LAUNCH(bf16_t, false); }
     else { if (per_op_rounding) ATOMA_RC_LAUNCH(f16_t, true); else ATOMA_RC_LAUNCH(f16_t, false); }
 #undef ATOMA_RC_LAUNCH

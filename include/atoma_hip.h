@@ -379,7 +379,9 @@ int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int6
  * head, bit 1 = smaller groups, bit 2 = groups of 2..4 when b * h_k <= 64; default 5), "decode_fp8_mqk" (fp8 KV cache: 1 = q.K^T of
  * the converted K on the matrix cores [default], 0 = v_dot2c), "decode_fp8_wg" (fp8: the 8 kv-head wavefronts of a sequence in one
  * workgroup: 0 never, 1 split-KV launches [default], 2 always).  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
- * software-pipelined one-wave-per-SIMD kernel).  Defaults also come from ATOMA_DECODE_{P,NT,STREAM,WAVES_PER_CU,
+ * software-pipelined one-wave-per-SIMD kernel).  RoPE: "rope_table_rows" (rows of the caller's cos / sin tables; positions beyond
+ * them then read the last row instead of memory behind the table -- the FFI carries no table length; 0 = unchecked [default]).
+ * Defaults also come from ATOMA_DECODE_{P,NT,STREAM,WAVES_PER_CU,
  * MIN_TILES,MQK}; ATOMA_PREFILL_CFG overrides "prefill_cfg". */
 int atoma_set_option(const char *name, int value);
 

@@ -176,3 +176,26 @@ def test_kernels_against_torch_fixtures(gpu, tag, dtype):
     fused = gpu_rope(gpu, x, cos, sin, pos, dtype, per_op=0)
     d = ulps_apart(fused, fx[f"rope_{tag}_fused"], dtype)
     assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())     # fma contraction: a boundary flip at most
+
+
+def test_rope_positions_beyond_the_table_read_its_last_row_when_the_option_is_set(gpu):
+    """the FFI carries no table length.  With atoma_set_option("rope_table_rows", n) a position >= n (or < 0) uses the
+    table's last (first) row instead of memory behind it; unset, the kernels behave as before."""
+    rng = np.random.default_rng(77)
+    T, h, d, rows = 6, 4, 64, 10
+    x = rand_half(rng, (T, h, d), BF16)
+    cos, sin = rand_half(rng, (rows, d // 2), BF16), rand_half(rng, (rows, d // 2), BF16)
+    pos = np.array([0, 9, 10, 500, -3, 4], np.int64)
+    clamped = np.clip(pos, 0, rows - 1)
+    dx, dc, ds = (gpu.DeviceBuffer.from_numpy(a) for a in (x, cos, sin))
+    outs = []
+    try:
+        assert gpu.lib.atoma_set_option(b"rope_table_rows", rows) == 0
+        for p_ in (pos, clamped):
+            dp, dy = gpu.DeviceBuffer.from_numpy(p_), gpu.DeviceBuffer(x.size * 2)
+            assert gpu.lib.atoma_rope(dx.ptr, dy.ptr, dc.ptr, ds.ptr, dp.ptr, T, h, d, h * d, d, h * d, d, BF16, 1, None) == 0, gpu.last_error()
+            gpu.synchronize()
+            outs.append(dy.numpy(np.uint16, x.shape))
+    finally:
+        gpu.lib.atoma_set_option(b"rope_table_rows", 0)
+    assert np.array_equal(outs[0], outs[1])
