@@ -131,13 +131,16 @@ def test_llama_decode_step_op_by_op(gpu, graph):
     assert np.array_equal(step.next_ids.numpy(np.int32, (B,)), to_f32(logits, BF16).argmax(1))
 
 
-def test_llama_decode_step_fused_epilogues_are_bit_identical(gpu):
-    """Residual adds and SiLU.up folded into the projections' split merge keep the reference's rounding points, so the
-    fused step must reproduce the op-by-op step bit for bit (logits, next tokens, caches)."""
+@pytest.mark.parametrize("B", [3, 2, 24, 64])
+def test_llama_decode_step_fused_epilogues_are_bit_identical(gpu, B):
+    """Residual adds and SiLU.up folded into the projections' split merge (and, at 1-2 rows, the RMSNorms folded into the q/k/v and
+    gate/up projections) keep the reference's rounding points, so the fused step must reproduce the op-by-op step bit for bit
+    (logits, next tokens, caches) -- at 2-3 rows on the weight-streaming kernel, at 24 / 64 rows on the 17..64-row kernel; the
+    op-by-op step runs on the library's own projection kernels too (own_projections), the vendor GEMM rounds differently."""
     import decode_step as DS
     rng = np.random.default_rng(12)
     cfg = DS.Config(layers=3, hidden=512, heads=4, kv_heads=2, head_dim=128, intermediate=1024, vocab=1008, page=16, max_pos=256)
-    B, ctx = 3, np.array([5, 33, 90])
+    ctx = np.array([5, 33, 90])[:B] if B <= 3 else rng.integers(1, 120, B)
     lens = (ctx + 1).astype(np.int32)
     blocks = [(int(L) + cfg.page - 1) // cfg.page for L in lens]
     num_pages = sum(blocks) + 1
@@ -162,7 +165,8 @@ def test_llama_decode_step_fused_epilogues_are_bit_identical(gpu):
     slots = np.array([CO.slot_mapping_for(bt[i], int(ctx[i]), int(ctx[i]) + 1, cfg.page)[0] for i in range(B)], np.int64)
     res = []
     for fused, fuse_norm in ((False, False), (True, False), (False, True)):   # op by op / fused projection epilogues / fused add + RMSNorm
-        step = DS.DecodeStep(cfg, B, num_pages, bt.shape[1], w, st, fused_epilogues=fused, fuse_norm=fuse_norm)
+        step = DS.DecodeStep(cfg, B, num_pages, bt.shape[1], w, st, fused_epilogues=fused, fuse_norm=fuse_norm, own_projections=True)
+        assert step.fused == fused
         for l in range(cfg.layers):
             step.kc[l].upload(kc0[l])
             step.vc[l].upload(vc0[l])

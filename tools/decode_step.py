@@ -34,14 +34,20 @@ class DecodeStep:
     """Device-resident weights, caches and activations of a model + `run()` = one decode step for `batch` sequences."""
 
     def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False, fused_epilogues=False, fuse_norm=True,
-                 allreduce=None, kv_fp8=False, kv_scale=0.05):
+                 allreduce=None, kv_fp8=False, kv_scale=0.05, own_projections=False):
         """allreduce(ptr, count): in-place sum of a [batch, hidden] bf16 tensor over the tensor-parallel ranks, enqueued on
         `stream` -- called after the o and the down projection when `cfg` / `weights` are ONE rank's shard
         (llama_nccl.rs:139,195 via TensorParallelRowLinear, multi_gpu.rs:48-50); None = not tensor parallel."""
         c = self.cfg = cfg
         self.B, self.stream, self.keep = batch, stream, keep_intermediates
         self.allreduce = allreduce
-        self.fused = fused_epilogues and not keep_intermediates and batch <= 4 and allreduce is None   # residual adds and SiLU.up inside the projections' split merge (weight-streaming kernel: batches it serves); a TP rank must all-reduce before the residual
+        # Residual adds, SiLU.up (and at 1-2 rows the RMSNorms) inside the library's own projection kernels.  Up to 128 rows that is the
+        # faster step although the vendor GEMM wins most of the single products from 5 rows up (three launches per layer fewer:
+        # batch 8 5.17 -> 4.62 ms, 32 7.58 -> 6.96, 64 11.2 -> 10.3, 96 14.9 -> 14.6, 128 16.9 -> 16.8; at 256 rows 19.4 -> 20.1, so
+        # the C3 batch stays on the vendor GEMM; DESIGN.md 4.9); a TP rank must all-reduce before the residual.
+        self.fused = fused_epilogues and not keep_intermediates and batch <= int(os.environ.get("ATOMA_STEP_FUSED_MAX_BATCH", "128")) and allreduce is None
+        # own_projections: the op-by-op path on atoma_linear_decode at every batch (tests: the fused step must equal it bit for bit)
+        self.linear = ah.lib.atoma_linear_decode if own_projections else ah.lib.atoma_linear
         self.norm_in_proj = os.environ.get("ATOMA_STEP_NORM_IN_PROJ", "1") != "0"   # fused path: RMSNorm inside the q/k/v and gate/up projections (A/B switch)
         self.fuse_norm = fuse_norm and not keep_intermediates and not self.fused   # residual add + the RMSNorm that follows it in one kernel
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
@@ -114,7 +120,7 @@ class DecodeStep:
             else:
                 if not (self.fuse_norm and l > 0):         # with fuse_norm the previous layer's last add produced xn already
                     self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
-                self._ok(L.atoma_linear(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, B, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
+                self._ok(self.linear(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, B, H, qkvw, H, H, qkvw, BF16, s), "qkv projection")
             qkv_pre = None
             if self.keep:                                   # RoPE works in place: keep the projection's output for the checker
                 qkv_pre = self._buf("qkv_pre", l, B * qkvw * 2)
@@ -154,7 +160,7 @@ class DecodeStep:
                 self._ok(L.atoma_linear_decode_residual(act.ptr, self.w["wdown"][l].ptr, x1.ptr, x2.ptr, B, c.inter, H, c.inter, c.inter, H, H, BF16, s), "down projection + residual")
             else:
                 o = self._buf("o", l, B * H * 2)
-                self._ok(L.atoma_linear(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
+                self._ok(self.linear(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
                 if self.allreduce:
                     self.allreduce(o.ptr, B * H)
                 if self.fuse_norm:
@@ -163,10 +169,10 @@ class DecodeStep:
                     self._ok(L.atoma_add(x.ptr, o.ptr, x1.ptr, B * H, BF16, s), "residual add")
                     self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
                 gu = self._buf("gu", l, B * 2 * c.inter * 2)
-                self._ok(L.atoma_linear(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
+                self._ok(self.linear(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
                 self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
                 dn = self._buf("dn", l, B * H * 2)
-                self._ok(L.atoma_linear(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
+                self._ok(self.linear(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
                 if self.allreduce:
                     self.allreduce(dn.ptr, B * H)
                 if self.fuse_norm:                       # ... + the next layer's input norm (or the final norm)
@@ -180,7 +186,7 @@ class DecodeStep:
             x = x2
         if not self.fuse_norm:
             self._ok(L.atoma_rms_norm(x.ptr, self.w["norm_f"].ptr, xf.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
-        self._ok(L.atoma_linear(xf.ptr, self.w["lm_head"].ptr, self.logits.ptr, B, H, c.vocab, H, H, c.vocab, BF16, s), "lm_head")
+        self._ok(self.linear(xf.ptr, self.w["lm_head"].ptr, self.logits.ptr, B, H, c.vocab, H, H, c.vocab, BF16, s), "lm_head")
         self._ok(L.atoma_argmax_rows(self.logits.ptr, B, c.vocab, c.vocab, BF16, self.next_ids.ptr, self.next_val.ptr, s), "argmax")
         if self.keep:
             self.trace.append(("head", 0, dict(x=x, xf=xf, logits=self.logits)))
