@@ -56,6 +56,10 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="do not measure HBM traffic with rocprofv3 PMC passes inside this run")
     ap.add_argument("--no-extra", action="store_true", help="only the headline (profiling runs): skip the end-to-end extras")
     ap.add_argument("--tp-step", action="store_true", help="N = 1: also time the whole 70B-shaped decode step on this GPU (226 GB)")
+    ap.add_argument("--allreduce-in-step", action="store_true",
+                    help="N > 1: also all-reduce a [B, hidden] bf16 tensor inside every timed step (round 1's step).  Off by default: "
+                         "paged attention shards by kv head with NO exchange step; the tensor-parallel all-reduces belong to the layer "
+                         "and are timed, with both engines, in extra.tp_step")
     ap.add_argument("--cpu-sample-seqs", type=int, default=64)
     args = ap.parse_args()
 
@@ -124,7 +128,7 @@ def main():
                    cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt,
                    block_table_batch_stride=pages_per_seq, page_block_size=page, force_split_kernel=True,
                    unpadded_lse=False)
-        if comm is not None:
+        if comm is not None and args.allreduce_in_step:
             assert ah.lib.atoma_allreduce_sum(comm, act.ptr, act_out.ptr, B * h * d, BF16, None) == 0, ah.last_error()
 
     def barrier():
@@ -171,7 +175,10 @@ def main():
                                % (B, h, hk, d, S, page, "identity" if args.identity_table else "random-permutation",
                                   n_pages),
                    "parallelism": "tp%d (kv-head shards)" % world, "step": "one run_mha decode call over the batch"
-                   + (" + all-reduce of [B, h*d] bf16" if comm is not None else "")},
+                   + (" + all-reduce of [B, h*d] bf16" if (comm is not None and args.allreduce_in_step) else ""),
+                   "collective": ("all-reduce of [B, hidden] bf16 inside the timed step (--allreduce-in-step)" if (comm is not None and args.allreduce_in_step)
+                                  else "none in the timed step: the path shards by kv head without an exchange; the layer's tensor-parallel "
+                                       "all-reduces are timed in extra.tp_step" if world > 1 else "n/a (one GPU)")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "paged_decode_kernel<bf16,128,G=4>", "kernel_ms": round(kern_ms, 4),
