@@ -155,7 +155,10 @@ def bench_prefill():
     cfg = int(os.environ.get("ATOMA_PREFILL_CFG", "0"))
     ah.lib.atoma_set_option(b"prefill_cfg", cfg)
     rng = np.random.default_rng(1)
-    for S, nseq, d in ((2048, 4, 128), (4096, 2, 128), (512, 16, 128), (2048, 16, 128), (2048, 16, 64)):
+    shapes = ((2048, 4, 128), (4096, 2, 128), (512, 16, 128), (2048, 16, 128), (2048, 16, 64))
+    if os.environ.get("ATOMA_BENCH_PREFILL_SHAPE"):    # e.g. "2048x16x128": one shape, for counter passes
+        shapes = (tuple(int(t) for t in os.environ["ATOMA_BENCH_PREFILL_SHAPE"].split("x")),)
+    for S, nseq, d in shapes:
         h, hk = 32, 8
         T = S * nseq
         q, k, v = rand_dev(rng, T * h * d * 2), rand_dev(rng, T * hk * d * 2), rand_dev(rng, T * hk * d * 2)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""gpurun_out/pfprof_<tag> + pfpmc_<tag>_* (tools/prefill_pmc.sh) -> profiles/<tag>_prefill_pmc.json and
+profiles/<tag>_prefill_kernel_stats.csv: duration, counters per launch, effective clock, MFMA pipe busy fraction at that clock
+(SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs: / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8 XCDs)), VALU instructions per MFMA."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+dur = None
+for f in glob.glob(os.path.join(root, "gpurun_out", f"pfprof_{tag}", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(out, f"{tag}_prefill_kernel_stats.csv"))
+    for r in csv.DictReader(open(f)):
+        if "prefill_mfma_kernel" in r["Name"]:
+            dur, name = float(r["AverageNs"]), r["Name"]
+ctr = collections.defaultdict(list)
+for f in glob.glob(os.path.join(root, "gpurun_out", f"pfpmc_{tag}_*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        if "prefill_mfma_kernel" in r["Kernel_Name"]:
+            ctr[r["Counter_Name"]].append(float(r["Counter_Value"]))
+c = {k: sum(v) / len(v) for k, v in ctr.items()}
+S, nseq, h, d = 2048, 16, 32, 128
+flops = 4.0 * S * S * h * d / 2 * nseq
+res = {"kernel": name.split("(")[0], "workload": "S=2048 x16, h=32, h_k=8, d=128, causal, bf16", "counters_mean_per_launch": c, "duration_ns": dur,
+       "flops": flops, "TFLOPs": round(flops / dur / 1e3, 1), "frac_of_2.5PF": round(flops / dur / 1e3 / 2500, 4)}
+if "GRBM_GUI_ACTIVE" in c:
+    gui = c["GRBM_GUI_ACTIVE"] / 8          # the counter is summed over the 8 XCDs
+    res["effective_clock_GHz"] = round(gui / dur, 3)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        res["mfma_pipe_busy_frac_at_actual_clock"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * gui), 4)
+if c.get("SQ_INSTS_MFMA"):
+    res["valu_insts_per_mfma"] = round(c.get("SQ_INSTS_VALU", 0) / c["SQ_INSTS_MFMA"], 2)
+res["note"] = "counter passes run slower than un-profiled launches (lower clock under the profiler); duration_ns is from the --kernel-trace --stats pass"
+json.dump(res, open(os.path.join(out, f"{tag}_prefill_pmc.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))
