@@ -852,18 +852,18 @@ template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t s
 
 // 17..64 rows: linear_mid_kernel (x staged through LDS once per workgroup).  Needs 64 output features per workgroup.
 static const int linear_mid = getenv("ATOMA_LINEAR_MID") ? atoi(getenv("ATOMA_LINEAR_MID")) : 1;
-static const int linear_mid_wg_per_cu = getenv("ATOMA_LINEAR_MID_WG_PER_CU") ? atoi(getenv("ATOMA_LINEAR_MID_WG_PER_CU")) : 2;
+static const float linear_mid_wg_per_cu = getenv("ATOMA_LINEAR_MID_WG_PER_CU") ? (float)atof(getenv("ATOMA_LINEAR_MID_WG_PER_CU")) : 1.f;
 template <typename T> static int launch_linear_mid(LinearParams &p, hipStream_t stream) {
     const bool pair = p.epilogue == 2;
     const int out_n = pair ? p.n / 2 : p.n;
     if (out_n % 64) return 1;                                  // not served: the caller falls through to linear_decode_kernel
     const int64_t tiles_n = out_n / 64, chunks = p.k / 128;
     const int ct = (p.batch + 15) / 16;
-    // Split K so that the workgroups fill the resident slots (2 per CU) in whole rounds: the largest split count whose
+    // Split K so that the workgroups fill one round of the CUs (linear_mid_wg_per_cu per CU): the largest split count whose
     // workgroups still fit one round, never below 4 chunks (512 inputs) per split.  The count is derived from the W ROWS
     // (p.n / 64), not from the workgroups, so that the stacked gate / up launch with its SiLU.up epilogue splits K exactly like
     // the plain projection of the same matrix and stays bit-identical to projection + atoma_silu_mul.
-    const int64_t target = (int64_t)device_num_cus() * linear_mid_wg_per_cu, row_tiles = p.n / 64;
+    const int64_t target = (int64_t)((float)device_num_cus() * linear_mid_wg_per_cu), row_tiles = p.n / 64;
     int64_t splits = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(row_tiles, 1), chunks / 4));
     p.chunks_per_split = (int)cdiv(chunks, splits);
     p.splits = (int)cdiv(chunks, p.chunks_per_split);
