@@ -799,11 +799,14 @@ constexpr int LINEAR_NORM_MAX_BATCH = 2;
 static const int linear_gemv = getenv("ATOMA_LINEAR_GEMV") ? atoi(getenv("ATOMA_LINEAR_GEMV")) : 1;
 static const int linear_gemv_max_batch = getenv("ATOMA_LINEAR_GEMV_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_GEMV_MAX_BATCH")) : 4;
 template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t stream) {
-    static const int gemv_wpc = getenv("ATOMA_LINEAR_GEMV_WAVES_PER_CU") ? atoi(getenv("ATOMA_LINEAR_GEMV_WAVES_PER_CU")) : 8;
+    static const int gemv_wpc = getenv("ATOMA_LINEAR_GEMV_WAVES_PER_CU") ? atoi(getenv("ATOMA_LINEAR_GEMV_WAVES_PER_CU")) : 32;
     const bool pair = p.epilogue == 2;
     const int64_t tiles = (pair ? p.n / 2 : p.n) / 16, chunks = p.k / 128;
+    // wavefronts per workgroup (the K split inside it) from the W ROWS, not from the workgroups: the stacked gate / up launch then
+    // splits K exactly like the plain projection of the same matrix and stays bit-identical to projection + atoma_silu_mul
+    const int64_t row_tiles = p.n / 16;
     int nw = 1;
-    while (nw < 8 && tiles * nw * 2 <= (int64_t)device_num_cus() * gemv_wpc && chunks / (nw * 2) >= 4) nw *= 2;
+    while (nw < 8 && row_tiles * nw * 2 <= (int64_t)device_num_cus() * gemv_wpc && chunks / (nw * 2) >= 4) nw *= 2;
     const dim3 grid((unsigned)tiles), block(64 * nw);
     const bool norm = p.norm_w != nullptr;
 #define ATOMA_GV3(NW_, NB_) do { if (pair) hipLaunchKernelGGL((linear_gemv_kernel<T, NW_, true, NB_, 2>), grid, block, 0, stream, p); \
@@ -829,9 +832,12 @@ static const int linear_wg_max_batch = getenv("ATOMA_LINEAR_WG_MAX_BATCH") ? ato
 // wavefronts per workgroup: as many as keep ~8 wavefronts per CU streaming, each with at least 4 chunks (512 inputs)
 template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t stream) {
     const bool pair = p.epilogue == 2;
-    const int64_t tiles = (pair ? p.n / 2 : p.n) / 16, chunks = p.k / 128;
+    const int64_t tiles = (pair ? p.n / 2 : p.n) / 16, chunks = p.k / 128, row_tiles = p.n / 16;   // nw from the W rows: see launch_linear_gemv
     int nw = 1;
-    while (nw < 8 && tiles * nw * 2 <= (int64_t)device_num_cus() * 8 && chunks / (nw * 2) >= 4) nw *= 2;
+    // Measured in the whole 8B step (5..16 rows): 4 wavefronts per workgroup for q/k/v, o and down, ONE for gate/up beats the
+    // earlier 4 / 8 / 8 / 2 by 7-10 % (fewer, longer streams per CU; the LDS merge of 8 partial sums is not free).
+    static const int wg_wpc = getenv("ATOMA_LINEAR_WG_WAVES_PER_CU") ? atoi(getenv("ATOMA_LINEAR_WG_WAVES_PER_CU")) : 6;
+    while (nw < 8 && row_tiles * nw * 2 <= (int64_t)device_num_cus() * wg_wpc && chunks / (nw * 2) >= 4) nw *= 2;
     static const int relay_on = getenv("ATOMA_LINEAR_RELAY") ? atoi(getenv("ATOMA_LINEAR_RELAY")) : 1;
     if (!relay_on && nw == 1 && p.epilogue == 0) return 1;   // MFMA-layout loads: the split-free path visits 512 bytes per row and is 3-5 % faster
     const dim3 grid((unsigned)tiles), block(64 * nw);
@@ -852,6 +858,7 @@ template <typename T> static int launch_linear_wg(LinearParams &p, hipStream_t s
 
 // 17..64 rows: linear_mid_kernel (x staged through LDS once per workgroup).  Needs 64 output features per workgroup.
 static const int linear_mid = getenv("ATOMA_LINEAR_MID") ? atoi(getenv("ATOMA_LINEAR_MID")) : 1;
+// measured in the whole step: ONE round of workgroups beats two (fewer partials to merge), no split at all loses
 static const float linear_mid_wg_per_cu = getenv("ATOMA_LINEAR_MID_WG_PER_CU") ? (float)atof(getenv("ATOMA_LINEAR_MID_WG_PER_CU")) : 1.f;
 template <typename T> static int launch_linear_mid(LinearParams &p, hipStream_t stream) {
     const bool pair = p.epilogue == 2;
@@ -898,7 +905,8 @@ template <typename T> static int launch_linear_big(LinearParams &p, hipStream_t 
     const int64_t row_tiles = p.n / 128, chunks = p.k / 128;
     // split K (in units of 128 inputs) until the workgroups fill one round of the CUs; derived from the W rows, so that the
     // stacked gate / up launch with its epilogue splits exactly like the plain projection (bit-identical results)
-    const int64_t target = device_num_cus();
+    static const float big_wg_per_cu = getenv("ATOMA_LINEAR_BIG_WG_PER_CU") ? (float)atof(getenv("ATOMA_LINEAR_BIG_WG_PER_CU")) : 1.f;
+    const int64_t target = (int64_t)((float)device_num_cus() * big_wg_per_cu);
     int64_t splits = std::max<int64_t>(1, std::min<int64_t>(target / std::max<int64_t>(row_tiles, 1), chunks / 4));
     p.chunks_per_split = (int)cdiv(chunks, splits);
     p.splits = (int)cdiv(chunks, p.chunks_per_split);

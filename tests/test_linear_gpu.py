@@ -118,6 +118,25 @@ def test_linear_decode_fused_epilogues_match_the_separate_ops(gpu):
     assert d.max() <= 1 and (d > 0).mean() < 0.01
 
 
+@pytest.mark.parametrize("B", [1, 2, 4, 8, 16])
+def test_fused_gate_up_equals_projection_plus_silu_mul_at_model_shapes(gpu, B):
+    """The stacked gate / up launch has half as many workgroups as the plain projection of the same matrix; its K split (wavefronts
+    per workgroup) is derived from the weight rows, so the two must still agree bit for bit at the shapes where the split is not 1
+    (Llama-3.1-8B MLP: [2 x 14336, 4096]) -- weight-streaming kernels at 1..4 and 5..16 rows."""
+    rng = np.random.default_rng(100 + B)
+    K, I = 4096, 14336
+    x = rand_half(rng, (B, K), BF16)
+    wgu = rand_half(rng, (2 * I, K), BF16, K ** -0.5)
+    dx, dw = gpu.DeviceBuffer.from_numpy(x), gpu.DeviceBuffer.from_numpy(wgu)
+    gu, act, act2 = gpu.DeviceBuffer(B * 2 * I * 2), gpu.DeviceBuffer(B * I * 2), gpu.DeviceBuffer(B * I * 2)
+    L = gpu.lib
+    assert L.atoma_linear_decode(dx.ptr, dw.ptr, gu.ptr, B, K, 2 * I, K, K, 2 * I, BF16, None) == 0, gpu.last_error()
+    assert L.atoma_silu_mul(gu.ptr, gu.ptr + I * 2, act.ptr, B, I, 2 * I, 2 * I, I, BF16, None) == 0, gpu.last_error()
+    assert L.atoma_linear_decode_silu_mul(dx.ptr, dw.ptr, act2.ptr, B, K, I, K, K, I, BF16, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    assert np.array_equal(act.numpy(np.uint16, (B, I)), act2.numpy(np.uint16, (B, I)))
+
+
 @pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("B,K,N,I", [(1, 4096, 6144, 14336), (2, 4096, 512, 1024), (3, 8192, 1280, 3584), (4, 2048, 1024, 512), (1, 128, 16, 16),
                                      (4, 16384, 256, 128), (7, 4096, 512, 768), (40, 1024, 256, 256)])
