@@ -797,7 +797,10 @@ __global__ void __launch_bounds__(64 * NW) linear_gemv_kernel(const LinearParams
 
 constexpr int LINEAR_NORM_MAX_BATCH = 2;
 static const int linear_gemv = getenv("ATOMA_LINEAR_GEMV") ? atoi(getenv("ATOMA_LINEAR_GEMV")) : 1;
-static const int linear_gemv_max_batch = getenv("ATOMA_LINEAR_GEMV_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_GEMV_MAX_BATCH")) : 4;
+// Measured inside the 8B decode step: the VALU kernel wins at ONE row (3.33 against 3.49 ms); from 2 rows up the workgroup kernel
+// with the matrix cores is faster (batch 2: 3.75 -> 3.64 ms, 3: 3.85 -> 3.79, 4: 4.00 -> 3.92), although the single-kernel benchmark
+// still favoured this one up to 4 rows.
+static const int linear_gemv_max_batch = getenv("ATOMA_LINEAR_GEMV_MAX_BATCH") ? atoi(getenv("ATOMA_LINEAR_GEMV_MAX_BATCH")) : 1;
 template <typename T> static int launch_linear_gemv(LinearParams &p, hipStream_t stream) {
     static const int gemv_wpc = getenv("ATOMA_LINEAR_GEMV_WAVES_PER_CU") ? atoi(getenv("ATOMA_LINEAR_GEMV_WAVES_PER_CU")) : 32;
     const bool pair = p.epilogue == 2;

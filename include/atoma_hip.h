@@ -241,8 +241,8 @@ int atoma_linear_decode_silu_mul(const void *x, const void *w_gate_up, void *y, 
                                  int64_t x_row_stride, int64_t w_row_stride, int64_t y_row_stride, int dtype, void *stream);
 
 /* The RMSNorm in FRONT of a projection folded into it (llama.rs:402 -> 269-271 for q/k/v, :408 -> 364-365 for gate/up):
- * y = rms_norm(x; norm_weight, eps) . w^T, and the _silu_mul form of the stacked gate/up projection on top of that.  At 1 and 2 rows
- * the projection kernel derives each row's scale itself with atoma_rms_norm's own arithmetic and
+ * y = rms_norm(x; norm_weight, eps) . w^T, and the _silu_mul form of the stacked gate/up projection on top of that.  On the rows the
+ * VALU streaming kernel serves (1 by default, ATOMA_LINEAR_GEMV_MAX_BATCH up to 2) the projection kernel derives each row's scale itself with atoma_rms_norm's own arithmetic and
  * normalises its input on the way in: bit-identical to atoma_rms_norm followed by atoma_linear_decode[_silu_mul], one launch
  * less per norm.  Larger batches run exactly those two calls, through xn_scratch [batch, in_features] (16-byte aligned; may be
  * NULL when the batch never exceeds the limit).  norm_weight [in_features], 16-byte aligned; in_features <= 16384. */

@@ -41,7 +41,7 @@ class DecodeStep:
         c = self.cfg = cfg
         self.B, self.stream, self.keep = batch, stream, keep_intermediates
         self.allreduce = allreduce
-        # Residual adds, SiLU.up (and at 1-2 rows the RMSNorms) inside the library's own projection kernels.  Up to 128 rows that is the
+        # Residual adds, SiLU.up (and at 1 row the RMSNorms) inside the library's own projection kernels.  Up to 128 rows that is the
         # faster step although the vendor GEMM wins most of the single products from 5 rows up (three launches per layer fewer:
         # batch 8 5.17 -> 4.62 ms, 32 7.58 -> 6.96, 64 11.2 -> 10.3, 96 14.9 -> 14.6, 128 16.9 -> 16.8; at 256 rows 19.4 -> 20.1, so
         # the C3 batch stays on the vendor GEMM); a TP rank must all-reduce before the residual.
