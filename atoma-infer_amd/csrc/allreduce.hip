@@ -75,6 +75,8 @@ struct Comm {
     int mode = AR_RCCL;
     int64_t xgmi_auto_max = 8 << 20;
     std::string xgmi_note;       // why the direct path is unavailable, if it is
+    bool xgmi_tried = false;     // comm_setup_xgmi ran (it is collective: once per communicator, on every rank)
+    bool xgmi_allowed = true;    // ATOMA_XGMI_SETUP != 0
 };
 
 }  // namespace atoma
@@ -103,34 +105,50 @@ int atoma_xgmi_destroy(void *xg);
 // lands in atoma_comm_info().
 static void comm_setup_xgmi(atoma::Rccl *r, atoma::Comm *c) {
     using namespace atoma;
+    c->xgmi_tried = true;
     const char *mb = getenv("ATOMA_XGMI_MAX_BYTES");
     const int64_t cap = mb ? atoll(mb) : (int64_t)(8 << 20);
     c->xgmi_auto_max = cap;
     if (c->world > 8) { c->xgmi_note = "direct path supports up to 8 ranks"; return; }
     if (!r->AllGather) { c->xgmi_note = "ncclAllGather not found"; return; }
+    // The two exchanges below are COLLECTIVE: every rank that got this far takes part in both, whatever happened to it locally --
+    // a local failure travels in the payload (byte 127 of the handle / the agreement flag), never as a skipped call that would
+    // leave the peers blocked inside RCCL.  The exchange buffers therefore come first.
+    unsigned char *dsend = nullptr, *drecv = nullptr;
+    std::vector<unsigned char> all((size_t)c->world * 128, 0);
+    if (hipMalloc(reinterpret_cast<void **>(&dsend), 128) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&drecv), all.size()) != hipSuccess ||
+        hipMemset(dsend, 0, 128) != hipSuccess) {
+        // no device memory for a 128-byte message: RCCL itself cannot work on this rank either
+        (void)hipGetLastError();
+        if (dsend) (void)hipFree(dsend);
+        if (drecv) (void)hipFree(drecv);
+        c->xgmi_note = "could not allocate the handle exchange buffers";
+        return;
+    }
     void *xg = nullptr;
     int ok = atoma_xgmi_create(&xg, c->rank, c->world, c->device, cap) == 0;
     std::string why = ok ? "" : atoma_last_error();
     unsigned char mine[128] = {0};
     if (ok && atoma_xgmi_handle(xg, mine) != 0) { ok = 0; why = atoma_last_error(); }
-    // exchange the handles (and, in byte 127, whether this rank is still healthy) through RCCL
+    // exchange the handles (and, in byte 127, whether this rank is still healthy) through RCCL; dsend holds zeros (= unhealthy)
+    // until the upload succeeds
     mine[127] = ok ? 1 : 0;
-    unsigned char *dsend = nullptr, *drecv = nullptr;
-    std::vector<unsigned char> all((size_t)c->world * 128, 0);
-    bool xok = hipMalloc(reinterpret_cast<void **>(&dsend), 128) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&drecv), all.size()) == hipSuccess &&
-               hipMemcpy(dsend, mine, 128, hipMemcpyHostToDevice) == hipSuccess &&
-               r->AllGather(dsend, drecv, 128, 0 /* ncclInt8 */, c->comm, nullptr) == 0 && hipStreamSynchronize(nullptr) == hipSuccess &&
-               hipMemcpy(all.data(), drecv, all.size(), hipMemcpyDeviceToHost) == hipSuccess;
+    if (hipMemcpy(dsend, mine, 128, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); ok = 0; if (why.empty()) why = "handle upload failed"; }
+    bool xok = r->AllGather(dsend, drecv, 128, 0 /* ncclInt8 */, c->comm, nullptr) == 0;
+    xok = hipStreamSynchronize(nullptr) == hipSuccess && xok;
+    xok = xok && hipMemcpy(all.data(), drecv, all.size(), hipMemcpyDeviceToHost) == hipSuccess;
     if (!xok) { (void)hipGetLastError(); ok = 0; if (why.empty()) why = "handle all-gather over RCCL failed"; }
     for (int q = 0; q < c->world && xok; ++q)
         if (!all[(size_t)q * 128 + 127]) { ok = 0; if (why.empty()) why = "rank " + std::to_string(q) + " could not create its staging region"; }
     for (int q = 0; q < c->world; ++q) all[(size_t)q * 128 + 127] = 0;
     if (ok && atoma_xgmi_connect(xg, all.data()) != 0) { ok = 0; why = atoma_last_error(); }
-    // agreement: sum of the ranks' ok flags must equal the world size
+    // agreement: sum of the ranks' ok flags must equal the world size (dsend still holds a zero in its first word if the upload fails)
     float flag = ok ? 1.f : 0.f, total = 0.f;
-    bool aok = xok && hipMemcpy(dsend, &flag, 4, hipMemcpyHostToDevice) == hipSuccess &&
-               r->AllReduce(dsend, drecv, 1, NCCL_FLOAT32, NCCL_SUM, c->comm, nullptr) == 0 && hipStreamSynchronize(nullptr) == hipSuccess &&
-               hipMemcpy(&total, drecv, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipMemset(dsend, 0, 4);
+    (void)hipMemcpy(dsend, &flag, 4, hipMemcpyHostToDevice);
+    bool aok = r->AllReduce(dsend, drecv, 1, NCCL_FLOAT32, NCCL_SUM, c->comm, nullptr) == 0;
+    aok = hipStreamSynchronize(nullptr) == hipSuccess && aok;
+    aok = aok && hipMemcpy(&total, drecv, 4, hipMemcpyDeviceToHost) == hipSuccess;
     if (dsend) (void)hipFree(dsend);
     if (drecv) (void)hipFree(drecv);
     (void)hipGetLastError();
@@ -160,8 +178,14 @@ int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128
     }
     const char *m = getenv("ATOMA_ALLREDUCE");
     c->mode = (m && !strcmp(m, "xgmi")) ? atoma::AR_XGMI : ((m && !strcmp(m, "auto")) ? atoma::AR_AUTO : atoma::AR_RCCL);
-    const char *setup = getenv("ATOMA_XGMI_SETUP");       // 0: never build the direct path (saves the staging memory)
-    if (!(setup && atoi(setup) == 0)) comm_setup_xgmi(r, c);
+    // The direct path (a 2 x cap uncached staging region + two RCCL collectives to exchange and agree on the handles) is built
+    // only when it will be used: at init when the environment selects it (ATOMA_ALLREDUCE=xgmi|auto, or ATOMA_XGMI_SETUP=1),
+    // otherwise on the first atoma_comm_set_mode(xgmi | auto) -- which every rank must call alike (it is collective then).
+    // A plain RCCL communicator pays nothing.  ATOMA_XGMI_SETUP=0: never.
+    const char *setup = getenv("ATOMA_XGMI_SETUP");
+    c->xgmi_allowed = !(setup && atoi(setup) == 0);
+    if (c->xgmi_allowed && (c->mode != atoma::AR_RCCL || (setup && atoi(setup) == 1))) comm_setup_xgmi(r, c);
+    else c->xgmi_note = c->xgmi_allowed ? "not built yet (atoma_comm_set_mode builds it)" : "disabled by ATOMA_XGMI_SETUP=0";
     *comm_out = c;
     return 0;
 }
@@ -172,6 +196,12 @@ int atoma_comm_set_mode(void *comm, int mode) {
     atoma::clear_error();
     auto *c = static_cast<atoma::Comm *>(comm);
     if (!c || mode < 0 || mode > 2) { atoma::set_error("atoma_comm_set_mode: bad argument"); return -1; }
+    if (mode != atoma::AR_RCCL && !c->xgmi && !c->xgmi_tried && c->xgmi_allowed) {   // lazy, collective build of the direct path
+        atoma::Rccl *r = atoma::rccl();
+        if (!r) return -1;
+        if (!atoma::check_hip(hipSetDevice(c->device), "hipSetDevice")) return -1;
+        comm_setup_xgmi(r, c);
+    }
     if (mode == atoma::AR_XGMI && !c->xgmi) { atoma::set_error("atoma_comm_set_mode: the direct xGMI path is unavailable: " + c->xgmi_note); return -1; }
     c->mode = mode;
     return 0;

@@ -34,6 +34,8 @@ struct LtApi {
     decltype(&hipblasLtMatmulPreferenceDestroy) pref_destroy = nullptr;
     decltype(&hipblasLtMatmulAlgoGetHeuristic) heuristic = nullptr;
     decltype(&hipblasLtMatmul) matmul = nullptr;
+    decltype(&hipblasLtMatmulDescDestroy) desc_destroy = nullptr;        // optional: a library without them only leaks on error paths
+    decltype(&hipblasLtMatrixLayoutDestroy) layout_destroy = nullptr;
     bool ok = false;
 };
 
@@ -53,6 +55,8 @@ static LtApi &lt_api() {
         ATOMA_LT_SYM(pref_destroy, hipblasLtMatmulPreferenceDestroy);
         ATOMA_LT_SYM(heuristic, hipblasLtMatmulAlgoGetHeuristic);
         ATOMA_LT_SYM(matmul, hipblasLtMatmul);
+        ATOMA_LT_SYM(desc_destroy, hipblasLtMatmulDescDestroy);
+        ATOMA_LT_SYM(layout_destroy, hipblasLtMatrixLayoutDestroy);
 #undef ATOMA_LT_SYM
         a.ok = a.create && a.desc_create && a.desc_set && a.layout_create && a.pref_create && a.pref_set && a.pref_destroy &&
                a.heuristic && a.matmul;
@@ -66,6 +70,19 @@ struct GemmPlan {
     hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
     hipblasLtMatmulAlgo_t algo;
     size_t workspace = 0;
+};
+// a plan that does not end up in the cache gives its descriptor and layouts back (a shape first seen during a
+// capture leaked them on every call until an eager call tuned it; so did every error path of the plan builder)
+struct PlanGuard {
+    LtApi &api;
+    GemmPlan &pl;
+    bool keep = false;
+    ~PlanGuard() {
+        if (keep) return;
+        if (pl.desc && api.desc_destroy) api.desc_destroy(pl.desc);
+        for (hipblasLtMatrixLayout_t l : {pl.a, pl.b, pl.c})
+            if (l && api.layout_destroy) api.layout_destroy(l);
+    }
 };
 struct LtDevice {
     hipblasLtHandle_t handle = nullptr;
@@ -118,6 +135,7 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
     LT_DBG("gemm batch=%lld k=%lld n=%lld stream=%p plan %s", (long long)batch, (long long)k, (long long)n, (void *)stream, it == d.plans.end() ? "MISS" : "hit");
     if (it == d.plans.end()) {
         GemmPlan pl;
+        PlanGuard guard{api, pl};
         const hipDataType t = dtype == ATOMA_BF16 ? HIP_R_16BF : HIP_R_16F;
         if (!lt_ok(api.desc_create(&pl.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F), "MatmulDescCreate")) return -1;
         const int32_t op_t = HIPBLAS_OP_T, op_n = HIPBLAS_OP_N;
@@ -194,6 +212,7 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
             return lt_ok(api.matmul(d.handle, pl.desc, &alpha1, w, pl.a, x, pl.b, &beta0, y, pl.c, y, pl.c, &pl.algo, lt_ws,
                                     LT_WORKSPACE_BYTES, stream), "Matmul") ? 0 : -1;
         }
+        guard.keep = true;
         it = d.plans.emplace(key, pl).first;
     }
     const GemmPlan &pl = it->second;

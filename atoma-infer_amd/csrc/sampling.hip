@@ -534,12 +534,114 @@ __global__ void __launch_bounds__(SAMPLE_THREADS) sample_full_kernel(const void 
     }
 }
 
+// ---- full-row nucleus (top-p whose nucleus is larger than the sorted top-1024 list) ----
+// Candle's sample_topp keeps EVERY token, most probable first, until the cumulative probability reaches top_p.  When the
+// 1024 most probable tokens do not get there (high temperature / flat rows over a 128k vocabulary) the nucleus is found over
+// the whole row without sorting it: a crossing position in the order (logit descending, index ascending) is
+//   the largest key t whose tail weight W(t) = sum of the weights of all tokens with key >= t satisfies the predicate
+//   (bisection over the 32-bit order key, one pass over the row per step, fixed summation order => every thread sees the same
+//   sums), then the tokens that share that key, in index order, one equal weight at a time.
+// Rare path: ~35 passes over an L2-resident row by 256 threads.
+struct Crossing { int token; float cum; };          // cum = running weight including `token`
+
+template <typename T>
+__device__ float tail_weight(const char *row, int vocab, float m, float inv_temp, uint32_t t, float *red) {
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < vocab; i += 256) {
+        const float x = sample_clean(load1<T>(row, i));
+        if (order_key(x) >= t) s += __expf((x - m) * inv_temp);
+    }
+    s = wave_sum(s);
+    __syncthreads();                                 // red is reused by every call
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// STRICT: first position whose running sum EXCEEDS target (the draw); else: first position whose running sum REACHES it (the
+// nucleus cut).  If no position qualifies (target beyond the row's total after rounding) the last token with any weight.
+template <typename T, bool STRICT>
+__device__ Crossing sorted_crossing(const char *row, int vocab, float m, float inv_temp, float target, float *red, int *ired) {
+    const int tid = threadIdx.x;
+    auto pred = [&](float w) { return STRICT ? w > target : w >= target; };
+    // keys of weighted tokens are > KEY_NEG_INF; lo: predicate holds (or nothing qualifies), hi: it does not
+    unsigned long long lo = KEY_NEG_INF + 1ull, hi = 1ull << 32;
+    float w_hi = 0.f;
+    const bool any = pred(tail_weight<T>(row, vocab, m, inv_temp, (uint32_t)lo, red));
+    if (!any) {                                      // the last weighted token in sorted order: smallest key, largest index
+        Best b{0xffffffffu, -1};
+        for (int i = tid; i < vocab; i += 256) {
+            const uint32_t k = order_key(sample_clean(load1<T>(row, i)));
+            if (k > KEY_NEG_INF && (k < b.v || (k == b.v && i > b.i))) { b.v = k; b.i = i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            Best o{(uint32_t)__shfl_xor((int)b.v, off, 64), __shfl_xor(b.i, off, 64)};
+            if (o.v < b.v || (o.v == b.v && o.i > b.i)) b = o;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { ired[tid >> 6] = (int)b.v; ired[4 + (tid >> 6)] = b.i; }
+        __syncthreads();
+        Best r{(uint32_t)ired[0], ired[4]};
+        for (int w = 1; w < 4; ++w) {
+            Best o{(uint32_t)ired[w], ired[4 + w]};
+            if (o.v < r.v || (o.v == r.v && o.i > r.i)) r = o;
+        }
+        return Crossing{r.i < 0 ? 0 : r.i, tail_weight<T>(row, vocab, m, inv_temp, KEY_NEG_INF + 1u, red)};
+    }
+    while (hi - lo > 1) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        const float w = tail_weight<T>(row, vocab, m, inv_temp, (uint32_t)mid, red);
+        if (pred(w)) lo = mid; else { hi = mid; w_hi = w; }
+    }
+    // tokens with key == lo share one weight; position j (index order) has running sum w_hi + (j + 1) * wt
+    const uint32_t key = (uint32_t)lo;
+    const int per = (vocab + 255) / 256, i0 = tid * per, i1 = min(vocab, i0 + per);
+    int cnt = 0;
+    float wt = 0.f;
+    for (int i = i0; i < i1; ++i) {
+        const float x = sample_clean(load1<T>(row, i));
+        if (order_key(x) == key) { ++cnt; wt = __expf((x - m) * inv_temp); }
+    }
+    // exclusive prefix of the counts over the 256 threads (contiguous ranges => index order) and the shared weight
+    int inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(inc, off, 64);
+        if ((tid & 63) >= off) inc += y;
+    }
+    const float wmax = wave_max(wt);
+    __syncthreads();
+    if ((tid & 63) == 63) ired[tid >> 6] = inc;
+    if ((tid & 63) == 0) red[tid >> 6] = wmax;
+    __syncthreads();
+    int before = inc - cnt;
+    for (int w = 0; w < (tid >> 6); ++w) before += ired[w];
+    const int n_ties = ired[0] + ired[1] + ired[2] + ired[3];
+    wt = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int jl = 0, jh = n_ties - 1;                     // smallest j with pred(w_hi + (j + 1) wt); j = n_ties - 1 qualifies (= W(lo))
+    while (jl < jh) {
+        const int jm = (jl + jh) >> 1;
+        if (pred(w_hi + (float)(jm + 1) * wt)) jh = jm; else jl = jm + 1;
+    }
+    __syncthreads();
+    if (before <= jl && jl < before + cnt) {         // exactly one thread owns the jl-th tie
+        int seen = before;
+        for (int i = i0; i < i1; ++i)
+            if (order_key(sample_clean(load1<T>(row, i))) == key && seen++ == jl) ired[8] = i;
+    }
+    __syncthreads();
+    return Crossing{ired[8], w_hi + (float)(jl + 1) * wt};
+}
+
 // top-k / top-p: `vals`, `idxs` [rows][k] from atoma_topk_rows (value descending, index ascending); one wave per row
 template <typename T>
 __global__ void __launch_bounds__(256) sample_topk_kernel(const void *__restrict__ logits, int64_t row_stride_bytes, int vocab, const float *__restrict__ vals,
                                                           const int32_t *__restrict__ idxs, int k, float inv_temp, float top_p, const float *__restrict__ u,
-                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_logit) {
+                                                          int32_t *__restrict__ out_idx, float *__restrict__ out_logit, int full_row_nucleus) {
     __shared__ float red[4];
+    __shared__ int ired[12];
     const char *row = static_cast<const char *>(logits) + (int64_t)blockIdx.x * row_stride_bytes;
     const float *v = vals + (int64_t)blockIdx.x * k;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -553,13 +655,15 @@ __global__ void __launch_bounds__(256) sample_topk_kernel(const void *__restrict
         __syncthreads();
         denom = red[0] + red[1] + red[2] + red[3];
     }
-    if (wave != 0) return;
+    // full_row_nucleus (top-p with no top-k): the sorted list is only the first 1024 tokens of the order; when their weight does
+    // not reach top_p * denom the nucleus continues beyond it and all four wavefronts find it over the whole row
+    if (wave != 0 && !full_row_nucleus) return;
     // kept prefix of the sorted list: all k, or up to (and including) the token whose cumulative probability reaches top_p
     int keep = k;
     float total = 0.f;
+    bool cut = false;
     {
         float base = 0.f;
-        bool cut = false;
         for (int c0 = 0; c0 < k && !cut; c0 += 64) {
             const float w = c0 + lane < k ? __expf((sample_clean(v[c0 + lane]) - m) * inv_temp) : 0.f;
             float inc = w;
@@ -582,6 +686,19 @@ __global__ void __launch_bounds__(256) sample_topk_kernel(const void *__restrict
             base += __shfl(inc, 63, 64);
             total = base;
         }
+    }
+    if (full_row_nucleus) {
+        // every wavefront ran the scan above on the same values: `cut` is uniform over the workgroup
+        if (!cut && k < vocab) {
+            const Crossing nucleus = sorted_crossing<T, false>(row, vocab, m, inv_temp, top_p * denom, red, ired);
+            const Crossing pick = sorted_crossing<T, true>(row, vocab, m, inv_temp, u[blockIdx.x] * nucleus.cum, red, ired);
+            if (tid == 0) {
+                out_idx[blockIdx.x] = pick.token;
+                if (out_logit) out_logit[blockIdx.x] = load1<T>(row, pick.token);
+            }
+            return;
+        }
+        if (wave != 0) return;
     }
     const float draw = u[blockIdx.x] * total;
     float base = 0.f;
@@ -630,14 +747,17 @@ extern "C" int atoma_sample_rows(const void *logits, int64_t rows, int64_t vocab
 #undef ATOMA_SF
         return ATOMA_CHECK_LAUNCH("sample_rows") ? 0 : -1;
     }
-    // top-p without top-k: the nucleus is searched among the 1024 most probable tokens (it ends there for any real distribution)
-    const int64_t k = std::min<int64_t>((top_k > 0 && top_k < vocab) ? top_k : TOPK_MAX, vocab);
+    // top-p without top-k: the nucleus is searched among the 1024 most probable tokens first (it ends there for any peaked
+    // distribution); a row whose 1024 most probable tokens do not reach top_p continues over the whole row (sorted_crossing)
+    const bool have_k = top_k > 0 && top_k < vocab;
+    const int64_t k = std::min<int64_t>(have_k ? top_k : TOPK_MAX, vocab);
+    const int full_row = !have_k && top_p < 1.f;
     char *ws = static_cast<char *>(workspace(s, (size_t)rows * k * 8));
     if (!ws) return -1;
     float *vals = reinterpret_cast<float *>(ws);
     int32_t *idxs = reinterpret_cast<int32_t *>(ws + (size_t)rows * k * 4);
     if (atoma_topk_rows(logits, rows, vocab, row_stride, dtype, k, vals, idxs, stream) != 0) return -1;
-#define ATOMA_ST(TT) hipLaunchKernelGGL((sample_topk_kernel<TT>), dim3((unsigned)rows), dim3(256), 0, s, logits, stride_bytes, (int)vocab, vals, idxs, (int)k, inv_temp, top_p, u, out_idx, out_logit)
+#define ATOMA_ST(TT) hipLaunchKernelGGL((sample_topk_kernel<TT>), dim3((unsigned)rows), dim3(256), 0, s, logits, stride_bytes, (int)vocab, vals, idxs, (int)k, inv_temp, top_p, u, out_idx, out_logit, full_row)
     if (dtype == ATOMA_F32) ATOMA_ST(float); else if (dtype == ATOMA_BF16) ATOMA_ST(bf16_t); else ATOMA_ST(f16_t);
 #undef ATOMA_ST
     return ATOMA_CHECK_LAUNCH("sample_rows (top-k / top-p)") ? 0 : -1;

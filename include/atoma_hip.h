@@ -196,7 +196,10 @@ int atoma_paged_decode_fp8(const void *q, const void *k_cache, const void *v_cac
 /* ---- KV block container: a checksummed, self-describing image of a set of pages of EVERY layer, for
  * handing KV blocks to another engine or to disk.  The reference only swaps raw pages between two caches of one process
  * (csrc/src/cache_manager.rs:18-128, worker.rs:602-632); this is that swap with one contiguous destination.  Image =
- * header | int64 block ids [n] | (fp8 only) f32 scales [2][layers][h_k] | payload [layer][K|V][block][page bytes].
+ * header | int64 block ids [n] | (fp8 only) f32 scales [2][layers][h_k] | zeros up to a multiple of 256 bytes |
+ * payload [layer][K|V][block][page bytes].  Format version 2: the checksum covers the header (checksum field zeroed) and
+ * everything after it, and a reader re-derives page_bytes / payload_offset / total_bytes from the geometry (overflow-checked)
+ * and refuses a header that states anything else -- nothing it dereferences comes from unchecked bytes.
  * k_caches / v_caches: HOST arrays of per-layer DEVICE pointers [nb, block_size, h_k, d]; ids on the HOST; dtype f16 / bf16 /
  * ATOMA_U8 (= fp8 e4m3fn cache).  pack synchronises the stream (it checksums the bytes); unpack is stream-ordered and
  * verifies magic, version, geometry and checksum first.  Pinned host memory (atoma_host_alloc) moves with one gather /
@@ -306,8 +309,11 @@ int atoma_comm_destroy(void *comm);
 /* Engine behind atoma_allreduce_sum: 0 = RCCL's ncclAllReduce (default), 1 = the direct xGMI kernels below (error when
  * they could not be brought up), 2 = auto (direct up to ATOMA_XGMI_MAX_BYTES, default 8 MiB, when the message is a
  * multiple of 16 bytes and 16-byte aligned; RCCL otherwise).  Initial value from ATOMA_ALLREDUCE=rccl|xgmi|auto.  All
- * ranks must choose the same mode.  atoma_comm_init builds the direct path over the RCCL communicator (all-gather of the
- * staging handles + an agreement round) unless ATOMA_XGMI_SETUP=0; atoma_comm_info says "xgmi: ready" or why not. */
+ * ranks must choose the same mode, in the same order of calls: the direct path is built over the RCCL communicator (staging
+ * region + all-gather of the handles + an agreement round, both collective and joined by every rank whatever failed locally)
+ * only when it is first selected -- inside atoma_comm_init when ATOMA_ALLREDUCE=xgmi|auto (or ATOMA_XGMI_SETUP=1), else inside
+ * the first atoma_comm_set_mode(1 | 2); never with ATOMA_XGMI_SETUP=0.  A communicator that stays on RCCL allocates nothing
+ * and runs no extra collective.  atoma_comm_info says "xgmi: ready" or why not. */
 int atoma_comm_set_mode(void *comm, int mode);
 const char *atoma_comm_info(void *comm);
 

@@ -14,8 +14,9 @@ M64 = (1 << 64) - 1
 K = 0x9E3779B97F4A7C15
 
 
-def checksum(data):
-    b = bytes(data)
+def checksum(header_zeroed, body):
+    """64-bit multiply-mix over the header (checksum field zeroed) followed by the body."""
+    b = bytes(header_zeroed) + bytes(body)
     h = (K ^ len(b)) & M64
     n8 = len(b) // 8
     for w in np.frombuffer(b[:n8 * 8], "<u8"):
@@ -35,19 +36,23 @@ def pack(k_caches, v_caches, block_ids, dtype, k_scales=None, v_scales=None):
     body = ids.tobytes()
     if dtype == U8:
         body += np.asarray(k_scales, np.float32).tobytes() + np.asarray(v_scales, np.float32).tobytes()
+    body += b"\0" * (-(HEADER.size + len(body)) % 256)          # the payload starts on a multiple of 256 bytes
     payload_offset = HEADER.size + len(body)
     for l in range(L):
         body += k_caches[l][ids].tobytes() + v_caches[l][ids].tobytes()
     page_bytes = page * hk * d * ELT[dtype]
     total = HEADER.size + len(body)
-    head = HEADER.pack(MAGIC, 1, dtype, L, hk, d, page, len(ids), page_bytes, payload_offset, total, checksum(body), b"\0" * 56)
-    return head + body
+    fields = [MAGIC, 2, dtype, L, hk, d, page, len(ids), page_bytes, payload_offset, total, 0, b"\0" * 56]
+    fields[11] = checksum(HEADER.pack(*fields), body)
+    return HEADER.pack(*fields) + body
 
 
 def unpack(image, k_caches, v_caches, dst_ids):
     """Scatter an image into caches (in place); returns (block ids, k_scales, v_scales)."""
     magic, ver, dtype, L, hk, d, page, n, page_bytes, off, total, cs, _ = HEADER.unpack(image[:HEADER.size])
-    assert magic == MAGIC and ver == 1 and total == len(image) and checksum(image[HEADER.size:]) == cs
+    zeroed = HEADER.pack(magic, ver, dtype, L, hk, d, page, n, page_bytes, off, total, 0, _)
+    assert magic == MAGIC and ver == 2 and total == len(image) and checksum(zeroed, image[HEADER.size:]) == cs
+    assert page_bytes == page * hk * d * ELT[dtype] and off == -(-(HEADER.size + 8 * n + (8 * L * hk if dtype == U8 else 0)) // 256) * 256
     ids = np.frombuffer(image, np.int64, n, HEADER.size)
     ks = vs = None
     if dtype == U8:

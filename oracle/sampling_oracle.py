@@ -21,8 +21,6 @@ def kept_weights(logits_row, temperature, top_k=0, top_p=1.0):
     order = np.lexsort((np.arange(n), -x))                 # logit descending, index ascending
     if 0 < top_k < n:
         order = order[:top_k]
-    elif top_p < 1.0:
-        order = order[:1024]
     ww = w[order]
     if top_p < 1.0:
         cum = np.cumsum(ww) / w.sum()

@@ -29,6 +29,24 @@ def test_oracle_image_parses_in_the_library():
     assert bytes(hdr) == img[:128]
     buf[200] ^= 0x10
     assert lib.atoma_kv_read_header(buf.ctypes.data, len(img), hdr) == -1 and b"checksum" in lib.atoma_last_error()
+    buf[200] ^= 0x10
+    # a crafted header: every field that a reader would dereference is either covered by the checksum or re-derived from the
+    # geometry -- flipping page_bytes / payload_offset / a geometry field (with or without a recomputed checksum) is refused
+    fields = list(KF.HEADER.unpack(img[:128]))
+    for idx, val in ((8, fields[8] * 2), (9, fields[9] + 256), (9, 128 + 8 * 3), (3, fields[3] + 1), (7, (1 << 62))):
+        f = list(fields)
+        f[idx] = val
+        for fix_checksum in (False, True):
+            f[11] = 0
+            if fix_checksum:
+                f[11] = KF.checksum(KF.HEADER.pack(*f), img[128:])
+            else:
+                f[11] = fields[11]
+            forged = np.frombuffer(KF.HEADER.pack(*f) + img[128:], np.uint8).copy()
+            assert lib.atoma_kv_read_header(forged.ctypes.data, len(forged), hdr) == -1, (idx, val, fix_checksum)
+    # geometry whose byte count leaves int64 is refused, not wrapped
+    assert lib.atoma_kv_blocks_packed_size(1 << 31, 1 << 31, 1 << 31, 16, 4, 1) == -1
+    assert fields[9] % 256 == 0                      # payload_offset: every page 16-byte aligned for the vector copy path
     kc2, vc2 = [np.zeros_like(a) for a in kc], [np.zeros_like(a) for a in vc]
     ids, _, _ = KF.unpack(img, kc2, vc2, [0, 5, 2])
     assert ids.tolist() == [4, 1, 3] and np.array_equal(kc2[1][5], kc[1][1]) and np.array_equal(vc2[0][2], vc[0][3])

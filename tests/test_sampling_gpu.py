@@ -210,6 +210,34 @@ def test_sample_rows_matches_oracle(gpu, dtype, rows, vocab, temperature, top_k,
     check_draws(x32, idx, u, temperature, top_k, top_p)
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("temperature,top_p,scale", [(1.0, 0.9, 1.0), (2.0, 0.95, 2.5), (1.0, 0.5, 0.25)])
+def test_top_p_nucleus_larger_than_the_sorted_list(gpu, dtype, temperature, top_p, scale):
+    """Flat rows over a 128k vocabulary: the 1024 most probable tokens hold a few per cent of the mass, so the nucleus of
+    Candle's sample_topp (every token, most probable first, until the cumulative probability reaches top_p) has tens of
+    thousands of members -- the full-row path of atoma_sample_rows (the distribution must not be truncated to the
+    sorted top-1024 list).  bf16 rows carry thousands of equal logits: the cut and the draw fall inside tie classes."""
+    rows, vocab = 24, 128256
+    rng = np.random.default_rng(int(top_p * 100) + dtype)
+    if dtype == F32:
+        logits = (rng.standard_normal((rows, vocab)) * scale).astype(np.float32)
+        x32 = logits
+    else:
+        logits = rand_half(rng, (rows, vocab), dtype, scale)
+        x32 = to_f32(logits, dtype)
+    logits[3, :] = logits[3, 0]                          # a constant row: one tie class of 128 256 tokens
+    x32 = x32.copy()
+    x32[3, :] = x32[3, 0]
+    u = rng.random(rows).astype(np.float32)
+    u[0], u[1] = 0.0, np.float32(1.0 - 2.0 ** -24)
+    idx, val = gpu_sample(gpu, logits, dtype, u, temperature, 0, top_p)
+    assert np.array_equal(val, x32[np.arange(rows), idx])
+    sizes = [len(SO.kept_weights(x32[r], temperature, 0, top_p)[0]) for r in range(rows)]
+    assert min(sizes) > 1024, "the test must exercise the full-row path"
+    check_draws(x32, idx, u, temperature, 0, top_p, slack=1e-4)
+    assert idx[3] == min(int(u[3] * sizes[3]), sizes[3] - 1) or abs(idx[3] - u[3] * sizes[3]) < 16   # constant row: u picks the position
+
+
 def test_sample_rows_distribution_and_degenerate_rows(gpu):
     """Equally spaced uniforms reproduce the distribution; -inf / NaN logits are never drawn; a one-hot row always returns its token;
     padded rows ignore the padding."""
