@@ -90,6 +90,7 @@ _opt("atoma_rope", [_vp, _vp, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i6
 _opt("atoma_rope_qk", [_vp, _vp, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp])
 _opt("atoma_rope_qk_cache", [_vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                              _int, _int, _vp])
+_opt("atoma_linear_decode_qkv_rope_cache", [_vp, _vp, _vp, _vp, _vp, _i64p, _vp, _vp, _i64p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp])
 _opt("atoma_embedding", [_vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp])
 _opt("atoma_add", [_vp, _vp, _vp, _i64, _int, _vp])
 _opt("atoma_silu_mul", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _vp])

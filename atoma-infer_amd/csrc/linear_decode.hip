@@ -17,39 +17,12 @@
 // the kernel differs from it by at most one unit in the last place (accumulation order).
 #include "common.h"
 #include "norm_shared.h"
+#include "linear_params.h"
 #include <algorithm>
 #include <stdlib.h>
 #include <type_traits>
 
 namespace atoma {
-
-void *workspace(hipStream_t stream, size_t bytes);   // paged_decode.hip: grow-only fp32 scratch per (device, stream)
-
-typedef unsigned int lu32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((ext_vector_type(4))) float lf32x4;
-
-template <typename T> __device__ __forceinline__ lf32x4 lin_mfma(const lu32x4 &a, const lu32x4 &b, lf32x4 c);
-template <> __device__ __forceinline__ lf32x4 lin_mfma<bf16_t>(const lu32x4 &a, const lu32x4 &b, lf32x4 c) {
-    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ lf32x4 lin_mfma<f16_t>(const lu32x4 &a, const lu32x4 &b, lf32x4 c) {
-    typedef __attribute__((ext_vector_type(8))) _Float16 v8;
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
-}
-
-struct LinearParams {
-    const uint16_t *x, *w;
-    uint16_t *y;
-    float *partial;              // [splits][batch][n] fp32, or null when splits == 1
-    int64_t x_row_stride, w_row_stride, y_row_stride;   // elements
-    int batch, n, k, splits, chunks_per_split;           // chunk = 128 inputs
-    int epilogue;                // 0 none; 1 out = round(y) + aux (residual add); 2 out[:, i] = silu(y[:, i]) * y[:, n/2 + i] (stacked gate / up)
-    const uint16_t *aux;         // epilogue 1: the residual [batch, n]
-    int64_t aux_row_stride;
-    const uint16_t *norm_w;      // non-null: x is RMS-normalised with this weight [k] on the way in (linear_gemv_kernel<.., NORM>)
-    float norm_eps;
-};
 
 // lane = 16.grp + col.  A operand: W[n0 + 16r + col][k0 + 32s + 8.grp ..+7] for the RT row tiles r of the wave;
 // B operand: x[16c + col][same k] for the CT column tiles c (batch rows 16c .. 16c+15), each shared by the RT row tiles;
@@ -462,6 +435,7 @@ __global__ void __launch_bounds__(256, 2) linear_mid_kernel(const LinearParams p
         }
     }
 }
+
 
 // Batches of 65..256 rows (continuous batching at bs <= 256, config[2]): 2.B flop per weight byte reaches the machine balance
 // here, so this is a real GEMM tile -- one workgroup of 4 wavefronts (one per SIMD, 512 registers) owns 128 weight rows
@@ -900,6 +874,7 @@ template <typename T> static int launch_linear_mid(LinearParams &p, hipStream_t 
     return 0;
 }
 
+
 // 65..256 rows: linear_big_kernel.  128 weight rows per workgroup (PAIR: 64 gate + 64 up), one workgroup per CU.
 template <typename T> static int launch_linear_big(LinearParams &p, hipStream_t stream) {
     const bool pair = p.epilogue == 2;
@@ -948,6 +923,18 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
         if (rc <= 0) return rc;
         set_error("linear_decode: more than 64 rows need out_features and in_features to be multiples of 128");
         return -1;
+    }
+    if (p.batch > 16) {
+        int rc = launch_linear_tile(p, std::is_same<T, bf16_t>::value ? ATOMA_BF16 : ATOMA_F16, stream);
+        if (rc < 0) return rc;
+        if (rc == 0) {
+            if (p.partial) {
+                const int out_n = p.epilogue == 2 ? p.n / 2 : p.n;
+                hipLaunchKernelGGL((linear_reduce_kernel<T>), dim3((unsigned)cdiv((int64_t)p.batch * out_n, 1024)), dim3(256), 0, stream, p);
+                if (!ATOMA_CHECK_LAUNCH("linear_reduce_kernel")) return -1;
+            }
+            return 0;
+        }
     }
     if (linear_mid && p.batch > 16) {
         const int rc = launch_linear_mid<T>(p, stream);

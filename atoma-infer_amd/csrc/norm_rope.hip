@@ -11,6 +11,7 @@
 // [T, h, d] layout the projections produce and fuses the cos/sin index_select.
 #include "common.h"
 #include "norm_shared.h"
+#include "linear_params.h"
 
 #include <atomic>
 #include <math.h>
@@ -133,15 +134,13 @@ __device__ __forceinline__ int64_t rope_pos(int64_t pos, int64_t table_rows) {
 // PER_OP = Candle's arithmetic in the tensor dtype: every product and the sum are rounded.
 // ------------------------------------------------------------------------------------------
 template <typename T, bool PER_OP>
-__device__ __forceinline__ void rope_chunk(const uint16_t *x, uint16_t *y, const uint16_t *cosr, const uint16_t *sinr,
-                                           int half, int c, uint16_t *y_copy = nullptr) {
+__device__ __forceinline__ void rope_chunk_vals(const float (&x1)[8], const float (&x2)[8], uint16_t *y, const uint16_t *cosr, const uint16_t *sinr,
+                                                int half, int c, uint16_t *y_copy = nullptr) {
     // No contraction here: for f16 the compiler narrows the f32 expressions below to half
     // arithmetic (legitimately -- f32 carries 2p+2 bits) and would then fuse mul+sub into one
     // v_fma_f16, i.e. drop exactly the intermediate rounding PER_OP exists to reproduce.
 #pragma clang fp contract(off)
-    float x1[8], x2[8], cs[8], sn[8], y1[8], y2[8];
-    unpack8<T>(*reinterpret_cast<const uint4 *>(x + c * 8), x1);
-    unpack8<T>(*reinterpret_cast<const uint4 *>(x + half + c * 8), x2);
+    float cs[8], sn[8], y1[8], y2[8];
     unpack8<T>(*reinterpret_cast<const uint4 *>(cosr + c * 8), cs);
     unpack8<T>(*reinterpret_cast<const uint4 *>(sinr + c * 8), sn);
 #pragma unroll
@@ -161,6 +160,14 @@ __device__ __forceinline__ void rope_chunk(const uint16_t *x, uint16_t *y, const
         *reinterpret_cast<uint4 *>(y_copy + c * 8) = lo;
         *reinterpret_cast<uint4 *>(y_copy + half + c * 8) = hi;
     }
+}
+template <typename T, bool PER_OP>
+__device__ __forceinline__ void rope_chunk(const uint16_t *x, uint16_t *y, const uint16_t *cosr, const uint16_t *sinr,
+                                           int half, int c, uint16_t *y_copy = nullptr) {
+    float x1[8], x2[8];
+    unpack8<T>(*reinterpret_cast<const uint4 *>(x + c * 8), x1);
+    unpack8<T>(*reinterpret_cast<const uint4 *>(x + half + c * 8), x2);
+    rope_chunk_vals<T, PER_OP>(x1, x2, y, cosr, sinr, half, c, y_copy);
 }
 
 // Two tensors (q and k) in one launch; nb heads == 0 disables the second.
@@ -249,6 +256,67 @@ rope_cache_kernel(uint16_t *__restrict__ q, uint16_t *__restrict__ k, const uint
             const int j = i - n_rope, hk = j / vpr, c = j - hk * vpr;
             *reinterpret_cast<uint4 *>(v_cache + row + (int64_t)hk * head_dim + c * 8) =
                 *reinterpret_cast<const uint4 *>(v + t * v_ts + (int64_t)hk * head_dim + c * 8);
+        }
+    }
+}
+
+// The same pass fed by the fp32 K-split partials of the q/k/v projection instead of its rounded output: the merge kernel of the
+// projection, RoPE and the cache write in ONE launch (the tensor-parallel rank's 1280-row q/k/v shard is split 8 ways over K; its
+// merge used to be a launch of its own in front of this one).  Sum over the splits in split order, ONE rounding to the storage
+// dtype -- exactly what linear_reduce_kernel writes -- then the arithmetic of rope_cache_kernel on those values: bit-identical to
+// projection + atoma_rope_qk_cache.  partial [splits][tokens][width] fp32, width = (heads_q + 2 heads_kv) head_dim; out [tokens, out_ts].
+template <typename T, bool PER_OP>
+__global__ void __launch_bounds__(256)
+qkv_partials_rope_cache_kernel(const float *__restrict__ partial, int splits, int64_t tokens, uint16_t *__restrict__ out, int64_t out_ts,
+                               uint16_t *__restrict__ k_cache, uint16_t *__restrict__ v_cache, const int64_t *__restrict__ slot_mapping,
+                               const uint16_t *__restrict__ cos_t, const uint16_t *__restrict__ sin_t, const int64_t *__restrict__ positions,
+                               int heads_q, int heads_kv, int head_dim, int64_t block_stride, int page_size, int64_t table_rows) {
+    const int64_t t = blockIdx.x;
+    const int half = head_dim >> 1, cpr = half >> 3, vpr = head_dim >> 3;
+    const int width = (heads_q + 2 * heads_kv) * head_dim;
+    const int64_t pos = rope_pos(positions[t], table_rows), slot = slot_mapping[t];
+    const uint16_t *cosr = cos_t + pos * half, *sinr = sin_t + pos * half;
+    const int64_t row = slot >= 0 ? (slot / page_size) * block_stride + (slot % page_size) * (int64_t)heads_kv * head_dim : 0;
+    const int n_rope = (heads_q + heads_kv) * cpr, total = n_rope + heads_kv * vpr;
+    const int64_t plane = tokens * width;
+    auto sum8 = [&](int n, float (&v)[8]) {        // 8 consecutive outputs of token t: splits added in order, rounded once
+        const float *src = partial + t * width + n;
+        float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+        for (int s0 = 1; s0 < splits; s0 += 8) {   // up to 8 splits' loads in flight, then the adds in split order
+            float4 c[8], d[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s0 + j < splits) {
+                    c[j] = *reinterpret_cast<const float4 *>(src + (s0 + j) * plane);
+                    d[j] = *reinterpret_cast<const float4 *>(src + (s0 + j) * plane + 4);
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s0 + j < splits) {
+                    a.x += c[j].x; a.y += c[j].y; a.z += c[j].z; a.w += c[j].w;
+                    b.x += d[j].x; b.y += d[j].y; b.z += d[j].z; b.w += d[j].w;
+                }
+        }
+        v[0] = round_through<T>(a.x); v[1] = round_through<T>(a.y); v[2] = round_through<T>(a.z); v[3] = round_through<T>(a.w);
+        v[4] = round_through<T>(b.x); v[5] = round_through<T>(b.y); v[6] = round_through<T>(b.z); v[7] = round_through<T>(b.w);
+    };
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        if (i < n_rope) {
+            const int head = i / cpr, c = i - head * cpr;          // heads_q q heads, then the k heads: consecutive in the projection's output
+            float x1[8], x2[8];
+            sum8(head * head_dim + c * 8, x1);
+            sum8(head * head_dim + half + c * 8, x2);
+            uint16_t *y = out + t * out_ts + (int64_t)head * head_dim;
+            const int hk = head - heads_q;
+            rope_chunk_vals<T, PER_OP>(x1, x2, y, cosr, sinr, half, c, hk >= 0 && slot >= 0 ? k_cache + row + (int64_t)hk * head_dim : nullptr);
+        } else {
+            const int j = i - n_rope, hk = j / vpr, c = j - hk * vpr;
+            float v[8];
+            const int n = (heads_q + heads_kv + hk) * head_dim + c * 8;
+            sum8(n, v);
+            const uint4 packed = pack8<T>(v);
+            *reinterpret_cast<uint4 *>(out + t * out_ts + n) = packed;
+            if (slot >= 0) *reinterpret_cast<uint4 *>(v_cache + row + (int64_t)hk * head_dim + c * 8) = packed;
         }
     }
 }
@@ -356,6 +424,55 @@ int atoma_rope_qk_cache(void *q, void *k, const void *v, void *k_cache, void *v_
     else { if (per_op_rounding) ATOMA_RC_LAUNCH(f16_t, true); else ATOMA_RC_LAUNCH(f16_t, false); }
 #undef ATOMA_RC_LAUNCH
     return ATOMA_CHECK_LAUNCH("rope_qk_cache") ? 0 : -1;
+}
+
+// q/k/v projection -> RoPE(q, k) -> KV-cache write (llama.rs:269-271 -> 273-303 -> cache_manager.rs:404-535) behind one entry:
+// qkv_out [batch, out_row_stride] receives the projection's output with q and k rotated (what atoma_linear_decode followed by
+// atoma_rope_qk_cache on q = qkv_out, k = qkv_out + h.d, v = qkv_out + (h + h_k).d leave there), bit for bit.  When the projection
+// splits K over more than two workgroups (matrices with few rows: a tensor-parallel shard) its fp32 partials are merged by the
+// RoPE / cache kernel itself: two launches instead of three.  Otherwise the two ops run one after the other.
+int atoma_linear_decode_qkv_rope_cache(const void *x, const void *w_qkv, void *qkv_out, void *k_cache, void *v_cache, const int64_t *slot_mapping,
+                                       const void *cos_table, const void *sin_table, const int64_t *positions, int64_t batch, int64_t in_features,
+                                       int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t x_row_stride, int64_t w_row_stride,
+                                       int64_t out_row_stride, int64_t block_stride, int64_t page_size, int dtype, int per_op_rounding, void *stream) {
+    using namespace atoma;
+    clear_error();
+    const int64_t width = (num_q_heads + 2 * num_kv_heads) * head_dim;
+    auto two_ops = [&]() {
+        if (atoma_linear_decode(x, w_qkv, qkv_out, batch, in_features, width, x_row_stride, w_row_stride, out_row_stride, dtype, stream) != 0) return -1;
+        auto *o = static_cast<uint16_t *>(qkv_out);
+        return atoma_rope_qk_cache(o, o + num_q_heads * head_dim, o + (num_q_heads + num_kv_heads) * head_dim, k_cache, v_cache, slot_mapping, cos_table,
+                                   sin_table, positions, batch, num_q_heads, num_kv_heads, head_dim, out_row_stride, out_row_stride, out_row_stride,
+                                   block_stride, page_size, dtype, per_op_rounding, stream);
+    };
+    // the fused route: exactly the checks of the two entry points that matter for it; anything unusual takes the two ops (and their messages)
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_qkv) | reinterpret_cast<uintptr_t>(qkv_out) |
+                           reinterpret_cast<uintptr_t>(k_cache) | reinterpret_cast<uintptr_t>(v_cache) | reinterpret_cast<uintptr_t>(cos_table) |
+                           reinterpret_cast<uintptr_t>(sin_table);
+    const bool plain = (dtype == ATOMA_F16 || dtype == ATOMA_BF16) && batch > 16 && batch <= 64 && num_q_heads > 0 && num_kv_heads > 0 &&
+                       head_dim > 0 && head_dim % 16 == 0 && in_features > 0 && in_features % 128 == 0 && page_size > 0 && !(ptrs & 15u) &&
+                       x_row_stride >= in_features && w_row_stride >= in_features && out_row_stride >= width &&
+                       !(x_row_stride % 8 || w_row_stride % 8 || out_row_stride % 8 || block_stride % 8) && slot_mapping && positions;
+    if (!plain) return two_ops();
+    LinearParams p{};
+    p.x = static_cast<const uint16_t *>(x);
+    p.w = static_cast<const uint16_t *>(w_qkv);
+    p.y = static_cast<uint16_t *>(qkv_out);
+    p.x_row_stride = x_row_stride; p.w_row_stride = w_row_stride; p.y_row_stride = out_row_stride;
+    p.batch = (int)batch; p.n = (int)width; p.k = (int)in_features;
+    const auto s = static_cast<hipStream_t>(stream);
+    if (!linear_tile_leaves_partials(p, dtype)) return two_ops();
+    const int rc = launch_linear_tile(p, dtype, s);
+    if (rc != 0 || !p.partial) { if (rc < 0) return -1; set_error("linear_decode_qkv_rope_cache: the projection plan changed under the call"); return -1; }
+#define ATOMA_QRC(TT, PO)                                                                                                                     \
+    hipLaunchKernelGGL((qkv_partials_rope_cache_kernel<TT, PO>), dim3((unsigned)batch), dim3(256), 0, s, p.partial, p.splits, batch,          \
+                       static_cast<uint16_t *>(qkv_out), out_row_stride, static_cast<uint16_t *>(k_cache), static_cast<uint16_t *>(v_cache),   \
+                       slot_mapping, static_cast<const uint16_t *>(cos_table), static_cast<const uint16_t *>(sin_table), positions,           \
+                       (int)num_q_heads, (int)num_kv_heads, (int)head_dim, block_stride, (int)page_size, rope_table_rows.load())
+    if (dtype == ATOMA_BF16) { if (per_op_rounding) ATOMA_QRC(bf16_t, true); else ATOMA_QRC(bf16_t, false); }
+    else { if (per_op_rounding) ATOMA_QRC(f16_t, true); else ATOMA_QRC(f16_t, false); }
+#undef ATOMA_QRC
+    return ATOMA_CHECK_LAUNCH("linear_decode_qkv_rope_cache") ? 0 : -1;
 }
 
 // models/src/llama.rs:146-200 (Cache::new): f32 arithmetic throughout, table rounded to the model dtype.

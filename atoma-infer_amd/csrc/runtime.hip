@@ -14,6 +14,7 @@ void clear_error() { g_error.clear(); }
 bool has_error() { return !g_error.empty(); }
 
 bool set_decode_option(const std::string &name, int value);  // paged_decode.hip
+bool set_linear_tile_option(const std::string &name, int value);  // linear_tile.hip
 
 int device_num_cus() {
     // The reference queries cudaDeviceGetAttribute on EVERY attention call
@@ -86,6 +87,34 @@ void *workspace(hipStream_t stream, size_t bytes) {
     return fresh;
 }
 
+// Arrival counters of the kernels that merge their own split-K / split-KV pieces (the last workgroup to arrive at a tile reduces
+// it): SYNC_COUNTERS zero-initialised words per (device, stream), allocated once and kept zero by the kernels themselves (the last
+// arriver of a tile puts its counter back to zero), so that a captured graph replays without a memset node.  Kernels of one stream
+// run one after the other and may share the words.
+constexpr size_t SYNC_COUNTERS = 8192;
+struct SyncWords { int device; hipStream_t stream; unsigned *ptr; };
+static std::vector<SyncWords> g_sync;
+unsigned *sync_counters(hipStream_t stream) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(*g_ws_mu);
+    for (auto &w : g_sync)
+        if (w.device == dev && w.stream == stream) return w.ptr;
+    if (stream_is_capturing(stream)) {
+        set_error("the arrival counters of this stream do not exist yet and cannot be allocated during hipGraph capture: call atoma_warmup "
+                  "for this stream before capturing, or run the same call once eagerly first");
+        return nullptr;
+    }
+    unsigned *ptr = nullptr;
+    if (!check_hip(hipMalloc(reinterpret_cast<void **>(&ptr), SYNC_COUNTERS * sizeof(unsigned)), "sync counters hipMalloc")) return nullptr;
+    if (!check_hip(hipMemset(ptr, 0, SYNC_COUNTERS * sizeof(unsigned)), "sync counters hipMemset") || !check_hip(hipDeviceSynchronize(), "sync counters")) {
+        (void)hipFree(ptr);
+        return nullptr;
+    }
+    g_sync.push_back(SyncWords{dev, stream, ptr});
+    return ptr;
+}
+
 size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k);   // paged_decode.hip
 int release_gemm_workspaces();                                                       // linear_gemm.hip
 
@@ -134,6 +163,7 @@ int atoma_compute_num_splits(int64_t batch_size, int64_t num_heads, int64_t head
 int atoma_set_option(const char *name, int value) {
     atoma::clear_error();
     if (name && atoma::set_decode_option(name, value)) return 0;
+    if (name && atoma::set_linear_tile_option(name, value)) return 0;
     atoma::set_error(std::string("atoma_set_option: unknown option ") + (name ? name : "(null)"));
     return -1;
 }
@@ -156,6 +186,7 @@ int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num
     const size_t need = std::max(atoma::decode_workspace_bound((int)std::min<int64_t>(max_batch, 1 << 20), (int)num_heads, (int)num_kv_heads,
                                                                (int)head_dim, (int)std::min<int64_t>(max_seqlen_k, 1 << 30)),
                                  (size_t)extra_bytes);
+    if (!atoma::sync_counters(static_cast<hipStream_t>(stream))) return -1;
     if (need == 0) return 0;
     return atoma::workspace(static_cast<hipStream_t>(stream), need) ? 0 : -1;
 }
@@ -168,8 +199,11 @@ int atoma_release_workspaces(void) {
         if (w.ptr && hipFree(w.ptr) != hipSuccess) { (void)hipGetLastError(); rc = -1; }
     for (void *p : atoma::g_ws_retired)
         if (hipFree(p) != hipSuccess) { (void)hipGetLastError(); rc = -1; }
+    for (auto &w : atoma::g_sync)
+        if (w.ptr && hipFree(w.ptr) != hipSuccess) { (void)hipGetLastError(); rc = -1; }
     atoma::g_ws.clear();
     atoma::g_ws_retired.clear();
+    atoma::g_sync.clear();
     if (atoma::release_gemm_workspaces() != 0) rc = -1;
     if (rc) atoma::set_error("atoma_release_workspaces: hipFree failed");
     return rc;

@@ -168,6 +168,17 @@ int atoma_rope_qk_cache(void *q, void *k, const void *v, void *k_cache, void *v_
                         int64_t k_token_stride, int64_t v_token_stride, int64_t block_stride, int64_t page_size, int dtype,
                         int per_op_rounding, void *stream);
 
+/* q/k/v projection -> RoPE(q, k) -> KV-cache write behind one entry (llama.rs:269-271 -> 273-303 -> cache_manager.rs:404-535):
+ * qkv_out [batch, out_row_stride] = x . w_qkv^T with q (heads first) and k rotated in place, the rotated k and v also stored at
+ * slot_mapping[t] -- bit for bit what atoma_linear_decode followed by atoma_rope_qk_cache(q = qkv_out, k = qkv_out + h.d,
+ * v = qkv_out + (h + h_k).d) leaves.  For 17..64 rows and a matrix whose K is split over more than two workgroups (few rows: the
+ * shard of a tensor-parallel rank) the fp32 partials are merged by the RoPE / cache kernel itself (two launches instead of three);
+ * every other case runs the two ops. */
+int atoma_linear_decode_qkv_rope_cache(const void *x, const void *w_qkv, void *qkv_out, void *k_cache, void *v_cache, const int64_t *slot_mapping,
+                                       const void *cos_table, const void *sin_table, const int64_t *positions, int64_t batch, int64_t in_features,
+                                       int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim, int64_t x_row_stride, int64_t w_row_stride,
+                                       int64_t out_row_stride, int64_t block_stride, int64_t page_size, int dtype, int per_op_rounding, void *stream);
+
 /* ---- fp8 (OCP e4m3fn) KV cache (the reference's roadmap "quantization", README.md:35) ----
  * The cache keeps the reference's layout [num_blocks, block_size, h_k, d] with ONE byte per element; k_scale / v_scale are
  * DEVICE arrays f32[h_k] of per-kv-head dequantisation scales (value = e4m3 * scale).  copy_blocks_* / atoma_swap_blocks*

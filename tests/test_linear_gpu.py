@@ -214,6 +214,11 @@ def test_linear_decode_big_exact_cases(gpu):
 
 
 @pytest.mark.parametrize("B,K,N,I", [(17, 1024, 512, 768), (40, 4096, 1024, 1024), (64, 1024, 256, 128), (33, 8192, 512, 3584), (64, 2048, 4096, 2048),
+                                     # linear_ks_kernel (one launch, K interleaved over the wavefronts): the shapes of one rank of the 70B TP = 8 job
+                                     # (K split over workgroups for the 1280-row q/k/v shard only), 1 / 9 / 8 chunks of 256 inputs (short path, tail
+                                     # path, exactly one unrolled iteration), 16- and 32-row workgroups, row counts that are not a multiple of 32
+                                     (64, 8192, 1280, 3584), (64, 1024, 8192, 256), (48, 3584, 8192, 512), (17, 256, 32, 16), (31, 2304, 48, 80),
+                                     (64, 2048, 6144, 1024), (50, 4352, 4112, 48), (20, 1280, 128, 64),   # K = 1280: not a multiple of 256 -> linear_mid_kernel
                                      (65, 1024, 256, 128), (130, 4096, 1024, 1024), (256, 2048, 4096, 14336), (256, 14336, 512, 256)])
 def test_linear_mid_batch_epilogues_match_the_separate_ops(gpu, B, K, N, I):
     """17..64 rows (linear_mid_kernel: one workgroup per 64 features) and 65..256 rows (linear_big_kernel), with and without K
@@ -287,3 +292,39 @@ def test_linear_any_batch_strides_exactness_and_errors(gpu):
     assert "multiple of 8" in gpu.last_error()
     assert gpu.lib.atoma_linear(dx.ptr + 2, dw.ptr, dy.ptr, 100, K, N, K + 64, K, ys, BF16, None) == -1
     assert "aligned" in gpu.last_error()
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("B,K,h,hk,d", [(64, 8192, 8, 1, 128), (33, 2048, 4, 2, 64), (64, 4096, 32, 8, 128), (17, 1024, 2, 1, 128), (8, 1024, 2, 1, 128)])
+def test_qkv_projection_rope_cache_entry_is_the_two_ops_bit_for_bit(gpu, dtype, B, K, h, hk, d):
+    """atoma_linear_decode_qkv_rope_cache = atoma_linear_decode followed by atoma_rope_qk_cache on the same buffers, bit for bit: the
+    shard of a tensor-parallel rank (1280 rows, K split 8 ways: the RoPE / cache kernel merges the fp32 partials itself), shapes whose
+    projection merges inside its launch or does not split at all, and a batch outside 17..64 (the entry runs the two ops)."""
+    rng = np.random.default_rng(B + K + h)
+    width, page, nb = (h + 2 * hk) * d, 16, 12
+    x = rand_half(rng, (B, K), dtype)
+    w = rand_half(rng, (width, K), dtype, K ** -0.5)
+    cos = rand_half(rng, (4096, d // 2), dtype)
+    sin = rand_half(rng, (4096, d // 2), dtype)
+    pos = rng.integers(0, 4096, B).astype(np.int64)
+    slots = rng.permutation(nb * page)[:B].astype(np.int64)
+    slots[B // 2] = -1                                      # a padding token: rotated, not cached
+    dx, dw, dc, ds, dp, dsl = (gpu.DeviceBuffer.from_numpy(a) for a in (x, w, cos, sin, pos, slots))
+    outs = []
+    for fused in (False, True):
+        qkv = gpu.DeviceBuffer.zeros((B, width), np.uint16)
+        kc, vc = gpu.DeviceBuffer.zeros((nb * page * hk * d,), np.uint16), gpu.DeviceBuffer.zeros((nb * page * hk * d,), np.uint16)
+        L = gpu.lib
+        if fused:
+            rc = L.atoma_linear_decode_qkv_rope_cache(dx.ptr, dw.ptr, qkv.ptr, kc.ptr, vc.ptr, dsl.ptr, dc.ptr, ds.ptr, dp.ptr, B, K, h, hk, d, K, K, width,
+                                                      page * hk * d, page, dtype, 1, None)
+            assert rc == 0, gpu.last_error()
+        else:
+            assert L.atoma_linear_decode(dx.ptr, dw.ptr, qkv.ptr, B, K, width, K, K, width, dtype, None) == 0, gpu.last_error()
+            assert L.atoma_rope_qk_cache(qkv.ptr, qkv.ptr + h * d * 2, qkv.ptr + (h + hk) * d * 2, kc.ptr, vc.ptr, dsl.ptr, dc.ptr, ds.ptr, dp.ptr, B, h, hk, d,
+                                         width, width, width, page * hk * d, page, dtype, 1, None) == 0, gpu.last_error()
+        gpu.synchronize()
+        outs.append((qkv.numpy(np.uint16, (B, width)), kc.numpy(np.uint16, (nb * page * hk * d,)), vc.numpy(np.uint16, (nb * page * hk * d,))))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[0][1].any() and outs[0][2].any()

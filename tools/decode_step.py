@@ -48,6 +48,8 @@ class DecodeStep:
         self.fused = fused_epilogues and not keep_intermediates and batch <= int(os.environ.get("ATOMA_STEP_FUSED_MAX_BATCH", "128")) and allreduce is None
         # own_projections: the op-by-op path on atoma_linear_decode at every batch (tests: the fused step must equal it bit for bit)
         self.linear = ah.lib.atoma_linear_decode if own_projections else ah.lib.atoma_linear
+        # 17..64 rows on the fused path: the q/k/v projection, RoPE and the cache write behind one entry (atoma_linear_decode_qkv_rope_cache)
+        self.qkv_fused = self.fused and 16 < batch <= 64 and os.environ.get("ATOMA_STEP_QKV_FUSED", "1") != "0"
         self.norm_in_proj = os.environ.get("ATOMA_STEP_NORM_IN_PROJ", "1") != "0"   # fused path: RMSNorm inside the q/k/v and gate/up projections (A/B switch)
         self.fuse_norm = fuse_norm and not keep_intermediates and not self.fused   # residual add + the RMSNorm that follows it in one kernel
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
@@ -114,7 +116,12 @@ class DecodeStep:
         for l in range(c.layers):
             xn = self._buf("xn1", l, B * H * 2)
             qkv = self._buf("qkv", l, B * qkvw * 2)
-            if self.fused and self.norm_in_proj:            # the input norm inside the projection (batch <= 4: no launch of its own)
+            if self.qkv_fused and not self.kv_fp8:          # 17..64 rows: projection -> RoPE -> cache write behind one entry
+                self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+                self._ok(L.atoma_linear_decode_qkv_rope_cache(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr,
+                                                              self.w["cos"].ptr, self.w["sin"].ptr, self.pos.ptr, B, H, c.h, c.hk, c.d, H, H, qkvw,
+                                                              c.page * c.hk * c.d, c.page, BF16, 1, s), "qkv projection + rope + cache write")
+            elif self.fused and self.norm_in_proj:          # the input norm inside the projection (batch <= 4: no launch of its own)
                 self._ok(L.atoma_linear_decode_rmsnorm(x.ptr, self.w["norm1"][l].ptr, c.eps, self.w["wqkv"][l].ptr, qkv.ptr, xn.ptr, B, H, qkvw, H, H, qkvw,
                                                        BF16, s), "rms_norm + qkv projection")
             else:
@@ -135,9 +142,10 @@ class DecodeStep:
                                                   self.lens.ptr, B, c.h, c.hk, c.d, self.max_blocks, c.page, qkvw, c.d, hd, c.d, c.page * c.hk * c.d,
                                                   c.hk * c.d, c.d, c.d ** -0.5, BF16, s), "paged decode over the fp8 cache")
             else:
-                self._ok(L.atoma_rope_qk_cache(qkv.ptr, kptr, vptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr, self.w["cos"].ptr,
-                                               self.w["sin"].ptr, self.pos.ptr, B, c.h, c.hk, c.d, qkvw, qkvw, qkvw, c.page * c.hk * c.d,
-                                               c.page, BF16, 1, s), "rope + cache write")
+                if not self.qkv_fused:                      # (fused: rotated and cached by the projection's own merge kernel above)
+                    self._ok(L.atoma_rope_qk_cache(qkv.ptr, kptr, vptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr, self.w["cos"].ptr,
+                                                   self.w["sin"].ptr, self.pos.ptr, B, c.h, c.hk, c.d, qkvw, qkvw, qkvw, c.page * c.hk * c.d,
+                                                   c.page, BF16, 1, s), "rope + cache write")
                 ah.run_mha(qkv, self.kc[l], self.vc[l], att, b=B, h=c.h, h_k=c.hk, d=c.d, seqlen_q=1, seqlen_k=self.max_blocks * c.page,
                            softmax_scale=c.d ** -0.5, is_bf16=BF16, q_strides=(qkvw, qkvw, c.d), o_strides=(hd, hd, c.d),
                            k_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d), v_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d),
