@@ -111,6 +111,7 @@ _opt("atoma_kv_blocks_packed_size", [_i64, _i64, _i64, _i64, _i64, _int], _i64)
 _opt("atoma_kv_pack_blocks", [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _int, _vp, _vp, _vp, _i64, _vp])
 _opt("atoma_kv_read_header", [_vp, _i64, _vp])
 _opt("atoma_kv_unpack_blocks", [_vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _int, _vp, _i64, _vp, _vp, _vp])
+_opt("atoma_last_decode_kernel", [], C.c_char_p)
 _opt("atoma_warmup", [_vp, _i64, _i64, _i64, _i64, _i64, _i64])
 _opt("atoma_reserve_workspace", [_vp, _i64])
 _opt("atoma_release_workspaces", [])

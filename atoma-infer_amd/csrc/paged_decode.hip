@@ -67,6 +67,8 @@ struct DecodeParams {
     int stream_waves;      // > 0: balanced mode available -- this many wavefronts share the batch's tiles evenly (decode_run_items)
     int group_tile;        // q heads per wavefront (the kernel's G)
     const float *k_scale, *v_scale;   // fp8 (e4m3fn) KV cache: per-kv-head dequantisation scales [h_k]; null for 16-bit caches
+    int wg_splits;         // > 0: workgroup-merged split mode (paged_decode_wg_kernel): KV pieces per sequence = wg_splits x wavefronts per workgroup
+    unsigned *counters;    // ... and its arrival counter per (sequence, kv head, q-head chunk), zero between launches
     int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
     float scale, scale_log2;
 };
@@ -119,6 +121,7 @@ struct DecodeWork {
     int64_t kv_row0;   // first row of this sequence in a varlen (cumulative) K/V tensor
     int64_t prow;      // row of q head hq0's fp32 partial in o_accum / lse_accum (head hq0 + i: prow + i)
     bool partial;      // write fp32 partials for the combine kernel (true) or the final output (false)
+    float *sink_o, *sink_lse;   // SINK variants of the item functions: this wavefront's normalised O [heads][D] and LSE [heads] go here (LDS)
 };
 __device__ __forceinline__ void decode_map_work(const DecodeParams &p, int id, DecodeWork &w) {
     const int hk_chunks = p.h_k * p.gchunks;
@@ -278,13 +281,13 @@ template <bool STREAM, int NWG = 1, typename F> __device__ __forceinline__ void 
     }
 }
 
-template <typename T, int D, int G, int P, bool NT>
+template <typename T, int D, int G, int P, bool NT, bool SINK = false>
 __device__ __forceinline__ void paged_decode_item(const DecodeParams &p, const DecodeWork &wk) {
     constexpr int LPR = D / 8;     // lanes per row
     constexpr int RPI = 64 / LPR;  // rows per load instruction
     constexpr int IPP = 16 / RPI;  // load instructions per 16-token tile
     static_assert(IPP >= 2 && IPP % 2 == 0, "token pairs for the P.V dot2");
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, dc = lane % LPR;
 
     const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
@@ -566,7 +569,12 @@ __device__ __forceinline__ void paged_decode_item(const DecodeParams &p, const D
         const float inv = empty ? 0.f : 1.f / l[gq];
         // natural-log LSE: m*scale + ln(l); m is already scaled by scale*log2e
         const float lse = empty ? INFINITY : (m[gq] + __builtin_amdgcn_logf(l[gq])) * 0.6931471805599453f;
-        if (!partial) {
+        if constexpr (SINK) {   // workgroup-merged split mode: the piece's result stays on the CU
+            float4 *dst = reinterpret_cast<float4 *>(wk.sink_o + gq * D + dc * 8);
+            dst[0] = make_float4(o[gq][0] * inv, o[gq][1] * inv, o[gq][2] * inv, o[gq][3] * inv);
+            dst[1] = make_float4(o[gq][4] * inv, o[gq][5] * inv, o[gq][6] * inv, o[gq][7] * inv);
+            if (dc == 0) wk.sink_lse[gq] = empty ? -INFINITY : lse;
+        } else if (!partial) {
             uint4 w4;
             w4.x = pack2<T>(o[gq][0] * inv, o[gq][1] * inv);
             w4.y = pack2<T>(o[gq][2] * inv, o[gq][3] * inv);
@@ -894,10 +902,10 @@ template <> __device__ __forceinline__ f32x4_v mfma16<f16_t>(const u32x4 &a, con
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
 }
 
-template <typename T, int G, int P, bool NT>
+template <typename T, int G, int P, bool NT, bool SINK = false>
 __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, const DecodeWork &wk) {
     constexpr int D = 128;
-    const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, col = lane & 15;
 
     const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
     const int64_t kv_row0 = wk.kv_row0;
@@ -1124,7 +1132,12 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
         const bool empty = !(lh[h] > 0.f);
         const float inv = empty ? 0.f : 1.f / lh[h];
         const float lse = empty ? INFINITY : (mh[h] + __builtin_amdgcn_logf(lh[h])) * 0.6931471805599453f;
-        if (!partial) {
+        if constexpr (SINK) {   // workgroup-merged split mode: the piece's result stays on the CU
+            float4 *dst = reinterpret_cast<float4 *>(wk.sink_o + h * D + col * 8);
+            dst[0] = make_float4(o[h][0] * inv, o[h][1] * inv, o[h][2] * inv, o[h][3] * inv);
+            dst[1] = make_float4(o[h][4] * inv, o[h][5] * inv, o[h][6] * inv, o[h][7] * inv);
+            if (col == 0) wk.sink_lse[h] = empty ? -INFINITY : lse;
+        } else if (!partial) {
             uint4 w4;
             w4.x = pack2<T>(o[h][0] * inv, o[h][1] * inv);
             w4.y = pack2<T>(o[h][2] * inv, o[h][3] * inv);
@@ -1379,6 +1392,110 @@ __global__ void __launch_bounds__(64 * NWG, 2) paged_decode_fp8_mqk_kernel(const
 
 // LSE-weighted merge of the split partials: /root/reference/csrc/kernels/flash_fwd_kernel.h:1204-1236.
 // One wavefront per (b, q head); lane i owns D/64 output pairs.
+// ---- split-KV for batches that do not fill the chip, merged INSIDE the launch ----
+// The split kernels above leave one fp32 partial per (wavefront, q head) in HBM and decode_combine_kernel -- a second launch with a
+// chain of dependent loads -- merges them: 4.3-11 us on top of a 15-35 us kernel (batch 1..64, the tensor-parallel rank's h_k = 1).
+// Here a workgroup of NWG = 2 / 4 / 8 wavefronts owns NWG consecutive pieces of ONE (sequence, kv head, q-head chunk): every
+// wavefront streams its piece exactly as before (the same item functions), leaves its normalised O and LSE in LDS, and the workgroup
+// merges the NWG pieces there with the combine kernel's arithmetic (LSE weights, pieces in order).  A sequence that spans several
+// workgroups (wg_splits > 1, at most a handful) goes through fp32 partials once more: every workgroup publishes its merged piece
+// write-through (agent-scope 8-byte stores), takes a ticket on the sequence's arrival counter, and the LAST one to arrive reads them all
+// back (agent-scope loads: past its L1 / L2), merges in piece order and writes the output -- nobody waits for anybody, so the launch
+// needs no co-residency, and the result does not depend on who came last.  Counters return to zero (graph replays need no memset).
+template <typename T, int D, int G, int P, bool NT, bool MQK, int NWG>
+__global__ void __launch_bounds__(64 * NWG, 2) paged_decode_wg_kernel(const DecodeParams p) {
+    __shared__ __attribute__((aligned(16))) float s_o[NWG][G][D];
+    __shared__ float s_lse[NWG][G];
+    __shared__ unsigned s_ticket;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hk_chunks = p.h_k * p.gchunks;
+    int id = blockIdx.x;                                   // (kv head, q-head chunk) fastest, then the sequence, the piece group slowest
+    const int hkc = id % hk_chunks;
+    id /= hk_chunks;
+    DecodeWork wk;
+    wk.b = id % p.b;
+    const int wg_split = id / p.b;
+    wk.hk = hkc / p.gchunks;
+    wk.gc = hkc % p.gchunks;
+    wk.split = wg_split * NWG + wave;
+    wk.L = decode_seq_len(p, wk.b);
+    wk.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + wk.b) : 0;
+    wk.n_tiles = (wk.L + 15) >> 4;
+    const int per = (wk.n_tiles + p.num_splits - 1) / p.num_splits;
+    wk.t0 = wk.split * per;
+    wk.t1 = min(wk.t0 + per, wk.n_tiles);
+    wk.partial = true;
+    wk.prow = 0;
+    wk.sink_o = &s_o[wave][0][0];
+    wk.sink_lse = &s_lse[wave][0];
+    if constexpr (MQK) paged_decode_mqk_item<T, G, P, NT, true>(p, wk);
+    else paged_decode_item<T, D, G, P, NT, true>(p, wk);
+    __syncthreads();
+
+    const int hq0 = wk.hk * p.g + wk.gc * G, nq = min(G, p.g - wk.gc * G);
+    const bool last_level = p.wg_splits <= 1;
+    // merge of n pieces of head h, elements 2.d2 and 2.d2 + 1: decode_combine_kernel's arithmetic, pieces in order
+    auto merge = [&](int n, auto lse_of, auto o_of, float &lse_out, float &o0, float &o1) {
+        float mx = -INFINITY;
+        for (int i = 0; i < n; ++i) mx = fmaxf(mx, lse_of(i));
+        const float ms = mx == -INFINITY ? 0.f : mx;
+        float tot = 0.f;
+        for (int i = 0; i < n; ++i) tot += __expf(lse_of(i) - ms);
+        const bool empty = !(tot > 0.f);
+        const float lse = empty ? INFINITY : __logf(tot) + ms;
+        o0 = o1 = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const float w = empty ? 0.f : __expf(lse_of(i) - lse);
+            const float2 v = o_of(i);
+            o0 += w * v.x;
+            o1 += w * v.y;
+        }
+        lse_out = lse;
+    };
+    auto store_final = [&](int h, int d2, float lse, float o0, float o1) {
+        const int hq = hq0 + h;
+        *reinterpret_cast<uint32_t *>(p.o + (int64_t)wk.b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + 2 * d2) = pack2<T>(o0, o1);
+        if (p.lse && d2 == 0) p.lse[(int64_t)wk.b * p.h + hq] = lse;
+    };
+    for (int idx = tid; idx < nq * (D / 2); idx += 64 * NWG) {
+        const int h = idx / (D / 2), d2 = idx - h * (D / 2);
+        float lse, o0, o1;
+        merge(NWG, [&](int i) { return s_lse[i][h]; }, [&](int i) { return *reinterpret_cast<const float2 *>(&s_o[i][h][2 * d2]); }, lse, o0, o1);
+        if (last_level) {
+            store_final(h, d2, lse, o0, o1);
+        } else {      // this workgroup's piece: fp32, write-through, for the last arriver (LSE of an empty piece: -inf, as the split kernels write it)
+            const int64_t row = ((int64_t)wg_split * p.b + wk.b) * p.h + hq0 + h;
+            const unsigned long long bits = ((unsigned long long)__float_as_uint(o1) << 32) | __float_as_uint(o0);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(p.o_accum + row * D + 2 * d2), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d2 == 0) __hip_atomic_store(reinterpret_cast<unsigned *>(p.lse_accum + row), __float_as_uint(lse == INFINITY ? -INFINITY : lse), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (last_level) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wavefront drains, then ONE ticket per workgroup
+    __syncthreads();
+    unsigned *counter = p.counters + ((int64_t)wk.b * hk_chunks + hkc);
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1 == (unsigned)p.wg_splits) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ticket = t;
+    }
+    __syncthreads();
+    if (s_ticket + 1 != (unsigned)p.wg_splits) return;
+    for (int idx = tid; idx < nq * (D / 2); idx += 64 * NWG) {
+        const int h = idx / (D / 2), d2 = idx - h * (D / 2);
+        const int64_t row0 = (int64_t)wk.b * p.h + hq0 + h, step = (int64_t)p.b * p.h;
+        float lse, o0, o1;
+        merge(p.wg_splits,
+              [&](int i) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p.lse_accum + row0 + i * step), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); },
+              [&](int i) {
+                  const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p.o_accum + (row0 + i * step) * D + 2 * d2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  return make_float2(__uint_as_float((unsigned)bits), __uint_as_float((unsigned)(bits >> 32)));
+              },
+              lse, o0, o1);
+        store_final(h, d2, lse, o0, o1);
+    }
+}
+
 template <typename T, int D>
 __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p) {
     const int lane = threadIdx.x;
@@ -1475,6 +1592,8 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
 // host side
 // ------------------------------------------------------------------------------------------
 void *workspace(hipStream_t stream, size_t bytes);   // runtime.hip: grow-only scratch per (device, stream), never freed under a graph
+unsigned *sync_counters(hipStream_t stream);         // runtime.hip: zero-initialised arrival counters per (device, stream)
+constexpr int64_t DECODE_WG_MAX_COUNTERS = 8192;     // = SYNC_COUNTERS of runtime.hip
 
 // Split count for THIS kernel: enough wavefronts to fill the resident slots of every CU (8, or 4 for the
 // 512-register G = 8 / d = 128 variant), never fewer than `min_tiles` 16-token tiles per split.  (The reference's heuristic, lib.rs:2122-2199,
@@ -1515,6 +1634,7 @@ struct DecodeOptions {
     opt_int min_tiles{env_int("ATOMA_DECODE_MIN_TILES", 8)};
     opt_int fp8_wg{env_int("ATOMA_DECODE_FP8_WG", 1)};     // fp8 KV cache: 8 wavefronts (the kv heads of a sequence) per workgroup: 0 never, 1 split-KV launches, 2 always
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
+    opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
     opt_int mqk{env_int("ATOMA_DECODE_MQK", 5)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches
 };
 static DecodeOptions &decode_options() {
@@ -1534,6 +1654,7 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_waves_per_cu") o.waves_per_cu = value;
     else if (name == "decode_min_tiles") o.min_tiles = value;
     else if (name == "decode_mqk") o.mqk = value;
+    else if (name == "decode_wg_merge") o.wg_merge = value;
     else if (name == "decode_fp8_mqk") o.fp8_mqk = value;
     else if (name == "decode_fp8_wg") o.fp8_wg = value;
     else return false;
@@ -1569,16 +1690,70 @@ static void launch_decode_cfg(DecodeParams &p, hipStream_t stream) {
         static const int occ = resident_waves_per_cu(paged_decode_kernel<T, D, G, P, MINW, NT, true>);
         set_stream_waves(p, occ);
     }
+    note_decode_kernel("paged_decode_kernel", decode_tname<T>(), D, G, P, NT,
+                       p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? (std::to_string(p.num_splits) + " KV splits + combine").c_str() : "one wavefront per (sequence, kv head)"));
     if (p.stream_waves > 0) hipLaunchKernelGGL((paged_decode_kernel<T, D, G, P, MINW, NT, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
     else hipLaunchKernelGGL((paged_decode_kernel<T, D, G, P, MINW, NT, false>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+}
+
+// Split-KV merged inside the launch: workgroups of NWG = 8 / 4 / 2 wavefronts, wg_splits workgroups per sequence (p.num_splits is
+// rounded down to a multiple of NWG).  False when this launch must take the split + combine kernels instead.
+// Which decode kernel the dispatcher took last on this thread (bench.py labels its roofline line with it instead of a literal)
+static thread_local std::string g_last_decode_kernel;
+template <typename T> static const char *decode_tname() { return std::is_same<T, bf16_t>::value ? "bf16" : "f16"; }
+static void note_decode_kernel(const char *kernel, const char *t, int d, int g, int p, bool nt, const char *mode) {
+    g_last_decode_kernel = std::string(kernel) + "<" + t + ",D=" + std::to_string(d) + ",G=" + std::to_string(g) + ",P=" + std::to_string(p) +
+                           (nt ? ",nt" : "") + "," + mode + ">";
+}
+
+static int decode_wg_waves(const DecodeParams &p) {
+    // wavefronts per workgroup: as many as keep one workgroup on every CU (a CU holds only ~40-50 KB of requests in flight whatever its
+    // wavefronts ask for, DESIGN.md 4.8c: 128 workgroups of 8 wavefronts stream slower than 1024 single wavefronts on 256 CUs)
+    const int64_t waves = (int64_t)p.b * p.h_k * p.gchunks * p.num_splits;
+    int nwg = 2;
+    while (nwg < 8 && nwg * 2 <= p.num_splits && waves / (nwg * 2) >= device_num_cus()) nwg *= 2;
+    return nwg;
+}
+// Option decode_wg_merge: 1 (default) = only launches whose pieces all fit ONE workgroup per sequence (the merge never leaves the CU:
+// the 70B TP = 8 shard at batch 256: 95.5 -> 87.8 us); 2 = also with a last-arriver merge across workgroups -- measured level with the
+// combine kernel (shard at batch 64: 33.1 vs 31.8 us; 16 x 8192: 96.6 vs 97.9), so the two-kernel route keeps those; 0 = never.
+static bool decode_wg_applicable(const DecodeParams &p) {
+    const int opt = decode_options().wg_merge;
+    if (p.num_splits <= 1 || p.stream_waves != 0 || opt == 0 || p.k_scale || (int64_t)p.b * p.h_k * p.gchunks > DECODE_WG_MAX_COUNTERS) return false;
+    if ((int64_t)p.b * p.h_k * p.gchunks * p.num_splits / 2 < device_num_cus() && opt < 3) return false;   // too few wavefronts to pair them up
+    return opt >= 2 || p.num_splits / decode_wg_waves(p) <= 1;
+}
+template <typename T, int D, int G, int P, bool NT, bool MQK>
+static bool launch_decode_wg(DecodeParams &p, hipStream_t stream) {
+    const int nwg = decode_wg_waves(p);
+    p.wg_splits = p.num_splits / nwg;
+    p.num_splits = p.wg_splits * nwg;
+    if (p.wg_splits > 1) {
+        p.counters = sync_counters(stream);
+        if (!p.counters) return false;
+    }
+    const dim3 grid((unsigned)((int64_t)p.b * p.h_k * p.gchunks * p.wg_splits));
+    note_decode_kernel(MQK ? "paged_decode_wg_kernel(matrix-core scores)" : "paged_decode_wg_kernel", decode_tname<T>(), D, G, P, NT,
+                       (std::to_string(nwg) + " wavefronts x " + std::to_string(p.wg_splits) + " workgroups per sequence, merged in the launch").c_str());
+    if (nwg == 8) hipLaunchKernelGGL((paged_decode_wg_kernel<T, D, G, P, NT, MQK, 8>), grid, dim3(512), 0, stream, p);
+    else if (nwg == 4) hipLaunchKernelGGL((paged_decode_wg_kernel<T, D, G, P, NT, MQK, 4>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((paged_decode_wg_kernel<T, D, G, P, NT, MQK, 2>), grid, dim3(128), 0, stream, p);
+    return ATOMA_CHECK_LAUNCH("paged_decode_wg_kernel");
 }
 
 // d = 128: scores on the matrix cores (paged_decode_mqk_kernel), any G at two wavefronts per SIMD
 template <typename T, int G>
 static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
+    const bool p3 = decode_options().p >= 3 && G <= 4, nt = decode_options().nt != 0;
+    if (decode_wg_applicable(p)) {
+        if (nt) { if (p3) launch_decode_wg<T, 128, G, 3, true, true>(p, stream); else launch_decode_wg<T, 128, G, 2, true, true>(p, stream); }
+        else { if (p3) launch_decode_wg<T, 128, G, 3, false, true>(p, stream); else launch_decode_wg<T, 128, G, 2, false, true>(p, stream); }
+        return;
+    }
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
     if (p.stream_waves > 0) set_stream_waves(p, 8);   // __launch_bounds__(64, 2)
-    const bool p3 = decode_options().p >= 3 && G <= 4, nt = decode_options().nt != 0;
+    note_decode_kernel("paged_decode_mqk_kernel", decode_tname<T>(), 128, G, p3 ? 3 : 2, nt,
+                       p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? (std::to_string(p.num_splits) + " KV splits + combine").c_str() : "one wavefront per (sequence, kv head)"));
 #define ATOMA_MQK(P_, NT_, S_) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, P_, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p)
 #define ATOMA_MQK_S(P_, NT_) do { if (p.stream_waves > 0) ATOMA_MQK(P_, NT_, true); else ATOMA_MQK(P_, NT_, false); } while (0)
     if (nt) { if (p3) ATOMA_MQK_S(3, true); else ATOMA_MQK_S(2, true); }
@@ -1599,6 +1774,13 @@ static void launch_decode_tdg(DecodeParams &p, hipStream_t stream) {
     constexpr int MINW = (G >= 8 && D >= 128) ? 1 : 2;
     const int cfg_p = decode_options().p, cfg_nt = decode_options().nt;
     const int P = (G >= 8 && cfg_p > 2) ? 2 : cfg_p;
+    if constexpr (MINW == 2) {                   // (the 8-head dot2 variant needs the 512 registers of one wavefront per SIMD)
+        if (decode_wg_applicable(p)) {
+            if (cfg_nt) { if (P >= 3) launch_decode_wg<T, D, G, 3, true, false>(p, stream); else launch_decode_wg<T, D, G, 2, true, false>(p, stream); }
+            else { if (P >= 3) launch_decode_wg<T, D, G, 3, false, false>(p, stream); else launch_decode_wg<T, D, G, 2, false, false>(p, stream); }
+            return;
+        }
+    }
     if (cfg_nt) {
         if (P >= 4) launch_decode_cfg<T, D, G, 4, MINW, true>(p, stream);
         else if (P == 3) launch_decode_cfg<T, D, G, 3, MINW, true>(p, stream);
@@ -1716,6 +1898,8 @@ static void launch_decode_fp8_g(DecodeParams &p, hipStream_t stream) {
     // workgroup's 8 wavefronts walk unrelated ranges -- so by default only launches that cannot take the balanced mode)
     const int wg_opt = decode_options().fp8_wg;
     const bool wg8 = mqk && ((int64_t)p.h_k * p.gchunks) % 8 == 0 && (wg_opt >= 2 || (wg_opt == 1 && p.stream_waves == 0));
+    note_decode_kernel(mqk ? "paged_decode_fp8_mqk_kernel" : "paged_decode_fp8_kernel", decode_tname<T>(), 128, G, 3, nt,
+                       p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? "KV splits + combine" : (wg8 ? "8 wavefronts per workgroup" : "one wavefront per (sequence, kv head)")));
 #define ATOMA_F8(NT_, S_) do { if (wg8) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, 3, NT_, S_, 8>), dim3((unsigned)cdiv(blocks, 8)), dim3(512), 0, stream, p); \
                                else if (mqk) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p); \
                                else hipLaunchKernelGGL((paged_decode_fp8_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p); } while (0)
@@ -1750,6 +1934,7 @@ void launch_paged_decode_fp8(DecodeParams &p, bool is_bf16, hipStream_t stream) 
 }
 
 bool decode_supported(int d) { return d == 64 || d == 128; }
+const char *last_decode_kernel() { return g_last_decode_kernel.c_str(); }
 
 void launch_paged_decode(DecodeParams &p, int d, bool is_bf16, hipStream_t stream) {
     if (is_bf16) {

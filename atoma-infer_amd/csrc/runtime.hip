@@ -116,6 +116,7 @@ unsigned *sync_counters(hipStream_t stream) {
 }
 
 size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k);   // paged_decode.hip
+const char *last_decode_kernel();                                                    // paged_decode.hip
 int release_gemm_workspaces();                                                       // linear_gemm.hip
 
 // /root/reference/csrc/src/lib.rs:2122-2167, f32 arithmetic as there.
@@ -208,6 +209,9 @@ int atoma_release_workspaces(void) {
     if (rc) atoma::set_error("atoma_release_workspaces: hipFree failed");
     return rc;
 }
+
+// Name and configuration of the decode kernel the dispatcher chose for the last decode call of this thread ("" before any)
+const char *atoma_last_decode_kernel(void) { return atoma::last_decode_kernel(); }
 
 int atoma_device_count(void) {
     int n = 0;

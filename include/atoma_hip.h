@@ -401,6 +401,9 @@ int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int6
  * Defaults also come from ATOMA_DECODE_{P,NT,STREAM,WAVES_PER_CU,
  * MIN_TILES,MQK}; ATOMA_PREFILL_CFG overrides "prefill_cfg". */
 int atoma_set_option(const char *name, int value);
+/* Name and configuration of the decode kernel the dispatcher chose for the last decode call of the calling thread (measurement
+ * tools label their numbers with it); "" before any call.  Valid until the thread's next decode call. */
+const char *atoma_last_decode_kernel(void);
 
 /* Library-owned scratch (the one piece of state behind the "stateless callee" of csrc/src/lib.rs -- the reference passes
  * caller scratch, lib.rs:1023-1042, and may drop it while the kernel still runs).  One grow-only block per (device, stream)

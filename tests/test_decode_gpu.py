@@ -102,6 +102,39 @@ def test_decode_split_kv_small_batch(gpu, B, L):
     assert np.isfinite(lse).all()
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("B,L,h,hk,d", [(3, 2048, 8, 1, 128), (2, 4096, 32, 8, 128), (64, 1024, 8, 1, 128), (5, 3000, 16, 8, 64), (9, 700, 5, 1, 128),
+                                         (40, 600, 8, 8, 128)])
+def test_decode_split_kv_merged_inside_the_launch(gpu, dtype, B, L, h, hk, d):
+    """paged_decode_wg_kernel (option decode_wg_merge): workgroups of 2 / 4 / 8 wavefronts merge their KV pieces in LDS; with 3 = forced
+    also the last-arriver merge across the workgroups of one sequence (agent-scope partials + arrival counter).  Ragged lengths incl. an
+    empty sequence, matrix-core (groups of 5, 8) and dot2 (groups of 1, 2, 4) score kernels, d = 64 / 128; every mode against the
+    oracle, the LSE output against the two-kernel route, and twice in a row (the counters must come back to zero)."""
+    rng = np.random.default_rng(B * 131 + L + h)
+    lens = np.array([max(0, L - 37 * i) for i in range(B)], np.int32)
+    lens[B // 2] = 0
+    page = 16
+    nb = int(sum((x + page - 1) // page for x in lens)) + 2
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+    q = rand_half(rng, (B, 1, h, d), dtype)
+    scale = np.float32(d ** -0.5)
+    ref = _oracle_decode(q, kc, vc, bt, lens, dtype)
+    outs = {}
+    try:
+        for mode in (0, 1, 3, 3):
+            assert gpu.lib.atoma_set_option(b"decode_wg_merge", mode) == 0
+            out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype)
+            for i, Li in enumerate(lens):
+                assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, int(Li)), what=f"decode_wg_merge={mode} seq {i} (L={Li})")
+            assert not out[B // 2].any() and np.isinf(lse[B // 2]).all()
+            outs.setdefault(mode, []).append((out, lse))
+    finally:
+        gpu.lib.atoma_set_option(b"decode_wg_merge", 1)
+    assert np.array_equal(outs[3][0][0], outs[3][1][0]), "the second forced launch differs: arrival counters not back at zero?"
+    live = lens > 0
+    assert np.allclose(outs[3][0][1][live], outs[0][0][1][live], rtol=1e-5, atol=1e-5)
+
+
 def _oracle_decode(q, kc, vc, bt, lens, dtype):
     B, _, h, d = q.shape
     hk, page = kc.shape[2], kc.shape[1]

@@ -19,8 +19,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world", [2])
-@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
-def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, monkeypatch):
+@pytest.mark.parametrize("graph,own", [(False, False), (True, False), (True, True)], ids=["eager", "hipgraph", "hipgraph-own-projections"])
+def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, own, monkeypatch):
+    """own: the rank's projections on the library's own kernels (gate/up with SiLU.up inside; tools/tp_step.py and bench.py run it so)."""
     monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "8000")
     import decode_step as DS
     import tp
@@ -70,7 +71,8 @@ def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, monkeypatch):
                 if live[0]:
                     assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], ptr, ptr, count, BF16, streams[r].s) == 0, gpu.last_error()
             w = DS.upload_weights(scfg, tp.shard_weights(host, cfg, r, world))
-            s = DS.DecodeStep(scfg, B, num_pages, bt.shape[1], w, streams[r], keep_intermediates=not graph, allreduce=allreduce)
+            s = DS.DecodeStep(scfg, B, num_pages, bt.shape[1], w, streams[r], keep_intermediates=not graph, allreduce=allreduce, fused_epilogues=own)
+            assert s.tp_own == own
             _, ks = tp.head_shard(cfg.h, cfg.hk, r, world)
             for l in range(cfg.layers):                        # the rank's KV cache holds its kv heads (worker.rs:584-591)
                 s.kc[l].upload(np.ascontiguousarray(kc0[l][:, :, ks]))

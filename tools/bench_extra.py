@@ -4,7 +4,9 @@
                    U[2048, 2560), block 16, hipGraph replay) -> ms, decode tokens/s/GPU, fraction of the byte roofline;
   prefill          causal varlen FlashAttention-2 prefill, 16 prompts of 2048 tokens, 32 q / 8 kv heads, d = 128
                    -> TFLOP/s and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak;
-  swap             CPU<->GPU KV swap of BASELINE configs[4]: 64 tensors (32 layers x K, V), 256 pages of 32 KiB, pinned host
+  c4_rank_step     one rank of the 70B TP = 8 decode step of configs[3] without its all-reduces (batch 64, context 4096, 80 layers);
+  swap             (+ the pinned hipMemcpyAsync ceiling of the same byte count beside it)
+                   CPU<->GPU KV swap of BASELINE configs[4]: 64 tensors (32 layers x K, V), 256 pages of 32 KiB, pinned host
                    memory, both directions -> GB/s over PCIe.
 Bench plumbing over the C ABI; synthetic data; nothing here imports oracle/."""
 import ctypes as C
@@ -105,12 +107,31 @@ def swap(iters=3, tensors=64, pages=256, nb=512, page_bytes=16 * 8 * 128 * 2, se
             assert ah.lib.atoma_swap_blocks_multi(s, d_, tensors, m.ctypes.data, pages, page_bytes, kind, st.s) == 0, ah.last_error()
         ms = _timed(st, run, iters, warm=1)
         res[label + "_GBps"] = round(tensors * pages * page_bytes / (ms * 1e-3) / 1e9, 1)
+    # The ceiling beside it: ONE contiguous pinned hipMemcpyAsync of the same byte count each way, timed the same way
+    total = tensors * pages * page_bytes
+    big_h, big_d = ah.lib.atoma_host_alloc(total), ah.DeviceBuffer(total)
+    for kind, label in ((2, "pinned_memcpy_d2h_GBps"), (1, "pinned_memcpy_h2d_GBps")):
+        def copy():
+            src, dst = (big_d.ptr, big_h) if kind == 2 else (big_h, big_d.ptr)
+            ah.hip_check(ah.hip.hipMemcpyAsync(dst, src, total, kind, st.s), "hipMemcpyAsync")
+        ms = _timed(st, copy, iters, warm=1)
+        res[label] = round(total / (ms * 1e-3) / 1e9, 1)
+    res["gpu_to_cpu_frac_of_memcpy"] = round(res["gpu_to_cpu_GBps"] / res["pinned_memcpy_d2h_GBps"], 3)
+    res["cpu_to_gpu_frac_of_memcpy"] = round(res["cpu_to_gpu_GBps"] / res["pinned_memcpy_h2d_GBps"], 3)
+    ah.lib.atoma_host_free(big_h)
     for p in host:
         ah.lib.atoma_host_free(p)
     return res
 
 
-def collect(which=("c3_decode_step", "c3_decode_step_fp8_kv", "prefill", "swap")):
+def c4_rank_step(iters=10):
+    """One rank of the Llama-3.1-70B TP = 8 decode step of configs[3] without its all-reduces (tools/rank_step.py): what a rank
+    computes between the exchanges, batch 64, context 4096, 80 layers."""
+    import rank_step
+    return rank_step.run(iters=iters)
+
+
+def collect(which=("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "swap")):
     out = {}
     for name in which:
         try:
@@ -123,4 +144,4 @@ def collect(which=("c3_decode_step", "c3_decode_step_fp8_kv", "prefill", "swap")
 if __name__ == "__main__":
     import json
     ah.set_device(0)
-    print(json.dumps(collect(tuple(sys.argv[1:]) or ("c3_decode_step", "c3_decode_step_fp8_kv", "prefill", "swap"))))
+    print(json.dumps(collect(tuple(sys.argv[1:]) or ("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "swap"))))

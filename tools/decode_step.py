@@ -45,11 +45,15 @@ class DecodeStep:
         # faster step although the vendor GEMM wins most of the single products from 5 rows up (three launches per layer fewer:
         # batch 8 5.17 -> 4.62 ms, 32 7.58 -> 6.96, 64 11.2 -> 10.3, 96 14.9 -> 14.6, 128 16.9 -> 16.8; at 256 rows 19.4 -> 20.1, so
         # the C3 batch stays on the vendor GEMM); a TP rank must all-reduce before the residual.
-        self.fused = fused_epilogues and not keep_intermediates and batch <= int(os.environ.get("ATOMA_STEP_FUSED_MAX_BATCH", "128")) and allreduce is None
+        own_ok = fused_epilogues and not keep_intermediates and batch <= int(os.environ.get("ATOMA_STEP_FUSED_MAX_BATCH", "128"))
+        self.fused = own_ok and allreduce is None
+        # A tensor-parallel rank: the library's own projection kernels as well -- q/k/v with RoPE and the cache write behind one entry,
+        # gate/up with SiLU.up inside; o and down stay plain (their outputs are partial sums: the all-reduce comes before the residual)
+        self.tp_own = own_ok and allreduce is not None
         # own_projections: the op-by-op path on atoma_linear_decode at every batch (tests: the fused step must equal it bit for bit)
-        self.linear = ah.lib.atoma_linear_decode if own_projections else ah.lib.atoma_linear
+        self.linear = ah.lib.atoma_linear_decode if (own_projections or self.tp_own) else ah.lib.atoma_linear
         # 17..64 rows on the fused path: the q/k/v projection, RoPE and the cache write behind one entry (atoma_linear_decode_qkv_rope_cache)
-        self.qkv_fused = self.fused and 16 < batch <= 64 and os.environ.get("ATOMA_STEP_QKV_FUSED", "1") != "0"
+        self.qkv_fused = (self.fused or self.tp_own) and 16 < batch <= 64 and os.environ.get("ATOMA_STEP_QKV_FUSED", "1") != "0"
         self.norm_in_proj = os.environ.get("ATOMA_STEP_NORM_IN_PROJ", "1") != "0"   # fused path: RMSNorm inside the q/k/v and gate/up projections (A/B switch)
         self.fuse_norm = fuse_norm and not keep_intermediates and not self.fused   # residual add + the RMSNorm that follows it in one kernel
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights
@@ -117,7 +121,8 @@ class DecodeStep:
             xn = self._buf("xn1", l, B * H * 2)
             qkv = self._buf("qkv", l, B * qkvw * 2)
             if self.qkv_fused and not self.kv_fp8:          # 17..64 rows: projection -> RoPE -> cache write behind one entry
-                self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
+                if not (self.fuse_norm and l > 0):         # with fuse_norm the previous layer's last add produced xn already
+                    self._ok(L.atoma_rms_norm(x.ptr, self.w["norm1"][l].ptr, xn.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
                 self._ok(L.atoma_linear_decode_qkv_rope_cache(xn.ptr, self.w["wqkv"][l].ptr, qkv.ptr, self.kc[l].ptr, self.vc[l].ptr, self.slots.ptr,
                                                               self.w["cos"].ptr, self.w["sin"].ptr, self.pos.ptr, B, H, c.h, c.hk, c.d, H, H, qkvw,
                                                               c.page * c.hk * c.d, c.page, BF16, 1, s), "qkv projection + rope + cache write")
@@ -176,9 +181,12 @@ class DecodeStep:
                 else:
                     self._ok(L.atoma_add(x.ptr, o.ptr, x1.ptr, B * H, BF16, s), "residual add")
                     self._ok(L.atoma_rms_norm(x1.ptr, self.w["norm2"][l].ptr, xn2.ptr, B, H, H, H, c.eps, BF16, s), "rms_norm")
-                gu = self._buf("gu", l, B * 2 * c.inter * 2)
-                self._ok(self.linear(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
-                self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
+                if self.tp_own:
+                    self._ok(L.atoma_linear_decode_silu_mul(xn2.ptr, self.w["wgu"][l].ptr, act.ptr, B, H, c.inter, H, H, c.inter, BF16, s), "gate/up projection + silu * up")
+                else:
+                    gu = self._buf("gu", l, B * 2 * c.inter * 2)
+                    self._ok(self.linear(xn2.ptr, self.w["wgu"][l].ptr, gu.ptr, B, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
+                    self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
                 dn = self._buf("dn", l, B * H * 2)
                 self._ok(self.linear(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
                 if self.allreduce:

@@ -100,7 +100,7 @@ class Rank:
         self.w = random_shard_weights(rng, self.c)
         pps = (ctx + 1 + self.c.page - 1) // self.c.page
         meta = np.random.default_rng(seed)                   # identical metadata on every rank
-        self.step = DS.DecodeStep(self.c, B, B * pps + 2, pps, self.w, self.stream,
+        self.step = DS.DecodeStep(self.c, B, B * pps + 2, pps, self.w, self.stream, fused_epilogues=True,
                                   allreduce=(lambda ptr, count: self.engine(ptr, count)) if world > 1 else None)
         bt = meta.permutation(B * pps).astype(np.int32).reshape(B, pps)
         pos = np.full(B, ctx)
