@@ -1683,6 +1683,14 @@ static void set_stream_waves(DecodeParams &p, int occupancy) {
     p.stream_waves = (int)std::min<int64_t>((int64_t)p.b * p.h_k * p.gchunks, (int64_t)device_num_cus() * wpc);
 }
 
+// Which decode kernel the dispatcher took last on this thread (bench.py labels its roofline line with it instead of a literal)
+static thread_local std::string g_last_decode_kernel;
+template <typename T> static const char *decode_tname() { return std::is_same<T, bf16_t>::value ? "bf16" : "f16"; }
+static void note_decode_kernel(const char *kernel, const char *t, int d, int g, int p, bool nt, const char *mode) {
+    g_last_decode_kernel = std::string(kernel) + "<" + t + ",D=" + std::to_string(d) + ",G=" + std::to_string(g) + ",P=" + std::to_string(p) +
+                           (nt ? ",nt" : "") + "," + mode + ">";
+}
+
 template <typename T, int D, int G, int P, int MINW, bool NT>
 static void launch_decode_cfg(DecodeParams &p, hipStream_t stream) {
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
@@ -1698,14 +1706,6 @@ static void launch_decode_cfg(DecodeParams &p, hipStream_t stream) {
 
 // Split-KV merged inside the launch: workgroups of NWG = 8 / 4 / 2 wavefronts, wg_splits workgroups per sequence (p.num_splits is
 // rounded down to a multiple of NWG).  False when this launch must take the split + combine kernels instead.
-// Which decode kernel the dispatcher took last on this thread (bench.py labels its roofline line with it instead of a literal)
-static thread_local std::string g_last_decode_kernel;
-template <typename T> static const char *decode_tname() { return std::is_same<T, bf16_t>::value ? "bf16" : "f16"; }
-static void note_decode_kernel(const char *kernel, const char *t, int d, int g, int p, bool nt, const char *mode) {
-    g_last_decode_kernel = std::string(kernel) + "<" + t + ",D=" + std::to_string(d) + ",G=" + std::to_string(g) + ",P=" + std::to_string(p) +
-                           (nt ? ",nt" : "") + "," + mode + ">";
-}
-
 static int decode_wg_waves(const DecodeParams &p) {
     // wavefronts per workgroup: as many as keep one workgroup on every CU (a CU holds only ~40-50 KB of requests in flight whatever its
     // wavefronts ask for, DESIGN.md 4.8c: 128 workgroups of 8 wavefronts stream slower than 1024 single wavefronts on 256 CUs)
