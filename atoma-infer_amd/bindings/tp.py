@@ -42,6 +42,27 @@ def rccl_comm(ah, dist, rank, world, device):
     return comm
 
 
+def xgmi_comm(ah, dist, rank, world, device, capacity_bytes):
+    """A direct-only communicator (atoma_xgmi_*: DESIGN.md 4.5) without RCCL: every rank creates its staging region, the 128-byte
+    handles travel over the rendezvous (gloo all-gather), every rank maps its peers.  What a host that does not want RCCL does
+    (INTEGRATION.md), and what lets two ranks share ONE device in the plumbing tests (RCCL refuses that)."""
+    import torch
+    h = C.c_void_p()
+    if ah.lib.atoma_xgmi_create(C.byref(h), rank, world, device, capacity_bytes) != 0:
+        raise RuntimeError(ah.last_error())
+    one = (C.c_uint8 * 128)()
+    if ah.lib.atoma_xgmi_handle(h, one) != 0:
+        raise RuntimeError(ah.last_error())
+    mine = torch.tensor(list(bytes(one)), dtype=torch.uint8)
+    allh = [torch.zeros(128, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(allh, mine)
+    blobs = (C.c_uint8 * (128 * world))(*[int(v) for t in allh for v in t.tolist()])
+    if ah.lib.atoma_xgmi_connect(h, blobs) != 0:
+        raise RuntimeError(ah.last_error())
+    dist.barrier()
+    return h
+
+
 def shard_config(cfg, world):
     """The model dimensions ONE rank of a `world`-way tensor-parallel job works with (llama_nccl.rs:165-166: heads and kv
     heads divided by the world size; the MLP width is split by TensorParallelColumnLinear / RowLinear).  hidden, vocab,

@@ -84,7 +84,11 @@ def main():
     import atoma_hip as ah
     from halfs import BF16, from_f32          # bindings/halfs.py (product-side plumbing; oracle/ is only used by cpu_baseline)
 
-    ah.set_device(local_rank)
+    # ATOMA_BENCH_ONE_DEVICE=1: every rank on device 0 (the plumbing test of tests/test_bench_multirank_gpu.py on a 1-GPU box; ranks
+    # then meet through the direct all-reduce over HIP IPC -- RCCL refuses two ranks on one device)
+    one_device = os.environ.get("ATOMA_BENCH_ONE_DEVICE") == "1"
+    device = 0 if one_device else local_rank
+    ah.set_device(device)
     B, S, h, hk, d, page = args.batch, args.seq, args.heads, args.kv_heads, args.head_dim, args.block_size
     import tp
     qs_, ks_ = tp.head_shard(h, hk, rank, world)               # this rank's head shard (kv-head TP)
@@ -114,12 +118,40 @@ def main():
     do = ah.DeviceBuffer(q.nbytes)
     scale = float(d ** -0.5)
 
-    comm = None
+    comm = None                      # RCCL-bootstrapped atoma_comm (one per GPU), or None
+    xgmi = None                      # direct-only communicator (atoma_xgmi_*, handles over gloo): ATOMA_BENCH_COMM=xgmi / one-device runs
+    comm_kind = os.environ.get("ATOMA_BENCH_COMM", "xgmi" if one_device else "rccl")
+    ranks_seen, rank_devices, comm_note = None, None, None
     if world > 1 or force_comm:
         import tp
-        comm = tp.rccl_comm(ah, dist, rank, world, local_rank)      # unique id from rank 0, one comm per GPU
+        import torch
+        if comm_kind == "rccl":
+            comm = tp.rccl_comm(ah, dist, rank, world, device)     # unique id from rank 0, one comm per GPU
+        else:
+            xgmi = tp.xgmi_comm(ah, dist, rank, world, device, 2 << 20)
         act = ah.DeviceBuffer.zeros((B, h * d), np.uint16)    # [B, hidden] activations to all-reduce
         act_out = ah.DeviceBuffer.zeros((B, h * d), np.uint16)
+        # ---- who is here: counted THROUGH the communicator (a sum all-reduce of ones over RCCL / the direct kernels), and the
+        # (rank, host, device, PCI bus id) of every rank gathered over the rendezvous -- so that the line proves its own rank count
+        ones = ah.DeviceBuffer.from_numpy(np.full(64, 0x3F80, np.uint16))          # bf16 1.0
+        rc = (ah.lib.atoma_allreduce_sum(comm, ones.ptr, ones.ptr, 64, BF16, None) if comm is not None
+              else ah.lib.atoma_xgmi_allreduce_sum(xgmi, ones.ptr, ones.ptr, 64, BF16, None))
+        ah.synchronize()
+        got = ones.numpy(np.uint16, (64,))
+        ranks_seen = int(round(float(np.frombuffer((got.astype(np.uint32) << 16).tobytes(), np.float32)[0]))) if rc == 0 else 0
+        import socket
+        bus = (C.c_char * 64)()
+        ah.hip.hipDeviceGetPCIBusId(bus, 64, device)
+        mine = {"rank": rank, "host": socket.gethostname(), "device": device, "pci_bus_id": bus.value.decode(errors="replace")}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        rank_devices = gathered
+        if comm is not None:
+            ah.lib.atoma_comm_set_mode(comm, 2)             # builds the direct path behind the communicator (collective), so that the line can say whether it came up
+            comm_note = ah.lib.atoma_comm_info(comm).decode()
+            ah.lib.atoma_comm_set_mode(comm, 0)
+        else:
+            comm_note = "direct kernels only (no RCCL communicator)"
 
     def step():
         ah.run_mha(dq, dkc, dvc, do, b=B, h=h_l, h_k=hk_l, d=d, seqlen_q=1, seqlen_k=pages_per_seq * page,
@@ -128,8 +160,10 @@ def main():
                    cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt,
                    block_table_batch_stride=pages_per_seq, page_block_size=page, force_split_kernel=True,
                    unpadded_lse=False)
-        if comm is not None and args.allreduce_in_step:
+        if args.allreduce_in_step and comm is not None:
             assert ah.lib.atoma_allreduce_sum(comm, act.ptr, act_out.ptr, B * h * d, BF16, None) == 0, ah.last_error()
+        elif args.allreduce_in_step and xgmi is not None:
+            assert ah.lib.atoma_xgmi_allreduce_sum(xgmi, act.ptr, act_out.ptr, B * h * d, BF16, None) == 0, ah.last_error()
 
     def barrier():
         ah.synchronize()
@@ -175,16 +209,23 @@ def main():
                                % (B, h, hk, d, S, page, "identity" if args.identity_table else "random-permutation",
                                   n_pages),
                    "parallelism": "tp%d (kv-head shards)" % world, "step": "one run_mha decode call over the batch"
-                   + (" + all-reduce of [B, h*d] bf16" if (comm is not None and args.allreduce_in_step) else ""),
-                   "collective": ("all-reduce of [B, hidden] bf16 inside the timed step (--allreduce-in-step)" if (comm is not None and args.allreduce_in_step)
+                   + (" + all-reduce of [B, h*d] bf16" if ((comm is not None or xgmi is not None) and args.allreduce_in_step) else ""),
+                   "collective": ("all-reduce of [B, hidden] bf16 inside the timed step (--allreduce-in-step)" if ((comm is not None or xgmi is not None) and args.allreduce_in_step)
                                   else "none in the timed step: the path shards by kv head without an exchange; the layer's tensor-parallel "
                                        "all-reduces are timed in extra.tp_step" if world > 1 else "n/a (one GPU)")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "paged_decode_kernel<bf16,128,G=4>", "kernel_ms": round(kern_ms, 4),
+                     "kernel": (ah.lib.atoma_last_decode_kernel() or b"").decode() or "unknown (library without atoma_last_decode_kernel)",
+                     "kernel_ms": round(kern_ms, 4),
                      "algorithmic_bytes_per_launch": rank_bytes},
     }
 
+    if world > 1 or force_comm:
+        out["ranks_seen"] = ranks_seen                      # sum of ones over the communicator: must equal n_gpus
+        out["ranks_expected"] = world
+        out["rank_devices"] = rank_devices                  # one entry per rank: host, device ordinal, PCI bus id
+        out["communicator"] = {"kind": "rccl (atoma_comm over ncclCommInitRank)" if comm is not None else "direct xGMI kernels over HIP IPC handles (no RCCL)",
+                               "info": comm_note}
     # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs of this same command, corrected as the MI355X guide prescribes:
     # tools/summarize_profiles.py); null when no profile of the default workload is present.
@@ -211,6 +252,7 @@ def main():
             b_.free()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         extra = {}
+        tp_progress = {}             # filled by tp_step.run as it goes: what the watchdog prints if the run does not come back
         watchdog = None
         if world > 1:
             # The N-rank step has never run on a multi-GPU box from this tree (the pool this was built on has 1-GPU boxes): if it
@@ -220,7 +262,8 @@ def main():
 
             def bail():
                 if rank == 0:
-                    out["extra"] = {"error": "the multi-GPU extras did not finish within %.0f s; headline only" % limit}
+                    out["tp_step"] = tp_summary(tp_progress, "did not finish within %.0f s: partial results" % limit)
+                    out["extra"] = {"error": "the multi-GPU extras did not finish within %.0f s" % limit, "tp_step_progress": tp_progress}
                     sys.stdout.write(json.dumps(out) + "\n")
                     sys.stdout.flush()
                 os._exit(0)
@@ -236,19 +279,29 @@ def main():
                     extra["tp_step"] = tp_step.run(steps=10)
             elif world > 1:
                 import tp_step
-                extra["tp_step"] = tp_step.run(steps=10, dist=dist, rank=rank, world=world, local_rank=local_rank, comm=comm)
+                small = os.environ.get("ATOMA_BENCH_TP_SMALL") == "1"     # plumbing tests: 2 layers, batch 8, context 256 (flagged in the output)
+                cfg = tp_step.DS.Config(2, 8192, 64, 8, 128, 28672, 128256) if small else tp_step.LLAMA_3_1_70B
+                extra["tp_step"] = tp_step.run(cfg, B=8 if small else 64, ctx=256 if small else 4096, steps=3 if small else 10, dist=dist, rank=rank, world=world,
+                                               local_rank=device, comm=comm, xgmi=xgmi, progress=tp_progress)
+                if small:
+                    extra["tp_step"]["reduced"] = "ATOMA_BENCH_TP_SMALL=1: 2 layers, batch 8, context 256 -- a plumbing run, not configs[3]"
         except Exception as e:              # never lose the headline to an extra
             extra["error"] = repr(e)
         if watchdog is not None:
             watchdog.cancel()
         out["extra"] = extra
+        if world > 1:
+            out["tp_step"] = tp_summary(extra.get("tp_step") or tp_progress, extra.get("error"))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N = 1 leg
         out["cpu_baseline"] = cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk_l, h_l)
-    if comm is not None:
+    if comm is not None or xgmi is not None:
         if dist is not None:
             dist.barrier()
-        ah.lib.atoma_comm_destroy(comm)
+        if comm is not None:
+            ah.lib.atoma_comm_destroy(comm)
+        else:
+            ah.lib.atoma_xgmi_destroy(xgmi)
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
@@ -257,6 +310,24 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stderr.flush()
         print(json.dumps(out), flush=True)
+
+
+def tp_summary(res, note=None):
+    """The tensor-parallel step of configs[3] at the TOP level of the line: step time with each all-reduce engine,
+    the all-reduce alone, which engines were available -- from tp_step.run's result, or from its progress record when it did not finish."""
+    eng = (res or {}).get("engines") or {}
+    pick = lambda name, key: (eng.get(name) or {}).get(key)
+    out = {"workload": (res or {}).get("workload"), "world": (res or {}).get("world"),
+           "rccl_step_ms": pick("rccl", "step_ms"), "xgmi_step_ms": pick("xgmi", "step_ms"),
+           "rccl_allreduce_us": pick("rccl", "allreduce_us"), "xgmi_allreduce_us": pick("xgmi", "allreduce_us"),
+           "engines_available": {k: v is not None for k, v in eng.items()}, "xgmi_setup": (res or {}).get("xgmi_setup"),
+           "tokens_per_s": (res or {}).get("tokens_per_s"), "step_frac_of_roofline": (res or {}).get("step_frac_of_roofline"),
+           "allreduces_per_step": (res or {}).get("allreduces_per_step"), "allreduce_message_bytes": (res or {}).get("allreduce_message_bytes")}
+    if (res or {}).get("reduced"):
+        out["reduced"] = res["reduced"]
+    if note:
+        out["note"] = note
+    return out
 
 
 def measure_traffic(argv):
@@ -309,6 +380,9 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     """The oracle's C restatement (fa_acausal over the gathered pages, f32, OpenMP) on the first
     `--cpu-sample-seqs` sequences of the same workload; throughput is per byte, so the sample
     scales linearly to the batch."""
+    # thread placement before libgomp starts: one thread per core, spread over the sockets (BASELINE.md section 3: all cores, pinned)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from util import oracle_c
     lib = oracle_c()
     Bs = min(args.cpu_sample_seqs, args.batch)
@@ -333,13 +407,15 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     # OpenMP scaling of this memory-streaming loop saturates well below the box's hardware-thread
     # count (256 on the MI355X host): pick the fastest thread count, then time it for ~10 s.
     forced = int(os.environ.get("ATOMA_BENCH_CPU_THREADS", 0))
-    cands = [forced] if forced else sorted({min(avail, c) for c in (16, 32, 64, 128, avail)})
+    cands = [forced] if forced else sorted({min(avail, c) for c in (4, 8, 16, 32, 64, 128, avail)})
+    sweep = {}
     best = None
     for c in cands:
         run(c)                                                      # warm the page cache / thread pool
         t0 = time.perf_counter()
         run(c)
         el = time.perf_counter() - t0
+        sweep[str(c)] = round(algorithmic_bytes(Bs, S, h, hk, d, page) / el / 1e9, 2)
         if best is None or el < best[0]:
             best = (el, c)
     cores = best[1]
@@ -350,12 +426,21 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
         reps_done += 1
     dt = (time.perf_counter() - t0) / reps_done
     nbytes = algorithmic_bytes(Bs, S, h, hk, d, page)
+    def read(path):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            return None
+    import glob
+    numa_nodes = len(glob.glob("/sys/devices/system/node/node[0-9]*")) or None
     return {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-            "host_hw_threads": avail,
+            "host_hw_threads": avail, "thread_sweep_GBps": sweep,
+            "placement": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"), "numa_nodes": numa_nodes,
+                          "cgroup_cpu_max": read("/sys/fs/cgroup/cpu.max"), "cpus_allowed": len(os.sched_getaffinity(0))},
             "sample": "first %d of %d sequences of the same workload (same tensors), %d repetitions, %.3f s each; "
                       "fa_acausal f32 restatement, one task per (sequence, kv head), K/V rows converted once per query group, "
                       "vectorised inner loops (oracle/c/oracle.c oracle_decode_grouped, gcc -O3 -march=x86-64-v3 -fopenmp); thread count = the "
-                      "fastest of 16/32/64/128/all" % (Bs, args.batch, reps_done, dt),
+                      "fastest of 4/8/16/32/64/128/all (thread_sweep_GBps), threads bound to cores and spread (placement)" % (Bs, args.batch, reps_done, dt),
             "decode_tokens_per_s": round(Bs / dt, 1)}
 
 

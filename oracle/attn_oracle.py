@@ -135,6 +135,52 @@ def attend_decode_online(qf, kf, vf, scale, dtype, tile=16, ngroups=4, group_of=
     return np.where(lt[:, None] > 0, ot / np.where(lt > 0, lt, np.float32(1))[:, None], np.float32(0)).astype(np.float32)
 
 
+def attend_prefill_online(qf, kf, vf, scale, causal, dtype, tile=64, defer=8.0):
+    """Prefill rows under the schedule of libatoma_hip's MFMA prefill kernel (csrc/prefill_mfma.hip, prefill_cfg = 0), with the
+    reference's arithmetic (softmax.h:65-91,135-185): keys arrive in tiles of ``tile`` (64); per row, the running max (exp2
+    domain) is raised to max(m, tile max) only when that exceeds m + ``defer`` (the deferred raise: p <= 2^defer), O and the row
+    sum are rescaled by exp2(m_old - m_new) when it is; p = exp2(fma(s, scale.log2e, -m)) in f32, the row sum takes the
+    UNROUNDED p, P.V takes p rounded to the storage dtype, f32 accumulation, one division at the end.  Why: rounding p to bf16
+    depends on which running max it is taken against, so against the f32 definition rows with few keys can only be held to
+    2^-9.|v| (tests/test_oracle_schedules.py); against the kernel's OWN schedule every row is held to 1e-3 + 1 ulp.
+    ``qf [Lq,h,d]``, ``kf, vf [Lk,hk,d]`` float32; returns out f32 [Lq,h,d] (not yet rounded)."""
+    Lq, h, d = qf.shape
+    Lk, hk, _ = kf.shape
+    g = h // hk
+    out = np.zeros((Lq, h, d), np.float32)
+    if Lq == 0 or Lk == 0:
+        return out
+    sl2 = np.float32(np.float32(scale) * LOG2E)
+    rows = np.arange(Lq)[:, None]
+    shift = Lk - Lq
+    for head in range(h):
+        kh, vh = kf[:, head // g].astype(np.float32), vf[:, head // g].astype(np.float32)
+        m = np.full(Lq, -np.inf, np.float32)
+        l = np.zeros(Lq, np.float32)
+        o = np.zeros((Lq, d), np.float32)
+        for kv0 in range(0, Lk, tile):
+            cols = np.arange(kv0, min(kv0 + tile, Lk))[None, :]
+            s = (qf[:, head].astype(np.float32) @ kh[kv0:kv0 + tile].T).astype(np.float32)
+            if causal:
+                s = np.where(cols <= rows + shift, s, -np.inf).astype(np.float32)
+            mx = (s.max(1) * sl2).astype(np.float32)                 # raw max, then the scale (as the kernel)
+            m_cand = np.maximum(m, mx)
+            with np.errstate(invalid="ignore"):
+                raise_it = m_cand > m + np.float32(defer)            # m = -inf: any finite candidate raises
+            m_new = np.where(raise_it, m_cand, m).astype(np.float32)
+            ms = np.where(np.isfinite(m_new), m_new, np.float32(0)).astype(np.float32)
+            with np.errstate(invalid="ignore"):
+                alpha = np.where(np.isfinite(m), np.exp2(m - ms), np.float32(0)).astype(np.float32)
+                alpha = np.where(np.isfinite(m) | np.isfinite(m_new), alpha, np.float32(1))
+            pexp = (s.astype(np.float64) * np.float64(sl2) - ms[:, None].astype(np.float64)).astype(np.float32)   # one rounding: v_pk_fma_f32
+            p = np.exp2(pexp).astype(np.float32)
+            l = (l * alpha + p.sum(1, dtype=np.float32)).astype(np.float32)
+            o = (o * alpha[:, None] + round_through(p, dtype) @ vh[kv0:kv0 + tile]).astype(np.float32)
+            m = m_new
+        out[:, head] = np.where(l[:, None] > 0, o / np.where(l > 0, l, np.float32(1))[:, None], np.float32(0))
+    return out
+
+
 DECODE_SCHEDULES = {            # (head_dim, variant) -> (ngroups, group_of): row ownership of libatoma_hip's decode kernels
     (128, "dot2"): (4, lambda j: j % 4),      # paged_decode_item: 16 lanes per row, lane group `sub` loads rows sub + 4r
     (64, "dot2"): (8, lambda j: j % 8),       # 8 lanes per row, 8 rows per load instruction

@@ -1,0 +1,123 @@
+"""The whole Llama-3.1-8B-sized decode step of configs[2] at batch 256 (32 layers, hidden 4096, 32 q / 8 kv heads, vocabulary
+128 256) with a correctness check (VERDICT r2 test hole 6b): the hipGraph replay equals the eager step bit for bit -- on the bench's
+route (vendor GEMM at 256 rows, residual add + RMSNorm fused) and on the op-by-op route, which must also agree with each other --
+and every op of ONE layer is replayed on the CPU oracle for three sampled sequences with the inputs the device op saw."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from oracle import attn_oracle as A
+from oracle import elementwise_oracle as EO
+from oracle import linear_oracle as LO
+from oracle import norm_rope_oracle as NR
+from oracle.halfs import BF16, to_f32
+
+pytestmark = pytest.mark.gpu
+
+
+def ulps(a, b):
+    return int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max())
+
+
+def close_linear(got, ref, what):
+    g, r = to_f32(got, BF16), to_f32(ref, BF16)
+    assert (np.abs(g - r) <= 2.0 ** -7 * np.abs(r) + 3e-5).all(), what
+
+
+def test_8b_decode_step_batch_256(gpu):
+    import decode_step as DS
+    import tp_step as TS
+    rng = np.random.default_rng(256)
+    c = DS.LLAMA_3_1_8B
+    B = 256
+    w = TS.random_shard_weights(rng, c)                      # synthetic N(0,1) bf16 weights on the device (magnitudes blow activations up: fine for parity)
+    # activations stay finite only with sane scales: rescale the projections' random slabs is not possible in place -- instead use
+    # small norm weights so that every layer's input is O(0.02)
+    small = from_small(rng, c.hidden)
+    for l in range(c.layers):
+        w["norm1"][l].upload(small)
+        w["norm2"][l].upload(small)
+    w["norm_f"].upload(small)
+    ctx = rng.integers(128, 384, B)
+    pps = 384 // c.page + 1
+    bt = rng.permutation(B * pps).astype(np.int32).reshape(B, pps)
+    slots = bt[np.arange(B), ctx // c.page].astype(np.int64) * c.page + ctx % c.page
+    ids = rng.integers(0, c.vocab, B)
+    lens = (ctx + 1).astype(np.int32)
+    st = gpu.Stream()
+    LAYER, ROWS = 17, np.array([3, 100, 255])
+
+    def fresh(**kw):
+        s = DS.DecodeStep(c, B, B * pps + 2, pps, w, st, **kw)
+        s.set_inputs(ids, ctx, slots, lens, bt)
+        return s
+    # ---- the bench's route: eager, then a captured graph over the SAME caches (the step rewrites the same K/V rows with the same values)
+    step = fresh(fused_epilogues=True)
+    step.run()
+    st.synchronize()
+    logits_e = step.logits.numpy(np.uint16, (B, c.vocab))
+    ids_e = step.next_ids.numpy(np.int32, (B,))
+    assert np.isfinite(to_f32(logits_e, BF16)).all()
+    with gpu.Graph.capture(st) as g:
+        step.run()
+    step.logits.fill_bytes(0)
+    g.launch()
+    st.synchronize()
+    assert np.array_equal(step.logits.numpy(np.uint16, (B, c.vocab)), logits_e), "graph replay differs from the eager step"
+    assert np.array_equal(step.next_ids.numpy(np.int32, (B,)), ids_e)
+    kc_bench = step.kc[LAYER].numpy(np.uint16, ((B * pps + 2), c.page, c.hk, c.d))
+    del g, step
+    # ---- the op-by-op route with every intermediate kept; its logits must be the bench route's (add + RMSNorm fusion is bit-exact)
+    keep = fresh(keep_intermediates=True)
+    keep.run()
+    st.synchronize()
+    assert np.array_equal(keep.logits.numpy(np.uint16, (B, c.vocab)), logits_e), "op-by-op route differs from the bench's route"
+    shape = ((B * pps + 2), c.page, c.hk, c.d)
+    kc, vc = keep.kc[LAYER].numpy(np.uint16, shape), keep.vc[LAYER].numpy(np.uint16, shape)
+    assert np.array_equal(kc, kc_bench)
+    # ---- one layer on the oracle, three sampled sequences
+    name, l, t = keep.trace[1 + LAYER]
+    assert l == LAYER
+    H, I, hd, qw = c.hidden, c.inter, c.h * c.d, c.qkv
+    dl = lambda buf, shp: buf.numpy(np.uint16, shp)[ROWS]
+    host = {k: w[k][LAYER].numpy(np.uint16, shp) for k, shp in (("norm1", (H,)), ("norm2", (H,)), ("wqkv", (qw, H)), ("wo", (H, hd)), ("wgu", (2 * I, H)), ("wdown", (H, I)))}
+    cos, sin = DS.rope_tables(c)
+    x = dl(t["x"], (B, H))
+    xn1 = dl(t["xn1"], (B, H))
+    assert ulps(xn1, NR.rms_norm(x, host["norm1"], c.eps, BF16)) <= 1
+    qkv_pre = dl(t["qkv_pre"], (B, qw))
+    close_linear(qkv_pre, LO.linear(xn1, host["wqkv"], BF16), "qkv projection")
+    qkv = dl(t["qkv"], (B, qw))
+    n = len(ROWS)
+    q_pre, k_pre = qkv_pre[:, :hd].reshape(n, c.h, c.d), qkv_pre[:, hd:hd + c.hk * c.d].reshape(n, c.hk, c.d)
+    q_rot, k_rot = NR.rope(q_pre, cos, sin, ctx[ROWS], BF16), NR.rope(k_pre, cos, sin, ctx[ROWS], BF16)
+    assert np.array_equal(qkv[:, :hd].reshape(n, c.h, c.d), q_rot) and np.array_equal(qkv[:, hd:hd + c.hk * c.d].reshape(n, c.hk, c.d), k_rot)
+    for i, r in enumerate(ROWS):                                 # the new token's K / V sit in their slot
+        pg, off = int(slots[r]) // c.page, int(slots[r]) % c.page
+        assert np.array_equal(kc[pg, off], k_rot[i]) and np.array_equal(vc[pg, off].reshape(-1), qkv_pre[i, hd + c.hk * c.d:])
+    att = dl(t["att"], (B, hd))
+    ref = A.flash_attn_kv_cache(q_rot[:, None], kc, vc, c.d ** -0.5, BF16, bt[ROWS], lens[ROWS])[:, 0].reshape(n, hd)
+    a32, r32 = to_f32(att, BF16), to_f32(ref, BF16)
+    assert (np.abs(a32 - r32) <= 4e-3 + 2.0 ** -7 * np.abs(r32)).all(), "attention"
+    o = dl(t["o"], (B, H))
+    close_linear(o, LO.linear(att, host["wo"], BF16), "o projection")
+    x1 = dl(t["x1"], (B, H))
+    assert np.array_equal(x1, EO.add(x, o, BF16))
+    xn2 = dl(t["xn2"], (B, H))
+    assert ulps(xn2, NR.rms_norm(x1, host["norm2"], c.eps, BF16)) <= 1
+    gu = dl(t["gu"], (B, 2 * I))
+    close_linear(gu, LO.linear(xn2, host["wgu"], BF16), "gate/up projection")
+    act = dl(t["act"], (B, I))
+    assert ulps(act, EO.silu_mul(np.ascontiguousarray(gu[:, :I]), np.ascontiguousarray(gu[:, I:]), BF16)) <= 1
+    dn = dl(t["dn"], (B, H))
+    close_linear(dn, LO.linear(act, host["wdown"], BF16), "down projection")
+    x2 = dl(t["x2"], (B, H))
+    assert np.array_equal(x2, EO.add(x1, dn, BF16))
+
+
+def from_small(rng, hidden):
+    from oracle.halfs import from_f32
+    return from_f32((0.02 * (1 + 0.1 * rng.standard_normal(hidden))).astype(np.float32), BF16)

@@ -67,3 +67,22 @@ def test_online_oracle_entry_point_matches_f32_mode_within_policy():
             assert not got[0].any()
             for i, L in enumerate(lens):
                 assert_close(got[i], ref[i], BF16, atol=attn_atol(BF16, int(L)), what=f"{var} d={d} L={L}")
+
+
+def test_prefill_online_schedule_restates_the_definition():
+    """attend_prefill_online (64-key tiles, deferred raise of the running max) against the f32 definition: inside the P-rounding
+    bound on every row, identical to the one-tile kernel mode when the whole row fits one tile, and independent of the deferral
+    threshold up to that bound (threshold 0 = the textbook online softmax)."""
+    rng = np.random.default_rng(5)
+    L, h, hk, d = 300, 4, 2, 64
+    q, k, v = (to_f32(from_f32(rng.standard_normal(s).astype(np.float32), BF16), BF16) for s in ((L, h, d), (L, hk, d), (L, hk, d)))
+    scale = np.float32(d ** -0.5)
+    ref, _ = A.attend_rows(q, k, v, scale, causal=True)
+    bound = 2.0 ** -9 * np.abs(v).max() + 1e-5
+    for defer in (0.0, 8.0, 1e9):
+        o = A.attend_prefill_online(q, k, v, scale, True, BF16, defer=defer)
+        assert np.abs(o - ref).max() <= bound, defer
+    one_tile, _ = A.attend_rows(q[:40], k[:40], v[:40], scale, causal=True, mode="kernel", dtype=BF16)
+    o = A.attend_prefill_online(q[:40], k[:40], v[:40], scale, True, BF16, tile=64, defer=1e9)
+    # one tile, max taken once (the first tile always raises): the kernel-mode restatement up to the f32 order of the sums
+    assert np.abs(o - one_tile).max() < 2e-6

@@ -116,7 +116,7 @@ class Rank:
         return g
 
 
-def measure(ranks, engines, steps, barrier, reduce_max):
+def measure(ranks, engines, steps, barrier, reduce_max, progress=None):
     """ranks: the Rank objects THIS process drives (1 under torch.distributed.run, W with --virtual-ranks).
     engines: name -> list (one per local rank) of callables(ptr, count, stream) or None when unavailable."""
     out = {}
@@ -194,11 +194,15 @@ def measure(ranks, engines, steps, barrier, reduce_max):
             res["allreduce_us"] = reduce_max((time.perf_counter() - t0) * 1e6 / (5 * n_ar))
             res["allreduce_share_of_step"] = round(res["allreduce_us"] * n_ar / 1e3 / res["step_ms"], 3)
         out[name] = {k: round(v, 4) if isinstance(v, float) else v for k, v in res.items()}
+        if progress is not None:
+            progress.setdefault("engines", {})[name] = out[name]
     return out
 
 
-def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, world=1, local_rank=0, virtual_ranks=0, comm=None):
-    """dist: an initialised torch.distributed (gloo) module when world > 1, used only for barriers and max-over-ranks."""
+def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, world=1, local_rank=0, virtual_ranks=0, comm=None, xgmi=None, progress=None):
+    """dist: an initialised torch.distributed (gloo) module when world > 1, used only for barriers and max-over-ranks.  comm: an
+    atoma_comm (RCCL + the direct path behind it); xgmi: a direct-only communicator instead (tp.xgmi_comm); progress: a dict that
+    receives every engine's numbers as soon as they exist (bench.py's watchdog prints it if the run does not come back)."""
     barrier = (lambda: dist.barrier()) if dist is not None else (lambda: None)
 
     def reduce_max(x):
@@ -242,10 +246,17 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
     else:
         ranks = [Rank(full_cfg, rank, world, B, ctx, local_rank)]
         c = ranks[0].c
-        if world > 1:
+        if world > 1 and xgmi is not None:                   # direct kernels only (no RCCL communicator)
+            def via_xgmi(ptr, count, s):
+                assert ah.lib.atoma_xgmi_allreduce_sum(xgmi, ptr, ptr, count, BF16, s) == 0, ah.last_error()
+            engines = {"rccl": None, "xgmi": [via_xgmi]}
+            info = "xgmi: ready (direct-only communicator, no RCCL)"
+        elif world > 1:
             if comm is None:
                 comm = own_comm = tp.rccl_comm(ah, dist, rank, world, local_rank)
+            ah.lib.atoma_comm_set_mode(comm, 2)              # builds the direct path behind the communicator (collective: every rank alike)
             info = ah.lib.atoma_comm_info(comm).decode()
+            ah.lib.atoma_comm_set_mode(comm, 0)
 
             def via_comm(mode):
                 def f(ptr, count, s):
@@ -273,7 +284,9 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
         else:
             engines = {"none": [lambda ptr, count, s: None]}
             info = "single rank"
-    res = measure(ranks, engines, steps, barrier, reduce_max)
+    if progress is not None:
+        progress.update(workload="Llama-3.1-70B-shaped decode step, TP=%d" % world, world=world, xgmi_setup=info if world > 1 else None)
+    res = measure(ranks, engines, steps, barrier, reduce_max, progress)
     nbytes = step_bytes(c, B, ctx)
     out = {"workload": f"Llama-3.1-70B-shaped decode step (SURVEY C4), {full_cfg.layers} layers, batch {B}, context {ctx}, bf16, "
                        + (f"{virtual_ranks} ranks of a TP=8 job on ONE device (direct all-reduce only)" if virtual_ranks else f"TP={world}, one rank per GPU"),
