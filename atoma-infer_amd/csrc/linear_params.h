@@ -38,5 +38,11 @@ struct LinearParams {
 int launch_linear_tile(LinearParams &p, int dtype, hipStream_t stream);
 // true when launch_linear_tile would serve this product AND leave fp32 partials (more than two K splits)
 bool linear_tile_leaves_partials(const LinearParams &p, int dtype);
+// the q/k/v projection with RoPE and the KV-cache write as the tile kernel's epilogue (ONE launch): possible when the product is served,
+// not split over K beyond what the launch merges itself, and a tile holds both halves of a head
+bool linear_tile_can_rope(const LinearParams &p, int head_dim);
+int launch_linear_tile_rope(LinearParams &p, int dtype, hipStream_t stream, const uint16_t *cos_t, const uint16_t *sin_t, const int64_t *positions,
+                            const int64_t *slot_mapping, uint16_t *k_cache, uint16_t *v_cache, int64_t block_stride, int64_t table_rows, int heads_q,
+                            int heads_kv, int head_dim, int page_size, int per_op);
 
 }  // namespace atoma

@@ -47,16 +47,30 @@ __device__ __forceinline__ uint64_t tile_uniform64(uint64_t x) {
 }
 template <int N> __device__ __forceinline__ void tile_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// MODE 2 (the q/k/v projection with RoPE and the KV-cache write as its epilogue, atoma_linear_decode_qkv_rope_cache)
+struct TileRope {
+    const uint16_t *cos_t, *sin_t;       // [table rows][head_dim / 2]
+    const int64_t *positions, *slot_mapping;
+    uint16_t *k_cache, *v_cache;
+    int64_t block_stride, table_rows;    // elements; rope_pos() clamp
+    int heads_q, heads_kv, head_dim, page_size, per_op;
+};
 struct TileParams {
     LinearParams p;
-    float *slabs;                // in-launch 2-way merge: [tile][split][wave][group][lane] float4
+    float *slabs;                // in-launch merge: [tile][split][wave][group][lane] float4
     unsigned *counters;          // arrival counter per tile (zero between launches)
     int chunks_per_split;        // chunks of 128 inputs
-    int in_launch_merge;         // splits == 2 and merged here
+    int merge_splits;            // 2..4: K split this many ways and merged here by the last workgroup to arrive; 0: no in-launch merge
+    TileRope rope;
 };
+constexpr int TILE_PLAIN = 0, TILE_GATE_UP = 1, TILE_ROPE = 2;
 
-template <typename T, int NW, bool PAIR>
+// MODE: TILE_PLAIN rows n0 .. n0 + NW; TILE_GATE_UP (PAIR) NW/2 gate rows + the NW/2 matching up rows (p.n / 2 further down), SiLU.up
+// epilogue; TILE_ROPE the same pairing at a distance of head_dim / 2 inside every head's block of rows -- a lane then holds both partners
+// of a rotation -- with RoPE (q, k heads) and the KV-cache write (k, v heads) as the epilogue.
+template <typename T, int NW, int MODE>
 __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp) {
+    constexpr bool PAIR = MODE != TILE_PLAIN;
     const LinearParams &p = tp.p;
     constexpr int WAVES = 8;
     constexpr int NSLOT = NW == 128 ? 3 : 4;
@@ -69,11 +83,16 @@ __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp
     static_assert(!PAIR || GPW % 2 == 0 || NW == 32, "PAIR tile shape");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = lane >> 4, col = lane & 15;
-    const int out_n = PAIR ? p.n / 2 : p.n;
+    const int out_n = MODE == TILE_GATE_UP ? p.n / 2 : p.n;
     const int tiles = p.n / NW;
     const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
-    // tile row r -> W row: plain n0 + r; PAIR: the first NW/2 rows are gate rows n0 + r, the others the matching up rows
-    const int n0 = PAIR ? tile * (NW / 2) : tile * NW;
+    // tile row r -> W row: plain n0 + r; PAIR: the first NW/2 rows are rows n0 + r, the others their partners pair_dist further down
+    // (gate / up: p.n / 2; RoPE: head_dim / 2 inside the head's block of rows -- tiles per head = head_dim / NW)
+    const int half = MODE == TILE_ROPE ? tp.rope.head_dim / 2 : 0;
+    const int pair_dist = MODE == TILE_GATE_UP ? out_n : half;
+    int n0 = tile * NW;
+    if (MODE == TILE_GATE_UP) n0 = tile * (NW / 2);
+    if (MODE == TILE_ROPE) { const int tph = half / (NW / 2); n0 = (tile / tph) * tp.rope.head_dim + (tile % tph) * (NW / 2); }
     const int chunks_all = p.k >> 7;
     const int c0 = split * tp.chunks_per_split, c1 = min(c0 + tp.chunks_per_split, chunks_all), chunks = c1 - c0;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
@@ -87,7 +106,7 @@ __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp
         const int q = wave * PPW + i;
         isw[i] = q < PW;
         const int row = 4 * (isw[i] ? q : q - PW) + (lane >> 4);
-        const int64_t src_row = isw[i] ? (PAIR && row >= NW / 2 ? (int64_t)out_n + row - NW / 2 : (int64_t)row) : (int64_t)min(row, p.batch - 1);
+        const int64_t src_row = isw[i] ? (PAIR && row >= NW / 2 ? (int64_t)pair_dist + row - NW / 2 : (int64_t)row) : (int64_t)min(row, p.batch - 1);
         voff[i] = (uint32_t)(src_row * (isw[i] ? p.w_row_stride : p.x_row_stride) * 2 + ((lane & 15) ^ (row & 15)) * 16);
         dst[i] = (isw[i] ? 0 : WT) + 4 * (isw[i] ? q : q - PW) * 256;
     }
@@ -147,16 +166,17 @@ __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp
 #pragma unroll
         for (int a = 0; a < GPW; ++a) {
             const int r = grow[a] + 4 * grp;
-            const int n = PAIR ? (r >= NW / 2 ? out_n + n0 + r - NW / 2 : n0 + r) : n0 + r;
+            const int n = PAIR ? (r >= NW / 2 ? pair_dist + n0 + r - NW / 2 : n0 + r) : n0 + r;
             *reinterpret_cast<float4 *>(p.partial + ((int64_t)split * p.batch + brow) * p.n + n) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
         }
         return;
     }
-    if (tp.in_launch_merge) {
+    if (tp.merge_splits > 1) {
         // publish this workgroup's fp32 tile write-through (sc1: straight to memory, no release fence), drain, take a ticket; the
-        // second arriver reads its partner's tile (sc1 loads: past its own L1 / L2) and finishes -- a + b is the same either way round
-        float *mine = tp.slabs + ((int64_t)(tile * 2 + split) * WAVES + wave) * GPW * 256;
-        const float *theirs = tp.slabs + ((int64_t)(tile * 2 + (split ^ 1)) * WAVES + wave) * GPW * 256;
+        // LAST arriver reads the other splits' tiles (sc1 loads: past its own L1 / L2) and finishes.  The sum runs in split order
+        // (its own tile taken from registers at its own place), so the result does not depend on who came last.
+        const int S = tp.merge_splits;
+        float *mine = tp.slabs + ((int64_t)(tile * S + split) * WAVES + wave) * GPW * 256;
         const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(mine, 0, GPW * 1024, 0x00020000);
 #pragma unroll
         for (int a = 0; a < GPW; ++a)
@@ -166,19 +186,90 @@ __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp
         unsigned *ticket = reinterpret_cast<unsigned *>(smem);    // the ring is idle now (every DMA was waited for)
         if (tid == 0) {
             const unsigned t = __hip_atomic_fetch_add(tp.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == 1) __hip_atomic_store(tp.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            if (t + 1 == (unsigned)S) __hip_atomic_store(tp.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
             *ticket = t;
         }
         __syncthreads();
-        if (*ticket == 0) return;                                  // first arriver: the partner finishes the tile
-        const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(theirs), 0, GPW * 1024, 0x00020000);
+        if (*ticket + 1 != (unsigned)S) return;                    // not the last: somebody else finishes the tile
+        lf32x4 tot[GPW];
+        for (int sp = 0; sp < S; ++sp) {
+            float *theirs = tp.slabs + ((int64_t)(tile * S + sp) * WAVES + wave) * GPW * 256;
+            const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc(theirs, 0, GPW * 1024, 0x00020000);
 #pragma unroll
-        for (int a = 0; a < GPW; ++a) {
-            const lf32x4 o = __builtin_bit_cast(lf32x4, __builtin_amdgcn_raw_buffer_load_b128(tr, (a * 64 + lane) * 16, 0, 16 /* sc1 */));
-            acc[a] = split == 0 ? acc[a] + o : o + acc[a];
+            for (int a = 0; a < GPW; ++a) {
+                lf32x4 o = acc[a];
+                if (sp != split) o = __builtin_bit_cast(lf32x4, __builtin_amdgcn_raw_buffer_load_b128(tr, (a * 64 + lane) * 16, 0, 16 /* sc1 */));
+                tot[a] = sp == 0 ? o : tot[a] + o;
+            }
         }
+#pragma unroll
+        for (int a = 0; a < GPW; ++a) acc[a] = tot[a];
+        __syncthreads();                                           // (the ticket word is reused below)
     }
-    if constexpr (PAIR && GPW == 1) {                              // NW = 32: up tile -> LDS -> the gate wavefront of the same batch tile
+    if constexpr (MODE == TILE_ROPE) {
+        // ---- RoPE (q and k heads) + KV-cache write (k and v heads): rope_cache_kernel's arithmetic on the projection's ROUNDED output ----
+        const TileRope &rp = tp.rope;
+        lf32x4 other[GPW == 1 ? 1 : GPW];
+        if constexpr (GPW == 1) {                                  // NW = 32: the partner group lives in the neighbouring wavefront (h ^ 1)
+            lf32x4 *xch = reinterpret_cast<lf32x4 *>(smem + 1024);
+            __syncthreads();
+            xch[(ct * 2 + h) * 64 + lane] = acc[0];
+            __syncthreads();
+            other[0] = xch[(ct * 2 + (h ^ 1)) * 64 + lane];
+        }
+        if (brow >= p.batch) return;
+        const int tph = half / (NW / 2);
+        const int head = tile / tph;
+        const bool is_v = head >= rp.heads_q + rp.heads_kv, is_k = !is_v && head >= rp.heads_q;
+        const int64_t slot_ix = rp.slot_mapping[brow];
+        int64_t pos = rp.positions[brow];
+        pos = rp.table_rows > 0 ? (pos < 0 ? 0 : (pos >= rp.table_rows ? rp.table_rows - 1 : pos)) : pos;      // rope_pos() of norm_rope.hip
+        const int64_t crow = slot_ix >= 0 ? (slot_ix / rp.page_size) * rp.block_stride + (slot_ix % rp.page_size) * (int64_t)rp.heads_kv * rp.head_dim : 0;
+        constexpr int NP = GPW == 1 ? 1 : GPW / 2;                 // partner pairs held by this lane
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            // x1 = first-half element, x2 = its partner half further; this lane finishes `mine` of them (both when it holds both)
+            const lf32x4 &g1 = GPW == 1 ? (h == 0 ? acc[0] : other[0]) : acc[a];
+            const lf32x4 &g2 = GPW == 1 ? (h == 0 ? other[0] : acc[0]) : acc[a + GPW / 2];
+            const int j0 = (GPW == 1 ? 0 : grow[a]) + (tile % tph) * (NW / 2) + 4 * grp;   // index inside the half: 0 .. half - 1
+            float x1[4], x2[4], y1[4], y2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x1[i] = round_through<T>(g1[i]); x2[i] = round_through<T>(g2[i]); }
+            if (is_v) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { y1[i] = x1[i]; y2[i] = x2[i]; }
+            } else {
+#pragma clang fp contract(off)
+                const uint2 cw = *reinterpret_cast<const uint2 *>(rp.cos_t + pos * half + j0), sw = *reinterpret_cast<const uint2 *>(rp.sin_t + pos * half + j0);
+                const float cs[4] = {lo_to_f32<T>(cw.x), hi_to_f32<T>(cw.x), lo_to_f32<T>(cw.y), hi_to_f32<T>(cw.y)};
+                const float sn[4] = {lo_to_f32<T>(sw.x), hi_to_f32<T>(sw.x), lo_to_f32<T>(sw.y), hi_to_f32<T>(sw.y)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (rp.per_op) {
+                        y1[i] = round_through<T>(x1[i] * cs[i]) - round_through<T>(x2[i] * sn[i]);
+                        y2[i] = round_through<T>(x1[i] * sn[i]) + round_through<T>(x2[i] * cs[i]);
+                    } else {
+                        y1[i] = x1[i] * cs[i] - x2[i] * sn[i];
+                        y2[i] = x1[i] * sn[i] + x2[i] * cs[i];
+                    }
+                }
+            }
+            const int64_t col0 = (int64_t)head * rp.head_dim + j0;
+            const int hk = is_v ? head - rp.heads_q - rp.heads_kv : head - rp.heads_q;
+            uint16_t *cache = is_v ? rp.v_cache : rp.k_cache;
+            auto put = [&](const float (&y)[4], int64_t c) {
+                uint2 o;
+                o.x = pack2<T>(y[0], y[1]);
+                o.y = pack2<T>(y[2], y[3]);
+                *reinterpret_cast<uint2 *>(p.y + (int64_t)brow * p.y_row_stride + c) = o;
+                if ((is_k || is_v) && slot_ix >= 0) *reinterpret_cast<uint2 *>(cache + crow + (int64_t)hk * rp.head_dim + (c - (int64_t)head * rp.head_dim)) = o;
+            };
+            if (GPW > 1 || h == 0) put(y1, col0);
+            if (GPW > 1 || h == 1) put(y2, col0 + half);
+        }
+        return;
+    }
+    if constexpr (MODE == TILE_GATE_UP && GPW == 1) {              // NW = 32: up tile -> LDS -> the gate wavefront of the same batch tile
         lf32x4 *xch = reinterpret_cast<lf32x4 *>(smem + 1024);    // (the ring is idle; the first KiB may hold the merge ticket)
         __syncthreads();
         if (h == 1) xch[ct * 64 + lane] = acc[0];
@@ -198,7 +289,7 @@ __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp
         return;
     }
     if (brow >= p.batch) return;
-    if constexpr (PAIR && GPW >= 2) {                              // rounding points as in linear_reduce_kernel
+    if constexpr (MODE == TILE_GATE_UP && GPW >= 2) {              // rounding points as in linear_reduce_kernel
 #pragma unroll
         for (int a = 0; a < GPW / 2; ++a) {
             float v[4];
@@ -212,7 +303,7 @@ __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp
             o.y = pack2<T>(v[2], v[3]);
             *reinterpret_cast<uint2 *>(p.y + (int64_t)brow * p.y_row_stride + n0 + grow[a] + 4 * grp) = o;
         }
-    } else if constexpr (!PAIR) {
+    } else if constexpr (MODE == TILE_PLAIN) {
 #pragma unroll
         for (int a = 0; a < GPW; ++a) {
             const int n = n0 + grow[a] + 4 * grp;
@@ -245,23 +336,26 @@ bool set_linear_tile_option(const std::string &name, int value) {
 }
 
 // Workgroup shape and K split from the SHAPE OF W alone (p.n rows, p.k inputs), so that the stacked gate / up launch with its SiLU.up
-// epilogue, the residual epilogue and the plain projection of the same matrix split K alike and stay bit-identical to projection +
-// separate op.  Candidates: 128 / 64 / 32 rows per workgroup x 1 or 2 K splits (a 2-way split merges inside the launch), priced with
-// the measured model of DESIGN.md 4.8c -- a CU's time = (weight KB + 0.3 x KB of x) x 0.04 us, + 2 us for an in-launch merge, times
-// the rounds of workgroups over the CUs -- e.g. (64 rows, 2 splits) for the 70B shard's gate/up and down, (32 rows, 1 split) for its
-// o projection.  A matrix with so few rows that even the best candidate leaves more than 40 % of the CUs idle is split further over K
-// (powers of two) and leaves fp32 partials for the caller's reduce / RoPE kernel.
+// epilogue, the residual epilogue, the RoPE epilogue and the plain projection of the same matrix split K alike and stay bit-identical
+// to projection + separate op.  Candidates: 128 / 64 / 32 rows per workgroup x 1, 2 or 4 K splits (a split merges inside the launch),
+// priced with the measured model of DESIGN.md 4.8c -- a CU's time = (weight KB + 0.3 x KB of x) x 0.04 us, plus 1 us + 0.05 us per KB
+// the last arriver reads back for an in-launch merge, times the rounds of workgroups over the CUs -- e.g. (64 rows, 2 splits) for the
+// 70B shard's gate/up and down, (32 rows, 1 split) for its o projection, (32 rows, 4 splits) for its 1280-row q/k/v shard.  A matrix with
+// so few rows that even the best candidate leaves more than 40 % of the CUs idle is split further over K (powers of two) and leaves
+// fp32 partials for the caller's reduce / RoPE kernel.
+constexpr int TILE_MAX_MERGE = 4;
 static void tile_plan(int64_t n, int64_t k, int cus, int *nw_out, int *splits_out) {
     const int64_t chunks = k / 128;
     int best_nw = 0, best_s = 1;
     int64_t best_wgs = 0;
     double best_t = 1e30;
-    for (int s : {1, 2})
+    for (int s : {1, 2, 4})
         for (int nw : {128, 64, 32}) {
-            if (n % nw || chunks / s < 4) continue;
+            if (n % nw || chunks / s < 4 || n / nw > 4096) continue;
             const int64_t wgs = n / nw * s;
             const double kb = (double)(k / s) * 2.0 / 1024.0;
-            const double t = (double)cdiv(wgs, cus) * ((nw + 0.3 * 64) * kb * 0.04 + (s == 2 ? 2.0 : 0.0));
+            const double merge = s == 1 ? 0.0 : 1.0 + 0.05 * (nw * 64 * 4 / 1024.0) * (s - 1);
+            const double t = (double)cdiv(wgs, cus) * ((nw + 0.3 * 64) * kb * 0.04 + merge);
             if (t < best_t) { best_t = t; best_wgs = wgs; best_nw = nw; best_s = s; }
         }
     if (best_nw && best_wgs * 10 >= (int64_t)cus * 6) { *nw_out = best_nw; *splits_out = best_s; return; }
@@ -278,7 +372,7 @@ static void tile_plan(int64_t n, int64_t k, int cus, int *nw_out, int *splits_ou
 static void tile_route(const LinearParams &p, int *nw_out, int *splits_out) {
     *nw_out = 0;
     *splits_out = 1;
-    // p.n % 64: the PAIR kernel needs 64-row tiles, and the plain kernel must take the same route for the same matrix
+    // p.n % 64: the paired kernels need 64-row tiles at least once, and the plain kernel must take the same route for the same matrix
     if (!linear_tile_on || p.k % 128 || p.n % 64 || p.batch > 64 || p.batch < 1) return;
     int nw = 0, splits = 1;
     tile_plan(p.n, p.k, device_num_cus(), &nw, &splits);
@@ -287,7 +381,7 @@ static void tile_route(const LinearParams &p, int *nw_out, int *splits_out) {
     if ((nw != 32 && nw != 64 && nw != 128) || p.n % nw) return;
     const int64_t chunks = p.k / 128;
     splits = (int)cdiv(chunks, cdiv(chunks, splits));
-    if (splits == 2 && p.n / nw > 4096) return;
+    if (splits > 1 && splits <= TILE_MAX_MERGE && p.n / nw > 4096) return;   // one arrival counter per tile
     *nw_out = nw;
     *splits_out = splits;
 }
@@ -296,10 +390,16 @@ bool linear_tile_leaves_partials(const LinearParams &p, int dtype) {
     (void)dtype;
     int nw, splits;
     tile_route(p, &nw, &splits);
-    return nw != 0 && splits > 2;
+    return nw != 0 && splits > TILE_MAX_MERGE;
+}
+// the RoPE epilogue can ride on this product: served, merged inside the launch (or not split), and a tile holds both halves of a head
+bool linear_tile_can_rope(const LinearParams &p, int head_dim) {
+    int nw, splits;
+    tile_route(p, &nw, &splits);
+    return nw != 0 && splits <= TILE_MAX_MERGE && head_dim % 32 == 0 && nw / 2 <= head_dim / 2 && (head_dim / 2) % (nw / 2) == 0;
 }
 
-template <typename T> static int launch_linear_tile_t(LinearParams &p, hipStream_t stream) {
+template <typename T> static int launch_linear_tile_t(LinearParams &p, hipStream_t stream, const TileRope *rope) {
     int nw, splits;
     tile_route(p, &nw, &splits);
     if (nw == 0) return 1;
@@ -310,42 +410,46 @@ template <typename T> static int launch_linear_tile_t(LinearParams &p, hipStream
     p.splits = splits;
     p.partial = nullptr;
     const int64_t tiles = p.n / nw;
-    if (splits == 2) {
-        tp.in_launch_merge = 1;
-        tp.slabs = static_cast<float *>(workspace(stream, (size_t)tiles * 2 * nw * 64 * sizeof(float)));
+    if (splits > 1 && splits <= TILE_MAX_MERGE) {
+        tp.merge_splits = splits;
+        tp.slabs = static_cast<float *>(workspace(stream, (size_t)tiles * splits * nw * 64 * sizeof(float)));
         tp.counters = sync_counters(stream);
         if (!tp.slabs || !tp.counters) return -1;
-    } else if (splits > 2) {
+    } else if (splits > TILE_MAX_MERGE) {
+        if (rope) return 1;
         p.partial = static_cast<float *>(workspace(stream, (size_t)splits * p.batch * p.n * sizeof(float)));
         if (!p.partial) return -1;
     }
     tp.p = p;
-    const bool pair = p.epilogue == 2;
+    if (rope) tp.rope = *rope;
+    const int mode = rope ? TILE_ROPE : (p.epilogue == 2 ? TILE_GATE_UP : TILE_PLAIN);
     const dim3 grid((unsigned)(tiles * splits)), block(512);
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev < 0 || dev >= 64 ? 0 : dev;
-#define ATOMA_TILE(NW_) do { \
+#define ATOMA_TILE_M(NW_, MODE_) do { \
         const size_t lds = (size_t)((NW_) == 128 ? 3 : 4) * ((NW_) * 256 + 64 * 256); \
-        static std::atomic<bool> once_pair[64], once_plain[64];   /* per device: the attribute belongs to the device's code object */ \
-        if (pair) { \
-            { \
-                if (!once_pair[dev].load()) { if (!check_hip(hipFuncSetAttribute((const void *)linear_tile_kernel<T, NW_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "linear_tile LDS")) return -1; once_pair[dev] = true; } \
-                hipLaunchKernelGGL((linear_tile_kernel<T, NW_, true>), grid, block, lds, stream, tp); \
-            } \
-        } else { \
-            if (!once_plain[dev].load()) { if (!check_hip(hipFuncSetAttribute((const void *)linear_tile_kernel<T, NW_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "linear_tile LDS")) return -1; once_plain[dev] = true; } \
-            hipLaunchKernelGGL((linear_tile_kernel<T, NW_, false>), grid, block, lds, stream, tp); \
-        } } while (0)
+        static std::atomic<bool> once[64];   /* per device: the attribute belongs to the device's code object */ \
+        if (!once[dev].load()) { if (!check_hip(hipFuncSetAttribute((const void *)linear_tile_kernel<T, NW_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "linear_tile LDS")) return -1; once[dev] = true; } \
+        hipLaunchKernelGGL((linear_tile_kernel<T, NW_, MODE_>), grid, block, lds, stream, tp); } while (0)
+#define ATOMA_TILE(NW_) do { if (mode == TILE_ROPE) ATOMA_TILE_M(NW_, TILE_ROPE); else if (mode == TILE_GATE_UP) ATOMA_TILE_M(NW_, TILE_GATE_UP); else ATOMA_TILE_M(NW_, TILE_PLAIN); } while (0)
     if (nw == 128) ATOMA_TILE(128); else if (nw == 64) ATOMA_TILE(64); else ATOMA_TILE(32);
 #undef ATOMA_TILE
+#undef ATOMA_TILE_M
     return ATOMA_CHECK_LAUNCH("linear_tile_kernel") ? 0 : -1;
 }
 
-// 0 = launched (p.partial set when more than two K splits left fp32 partials: the caller runs linear_reduce_kernel), 1 = shape not
-// served, -1 = error
+// 0 = launched (p.partial set when more than TILE_MAX_MERGE K splits left fp32 partials: the caller runs linear_reduce_kernel), 1 = shape
+// not served, -1 = error
 int launch_linear_tile(LinearParams &p, int dtype, hipStream_t stream) {
-    return dtype == ATOMA_BF16 ? launch_linear_tile_t<bf16_t>(p, stream) : launch_linear_tile_t<f16_t>(p, stream);
+    return dtype == ATOMA_BF16 ? launch_linear_tile_t<bf16_t>(p, stream, nullptr) : launch_linear_tile_t<f16_t>(p, stream, nullptr);
+}
+// the q/k/v projection with RoPE + KV-cache write as its epilogue (one launch); only when linear_tile_can_rope
+int launch_linear_tile_rope(LinearParams &p, int dtype, hipStream_t stream, const uint16_t *cos_t, const uint16_t *sin_t, const int64_t *positions,
+                            const int64_t *slot_mapping, uint16_t *k_cache, uint16_t *v_cache, int64_t block_stride, int64_t table_rows, int heads_q,
+                            int heads_kv, int head_dim, int page_size, int per_op) {
+    TileRope r{cos_t, sin_t, positions, slot_mapping, k_cache, v_cache, block_stride, table_rows, heads_q, heads_kv, head_dim, page_size, per_op};
+    return dtype == ATOMA_BF16 ? launch_linear_tile_t<bf16_t>(p, stream, &r) : launch_linear_tile_t<f16_t>(p, stream, &r);
 }
 
 }  // namespace atoma

@@ -461,6 +461,12 @@ int atoma_linear_decode_qkv_rope_cache(const void *x, const void *w_qkv, void *q
     p.x_row_stride = x_row_stride; p.w_row_stride = w_row_stride; p.y_row_stride = out_row_stride;
     p.batch = (int)batch; p.n = (int)width; p.k = (int)in_features;
     const auto s = static_cast<hipStream_t>(stream);
+    if (linear_tile_can_rope(p, (int)head_dim)) {              // ONE launch: RoPE and the cache write are the projection's epilogue
+        const int rc = launch_linear_tile_rope(p, dtype, s, static_cast<const uint16_t *>(cos_table), static_cast<const uint16_t *>(sin_table), positions,
+                                               slot_mapping, static_cast<uint16_t *>(k_cache), static_cast<uint16_t *>(v_cache), block_stride,
+                                               rope_table_rows.load(), (int)num_q_heads, (int)num_kv_heads, (int)head_dim, (int)page_size, per_op_rounding);
+        if (rc <= 0) return rc;
+    }
     if (!linear_tile_leaves_partials(p, dtype)) return two_ops();
     const int rc = launch_linear_tile(p, dtype, s);
     if (rc != 0 || !p.partial) { if (rc < 0) return -1; set_error("linear_decode_qkv_rope_cache: the projection plan changed under the call"); return -1; }

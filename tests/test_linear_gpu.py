@@ -295,11 +295,14 @@ def test_linear_any_batch_strides_exactness_and_errors(gpu):
 
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
-@pytest.mark.parametrize("B,K,h,hk,d", [(64, 8192, 8, 1, 128), (33, 2048, 4, 2, 64), (64, 4096, 32, 8, 128), (17, 1024, 2, 1, 128), (8, 1024, 2, 1, 128)])
+@pytest.mark.parametrize("B,K,h,hk,d", [(64, 8192, 8, 1, 128), (33, 2048, 4, 2, 64), (64, 4096, 32, 8, 128), (17, 1024, 2, 1, 128), (8, 1024, 2, 1, 128),
+                                        (40, 8192, 2, 1, 128), (48, 2048, 16, 16, 128), (64, 1024, 8, 8, 64)])
 def test_qkv_projection_rope_cache_entry_is_the_two_ops_bit_for_bit(gpu, dtype, B, K, h, hk, d):
     """atoma_linear_decode_qkv_rope_cache = atoma_linear_decode followed by atoma_rope_qk_cache on the same buffers, bit for bit: the
-    shard of a tensor-parallel rank (1280 rows, K split 8 ways: the RoPE / cache kernel merges the fp32 partials itself), shapes whose
-    projection merges inside its launch or does not split at all, and a batch outside 17..64 (the entry runs the two ops)."""
+    shard of a tensor-parallel rank (1280 rows: 32-row tiles, K split 4 ways and merged inside the launch, RoPE + cache write as the
+    epilogue -- the rotation's partner sits in the neighbouring wavefront), 64- and 128-row tiles (both partners in one lane), d = 64,
+    a matrix with so few rows that K is split 8 ways (the RoPE / cache kernel merges the fp32 partials), MHA, and a batch outside
+    17..64 (the entry runs the two ops)."""
     rng = np.random.default_rng(B + K + h)
     width, page, nb = (h + 2 * hk) * d, 16, 12
     x = rand_half(rng, (B, K), dtype)
