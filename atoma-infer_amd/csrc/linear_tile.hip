@@ -439,6 +439,19 @@ template <typename T> static int launch_linear_tile_t(LinearParams &p, hipStream
     return ATOMA_CHECK_LAUNCH("linear_tile_kernel") ? 0 : -1;
 }
 
+// atoma_warmup: the kernels ask for more LDS than the default limit -- raise it for every variant on the current device now, so that a
+// hipGraph capture can be the first call (hipFuncSetAttribute is not a stream operation, but it has no business inside a capture)
+template <typename T, int NW, int MODE> static bool tile_prepare_one() {
+    const size_t lds = (size_t)(NW == 128 ? 3 : 4) * (NW * 256 + 64 * 256);
+    return check_hip(hipFuncSetAttribute((const void *)linear_tile_kernel<T, NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "linear_tile LDS");
+}
+template <typename T> static bool tile_prepare_t() {
+    return tile_prepare_one<T, 32, TILE_PLAIN>() && tile_prepare_one<T, 64, TILE_PLAIN>() && tile_prepare_one<T, 128, TILE_PLAIN>() &&
+           tile_prepare_one<T, 32, TILE_GATE_UP>() && tile_prepare_one<T, 64, TILE_GATE_UP>() && tile_prepare_one<T, 128, TILE_GATE_UP>() &&
+           tile_prepare_one<T, 32, TILE_ROPE>() && tile_prepare_one<T, 64, TILE_ROPE>() && tile_prepare_one<T, 128, TILE_ROPE>();
+}
+bool linear_tile_prepare() { return tile_prepare_t<bf16_t>() && tile_prepare_t<f16_t>(); }
+
 // 0 = launched (p.partial set when more than TILE_MAX_MERGE K splits left fp32 partials: the caller runs linear_reduce_kernel), 1 = shape
 // not served, -1 = error
 int launch_linear_tile(LinearParams &p, int dtype, hipStream_t stream) {

@@ -117,6 +117,7 @@ unsigned *sync_counters(hipStream_t stream) {
 
 size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k);   // paged_decode.hip
 const char *last_decode_kernel();                                                    // paged_decode.hip
+bool linear_tile_prepare();                                                          // linear_tile.hip
 int release_gemm_workspaces();                                                       // linear_gemm.hip
 
 // /root/reference/csrc/src/lib.rs:2122-2167, f32 arithmetic as there.
@@ -187,7 +188,7 @@ int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num
     const size_t need = std::max(atoma::decode_workspace_bound((int)std::min<int64_t>(max_batch, 1 << 20), (int)num_heads, (int)num_kv_heads,
                                                                (int)head_dim, (int)std::min<int64_t>(max_seqlen_k, 1 << 30)),
                                  (size_t)extra_bytes);
-    if (!atoma::sync_counters(static_cast<hipStream_t>(stream))) return -1;
+    if (!atoma::sync_counters(static_cast<hipStream_t>(stream)) || !atoma::linear_tile_prepare()) return -1;
     if (need == 0) return 0;
     return atoma::workspace(static_cast<hipStream_t>(stream), need) ? 0 : -1;
 }

@@ -146,12 +146,9 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         rank_devices = gathered
-        if comm is not None:
-            ah.lib.atoma_comm_set_mode(comm, 2)             # builds the direct path behind the communicator (collective), so that the line can say whether it came up
-            comm_note = ah.lib.atoma_comm_info(comm).decode()
-            ah.lib.atoma_comm_set_mode(comm, 0)
-        else:
-            comm_note = "direct kernels only (no RCCL communicator)"
+        # (the direct path behind an RCCL communicator is built later, inside the watchdog-protected extras: tp_step reports whether it
+        # came up -- it has never run across real links from this tree, and the headline must not depend on it)
+        comm_note = "RCCL communicator; direct path: see tp_step.xgmi_setup" if comm is not None else "direct kernels only (no RCCL communicator)"
 
     def step():
         ah.run_mha(dq, dkc, dvc, do, b=B, h=h_l, h_k=hk_l, d=d, seqlen_q=1, seqlen_k=pages_per_seq * page,

@@ -38,12 +38,17 @@ def check_line(d, full):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    lines = [l for l in open(os.path.join(ROOT, "profiles", "r02_bench.json")) if l.startswith("{")]
+    lines = [l for l in open(os.path.join(ROOT, "profiles", "r03_bench.json")) if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     check_line(d, full=True)
     assert d["n_gpus"] == 1 and "north_star" in BASE
     assert d["roofline"]["frac"] >= 0.70          # north_star: >= 70 % of HBM peak on the paged-attention decode micro-bench
+    assert "paged_decode" in d["roofline"]["kernel"] and "G=4" in d["roofline"]["kernel"]      # named by the dispatcher (atoma_last_decode_kernel)
+    sw = d["extra"]["swap"]
+    assert 0.9 < sw["gpu_to_cpu_frac_of_memcpy"] <= 1.05 and 0.9 < sw["cpu_to_gpu_frac_of_memcpy"] <= 1.05   # the swap against its pinned-memcpy ceiling
+    assert d["extra"]["c4_rank_step"]["ms_per_step"] < 9.5                                      # the 70B TP = 8 rank step (round 2: 10.3-10.5 ms)
+    assert set(d["cpu_baseline"]["placement"]) >= {"OMP_PROC_BIND", "numa_nodes", "cgroup_cpu_max", "cpus_allowed"}
 
 
 @pytest.mark.gpu

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import attn_oracle as A
-from oracle.halfs import BF16
+from oracle.halfs import BF16, to_f32
 from util import rand_half, make_paged_cache, assert_close, ATOL_VS_F32
 
 pytestmark = pytest.mark.gpu
@@ -137,6 +137,42 @@ def test_warmup_makes_first_call_capturable(gpu):
         st.synchronize()
         assert_close(do.numpy(np.uint16, shape), ref, BF16, atol=ATOL_VS_F32[BF16], what=f"captured without an eager call, B={B} L={L}")
     assert gpu.lib.atoma_warmup(st.s, 0, 8, 2, 128, 4096, 0) == -1 and "invalid" in gpu.last_error()
+
+
+def test_warmup_makes_projection_with_in_launch_merge_capturable(gpu):
+    """The 17..64-row projection kernel merges its K splits inside the launch: arrival counters, fp32 tiles in the stream's scratch and a
+    raised LDS limit.  After atoma_warmup (counters + the limit for every variant; extra_bytes covers the tiles) a CAPTURE may be the
+    first call, and replays -- the counters come back to zero each time -- reproduce the eager result bit for bit, also with new inputs."""
+    from oracle import linear_oracle as LO
+    from util import rand_half
+    assert gpu.lib.atoma_release_workspaces() == 0
+    rng = np.random.default_rng(13)
+    B, K, N = 48, 2048, 4096                              # 64-row tiles x 2 K splits x 128 workgroups... merged by the last arriver
+    st = gpu.Stream()
+    assert gpu.lib.atoma_warmup(st.s, 4, 8, 2, 128, 1024, 8 * N * 64 * 4) == 0, gpu.last_error()
+    x, w, r = rand_half(rng, (B, K), BF16), rand_half(rng, (N, K), BF16, K ** -0.5), rand_half(rng, (B, N), BF16)
+    dx, dw, dr = (gpu.DeviceBuffer.from_numpy(a) for a in (x, w, r))
+    y = gpu.DeviceBuffer.zeros((B, N), np.uint16)
+    with gpu.Graph.capture(st) as g:
+        assert gpu.lib.atoma_linear_decode_residual(dx.ptr, dw.ptr, dr.ptr, y.ptr, B, K, N, K, K, N, N, BF16, st.s) == 0, gpu.last_error()
+    for rep in range(3):
+        if rep == 2:
+            x = rand_half(rng, (B, K), BF16)
+            dx.upload(x)
+        y.fill_bytes(0)
+        g.launch()
+        st.synchronize()
+        got = to_f32(y.numpy(np.uint16, (B, N)), BF16)
+        ref = to_f32(LO.linear(x, w, BF16), BF16) + to_f32(r, BF16)
+        assert (np.abs(got - ref) <= 2.0 ** -6 * np.abs(ref) + 1e-2).all(), rep
+        if rep == 0:
+            first = y.numpy(np.uint16, (B, N)).copy()
+        if rep == 1:
+            assert np.array_equal(y.numpy(np.uint16, (B, N)), first)
+    yb = gpu.DeviceBuffer.zeros((B, N), np.uint16)
+    assert gpu.lib.atoma_linear_decode_residual(dx.ptr, dw.ptr, dr.ptr, yb.ptr, B, K, N, K, K, N, N, BF16, st.s) == 0
+    st.synchronize()
+    assert np.array_equal(yb.numpy(np.uint16, (B, N)), y.numpy(np.uint16, (B, N)))
 
 
 def test_scratch_growth_keeps_captured_graphs_valid(gpu):

@@ -349,7 +349,7 @@ def bench_linear_mid():
             x, y, r = rand_dev(rng, B * K * 2), ah.DeviceBuffer(B * N * 2), rand_dev(rng, B * N * 2)
             nbytes = N * K * 2 + B * K * 2 + B * N * 2
             ms = timeit(lambda: ah.lib.atoma_linear_decode(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None))
-            emit(f"L3 linear_mid {name} [{N} x {K}] batch={B}", ms, nbytes=nbytes)
+            emit(f"L3 own kernel (tile / mid) {name} [{N} x {K}] batch={B}", ms, nbytes=nbytes)
             ah.lib.atoma_linear(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None)
             ah.synchronize()
             time.sleep(0.1)
@@ -357,10 +357,10 @@ def bench_linear_mid():
             emit(f"L3 vendor GEMM {name} [{N} x {K}] batch={B}", ms_lt, nbytes=nbytes)
             if "gate_up" in name:
                 ms_f = timeit(lambda: ah.lib.atoma_linear_decode_silu_mul(x.ptr, w.ptr, y.ptr, B, K, N // 2, K, K, N // 2, 1, None))
-                emit(f"L3 linear_mid + SiLU.up epilogue {name} batch={B}", ms_f, nbytes=N * K * 2 + B * K * 2 + B * N)
+                emit(f"L3 own kernel + SiLU.up epilogue {name} batch={B}", ms_f, nbytes=N * K * 2 + B * K * 2 + B * N)
             elif "qkv" not in name:
                 ms_f = timeit(lambda: ah.lib.atoma_linear_decode_residual(x.ptr, w.ptr, r.ptr, y.ptr, B, K, N, K, K, N, N, 1, None))
-                emit(f"L3 linear_mid + residual epilogue {name} batch={B}", ms_f, nbytes=nbytes + B * N * 2)
+                emit(f"L3 own kernel + residual epilogue {name} batch={B}", ms_f, nbytes=nbytes + B * N * 2)
         w.free()
 
 

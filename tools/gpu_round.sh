@@ -3,7 +3,7 @@
 # per-kernel measurements, the C3-lite trace and the 70B step.  Run through gpurun:
 #   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r02'
 # then: python tools/summarize_profiles.py r02   (copies the summaries into profiles/)
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -15,7 +15,13 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TA
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -o decode -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-traffic > $OUT/pmc_write_$TAG.log 2>&1
 ATOMA_BENCH_STEP_CASES=256r timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_step_$TAG -o step -- python $REPO/tools/bench_kernels.py step > $OUT/prof_step_$TAG.log 2>&1
 ATOMA_BENCH_STEP_CASES=1 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_step1_$TAG -o step -- python $REPO/tools/bench_kernels.py step > $OUT/prof_step1_$TAG.log 2>&1
+# the 70B TP = 8 rank step (configs[3] without its all-reduces): whole step, and a kernel trace of 8 layers for the per-kernel breakdown
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_rank_$TAG -o step -- python $REPO/tools/rank_step.py --layers 8 --iters 3 > $OUT/prof_rank_$TAG.log 2>&1
 cd $REPO
+(timeout 400 python tools/rank_step.py --layers 80 --iters 20 2>&1 | tail -1) > $OUT/rank_step_$TAG.json
+(ATOMA_LINEAR_TILE=0 ATOMA_STEP_QKV_FUSED=0 timeout 400 python tools/rank_step.py --layers 80 --iters 20 2>&1 | tail -1) > $OUT/rank_step_r02route_$TAG.json
+(timeout 400 python tools/probes/linear64_ab.py 2>&1) > $OUT/linear64_ab_$TAG.jsonl
+(timeout 300 tools/probes/gemm64_probe 2>&1 | grep -v "^check") > $OUT/gemm64_probe_$TAG.txt
 (timeout 1500 python tools/bench_kernels.py decode decode_fp8 prefill prefill_paged cache norm sampling linear linear_mid linear_big graph step swap prep 2>&1) > $OUT/kernels_$TAG.jsonl
 (timeout 400 python tools/engine_trace.py 2>&1 | tail -1) > $OUT/trace_$TAG.json
 (timeout 400 python tools/engine_trace.py --model 70b-tp8-shard --requests 64 --prompt 4096 --decode-steps 256 2>&1 | tail -1) > $OUT/trace_70b_tp8_rank_$TAG.json

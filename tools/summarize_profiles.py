@@ -46,14 +46,17 @@ print(json.dumps(summary, indent=1))
 # per-kernel breakdown of one decode step (tools/step_breakdown.py over the kernel trace of `bench_kernels.py step`)
 import subprocess
 for sub, label, name in ((f"prof_step_{tag}", "Llama-3.1-8B decode step, batch 256, context U[2048,2560), bf16 KV", "step_breakdown_b256"),
-                         (f"prof_step1_{tag}", "Llama-3.1-8B decode step, batch 1, context 4096, bf16 KV", "step_breakdown_b1")):
+                         (f"prof_step1_{tag}", "Llama-3.1-8B decode step, batch 1, context 4096, bf16 KV", "step_breakdown_b1"),
+                         (f"prof_rank_{tag}", "one rank of the Llama-3.1-70B TP=8 decode step, batch 64, context 4096, 8 of 80 layers", "rank_step_breakdown")):
     for f in glob.glob(os.path.join(root, "gpurun_out", sub, "*kernel_trace.csv")):
         txt = subprocess.run([sys.executable, os.path.join(root, "tools", "step_breakdown.py"), f, label], capture_output=True, text=True).stdout
         open(os.path.join(out, f"{tag}_{name}.json"), "w").write(txt)
         print("wrote", f"{tag}_{name}.json")
 # plain copies of the builder-run measurement files
 for src, dst in ((f"bench_{tag}.log", f"{tag}_bench.json"), (f"kernels_{tag}.jsonl", f"{tag}_kernels.jsonl"), (f"trace_{tag}.json", f"{tag}_trace.json"),
-                 (f"trace_70b_tp8_rank_{tag}.json", f"{tag}_trace_70b_tp8_rank.json"), (f"tp_step_n1_{tag}.json", f"{tag}_tp_step_n1.json")):
+                 (f"trace_70b_tp8_rank_{tag}.json", f"{tag}_trace_70b_tp8_rank.json"), (f"tp_step_n1_{tag}.json", f"{tag}_tp_step_n1.json"),
+                 (f"rank_step_{tag}.json", f"{tag}_rank_step.json"), (f"rank_step_r02route_{tag}.json", f"{tag}_rank_step_r02_route.json"),
+                 (f"linear64_ab_{tag}.jsonl", f"{tag}_linear64_ab.jsonl"), (f"gemm64_probe_{tag}.txt", f"{tag}_gemm64_probe.txt")):
     p = os.path.join(root, "gpurun_out", src)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(out, dst))
