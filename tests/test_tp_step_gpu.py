@@ -19,17 +19,18 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world", [2])
-@pytest.mark.parametrize("graph,own", [(False, False), (True, False), (True, True)], ids=["eager", "hipgraph", "hipgraph-own-projections"])
-def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, own, monkeypatch):
-    """own: the rank's projections on the library's own kernels (gate/up with SiLU.up inside; tools/tp_step.py and bench.py run it so)."""
+@pytest.mark.parametrize("graph,own,B", [(False, False, 6), (True, False, 6), (True, True, 6), (True, True, 24)],
+                         ids=["eager", "hipgraph", "hipgraph-own-projections", "hipgraph-own-projections-24-rows"])
+def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, own, B, monkeypatch):
+    """own: the rank's projections on the library's own kernels (gate/up with SiLU.up inside; at 24 rows the LDS-DMA tile kernel with its
+    in-launch K-split merge and the q/k/v projection with RoPE + cache write as its epilogue; tools/tp_step.py and bench.py run it so)."""
     monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "8000")
     import decode_step as DS
     import tp
     from test_allreduce_xgmi_gpu import make_ranks
     rng = np.random.default_rng(21)
     cfg = DS.Config(layers=3, hidden=512, heads=8, kv_heads=2, head_dim=128, intermediate=1024, vocab=1008, page=16, max_pos=256)
-    B = 6
-    ctx = np.array([0, 17, 40, 64, 100, 130])
+    ctx = np.array([0, 17, 40, 64, 100, 130]) if B == 6 else np.sort(rng.integers(0, 131, B))
     lens = (ctx + 1).astype(np.int32)
     blocks = [(int(L) + cfg.page - 1) // cfg.page for L in lens]
     num_pages = sum(blocks) + 3
