@@ -331,3 +331,41 @@ def test_qkv_projection_rope_cache_entry_is_the_two_ops_bit_for_bit(gpu, dtype, 
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
     assert outs[0][1].any() and outs[0][2].any()
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("B,K,N", [(37, 2048, 4096), (64, 1024, 8192), (19, 8192, 1280), (48, 512, 256)])
+def test_tile_kernel_strides_padding_exactness(gpu, dtype, B, K, N):
+    """linear_tile_kernel (17..64 rows) with everything a caller may hand it: x rows that are slices of a wider buffer, weight rows with
+    padding between them, y (and the residual) in wider buffers whose padding must stay untouched, batches that are not a multiple
+    of 16, both dtypes; K split merged in the launch (4096 x 2048: 2 splits), not split (8192 x 1024), split 4 ways (1280 x 8192) and
+    a matrix of four 64-row tiles (fp32 partials + merge kernel).  Integer-valued inputs: every partial sum is exact in fp32, so the
+    result must be bit-exact whatever the split and the order of arrival -- ten runs in a row must agree to the bit."""
+    rng = np.random.default_rng(B + K + N + dtype)
+    from oracle.halfs import from_f32
+    xs, ws, ys, rs = K + 64, K + 128, N + 32, N + 8
+    xw = from_f32(rng.integers(-3, 4, (B, xs)).astype(np.float32), dtype)
+    ww = from_f32(rng.integers(-2, 3, (N, ws)).astype(np.float32), dtype)
+    res = from_f32(rng.integers(-8, 9, (B, rs)).astype(np.float32), dtype)
+    dx, dw, dr = (gpu.DeviceBuffer.from_numpy(a) for a in (xw, ww, res))
+    x, w = np.ascontiguousarray(xw[:, 32:32 + K]), np.ascontiguousarray(ww[:, 64:64 + K])
+    from oracle import elementwise_oracle as EO
+    exact = to_f32(x, dtype).astype(np.float64) @ to_f32(w, dtype).astype(np.float64).T          # small integers: exact in fp32 in any order
+    assert np.abs(exact).max() < 2 ** 20
+    want = from_f32(exact.astype(np.float32), dtype)          # the projection's one rounding
+    want_res = EO.add(want, np.ascontiguousarray(res[:, :N]), dtype)                              # then the residual add rounds again
+    first = None
+    for rep in range(10):
+        dy = gpu.DeviceBuffer(B * ys * 2)
+        dy.fill_bytes(0xAB)
+        assert gpu.lib.atoma_linear_decode_residual(dx.ptr + 32 * 2, dw.ptr + 64 * 2, dr.ptr, dy.ptr, B, K, N, xs, ws, rs, ys, dtype, None) == 0, gpu.last_error()
+        gpu.synchronize()
+        out = dy.numpy(np.uint16, (B, ys))
+        assert (out[:, N:] == 0xABAB).all()
+        assert np.array_equal(out[:, :N], want_res), rep
+        first = out if first is None else first
+        assert np.array_equal(out, first)
+    dy = gpu.DeviceBuffer(B * ys * 2)
+    assert gpu.lib.atoma_linear_decode(dx.ptr + 32 * 2, dw.ptr + 64 * 2, dy.ptr, B, K, N, xs, ws, ys, dtype, None) == 0, gpu.last_error()
+    gpu.synchronize()
+    assert np.array_equal(dy.numpy(np.uint16, (B, ys))[:, :N], want)
