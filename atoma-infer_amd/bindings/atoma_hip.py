@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "..", "lib", "libatoma_hip.so")
+# ATOMA_HIP_LIB: another build of the SAME library (the probe variants of `make timing` / `make fp8p`); never a different backend
+LIB_PATH = os.environ.get("ATOMA_HIP_LIB") or os.path.join(_HERE, "..", "lib", "libatoma_hip.so")
 
 F16, BF16 = 0, 1
 

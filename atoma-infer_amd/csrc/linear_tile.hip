@@ -13,11 +13,12 @@
 // ds_write; image [row][16-byte slot ^ (row & 15)]: the swizzle sits on the per-lane SOURCE address, fragment reads are
 // conflict-free), ring of 3-4 chunks of 128 inputs, one barrier per chunk, counted vmcnt so that the ring never drains;
 // v_mfma_f32_16x16x32 on ds_read_b128 fragments: wavefront w multiplies batch tile w >> 1 with half of the row groups.
-// K is split over 1 or 2 workgroups so that the grid fills the CUs; a 2-way split is merged INSIDE the launch: both workgroups
-// publish their fp32 tile (write-through stores), the one that arrives second adds its partner's and runs the epilogue (arrival
-// counter per tile, agent scope; no spinning: the first arriver just leaves).  More splits (the 1280-row q/k/v shard) go to fp32
-// partials for the caller's reduce / RoPE kernel.  fp32 accumulation in K order (split 0 + split 1), one rounding, then the epilogue
-// with the reference's rounding points -- the same for the PAIR and the plain kernel on the same matrix.
+// K is split over 1, 2 or 4 workgroups so that the grid fills the CUs; a split is merged INSIDE the launch: every workgroup publishes
+// its fp32 tile (write-through stores), the one that arrives LAST adds the others' in split order and runs the epilogue (arrival counter
+// per tile, agent scope; no spinning: the earlier arrivers just leave).  More splits (matrices with a handful of 64-row tiles) go to fp32
+// partials for the caller's reduce / RoPE kernel.  fp32 accumulation in K order (split 0 + split 1 + ..), one rounding, then the epilogue
+// with the reference's rounding points -- the same for the paired and the plain kernel on the same matrix.  Epilogues: none / residual
+// add / SiLU.up (MODE 1) / RoPE + KV-cache write (MODE 2, atoma_linear_decode_qkv_rope_cache).
 #include "linear_params.h"
 #include <algorithm>
 #include <atomic>

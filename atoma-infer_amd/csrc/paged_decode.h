@@ -1,0 +1,282 @@
+// Shared device-side pieces of the decode kernels (paged_decode.hip: 16-bit caches; paged_decode_fp8.hip: fp8 caches):
+// parameters, the wavefront -> work mapping, the balanced mode, small lane helpers.  See paged_decode.hip for the design.
+#pragma once
+#include "attn_params.h"
+#include <type_traits>
+
+#include <atomic>
+#include <stdlib.h>
+
+#ifndef DECODE_DEFAULT_P
+#define DECODE_DEFAULT_P 3
+#endif
+#ifndef DECODE_DEFAULT_NT
+#define DECODE_DEFAULT_NT 1
+#endif
+
+namespace atoma {
+
+struct DecodeParams {
+    const uint16_t *q, *k, *v;
+    uint16_t *o;
+    float *lse;            // [b][h] or nullptr
+    float *o_accum;        // [splits][b][h][D] fp32
+    float *lse_accum;      // [splits][b][h]
+    const int *block_table;
+    const int *cu_seqlens_k;
+    const int *seqused_k;
+    const float *alibi_slopes;
+    int64_t q_batch_stride, q_head_stride, o_batch_stride, o_head_stride;
+    int64_t k_batch_stride, k_row_stride, k_head_stride;
+    int64_t v_batch_stride, v_row_stride, v_head_stride;
+    int64_t block_table_batch_stride;
+    int alibi_batch_stride;
+    int page_size;         // tokens per page (multiple of 16); 0 = contiguous cache
+    int b, h, h_k, g, gchunks;
+    int seqlen_k;
+    int is_seqlens_k_cumulative;
+    int num_splits;        // KV splits per sequence (grid slots)
+    int stream_waves;      // > 0: balanced mode available -- this many wavefronts share the batch's tiles evenly (decode_run_items)
+    int group_tile;        // q heads per wavefront (the kernel's G)
+    const float *k_scale, *v_scale;   // fp8 (e4m3fn) KV cache: per-kv-head dequantisation scales [h_k]; null for 16-bit caches
+    int wg_splits;         // > 0: workgroup-merged split mode (paged_decode_wg_kernel): KV pieces per sequence = wg_splits x wavefronts per workgroup
+    unsigned *counters;    // ... and its arrival counter per (sequence, kv head, q-head chunk), zero between launches
+    int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
+    float scale, scale_log2;
+};
+
+// all-reduce over the LPR adjacent lanes that hold one row (DPP, no LDS)
+template <int LPR> __device__ __forceinline__ float row_allreduce(float x) {
+    if constexpr (LPR >= 2) x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    if constexpr (LPR >= 4) x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    if constexpr (LPR >= 8) x += __builtin_amdgcn_update_dpp(0.f, x, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    if constexpr (LPR >= 16) x += __builtin_amdgcn_update_dpp(0.f, x, 0x140, 0xf, 0xf, true); // row_mirror
+    if constexpr (LPR >= 32) x += __shfl_xor(x, 16, 64);
+    return x;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ uint32_t pack_pair(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack_pair<bf16_t>(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_v));  // v_cvt_pk_bf16_f32
+}
+template <> __device__ __forceinline__ uint32_t pack_pair<f16_t>(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_v));   // v_cvt_pk_f16_f32 (RNE)
+}
+
+// Read-only metadata (block table, lengths) through the constant address space: a wave-uniform index then always
+// becomes a scalar load (s_load), also inside the segment loop of the balanced mode where the compiler would
+// otherwise fall back to vector loads because output stores of the previous segment precede them.
+template <typename X> __device__ __forceinline__ X load_ro(const X *ptr) {
+    return *(const X __attribute__((address_space(4))) *)ptr;
+}
+// sequence length of batch entry b: /root/reference/csrc/kernels/block_info.h:16-23
+__device__ __forceinline__ int decode_seq_len(const DecodeParams &p, int b) {
+    if (p.seqused_k) return load_ro(p.seqused_k + b);
+    if (p.cu_seqlens_k == nullptr) return p.seqlen_k;
+    if (p.is_seqlens_k_cumulative) return load_ro(p.cu_seqlens_k + b + 1) - load_ro(p.cu_seqlens_k + b);
+    return load_ro(p.cu_seqlens_k + b);
+}
+
+// Workgroup (= one wavefront) -> (sequence, kv head, q-head chunk of the group, KV split) and the tile range it
+// owns.  The split index is slowest: the dispatcher places workgroups on CUs round-robin by index, so
+// wavefronts that exit at once must not be interleaved with the working ones -- measured 2.5x slower with the
+// split index in the middle (only every 4th CU of an XCD got work).
+struct DecodeWork {
+    int b, hk, gc, split;
+    int L, n_tiles, t0, t1;
+    int64_t kv_row0;   // first row of this sequence in a varlen (cumulative) K/V tensor
+    int64_t prow;      // row of q head hq0's fp32 partial in o_accum / lse_accum (head hq0 + i: prow + i)
+    bool partial;      // write fp32 partials for the combine kernel (true) or the final output (false)
+    bool balanced;     // this piece is a range of the balanced line (the fp8 kernel fetches K differently there)
+    float *sink_o, *sink_lse;   // SINK variants of the item functions: this wavefront's normalised O [heads][D] and LSE [heads] go here (LDS)
+};
+__device__ __forceinline__ void decode_map_work(const DecodeParams &p, int id, DecodeWork &w) {
+    const int hk_chunks = p.h_k * p.gchunks;
+    const int hkc = id % hk_chunks;
+    id /= hk_chunks;
+    w.b = id % p.b;
+    w.split = id / p.b;
+    w.hk = hkc / p.gchunks;
+    w.gc = hkc % p.gchunks;
+    w.L = decode_seq_len(p, w.b);
+    w.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + w.b) : 0;
+    w.n_tiles = (w.L + 15) >> 4;
+    const int per = (w.n_tiles + p.num_splits - 1) / p.num_splits;
+    w.t0 = w.split * per;
+    w.t1 = min(w.t0 + per, w.n_tiles);
+    w.partial = p.num_splits > 1;
+    w.balanced = false;
+    w.prow = ((int64_t)w.split * p.b + w.b) * p.h + w.hk * p.g + w.gc * p.group_tile;
+}
+
+// Balanced ("stream") mode for batches that fill the chip without KV splitting (b . h_k >= resident wavefronts / 2)
+// and whose lengths live on the device.  Why: the bandwidth of this kernel against the number of ACTIVE wavefronts
+// is concave (tools/probes/decode_curve.py: 1024 wavefronts reach 82 % of what 2048 do, 512 reach 52 %), so one
+// wavefront per (sequence, kv head) spends the second half of a ragged launch below the HBM rate, a single long
+// straggler streams alone at ~6 GB/s, and a batch of 1.2 x the resident wavefronts takes two rounds.  Instead all
+// tiles of the batch are laid on one line -- position = (kv head, q-head chunk) . T + prefix[b] + tile, T = tiles of
+// the batch -- and each of W wavefronts takes the same number of consecutive tiles (ceil(total / W), at least
+// DECODE_MIN_SHARE).  A wavefront's range covers the end of one sequence, whole sequences, and the beginning of
+// one more: whole sequences are written directly, the (at most two) cut pieces go to fp32 partial slots
+// [wavefront][first / last] and decode_combine_kernel merges the pieces of each cut sequence.  No atomics, no
+// queue, deterministic; every wavefront finishes at the same time by construction.
+// Uniform batches that are resident at once keep the one-wavefront-per-sequence path (same kernel, no partials).
+#define DECODE_STREAM_MAX_B 1024
+#define DECODE_MIN_SHARE 8
+struct DecodePlan {
+    int T;          // tiles of the batch (one kv head)
+    int share;      // tiles per wavefront
+    bool stream;    // balanced mode taken
+};
+// Prefix of tiles per sequence into LDS (cum[b], cum[p.b] = T); every wavefront computes the same plan.
+__device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, int *cum) {
+    const int lane = threadIdx.x & 63;
+    const int per = (p.b + 63) >> 6;
+    int local = 0, mx = 0;
+    for (int j = 0; j < per; ++j) {
+        const int b = lane * per + j;
+        const int n = b < p.b ? (decode_seq_len(p, b) + 15) >> 4 : 0;
+        local += n;
+        mx = max(mx, n);
+    }
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
+        mx = max(mx, __shfl_xor(mx, off, 64));
+    }
+    int run = incl - local;
+    for (int j = 0; j < per; ++j) {
+        const int b = lane * per + j;
+        if (b < p.b) {
+            cum[b] = run;
+            run += (decode_seq_len(p, b) + 15) >> 4;
+        }
+    }
+    mx = __builtin_amdgcn_readfirstlane(mx);   // every lane holds the maximum: make it a scalar for the compiler
+    DecodePlan pl;
+    pl.T = __builtin_amdgcn_readlane(incl, 63);
+    if (lane == 0) cum[p.b] = pl.T;
+    const int hk_chunks = p.h_k * p.gchunks;
+    const int64_t total = (int64_t)pl.T * hk_chunks;
+    pl.share = (int)max((total + p.stream_waves - 1) / p.stream_waves, (int64_t)DECODE_MIN_SHARE);
+    // one wavefront per (sequence, kv head) is already balanced when every sequence is (nearly) as long as the
+    // longest and all of them are resident at once: idle share 1 - mean/max below 4 %
+    const bool ragged = (int64_t)mx * p.b * 96 > (int64_t)pl.T * 100;
+    pl.stream = ragged || p.b * hk_chunks > p.stream_waves;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS writes above
+    __builtin_amdgcn_wave_barrier();
+    return pl;
+}
+
+// `item(p, wk)` is inlined exactly once.  In the balanced variant the kernel arguments are re-read through a pointer
+// the compiler cannot see through at the top of every segment: hoisting every field of DecodeParams out of the
+// segment loop costs ~20 SGPRs more than the 102 there are and the spills (v_readlane in the tile loop) cost 5 %.
+// NWG wavefronts per workgroup (default 1): wavefront index = blockIdx.x * NWG + wave.  Consecutive indices are the kv heads
+// of ONE sequence, so a workgroup of NWG wavefronts reads NWG adjacent head slices of every token row from one CU at about
+// the same time -- with 128-byte slices (fp8 cache, or d = 64 at 16 bits) a lone wavefront fetches half of a 256-byte
+// DRAM granule and its neighbour, dispatched to another XCD (block index % 8), fetches the other half some time later.
+template <bool STREAM, int NWG = 1, typename F> __device__ __forceinline__ void decode_run_items(const DecodeParams &p0, F &&item) {
+    DecodeWork wk;
+    const int wid = NWG == 1 ? (int)blockIdx.x : (int)blockIdx.x * NWG + (int)(threadIdx.x >> 6);
+    if (NWG > 1 && (int64_t)wid >= (int64_t)p0.b * p0.num_splits * p0.h_k * p0.gchunks) return;
+    if constexpr (!STREAM) {
+        decode_map_work(p0, wid, wk);
+        item(p0, wk);
+    } else {
+        __shared__ int cum[DECODE_STREAM_MAX_B + 1];
+        const DecodePlan pl = decode_make_plan(p0, cum);
+        if (wid == 0) {   // for the combine kernel
+            for (int i = threadIdx.x & 63; i <= p0.b; i += 64) p0.plan[2 + i] = cum[i];
+            if ((threadIdx.x & 63) == 0) { p0.plan[0] = pl.T; p0.plan[1] = pl.stream ? 1 : 0; }
+        }
+        const bool stream = pl.stream;
+        // position of this wavefront on the line.  The line is kv-head major, so wavefronts w and w + W / 8 walk the same
+        // sequences of adjacent heads: with 8 wavefronts per workgroup, give the 8 of a workgroup those ranges (W is a multiple of 8)
+        if (stream && wid >= p0.stream_waves) return;      // the line is shared by stream_waves wavefronts; the grid may hold more
+        const int lw = NWG == 1 ? wid : (wid % NWG) * (p0.stream_waves / NWG) + wid / NWG;
+        int pos = 0, end = 1, hkc = 0, r = 0, b = 0;       // host guarantees total < 2^31
+        bool first = true;
+        if (stream) {
+            const int64_t total = (int64_t)pl.T * p0.h_k * p0.gchunks;
+            const int64_t start = (int64_t)lw * pl.share;
+            if (start >= total) return;
+            pos = (int)start;
+            end = (int)min(start + pl.share, total);
+            hkc = pos / pl.T;
+            r = pos - hkc * pl.T;
+            int lo = 0, hi = p0.b;               // largest b with cum[b] <= r (the last of equal entries: empty sequences own no tile)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (__builtin_amdgcn_readfirstlane(cum[mid]) <= r) lo = mid; else hi = mid;   // LDS values are wave-uniform here
+            }
+            b = lo;
+        }
+        typedef const DecodeParams __attribute__((address_space(4))) *KernArg;
+        KernArg kp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+        for (;;) {
+            asm volatile("" : "+s"(kp));
+            const DecodeParams &p = *(const DecodeParams *)kp;
+            int seg = 1;
+            if (stream) {
+                const int c0 = __builtin_amdgcn_readfirstlane(cum[b]), c1 = __builtin_amdgcn_readfirstlane(cum[b + 1]);
+                seg = min(c1 - r, end - pos);
+                wk.b = b;
+                wk.hk = hkc / p.gchunks;
+                wk.gc = hkc % p.gchunks;
+                wk.split = 0;
+                wk.L = decode_seq_len(p, b);
+                wk.n_tiles = c1 - c0;
+                wk.t0 = r - c0;
+                wk.t1 = wk.t0 + seg;
+                wk.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + b) : 0;
+                wk.partial = seg != wk.n_tiles;
+                wk.balanced = true;
+                wk.prow = ((int64_t)lw * 2 + (first ? 0 : 1)) * p.group_tile;
+            } else {
+                decode_map_work(p, wid, wk);   // one wavefront per (sequence, kv head), final output
+            }
+            item(p, wk);
+            if (!stream) break;
+            first = false;
+            pos += seg;
+            r += seg;
+            if (pos >= end) break;
+            while (r == __builtin_amdgcn_readfirstlane(cum[b + 1])) {   // next sequence that owns tiles (or the next kv head's line)
+                if (++b == p.b) { b = 0; r = 0; ++hkc; }
+            }
+        }
+    }
+}
+
+template <int I, int N, typename F> __device__ __forceinline__ void decode_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        decode_static_for<I + 1, N>(f);
+    }
+}
+// value of lane `H` of this lane's 16-lane row
+template <int H> __device__ __forceinline__ uint32_t row_bcast(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + H, 0xf, 0xf, false);   // row_newbcast:H
+}
+template <int H> __device__ __forceinline__ float row_bcastf(float x) { return __uint_as_float(row_bcast<H>(__float_as_uint(x))); }
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_v;
+template <typename T> __device__ __forceinline__ f32x4_v mfma16(const u32x4 &a, const u32x4 &b, f32x4_v c);
+template <> __device__ __forceinline__ f32x4_v mfma16<bf16_t>(const u32x4 &a, const u32x4 &b, f32x4_v c) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_v mfma16<f16_t>(const u32x4 &a, const u32x4 &b, f32x4_v c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 v8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+
+}  // namespace atoma

@@ -29,257 +29,9 @@
 //    them (same math as the reference's combine kernel).
 //
 // Algorithmic HBM bytes per call: 2*B*S*h_k*D*2 (K,V once) + 2*B*h*D*2 + 4*B*ceil(S/page) + 4*B.
-#include "attn_params.h"
-#include <type_traits>
-
-#include <atomic>
-#include <stdlib.h>
-
-#ifndef DECODE_DEFAULT_P
-#define DECODE_DEFAULT_P 3
-#endif
-#ifndef DECODE_DEFAULT_NT
-#define DECODE_DEFAULT_NT 1
-#endif
+#include "paged_decode.h"
 
 namespace atoma {
-
-struct DecodeParams {
-    const uint16_t *q, *k, *v;
-    uint16_t *o;
-    float *lse;            // [b][h] or nullptr
-    float *o_accum;        // [splits][b][h][D] fp32
-    float *lse_accum;      // [splits][b][h]
-    const int *block_table;
-    const int *cu_seqlens_k;
-    const int *seqused_k;
-    const float *alibi_slopes;
-    int64_t q_batch_stride, q_head_stride, o_batch_stride, o_head_stride;
-    int64_t k_batch_stride, k_row_stride, k_head_stride;
-    int64_t v_batch_stride, v_row_stride, v_head_stride;
-    int64_t block_table_batch_stride;
-    int alibi_batch_stride;
-    int page_size;         // tokens per page (multiple of 16); 0 = contiguous cache
-    int b, h, h_k, g, gchunks;
-    int seqlen_k;
-    int is_seqlens_k_cumulative;
-    int num_splits;        // KV splits per sequence (grid slots)
-    int stream_waves;      // > 0: balanced mode available -- this many wavefronts share the batch's tiles evenly (decode_run_items)
-    int group_tile;        // q heads per wavefront (the kernel's G)
-    const float *k_scale, *v_scale;   // fp8 (e4m3fn) KV cache: per-kv-head dequantisation scales [h_k]; null for 16-bit caches
-    int wg_splits;         // > 0: workgroup-merged split mode (paged_decode_wg_kernel): KV pieces per sequence = wg_splits x wavefronts per workgroup
-    unsigned *counters;    // ... and its arrival counter per (sequence, kv head, q-head chunk), zero between launches
-    int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
-    float scale, scale_log2;
-};
-
-// all-reduce over the LPR adjacent lanes that hold one row (DPP, no LDS)
-template <int LPR> __device__ __forceinline__ float row_allreduce(float x) {
-    if constexpr (LPR >= 2) x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-    if constexpr (LPR >= 4) x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-    if constexpr (LPR >= 8) x += __builtin_amdgcn_update_dpp(0.f, x, 0x141, 0xf, 0xf, true);  // row_half_mirror
-    if constexpr (LPR >= 16) x += __builtin_amdgcn_update_dpp(0.f, x, 0x140, 0xf, 0xf, true); // row_mirror
-    if constexpr (LPR >= 32) x += __shfl_xor(x, 16, 64);
-    return x;
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> __device__ __forceinline__ uint32_t pack_pair(float lo, float hi);
-template <> __device__ __forceinline__ uint32_t pack_pair<bf16_t>(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_v));  // v_cvt_pk_bf16_f32
-}
-template <> __device__ __forceinline__ uint32_t pack_pair<f16_t>(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_v));   // v_cvt_pk_f16_f32 (RNE)
-}
-
-// Read-only metadata (block table, lengths) through the constant address space: a wave-uniform index then always
-// becomes a scalar load (s_load), also inside the segment loop of the balanced mode where the compiler would
-// otherwise fall back to vector loads because output stores of the previous segment precede them.
-template <typename X> __device__ __forceinline__ X load_ro(const X *ptr) {
-    return *(const X __attribute__((address_space(4))) *)ptr;
-}
-// sequence length of batch entry b: /root/reference/csrc/kernels/block_info.h:16-23
-__device__ __forceinline__ int decode_seq_len(const DecodeParams &p, int b) {
-    if (p.seqused_k) return load_ro(p.seqused_k + b);
-    if (p.cu_seqlens_k == nullptr) return p.seqlen_k;
-    if (p.is_seqlens_k_cumulative) return load_ro(p.cu_seqlens_k + b + 1) - load_ro(p.cu_seqlens_k + b);
-    return load_ro(p.cu_seqlens_k + b);
-}
-
-// Workgroup (= one wavefront) -> (sequence, kv head, q-head chunk of the group, KV split) and the tile range it
-// owns.  The split index is slowest: the dispatcher places workgroups on CUs round-robin by index, so
-// wavefronts that exit at once must not be interleaved with the working ones -- measured 2.5x slower with the
-// split index in the middle (only every 4th CU of an XCD got work).
-struct DecodeWork {
-    int b, hk, gc, split;
-    int L, n_tiles, t0, t1;
-    int64_t kv_row0;   // first row of this sequence in a varlen (cumulative) K/V tensor
-    int64_t prow;      // row of q head hq0's fp32 partial in o_accum / lse_accum (head hq0 + i: prow + i)
-    bool partial;      // write fp32 partials for the combine kernel (true) or the final output (false)
-    float *sink_o, *sink_lse;   // SINK variants of the item functions: this wavefront's normalised O [heads][D] and LSE [heads] go here (LDS)
-};
-__device__ __forceinline__ void decode_map_work(const DecodeParams &p, int id, DecodeWork &w) {
-    const int hk_chunks = p.h_k * p.gchunks;
-    const int hkc = id % hk_chunks;
-    id /= hk_chunks;
-    w.b = id % p.b;
-    w.split = id / p.b;
-    w.hk = hkc / p.gchunks;
-    w.gc = hkc % p.gchunks;
-    w.L = decode_seq_len(p, w.b);
-    w.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + w.b) : 0;
-    w.n_tiles = (w.L + 15) >> 4;
-    const int per = (w.n_tiles + p.num_splits - 1) / p.num_splits;
-    w.t0 = w.split * per;
-    w.t1 = min(w.t0 + per, w.n_tiles);
-    w.partial = p.num_splits > 1;
-    w.prow = ((int64_t)w.split * p.b + w.b) * p.h + w.hk * p.g + w.gc * p.group_tile;
-}
-
-// Balanced ("stream") mode for batches that fill the chip without KV splitting (b . h_k >= resident wavefronts / 2)
-// and whose lengths live on the device.  Why: the bandwidth of this kernel against the number of ACTIVE wavefronts
-// is concave (tools/probes/decode_curve.py: 1024 wavefronts reach 82 % of what 2048 do, 512 reach 52 %), so one
-// wavefront per (sequence, kv head) spends the second half of a ragged launch below the HBM rate, a single long
-// straggler streams alone at ~6 GB/s, and a batch of 1.2 x the resident wavefronts takes two rounds.  Instead all
-// tiles of the batch are laid on one line -- position = (kv head, q-head chunk) . T + prefix[b] + tile, T = tiles of
-// the batch -- and each of W wavefronts takes the same number of consecutive tiles (ceil(total / W), at least
-// DECODE_MIN_SHARE).  A wavefront's range covers the end of one sequence, whole sequences, and the beginning of
-// one more: whole sequences are written directly, the (at most two) cut pieces go to fp32 partial slots
-// [wavefront][first / last] and decode_combine_kernel merges the pieces of each cut sequence.  No atomics, no
-// queue, deterministic; every wavefront finishes at the same time by construction.
-// Uniform batches that are resident at once keep the one-wavefront-per-sequence path (same kernel, no partials).
-#define DECODE_STREAM_MAX_B 1024
-#define DECODE_MIN_SHARE 8
-struct DecodePlan {
-    int T;          // tiles of the batch (one kv head)
-    int share;      // tiles per wavefront
-    bool stream;    // balanced mode taken
-};
-// Prefix of tiles per sequence into LDS (cum[b], cum[p.b] = T); every wavefront computes the same plan.
-__device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, int *cum) {
-    const int lane = threadIdx.x & 63;
-    const int per = (p.b + 63) >> 6;
-    int local = 0, mx = 0;
-    for (int j = 0; j < per; ++j) {
-        const int b = lane * per + j;
-        const int n = b < p.b ? (decode_seq_len(p, b) + 15) >> 4 : 0;
-        local += n;
-        mx = max(mx, n);
-    }
-    int incl = local;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += y;
-        mx = max(mx, __shfl_xor(mx, off, 64));
-    }
-    int run = incl - local;
-    for (int j = 0; j < per; ++j) {
-        const int b = lane * per + j;
-        if (b < p.b) {
-            cum[b] = run;
-            run += (decode_seq_len(p, b) + 15) >> 4;
-        }
-    }
-    mx = __builtin_amdgcn_readfirstlane(mx);   // every lane holds the maximum: make it a scalar for the compiler
-    DecodePlan pl;
-    pl.T = __builtin_amdgcn_readlane(incl, 63);
-    if (lane == 0) cum[p.b] = pl.T;
-    const int hk_chunks = p.h_k * p.gchunks;
-    const int64_t total = (int64_t)pl.T * hk_chunks;
-    pl.share = (int)max((total + p.stream_waves - 1) / p.stream_waves, (int64_t)DECODE_MIN_SHARE);
-    // one wavefront per (sequence, kv head) is already balanced when every sequence is (nearly) as long as the
-    // longest and all of them are resident at once: idle share 1 - mean/max below 4 %
-    const bool ragged = (int64_t)mx * p.b * 96 > (int64_t)pl.T * 100;
-    pl.stream = ragged || p.b * hk_chunks > p.stream_waves;
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS writes above
-    __builtin_amdgcn_wave_barrier();
-    return pl;
-}
-
-// `item(p, wk)` is inlined exactly once.  In the balanced variant the kernel arguments are re-read through a pointer
-// the compiler cannot see through at the top of every segment: hoisting every field of DecodeParams out of the
-// segment loop costs ~20 SGPRs more than the 102 there are and the spills (v_readlane in the tile loop) cost 5 %.
-// NWG wavefronts per workgroup (default 1): wavefront index = blockIdx.x * NWG + wave.  Consecutive indices are the kv heads
-// of ONE sequence, so a workgroup of NWG wavefronts reads NWG adjacent head slices of every token row from one CU at about
-// the same time -- with 128-byte slices (fp8 cache, or d = 64 at 16 bits) a lone wavefront fetches half of a 256-byte
-// DRAM granule and its neighbour, dispatched to another XCD (block index % 8), fetches the other half some time later.
-template <bool STREAM, int NWG = 1, typename F> __device__ __forceinline__ void decode_run_items(const DecodeParams &p0, F &&item) {
-    DecodeWork wk;
-    const int wid = NWG == 1 ? (int)blockIdx.x : (int)blockIdx.x * NWG + (int)(threadIdx.x >> 6);
-    if (NWG > 1 && (int64_t)wid >= (int64_t)p0.b * p0.num_splits * p0.h_k * p0.gchunks) return;
-    if constexpr (!STREAM) {
-        decode_map_work(p0, wid, wk);
-        item(p0, wk);
-    } else {
-        __shared__ int cum[DECODE_STREAM_MAX_B + 1];
-        const DecodePlan pl = decode_make_plan(p0, cum);
-        if (wid == 0) {   // for the combine kernel
-            for (int i = threadIdx.x & 63; i <= p0.b; i += 64) p0.plan[2 + i] = cum[i];
-            if ((threadIdx.x & 63) == 0) { p0.plan[0] = pl.T; p0.plan[1] = pl.stream ? 1 : 0; }
-        }
-        const bool stream = pl.stream;
-        // position of this wavefront on the line.  The line is kv-head major, so wavefronts w and w + W / 8 walk the same
-        // sequences of adjacent heads: with 8 wavefronts per workgroup, give the 8 of a workgroup those ranges (W is a multiple of 8)
-        if (stream && wid >= p0.stream_waves) return;      // the line is shared by stream_waves wavefronts; the grid may hold more
-        const int lw = NWG == 1 ? wid : (wid % NWG) * (p0.stream_waves / NWG) + wid / NWG;
-        int pos = 0, end = 1, hkc = 0, r = 0, b = 0;       // host guarantees total < 2^31
-        bool first = true;
-        if (stream) {
-            const int64_t total = (int64_t)pl.T * p0.h_k * p0.gchunks;
-            const int64_t start = (int64_t)lw * pl.share;
-            if (start >= total) return;
-            pos = (int)start;
-            end = (int)min(start + pl.share, total);
-            hkc = pos / pl.T;
-            r = pos - hkc * pl.T;
-            int lo = 0, hi = p0.b;               // largest b with cum[b] <= r (the last of equal entries: empty sequences own no tile)
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (__builtin_amdgcn_readfirstlane(cum[mid]) <= r) lo = mid; else hi = mid;   // LDS values are wave-uniform here
-            }
-            b = lo;
-        }
-        typedef const DecodeParams __attribute__((address_space(4))) *KernArg;
-        KernArg kp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
-        for (;;) {
-            asm volatile("" : "+s"(kp));
-            const DecodeParams &p = *(const DecodeParams *)kp;
-            int seg = 1;
-            if (stream) {
-                const int c0 = __builtin_amdgcn_readfirstlane(cum[b]), c1 = __builtin_amdgcn_readfirstlane(cum[b + 1]);
-                seg = min(c1 - r, end - pos);
-                wk.b = b;
-                wk.hk = hkc / p.gchunks;
-                wk.gc = hkc % p.gchunks;
-                wk.split = 0;
-                wk.L = decode_seq_len(p, b);
-                wk.n_tiles = c1 - c0;
-                wk.t0 = r - c0;
-                wk.t1 = wk.t0 + seg;
-                wk.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + b) : 0;
-                wk.partial = seg != wk.n_tiles;
-                wk.prow = ((int64_t)lw * 2 + (first ? 0 : 1)) * p.group_tile;
-            } else {
-                decode_map_work(p, wid, wk);   // one wavefront per (sequence, kv head), final output
-            }
-            item(p, wk);
-            if (!stream) break;
-            first = false;
-            pos += seg;
-            r += seg;
-            if (pos >= end) break;
-            while (r == __builtin_amdgcn_readfirstlane(cum[b + 1])) {   // next sequence that owns tiles (or the next kv head's line)
-                if (++b == p.b) { b = 0; r = 0; ++hkc; }
-            }
-        }
-    }
-}
 
 template <typename T, int D, int G, int P, bool NT, bool SINK = false>
 __device__ __forceinline__ void paged_decode_item(const DecodeParams &p, const DecodeWork &wk) {
@@ -598,272 +350,6 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
 }
 
 // ------------------------------------------------------------------------------------------
-// fp8 (OCP e4m3fn) KV cache, d = 128 (/root/reference/README.md:35 roadmap "quantization").  The cache
-// keeps the reference's layout [nb, page, h_k, d] with ONE byte per element and a per-kv-head dequantisation scale
-// (value = e4m3 * scale[hk]); q and o stay bf16 / f16.  Decode is HBM-bound, so halving the K/V bytes is the lever:
-//   * a token row of one kv head is 128 bytes: 8 adjacent lanes read it with one 16-byte load each, a wave instruction
-//     covers 8 rows = 8 full 128-byte lines (1 KiB, as in the 16-bit kernel); a 16-token tile is 2 + 2 load instructions;
-//   * fp8 -> bf16 is exact: v_cvt_scalef32_pk_bf16_fp8 with scale 1.0 turns two bytes into one packed bf16 pair (8 per
-//     16-byte load), after which q.k and P.V are the same v_dot2c streams as in the 16-bit kernel;
-//   * the K scale folds into the softmax scale (scores = k_scale * q.k_q), the V scale into the final 1/l -- nothing per element.
-// Same work mapping, split-KV / balanced modes and combine kernel as the 16-bit path.  Groups of more than 4 q heads run
-// in chunks of 4 (K/V re-read per chunk).
-// ------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ uint32_t fp8x2_to_pair(uint32_t word, bool hi);
-template <> __device__ __forceinline__ uint32_t fp8x2_to_pair<bf16_t>(uint32_t word, bool hi) {
-    return hi ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(word, 1.0f, true))
-              : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(word, 1.0f, false));
-}
-template <> __device__ __forceinline__ uint32_t fp8x2_to_pair<f16_t>(uint32_t word, bool hi) {
-    return hi ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(word, 1.0f, true))
-              : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(word, 1.0f, false));
-}
-// 16 fp8 bytes -> 8 packed 16-bit pairs, element order preserved
-template <typename T> __device__ __forceinline__ void fp8x16_to_pairs(const u32x4 &v, uint32_t (&out)[8]) {
-    out[0] = fp8x2_to_pair<T>(v.x, false); out[1] = fp8x2_to_pair<T>(v.x, true);
-    out[2] = fp8x2_to_pair<T>(v.y, false); out[3] = fp8x2_to_pair<T>(v.y, true);
-    out[4] = fp8x2_to_pair<T>(v.z, false); out[5] = fp8x2_to_pair<T>(v.z, true);
-    out[6] = fp8x2_to_pair<T>(v.w, false); out[7] = fp8x2_to_pair<T>(v.w, true);
-}
-
-template <typename T, int G, int P, bool NT>
-__device__ __forceinline__ void paged_decode_fp8_item(const DecodeParams &p, const DecodeWork &wk) {
-    constexpr int D = 128;
-    constexpr int LPR = 8;         // lanes per 128-byte row
-    constexpr int RPI = 8;         // rows per load instruction
-    const int lane = threadIdx.x & 63;
-    const int sub = lane / LPR, dc = lane % LPR;   // row of the 8-row slab, 16-element chunk of the row
-
-    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
-    const bool partial = wk.partial;
-    const int hq0 = hk * p.g + gc * G;
-    const int nq = min(G, p.g - gc * G);
-
-    const float sl2 = p.scale_log2 * load_ro(p.k_scale + hk);   // scores = k_scale * (q . k_q)
-    float m[G], l[G], o[G][16];
-#pragma unroll
-    for (int gq = 0; gq < G; ++gq) {
-        m[gq] = -INFINITY;
-        l[gq] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[gq][e] = 0.f;
-    }
-
-    if (t0 < t1) {
-        uint32_t qv[G][8];   // q[head][16.dc ..+15] as 8 packed pairs, replicated over the 8 row groups
-#pragma unroll
-        for (int gq = 0; gq < G; ++gq) {
-            uint4 a = make_uint4(0, 0, 0, 0), c = a;
-            if (gq < nq) {
-                const uint4 *src = reinterpret_cast<const uint4 *>(p.q + (int64_t)b * p.q_batch_stride + (int64_t)(hq0 + gq) * p.q_head_stride + dc * 16);
-                a = src[0];
-                c = src[1];
-            }
-            qv[gq][0] = a.x; qv[gq][1] = a.y; qv[gq][2] = a.z; qv[gq][3] = a.w;
-            qv[gq][4] = c.x; qv[gq][5] = c.y; qv[gq][6] = c.z; qv[gq][7] = c.w;
-        }
-        // ---- loader: as paged_decode_item, strides in BYTES (one byte per element) ----
-        const uint32_t tpp = (uint32_t)(p.page_size >> 4);
-        const uint32_t tpp_magic = tpp > 1 ? (uint32_t)((0x100000000ull + tpp - 1) / tpp) : 0u;
-        const int last_pg = (L + p.page_size - 1) / p.page_size - 1;
-        const int *bt_row = p.block_table + (int64_t)b * p.block_table_batch_stride;
-        const char *kbase = reinterpret_cast<const char *>(p.k) + (int64_t)hk * p.k_head_stride;
-        const char *vbase = reinterpret_cast<const char *>(p.v) + (int64_t)hk * p.v_head_stride;
-        const int64_t k_row_bytes = p.k_row_stride, v_row_bytes = p.v_row_stride;
-        const int64_t k_page_bytes = p.k_batch_stride, v_page_bytes = p.v_batch_stride;
-        const uint32_t k_lane_off = (uint32_t)(sub * k_row_bytes + dc * 16);
-        const uint32_t v_lane_off = (uint32_t)(sub * v_row_bytes + dc * 16);
-        auto page_of = [&](int tile, uint32_t &tip) -> int {
-            if (tpp == 1) { tip = 0; return tile; }
-            const uint32_t pg = __umulhi((uint32_t)tile, tpp_magic);
-            tip = (uint32_t)tile - pg * tpp;
-            return (int)pg;
-        };
-        auto fetch_pid = [&](int tile) -> int {
-            uint32_t tip;
-            const int pg = min(page_of(tile, tip), last_pg);
-            return load_ro(bt_row + pg);
-        };
-        constexpr int AUX = NT ? 2 : 0;
-        auto issue = [&](u32x4 (&kb)[2], u32x4 (&vb)[2], int tile, int pid) {   // paged tiles always own their 16 rows
-            uint32_t tip;
-            (void)page_of(tile, tip);
-            const char *kt = kbase + (int64_t)pid * k_page_bytes + (int64_t)(tip << 4) * k_row_bytes;
-            const char *vt = vbase + (int64_t)pid * v_page_bytes + (int64_t)(tip << 4) * v_row_bytes;
-            const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(kt), 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vt), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) kb[r] = __builtin_amdgcn_raw_buffer_load_b128(kr, k_lane_off, (int)(r * RPI * k_row_bytes), AUX);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) vb[r] = __builtin_amdgcn_raw_buffer_load_b128(vr, v_lane_off, (int)(r * RPI * v_row_bytes), AUX);
-        };
-        auto compute = [&](const u32x4 (&kb)[2], const u32x4 (&vb)[2], int tile) {
-            float s[2][G];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                uint32_t kk[8];
-                fp8x16_to_pairs<T>(kb[r], kk);
-#pragma unroll
-                for (int gq = 0; gq < G; ++gq) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) a = dot2<T>(kk[i], qv[gq][i], a);
-                    s[r][gq] = row_allreduce<LPR>(a) * sl2;   // log2 domain
-                }
-            }
-            const int tok0 = (tile << 4) + sub;
-            if ((tile << 4) + 16 > L) {   // wave-uniform: ragged last tile
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-                    if (tok0 + r * RPI >= L) {
-#pragma unroll
-                        for (int gq = 0; gq < G; ++gq) s[r][gq] = -INFINITY;
-                    }
-            }
-            float mnew[G];
-            bool changed = false;
-#pragma unroll
-            for (int gq = 0; gq < G; ++gq) {
-                mnew[gq] = fmaxf(m[gq], fmaxf(s[0][gq], s[1][gq]));
-                changed |= mnew[gq] > m[gq];
-            }
-            if (__any(changed)) {
-#pragma unroll
-                for (int gq = 0; gq < G; ++gq) {
-                    const float ms = mnew[gq] == -INFINITY ? 0.f : mnew[gq];
-                    const float alpha = __builtin_amdgcn_exp2f(m[gq] - ms);
-                    l[gq] *= alpha;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[gq][e] *= alpha;
-                    m[gq] = mnew[gq];
-                }
-            }
-            uint32_t pp[G];
-#pragma unroll
-            for (int gq = 0; gq < G; ++gq) {
-                const float ms = m[gq] == -INFINITY ? 0.f : m[gq];
-                const float p0 = __builtin_amdgcn_exp2f(s[0][gq] - ms), p1 = __builtin_amdgcn_exp2f(s[1][gq] - ms);
-                l[gq] += p0 + p1;
-                pp[gq] = pack_pair<T>(p0, p1);   // tokens (sub, 8 + sub)
-            }
-            uint32_t va[8], vc[8];
-            fp8x16_to_pairs<T>(vb[0], va);
-            fp8x16_to_pairs<T>(vb[1], vc);
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const uint32_t lo = __builtin_amdgcn_perm(vc[w], va[w], 0x05040100u);  // (row sub, row 8 + sub) of element 2w
-                const uint32_t hi = __builtin_amdgcn_perm(vc[w], va[w], 0x07060302u);  // ... of element 2w + 1
-#pragma unroll
-                for (int gq = 0; gq < G; ++gq) {
-                    o[gq][2 * w] = dot2<T>(lo, pp[gq], o[gq][2 * w]);
-                    o[gq][2 * w + 1] = dot2<T>(hi, pp[gq], o[gq][2 * w + 1]);
-                }
-            }
-        };
-        // ---- software pipeline: P tiles in flight (every paged tile is complete: one code path, unconditional steady state) ----
-        u32x4 kb[P][2], vb[P][2];
-        int pid[P];
-        int t = t0;
-        if (t0 + 2 * P <= t1) {
-#pragma unroll
-            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
-#pragma unroll
-            for (int s = 0; s < P; ++s) {
-                issue(kb[s], vb[s], t0 + s, pid[s]);
-                pid[s] = fetch_pid(t0 + s + P);
-            }
-            for (; t + 2 * P <= t1; t += P) {
-#pragma unroll
-                for (int s = 0; s < P; ++s) {
-                    compute(kb[s], vb[s], t + s);
-                    issue(kb[s], vb[s], t + s + P, pid[s]);
-                    pid[s] = fetch_pid(t + s + 2 * P);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
-#pragma unroll
-            for (int s = 0; s < P; ++s)
-                if (t0 + s < t1) {
-                    issue(kb[s], vb[s], t0 + s, pid[s]);
-                    pid[s] = fetch_pid(t0 + s + P);
-                }
-        }
-        for (; t < t1; t += P) {
-#pragma unroll
-            for (int s = 0; s < P; ++s) {
-                if (t + s < t1) {
-                    compute(kb[s], vb[s], t + s);
-                    if (t + s + P < t1) {
-                        issue(kb[s], vb[s], t + s + P, pid[s]);
-                        pid[s] = fetch_pid(t + s + 2 * P);
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- merge the 8 row groups ----
-#pragma unroll
-    for (int gq = 0; gq < G; ++gq) {
-        float mt = m[gq];
-#pragma unroll
-        for (int off = LPR; off < 64; off <<= 1) mt = fmaxf(mt, __shfl_xor(mt, off, 64));
-        const float ms = mt == -INFINITY ? 0.f : mt;
-        const float w = __builtin_amdgcn_exp2f(m[gq] - ms);
-        float lt = l[gq] * w;
-#pragma unroll
-        for (int off = LPR; off < 64; off <<= 1) lt += __shfl_xor(lt, off, 64);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float x = o[gq][e] * w;
-#pragma unroll
-            for (int off = LPR; off < 64; off <<= 1) x += __shfl_xor(x, off, 64);
-            o[gq][e] = x;
-        }
-        m[gq] = mt;
-        l[gq] = lt;
-    }
-    if (sub != 0) return;
-    const float vs = load_ro(p.v_scale + hk);
-#pragma unroll
-    for (int gq = 0; gq < G; ++gq) {
-        if (gq >= nq) continue;
-        const int hq = hq0 + gq;
-        const bool empty = !(l[gq] > 0.f);
-        const float inv = empty ? 0.f : vs / l[gq];      // O = v_scale * sum(p v_q) / sum(p)
-        const float lse = empty ? INFINITY : (m[gq] + __builtin_amdgcn_logf(l[gq])) * 0.6931471805599453f;
-        if (!partial) {
-            uint4 w4[2];
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                w4[hlf].x = pack2<T>(o[gq][8 * hlf + 0] * inv, o[gq][8 * hlf + 1] * inv);
-                w4[hlf].y = pack2<T>(o[gq][8 * hlf + 2] * inv, o[gq][8 * hlf + 3] * inv);
-                w4[hlf].z = pack2<T>(o[gq][8 * hlf + 4] * inv, o[gq][8 * hlf + 5] * inv);
-                w4[hlf].w = pack2<T>(o[gq][8 * hlf + 6] * inv, o[gq][8 * hlf + 7] * inv);
-            }
-            uint4 *dst = reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + dc * 16);
-            dst[0] = w4[0];
-            dst[1] = w4[1];
-            if (p.lse && dc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
-        } else {
-            const int64_t row = wk.prow + gq;
-            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + dc * 16);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-                dst[q4] = make_float4(o[gq][4 * q4] * inv, o[gq][4 * q4 + 1] * inv, o[gq][4 * q4 + 2] * inv, o[gq][4 * q4 + 3] * inv);
-            if (dc == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
-        }
-    }
-}
-
-template <typename T, int G, int P, bool NT, bool STREAM>
-__global__ void __launch_bounds__(64, 2) paged_decode_fp8_kernel(const DecodeParams p) {
-    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_item<T, G, P, NT>(pp, wk); });
-}
-
-// ------------------------------------------------------------------------------------------
 // d = 128 variant with q.K^T on the matrix cores.  With 8 q heads per kv head (Llama-70B) the dot2 kernel
 // above does 8 flop per K/V byte on the VALU and is compute-bound (43 % of the HBM peak, one 512-register
 // wavefront per SIMD).  The scores of a 16-token tile for up to 16 q heads are one small matrix product,
@@ -879,29 +365,6 @@ __global__ void __launch_bounds__(64, 2) paged_decode_fp8_kernel(const DecodePar
 //     (grp, head) with one DPP row_newbcast per head and token pair.
 // VALU work per tile: ~100 + 16.G instead of ~70.G; 2 wavefronts per SIMD at any G.
 // ------------------------------------------------------------------------------------------
-template <int I, int N, typename F> __device__ __forceinline__ void decode_static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        decode_static_for<I + 1, N>(f);
-    }
-}
-// value of lane `H` of this lane's 16-lane row
-template <int H> __device__ __forceinline__ uint32_t row_bcast(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + H, 0xf, 0xf, false);   // row_newbcast:H
-}
-template <int H> __device__ __forceinline__ float row_bcastf(float x) { return __uint_as_float(row_bcast<H>(__float_as_uint(x))); }
-
-typedef __attribute__((ext_vector_type(4))) float f32x4_v;
-template <typename T> __device__ __forceinline__ f32x4_v mfma16(const u32x4 &a, const u32x4 &b, f32x4_v c);
-template <> __device__ __forceinline__ f32x4_v mfma16<bf16_t>(const u32x4 &a, const u32x4 &b, f32x4_v c) {
-    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ f32x4_v mfma16<f16_t>(const u32x4 &a, const u32x4 &b, f32x4_v c) {
-    typedef __attribute__((ext_vector_type(8))) _Float16 v8;
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
-}
-
 template <typename T, int G, int P, bool NT, bool SINK = false>
 __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, const DecodeWork &wk) {
     constexpr int D = 128;
@@ -1158,236 +621,6 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
 template <typename T, int G, int P, bool NT, bool STREAM>
 __global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodeParams p) {
     decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_mqk_item<T, G, P, NT>(pp, wk); });
-}
-
-// fp8 KV cache with q.K^T on the matrix cores (the VALU-bound dot2 variant above reaches 0.57 of HBM: the conversions and the
-// same dot products now fall on half the bytes).  Layout (lane = 16.grp + col), a 16-token tile = 2 + 2 loads of 16 bytes:
-//   * K load j: lane reads token `col`, bytes [64 j + 16 grp, + 16) of its 128-byte row -> 16 elements = the A operands of MFMA
-//     k-steps 2j and 2j + 1 (8 elements each); the k-slot <-> d mapping is a permutation of d, so Q^T is simply loaded with the
-//     same permutation: lane (grp, head col) holds q[d = 64 j + 16 grp + 8 u ..+7] for k-step 2j + u;
-//   * result: S^T[token 4.grp + i][head col], i = 0..3 -- one head per lane, softmax state two scalars per lane;
-//   * V load j: lane reads row 4.grp + 2j + (col >> 3), 16-byte chunk col & 7 (a wave instruction = 8 full 128-byte rows); the
-//     two rows a lane holds (j = 0, 1) form the token pair of the P.V dot2, and both belong to the lane's own 16-lane DPP row,
-//     where their probabilities live: head h's packed pair comes from lane (grp, h) by one row_newbcast.
-// ~140 VALU instructions per 4 KiB tile at 4 heads instead of ~250.
-template <typename T, int G, int P, bool NT>
-__device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p, const DecodeWork &wk) {
-    constexpr int D = 128;
-    const int lane = threadIdx.x & 63, grp = lane >> 4, col = lane & 15, vhalf = col >> 3, vc = col & 7;
-    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
-    const bool partial = wk.partial;
-    const int hq0 = hk * p.g + gc * G;
-    const int nq = min(G, p.g - gc * G);
-    const float sl2 = p.scale_log2 * load_ro(p.k_scale + hk);
-    float m = -INFINITY, l = 0.f;        // head `col`, this lane group's 4 tokens per tile
-    float o[G][16];                      // O[head][d = 16.vc ..+15] over this lane's two rows per tile
-#pragma unroll
-    for (int h = 0; h < G; ++h)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[h][e] = 0.f;
-
-    if (t0 < t1) {
-        u32x4 qb[4];                     // Q^T operand of k-step s = 2j + u: q[head col][64 j + 16 grp + 8 u ..+7]
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            qb[s4] = u32x4{0, 0, 0, 0};
-            if (col < nq)
-                qb[s4] = *reinterpret_cast<const u32x4 *>(p.q + (int64_t)b * p.q_batch_stride + (int64_t)(hq0 + col) * p.q_head_stride +
-                                                          64 * (s4 >> 1) + 16 * grp + 8 * (s4 & 1));
-        }
-        const uint32_t tpp = (uint32_t)(p.page_size >> 4);
-        const uint32_t tpp_magic = tpp > 1 ? (uint32_t)((0x100000000ull + tpp - 1) / tpp) : 0u;
-        const int last_pg = (L + p.page_size - 1) / p.page_size - 1;
-        const int *bt_row = p.block_table + (int64_t)b * p.block_table_batch_stride;
-        const char *kbase = reinterpret_cast<const char *>(p.k) + (int64_t)hk * p.k_head_stride;
-        const char *vbase = reinterpret_cast<const char *>(p.v) + (int64_t)hk * p.v_head_stride;
-        const int64_t k_row_bytes = p.k_row_stride, v_row_bytes = p.v_row_stride;
-        const int64_t k_page_bytes = p.k_batch_stride, v_page_bytes = p.v_batch_stride;
-        const uint32_t k_lane_off = (uint32_t)(col * k_row_bytes + grp * 16);                      // + 64 j
-        const uint32_t v_lane_off = (uint32_t)((4 * grp + vhalf) * v_row_bytes + vc * 16);         // + 2 j rows
-        auto page_of = [&](int tile, uint32_t &tip) -> int {
-            if (tpp == 1) { tip = 0; return tile; }
-            const uint32_t pg = __umulhi((uint32_t)tile, tpp_magic);
-            tip = (uint32_t)tile - pg * tpp;
-            return (int)pg;
-        };
-        auto fetch_pid = [&](int tile) -> int {
-            uint32_t tip;
-            const int pg = min(page_of(tile, tip), last_pg);
-            return load_ro(bt_row + pg);
-        };
-        constexpr int AUX = NT ? 2 : 0;
-        auto issue = [&](u32x4 (&kb)[2], u32x4 (&vb)[2], int tile, int pid) {
-            uint32_t tip;
-            (void)page_of(tile, tip);
-            const char *kt = kbase + (int64_t)pid * k_page_bytes + (int64_t)(tip << 4) * k_row_bytes;
-            const char *vt = vbase + (int64_t)pid * v_page_bytes + (int64_t)(tip << 4) * v_row_bytes;
-            const __amdgpu_buffer_rsrc_t kr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(kt), 0, 0x7fffffff, 0x00020000);
-            const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vt), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) kb[j] = __builtin_amdgcn_raw_buffer_load_b128(kr, k_lane_off, j * 64, AUX);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) vb[j] = __builtin_amdgcn_raw_buffer_load_b128(vr, v_lane_off, (int)(2 * j * v_row_bytes), AUX);
-        };
-        auto compute = [&](const u32x4 (&kb)[2], const u32x4 (&vb)[2], int tile) {
-            f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                uint32_t kk[8];
-                fp8x16_to_pairs<T>(kb[j], kk);
-                acc = mfma16<T>(u32x4{kk[0], kk[1], kk[2], kk[3]}, qb[2 * j], acc);
-                acc = mfma16<T>(u32x4{kk[4], kk[5], kk[6], kk[7]}, qb[2 * j + 1], acc);
-            }
-            float s[4];
-            const int tok0 = (tile << 4) + 4 * grp;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s[i] = acc[i] * sl2;
-            if ((tile << 4) + 16 > L) {  // wave-uniform: ragged last tile
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (tok0 + i >= L) s[i] = -INFINITY;
-            }
-            const float mnew = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), m);
-            if (__any(mnew > m)) {
-                const float ms = mnew == -INFINITY ? 0.f : mnew;
-                const float alpha = __builtin_amdgcn_exp2f(m - ms);
-                l *= alpha;
-                m = mnew;
-                decode_static_for<0, G>([&](auto Hc) {
-                    constexpr int h = decltype(Hc)::value;
-                    const float ah = row_bcastf<h>(alpha);
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[h][e] *= ah;
-                });
-            }
-            const float ms = m == -INFINITY ? 0.f : m;
-            float pr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pr[i] = __builtin_amdgcn_exp2f(s[i] - ms);
-            l += (pr[0] + pr[1]) + (pr[2] + pr[3]);
-            // token pairs of the V rows a lane holds: (4 grp + vhalf, 4 grp + 2 + vhalf)
-            const uint32_t pk_even = pack_pair<T>(pr[0], pr[2]), pk_odd = pack_pair<T>(pr[1], pr[3]);
-            uint32_t ph[G];
-            decode_static_for<0, G>([&](auto Hc) {
-                constexpr int h = decltype(Hc)::value;
-                const uint32_t e0 = row_bcast<h>(pk_even), e1 = row_bcast<h>(pk_odd);
-                ph[h] = vhalf ? e1 : e0;
-            });
-            uint32_t va[8], vc2[8];
-            fp8x16_to_pairs<T>(vb[0], va);
-            fp8x16_to_pairs<T>(vb[1], vc2);
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const uint32_t lo = __builtin_amdgcn_perm(vc2[w], va[w], 0x05040100u);
-                const uint32_t hi = __builtin_amdgcn_perm(vc2[w], va[w], 0x07060302u);
-#pragma unroll
-                for (int h = 0; h < G; ++h) {
-                    o[h][2 * w] = dot2<T>(lo, ph[h], o[h][2 * w]);
-                    o[h][2 * w + 1] = dot2<T>(hi, ph[h], o[h][2 * w + 1]);
-                }
-            }
-        };
-        u32x4 kb[P][2], vb[P][2];
-        int pid[P];
-        int t = t0;
-        if (t0 + 2 * P <= t1) {
-#pragma unroll
-            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
-#pragma unroll
-            for (int s = 0; s < P; ++s) {
-                issue(kb[s], vb[s], t0 + s, pid[s]);
-                pid[s] = fetch_pid(t0 + s + P);
-            }
-            for (; t + 2 * P <= t1; t += P) {
-#pragma unroll
-                for (int s = 0; s < P; ++s) {
-                    compute(kb[s], vb[s], t + s);
-                    issue(kb[s], vb[s], t + s + P, pid[s]);
-                    pid[s] = fetch_pid(t + s + 2 * P);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);
-#pragma unroll
-            for (int s = 0; s < P; ++s)
-                if (t0 + s < t1) {
-                    issue(kb[s], vb[s], t0 + s, pid[s]);
-                    pid[s] = fetch_pid(t0 + s + P);
-                }
-        }
-        for (; t < t1; t += P) {
-#pragma unroll
-            for (int s = 0; s < P; ++s) {
-                if (t + s < t1) {
-                    compute(kb[s], vb[s], t + s);
-                    if (t + s + P < t1) {
-                        issue(kb[s], vb[s], t + s + P, pid[s]);
-                        pid[s] = fetch_pid(t + s + 2 * P);
-                    }
-                }
-            }
-        }
-    }
-    // ---- merge: the 4 lane groups' (m, l) of head col; O over the 8 (grp, vhalf) row sets ----
-    float mt = m;
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float wgt = __builtin_amdgcn_exp2f(m - (mt == -INFINITY ? 0.f : mt));   // this lane group's weight for head col
-    float lt = l * wgt;
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
-    float mh[G], lh[G];
-    decode_static_for<0, G>([&](auto Hc) {
-        constexpr int h = decltype(Hc)::value;
-        const float wh = row_bcastf<h>(wgt);     // the group's weight for head h (same for both halves of the DPP row)
-        mh[h] = row_bcastf<h>(mt);
-        lh[h] = row_bcastf<h>(lt);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float x = o[h][e] * wh;
-            x += __shfl_xor(x, 8, 64);           // the other row of the pair set
-            x += __shfl_xor(x, 16, 64);
-            x += __shfl_xor(x, 32, 64);
-            o[h][e] = x;
-        }
-    });
-    if (lane >= 8) return;                       // lanes 0..7: d chunks 0..7
-    const float vs = load_ro(p.v_scale + hk);
-#pragma unroll
-    for (int h = 0; h < G; ++h) {
-        if (h >= nq) continue;
-        const int hq = hq0 + h;
-        const bool empty = !(lh[h] > 0.f);
-        const float inv = empty ? 0.f : vs / lh[h];
-        const float lse = empty ? INFINITY : (mh[h] + __builtin_amdgcn_logf(lh[h])) * 0.6931471805599453f;
-        if (!partial) {
-            uint4 w4[2];
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                w4[hlf].x = pack2<T>(o[h][8 * hlf + 0] * inv, o[h][8 * hlf + 1] * inv);
-                w4[hlf].y = pack2<T>(o[h][8 * hlf + 2] * inv, o[h][8 * hlf + 3] * inv);
-                w4[hlf].z = pack2<T>(o[h][8 * hlf + 4] * inv, o[h][8 * hlf + 5] * inv);
-                w4[hlf].w = pack2<T>(o[h][8 * hlf + 6] * inv, o[h][8 * hlf + 7] * inv);
-            }
-            uint4 *dst = reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + vc * 16);
-            dst[0] = w4[0];
-            dst[1] = w4[1];
-            if (p.lse && vc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
-        } else {
-            const int64_t row = wk.prow + h;
-            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + vc * 16);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-                dst[q4] = make_float4(o[h][4 * q4] * inv, o[h][4 * q4 + 1] * inv, o[h][4 * q4 + 2] * inv, o[h][4 * q4 + 3] * inv);
-            if (vc == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
-        }
-    }
-}
-
-template <typename T, int G, int P, bool NT, bool STREAM, int NWG = 1>
-__global__ void __launch_bounds__(64 * NWG, 2) paged_decode_fp8_mqk_kernel(const DecodeParams p) {
-    decode_run_items<STREAM, NWG>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_mqk_item<T, G, P, NT>(pp, wk); });
 }
 
 // LSE-weighted merge of the split partials: /root/reference/csrc/kernels/flash_fwd_kernel.h:1204-1236.
@@ -1887,8 +1120,11 @@ static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
 }
 
 // fp8 KV cache (d = 128): same planning (splits / balanced mode / scratch) as the 16-bit path, G <= 4 heads per wavefront
-template <typename T, int G>
-static void launch_decode_fp8_g(DecodeParams &p, hipStream_t stream) {
+// the fp8 kernels live in paged_decode_fp8.hip
+void launch_fp8_kernels(const DecodeParams &p, int G, bool is_bf16, bool nt, bool mqk, bool wg8, int64_t blocks, hipStream_t stream);
+int decode_fp8_tiles_in_flight();
+template <typename T>
+static void launch_decode_fp8_g(DecodeParams &p, int G, hipStream_t stream) {
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
     if (p.stream_waves > 0) set_stream_waves(p, 8);   // __launch_bounds__(64, 2)
     const bool nt = decode_options().nt != 0;
@@ -1898,14 +1134,9 @@ static void launch_decode_fp8_g(DecodeParams &p, hipStream_t stream) {
     // workgroup's 8 wavefronts walk unrelated ranges -- so by default only launches that cannot take the balanced mode)
     const int wg_opt = decode_options().fp8_wg;
     const bool wg8 = mqk && ((int64_t)p.h_k * p.gchunks) % 8 == 0 && (wg_opt >= 2 || (wg_opt == 1 && p.stream_waves == 0));
-    note_decode_kernel(mqk ? "paged_decode_fp8_mqk_kernel" : "paged_decode_fp8_kernel", decode_tname<T>(), 128, G, 3, nt,
+    note_decode_kernel(mqk ? "paged_decode_fp8_mqk_kernel" : "paged_decode_fp8_kernel", decode_tname<T>(), 128, G, decode_fp8_tiles_in_flight(), nt,
                        p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? "KV splits + combine" : (wg8 ? "8 wavefronts per workgroup" : "one wavefront per (sequence, kv head)")));
-#define ATOMA_F8(NT_, S_) do { if (wg8) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, 3, NT_, S_, 8>), dim3((unsigned)cdiv(blocks, 8)), dim3(512), 0, stream, p); \
-                               else if (mqk) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p); \
-                               else hipLaunchKernelGGL((paged_decode_fp8_kernel<T, G, 3, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p); } while (0)
-    if (nt) { if (p.stream_waves > 0) ATOMA_F8(true, true); else ATOMA_F8(true, false); }
-    else { if (p.stream_waves > 0) ATOMA_F8(false, true); else ATOMA_F8(false, false); }
-#undef ATOMA_F8
+    launch_fp8_kernels(p, G, std::is_same<T, bf16_t>::value, nt, mqk, wg8, blocks, stream);
     if (!ATOMA_CHECK_LAUNCH("paged_decode_fp8_kernel")) return;
     if (p.num_splits > 1 || p.stream_waves > 0) {
         hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
@@ -1922,11 +1153,7 @@ static void launch_decode_fp8(DecodeParams &p, hipStream_t stream) {
         p.lse_accum = ws + lp.rows * 128;
         p.plan = reinterpret_cast<int *>(ws + lp.rows * 129);
     }
-    switch (lp.G) {
-        case 1: launch_decode_fp8_g<T, 1>(p, stream); break;
-        case 2: launch_decode_fp8_g<T, 2>(p, stream); break;
-        default: launch_decode_fp8_g<T, 4>(p, stream); break;
-    }
+    launch_decode_fp8_g<T>(p, lp.G, stream);
 }
 void launch_paged_decode_fp8(DecodeParams &p, bool is_bf16, hipStream_t stream) {
     if (is_bf16) launch_decode_fp8<bf16_t>(p, stream);

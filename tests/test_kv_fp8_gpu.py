@@ -66,15 +66,21 @@ def test_rope_cache_fp8_equals_two_ops(gpu):
     assert np.array_equal(dkc.numpy(np.uint8, kc.shape), kc) and np.array_equal(dvc.numpy(np.uint8, vc.shape), vc)
 
 
-def gpu_decode_fp8(gpu, q, kc8, vc8, ks, vs, bt, lens, scale, dtype):
+def gpu_decode_fp8(gpu, q, kc8, vc8, ks, vs, bt, lens, scale, dtype, cache_strides=None):
+    """cache_strides = (block, row, head) in bytes for another physical layout of the same [nb, page, hk, d] pages (kc8 / vc8 are then
+    the flat byte images)"""
     B, h, d = q.shape
-    nb, page, hk, _ = kc8.shape
+    if cache_strides is None:
+        nb, page, hk, _ = kc8.shape
+        cache_strides = (page * hk * d, hk * d, d)
+    else:
+        page, hk = cache_strides[3], cache_strides[4]
     dq, dk, dv, dbt, dl = (gpu.DeviceBuffer.from_numpy(a) for a in (q, kc8, vc8, np.ascontiguousarray(bt, np.int32), np.ascontiguousarray(lens, np.int32)))
     dks, dvs = dev_scales(gpu, ks, vs)
     do = gpu.DeviceBuffer(q.nbytes)
     do.fill_bytes(0xFF)
     rc = gpu.lib.atoma_paged_decode_fp8(dq.ptr, dk.ptr, dv.ptr, do.ptr, dks.ptr, dvs.ptr, dbt.ptr, dl.ptr, B, h, hk, d, bt.shape[1], page,
-                                        h * d, d, h * d, d, page * hk * d, hk * d, d, float(scale), dtype, None)
+                                        h * d, d, h * d, d, cache_strides[0], cache_strides[1], cache_strides[2], float(scale), dtype, None)
     assert rc == 0, gpu.last_error()
     gpu.synchronize()
     return do.numpy(np.uint16, q.shape)
@@ -162,6 +168,33 @@ def test_decode_fp8_split_kv_balanced_and_invariants(gpu, qk_variant):
     assert np.array_equal(to_f32(out3, BF16), 2 * to_f32(base8, BF16))
     out4 = gpu_decode_fp8(gpu, q[:8], kc8, vc8, ks * 4, vs, bt[:8], lens[:8], sc / 4, BF16)
     assert np.array_equal(out4, base8)
+
+
+@pytest.mark.parametrize("h,hk", [(32, 8), (8, 2), (4, 4)])
+def test_decode_fp8_other_page_layouts_bit_identical(gpu, qk_variant, h, hk):
+    """The ABI takes the cache strides: head-major pages [nb][hk][page][d] and pages with padded rows must give the SAME bits as the
+    reference layout (the kernel's K / V fetch addresses are all derived from the strides; the arithmetic does not change) --
+    resident batch (full-line K fetch), a split sequence, and a ragged batch in the balanced mode."""
+    rng = np.random.default_rng(41 + h)
+    d, page = 128, 16
+    sc = np.float32(d ** -0.5)
+    for lens in (np.array([0, 1, 17, 64, 333, 600], np.int32), np.array([5000], np.int32), rng.integers(1, 700, 160).astype(np.int32)):
+        nb = int(sum((L + page - 1) // page for L in lens)) + 2
+        kc8, vc8, ks, vs, bt = make_fp8_cache(rng, nb, page, hk, d, lens)
+        q = rand_half(rng, (len(lens), h, d), BF16)
+        base = gpu_decode_fp8(gpu, q, kc8, vc8, ks, vs, bt, lens, sc, BF16)
+        # head-major pages
+        khm, vhm = np.ascontiguousarray(kc8.transpose(0, 2, 1, 3)), np.ascontiguousarray(vc8.transpose(0, 2, 1, 3))
+        out = gpu_decode_fp8(gpu, q, khm, vhm, ks, vs, bt, lens, sc, BF16, cache_strides=(page * hk * d, d, page * d, page, hk))
+        assert np.array_equal(out, base), "head-major pages"
+        # rows padded by 64 bytes, pages by one row
+        row = hk * d + 64
+        kp, vp = np.zeros((nb, page + 1, row), np.uint8), np.zeros((nb, page + 1, row), np.uint8)
+        kp[:, :page, :hk * d] = kc8.reshape(nb, page, hk * d)
+        vp[:, :page, :hk * d] = vc8.reshape(nb, page, hk * d)
+        kp[:, :, hk * d:], vp[:, :, hk * d:] = 0x7E, 0x7E        # large finite codes in the padding: a wrong address shows
+        out = gpu_decode_fp8(gpu, q, kp, vp, ks, vs, bt, lens, sc, BF16, cache_strides=((page + 1) * row, row, d, page, hk))
+        assert np.array_equal(out, base), "padded rows"
 
 
 def test_decode_fp8_rejects_bad_arguments(gpu):

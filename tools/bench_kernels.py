@@ -62,6 +62,8 @@ def emit(name, ms, nbytes=None, flops=None, **extra):
 
 
 def decode_case(name, B, S, h, hk, d=128, page=16, identity=False, ragged=False, seed=0, lens=None):
+    if os.environ.get("ATOMA_BENCH_DECODE_SHAPE") and os.environ["ATOMA_BENCH_DECODE_SHAPE"] not in name:   # one shape, for counter passes
+        return
     rng = np.random.default_rng(seed)
     pps = (S + page - 1) // page
     if lens is not None:       # explicit lengths (max S): only the pages the sequences own exist
@@ -83,10 +85,16 @@ def decode_case(name, B, S, h, hk, d=128, page=16, identity=False, ragged=False,
     o = ah.DeviceBuffer(B * h * d * 2)
     dbt, dl = ah.DeviceBuffer.from_numpy(bt), ah.DeviceBuffer.from_numpy(lens)
 
+    # the ABI takes strides: ATOMA_KV_LAYOUT=head_major lays a page out as [h_k][page][d] instead of the reference's [page][h_k][d]
+    kv_strides = (page * hk * d, hk * d, d)
+    if os.environ.get("ATOMA_KV_LAYOUT", "") == "head_major":
+        kv_strides = (page * hk * d, d, page * d)
+        name += " [head-major pages]"
+
     def run():
         ah.run_mha(q, kc, vc, o, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=pps * page, softmax_scale=d ** -0.5,
-                   is_bf16=1, q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
-                   v_strides=(page * hk * d, hk * d, d), cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt,
+                   is_bf16=1, q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=kv_strides,
+                   v_strides=kv_strides, cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt,
                    block_table_batch_stride=pps, page_block_size=page, force_split_kernel=True, unpadded_lse=False)
     ms = timeit(run)
     tot = int(lens.astype(np.int64).sum())
@@ -119,6 +127,8 @@ def bench_decode_fp8():
                                       ("C2c over fp8 KV: ragged U[2048,4096]", 256, 4096, 32, 8, True),
                                       ("fp8 KV, 70B TP=8 shard: B=64 h=8 hk=1 S=4096 (two chunks of 4 heads)", 64, 4096, 8, 1, False),
                                       ("fp8 KV, B=16 S=8192", 16, 8192, 32, 8, False)):
+        if os.environ.get("ATOMA_FP8_SHAPE") and os.environ["ATOMA_FP8_SHAPE"] not in name:   # one shape, for counter passes
+            continue
         d, page = 128, 16
         pps = S // page
         n_pages = int(B * pps * 1.125)
@@ -139,10 +149,16 @@ def bench_decode_fp8():
         vs = ah.DeviceBuffer.from_numpy(np.full(hk, 0.02, np.float32))
         dbt, dl = ah.DeviceBuffer.from_numpy(bt), ah.DeviceBuffer.from_numpy(lens)
 
+        # the ABI takes strides: ATOMA_FP8_LAYOUT=head_major lays a page out as [h_k][page][d] (a head's 16 rows = 2 KiB contiguous)
+        head_major = os.environ.get("ATOMA_FP8_LAYOUT", "") == "head_major"
+        row_stride, head_stride = (d, page * d) if head_major else (hk * d, d)
+
         def run():
             rc = ah.lib.atoma_paged_decode_fp8(q.ptr, kc.ptr, vc.ptr, o.ptr, ks.ptr, vs.ptr, dbt.ptr, dl.ptr, B, h, hk, d, pps, page, h * d, d, h * d, d,
-                                               page * hk * d, hk * d, d, d ** -0.5, 1, None)
+                                               page * hk * d, row_stride, head_stride, d ** -0.5, 1, None)
             assert rc == 0, ah.last_error()
+        if head_major:
+            name += " [head-major pages]"
         ms = timeit(run, iters=20)
         tok = int(lens.sum())
         nbytes = 2 * tok * hk * d + 2 * B * h * d * 2 + 4 * int(((lens + page - 1) // page).sum()) + 4 * B + 8 * hk
