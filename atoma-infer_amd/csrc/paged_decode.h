@@ -41,6 +41,8 @@ struct DecodeParams {
     const float *k_scale, *v_scale;   // fp8 (e4m3fn) KV cache: per-kv-head dequantisation scales [h_k]; null for 16-bit caches
     int wg_splits;         // > 0: workgroup-merged split mode (paged_decode_wg_kernel): KV pieces per sequence = wg_splits x wavefronts per workgroup
     unsigned *counters;    // ... and its arrival counter per (sequence, kv head, q-head chunk), zero between launches
+    int stream_force;      // the balanced line also for uniform resident batches (decode_plan_launch says when)
+    int fp8_klines;        // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays (not on the balanced line, not with a single kv head: contiguous rows), 2 always
     int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
     float scale, scale_log2;
 };
@@ -170,7 +172,7 @@ __device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, in
     // one wavefront per (sequence, kv head) is already balanced when every sequence is (nearly) as long as the
     // longest and all of them are resident at once: idle share 1 - mean/max below 4 %
     const bool ragged = (int64_t)mx * p.b * 96 > (int64_t)pl.T * 100;
-    pl.stream = ragged || p.b * hk_chunks > p.stream_waves;
+    pl.stream = ragged || p.b * hk_chunks > p.stream_waves || p.stream_force;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS writes above
     __builtin_amdgcn_wave_barrier();
     return pl;

@@ -850,7 +850,7 @@ int decode_num_splits(int64_t waves_per_split, int max_seqlen_k, int waves_per_c
 // Tuning knobs (atoma_set_option / environment, for A/B runs and tests):
 //   decode_p            ATOMA_DECODE_P            tiles in flight per wave (2..4)
 //   decode_nt           ATOMA_DECODE_NT           0/1 non-temporal K/V loads
-//   decode_stream       ATOMA_DECODE_STREAM       0/1 balanced mode for large batches with device-side lengths (decode_run_items)
+//   decode_stream       ATOMA_DECODE_STREAM       balanced mode for large batches with device-side lengths (decode_run_items): 0 off, 1 default, 2 always, 3 ragged only
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -868,6 +868,7 @@ struct DecodeOptions {
     opt_int fp8_wg{env_int("ATOMA_DECODE_FP8_WG", 1)};     // fp8 KV cache: 8 wavefronts (the kv heads of a sequence) per workgroup: 0 never, 1 split-KV launches, 2 always
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
     opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
+    opt_int fp8_klines{env_int("ATOMA_DECODE_FP8_KLINES", 1)};   // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays, 2 always
     opt_int mqk{env_int("ATOMA_DECODE_MQK", 5)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches
 };
 static DecodeOptions &decode_options() {
@@ -890,6 +891,7 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_wg_merge") o.wg_merge = value;
     else if (name == "decode_fp8_mqk") o.fp8_mqk = value;
     else if (name == "decode_fp8_wg") o.fp8_wg = value;
+    else if (name == "decode_fp8_klines") o.fp8_klines = value;
     else return false;
     return true;
 }
@@ -1038,6 +1040,7 @@ struct DecodeLaunchPlan {
     size_t rows;          // fp32 partial rows of D floats (+ 1 LSE each); 0 = no scratch
     size_t bytes;         // scratch bytes including the plan ints
 };
+int decode_fp8_mma_group();   // paged_decode_fp8.hip
 static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = false) {
     const int g = p.g;
     // matrix-core scores: d = 128, selected groups (option decode_mqk: bit 0 = groups of 5..8+ q heads, bit 1 = smaller ones, bit 2 below)
@@ -1047,7 +1050,8 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
     // at larger batches the two kernels tie or the dot2 kernel wins by 2-3 %, and MHA always prefers dot2.
     const bool tiny = g >= 2 && g <= 4 && (int64_t)p.b * p.h_k <= 64;
     const bool use_mqk = !fp8 && D == 128 && ((g > 4 && (mqk_opt & 1)) || (g <= 4 && (mqk_opt & 2)) || (tiny && (mqk_opt & 4)));
-    const int G = fp8 ? (g > 2 ? 4 : (g == 2 ? 2 : 1)) : (g >= 8 ? 8 : (g > 4 && use_mqk ? 8 : (g > 2 ? 4 : (g == 2 ? 2 : 1))));
+    // fp8: the matrix-core kernel takes up to 16 q heads per wavefront in one pass, the dot2 kernel 4
+    const int G = fp8 ? (decode_options().fp8_mqk != 0 ? decode_fp8_mma_group() : (g > 2 ? 4 : (g == 2 ? 2 : 1))) : (g >= 8 ? 8 : (g > 4 && use_mqk ? 8 : (g > 2 ? 4 : (g == 2 ? 2 : 1))));
     p.gchunks = (int)cdiv(g, G);
     if (p.num_splits <= 0) {
         const int64_t waves = (int64_t)p.b * p.h_k * p.gchunks;
@@ -1057,9 +1061,18 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
         p.num_splits = decode_num_splits(waves, p.seqlen_k, wpc, std::max(1, decode_options().min_tiles.load()));
     }
     p.group_tile = G;
+    // The balanced line also for uniform batches that are resident at once (option decode_stream: 0 = no balanced mode at all, 1 = ragged batches and, where measured
+    // faster, uniform ones, 2 = always, 3 = ragged batches only): the line is kv-head major, so the wavefronts an XCD receives back to back are the SAME head of 32 sequences and the 8
+    // wavefronts that land on one CU are the 8 kv heads of ONE sequence -- they walk the same token rows together.  Kernels whose K
+    // operand layout asks for half lines gain most (fp8: C2a 0.400 -> 0.347 ms; bf16 matrix-core kernel at 8 q heads per kv head, the
+    // 70B shape: 0.746 -> 0.677 ms); the dot2 kernels, whose requests are whole lines, are level (d = 128) or lose (d = 64):
+    // tools/probes/fp8_modes.sh, stream_force_ab.sh.
+    const int st_opt = decode_options().stream;
+    p.stream_force = st_opt == 2 || (st_opt == 1 && p.h_k > 1 && (fp8 || use_mqk));
+    p.fp8_klines = decode_options().fp8_klines;
     p.stream_waves = 0;
     const int64_t hk_chunks = (int64_t)p.h_k * p.gchunks, max_tiles = cdiv(p.seqlen_k, 16);
-    if (p.num_splits == 1 && decode_options().stream && (p.cu_seqlens_k || p.seqused_k) && p.b <= DECODE_STREAM_MAX_B &&
+    if (p.num_splits == 1 && st_opt != 0 && (p.cu_seqlens_k || p.seqused_k) && p.b <= DECODE_STREAM_MAX_B &&
         p.b * hk_chunks * max_tiles < (int64_t)1 << 31) {
         // enough wavefronts without splitting and the lengths are on the device: the kernel balances ragged batches itself
         p.stream_waves = (int)std::min<int64_t>(p.b * hk_chunks, (int64_t)device_num_cus() * DECODE_STREAM_MAX_WAVES_PER_CU);   // upper bound, set per kernel at launch
@@ -1134,7 +1147,7 @@ static void launch_decode_fp8_g(DecodeParams &p, int G, hipStream_t stream) {
     // workgroup's 8 wavefronts walk unrelated ranges -- so by default only launches that cannot take the balanced mode)
     const int wg_opt = decode_options().fp8_wg;
     const bool wg8 = mqk && ((int64_t)p.h_k * p.gchunks) % 8 == 0 && (wg_opt >= 2 || (wg_opt == 1 && p.stream_waves == 0));
-    note_decode_kernel(mqk ? "paged_decode_fp8_mqk_kernel" : "paged_decode_fp8_kernel", decode_tname<T>(), 128, G, decode_fp8_tiles_in_flight(), nt,
+    note_decode_kernel(mqk ? "paged_decode_fp8_mma_kernel" : "paged_decode_fp8_kernel", decode_tname<T>(), 128, G, decode_fp8_tiles_in_flight(), nt,
                        p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? "KV splits + combine" : (wg8 ? "8 wavefronts per workgroup" : "one wavefront per (sequence, kv head)")));
     launch_fp8_kernels(p, G, std::is_same<T, bf16_t>::value, nt, mqk, wg8, blocks, stream);
     if (!ATOMA_CHECK_LAUNCH("paged_decode_fp8_kernel")) return;

@@ -270,35 +270,66 @@ __global__ void __launch_bounds__(64, 2) paged_decode_fp8_kernel(const DecodePar
     decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_item<T, G, P, NT>(pp, wk); });
 }
 
-// fp8 KV cache with q.K^T on the matrix cores (the VALU-bound dot2 variant above reaches 0.57 of HBM: the conversions and the
-// same dot products now fall on half the bytes).  Layout (lane = 16.grp + col), a 16-token tile = 2 + 2 loads of 16 bytes:
-//   * K load j: lane reads token `col`, bytes [64 j + 16 grp, + 16) of its 128-byte row -> 16 elements = the A operands of MFMA
-//     k-steps 2j and 2j + 1 (8 elements each); the k-slot <-> d mapping is a permutation of d, so Q^T is simply loaded with the
-//     same permutation: lane (grp, head col) holds q[d = 64 j + 16 grp + 8 u ..+7] for k-step 2j + u;
-//   * result: S^T[token 4.grp + i][head col], i = 0..3 -- one head per lane, softmax state two scalars per lane;
-//   * V load j: lane reads row 4.grp + 2j + (col >> 3), 16-byte chunk col & 7 (a wave instruction = 8 full 128-byte rows); the
-//     two rows a lane holds (j = 0, 1) form the token pair of the P.V dot2, and both belong to the lane's own 16-lane DPP row,
-//     where their probabilities live: head h's packed pair comes from lane (grp, h) by one row_newbcast.
-// ~140 VALU instructions per 4 KiB tile at 4 heads instead of ~250.
+// fp8 KV cache with BOTH products on the matrix cores (round 3; the v_dot2c variant above stays behind option decode_fp8_mqk = 0).
+// What the counters said (profiles/r03_fp8_decode_counters.json): the first matrix-core version (q.K^T only) asked the L2 for every K line
+// twice -- the MFMA operand layout gives a token 4 lanes x 16 B = 64 B per instruction -- and a CU's request slots, not bytes, are what
+// runs out (0.098 requests per CU and cycle, the same as the bf16 kernel at 0.76 of HBM); and with that fixed the kernel is bound by its
+// own instruction stream (188 VALU instructions per 4 KiB tile at two wavefronts per SIMD), half of it the P.V dot2 pairs.  So:
+//   * K in FULL 128-byte lines: instruction jj fetches tokens 8 jj + (col & 7), the lane's 16 bytes are chunk grp + 4 (col >> 3) of the
+//     row (8 rows x 128 B per wave instruction).  MFMA row r < 8 then holds the d < 64 half of token 8 jj + r and row r + 8 the other
+//     half of the SAME token: the product with the first half of Q^T is right in rows 0..7 (lanes 0..31), with the second half in rows
+//     8..15 (lanes 32..63); the halves that sit in the wrong lanes change sides with one v_permlane32_swap per register and enter the
+//     other product as its C operand.  Result as before: S^T[token 4 grp + i][head col].  (On the balanced line the request format
+//     makes no difference -- timing probe 0.65 either way -- so its pieces keep the half-line fetch, 4 MFMAs and 8 VALU fewer.)
+//   * P.V as O[head][d] = P[head][token] . V[token][d] with v_mfma_f32_16x16x16: the A operand of lane (grp, col) is P[head col][tokens
+//     4 grp ..+3] -- exactly the four probabilities the lane has just computed, packed; the B operand is V[tokens 4 grp ..+3][one d]:
+//     the lane loads 8 bytes (d = 8 col ..+7) of each of its 4 token rows (a wave instruction = 4 rows x 128 B), converts them to pairs
+//     along d and re-pairs them along the tokens with v_perm (16 + 16 instructions instead of 16 + 16 + 64 v_dot2c at 4 heads);
+//     MFMA n = 0..7 accumulates O[head 4 grp + i][d = 8 col + n].  All 16 tokens of a tile enter one accumulator, so the running max
+//     of a head is common to its four lane groups (v_permlane16_swap + v_permlane32_swap per tile), the row sums stay per lane group
+//     and are added once at the end; the rare rescale fetches the heads' factors with ds_bpermute.
+//   * Any group size up to 16 q heads runs in ONE pass with the same 32 accumulator registers (the dot2 layouts needed 16 per head:
+//     groups of 8 took two passes over K / V).
+template <typename T> __device__ __forceinline__ f32x4_v mfma16k16(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, f32x4_v c);
+template <> __device__ __forceinline__ f32x4_v mfma16k16<bf16_t>(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, f32x4_v c) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u2{a0, a1}), __builtin_bit_cast(s16x4, u2{b0, b1}), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_v mfma16k16<f16_t>(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, f32x4_v c) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, u2{a0, a1}), __builtin_bit_cast(h16x4, u2{b0, b1}), c, 0, 0, 0);
+}
+// max over the four lanes (grp = 0..3) that share `col`
+__device__ __forceinline__ float col_max4(float x) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 #ifndef ATOMA_FP8_KLINES
 #define ATOMA_FP8_KLINES 1
 #endif
-constexpr bool FP8_KLINES = ATOMA_FP8_KLINES != 0;    // -DATOMA_FP8_KLINES=0: the half-line K fetch, kept for A/B (make fp8p)
-template <typename T, int G, int P, bool NT>
-__device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p, const DecodeWork &wk) {
-    constexpr int D = 128;
-    const int lane = threadIdx.x & 63, grp = lane >> 4, col = lane & 15, vhalf = col >> 3, vc = col & 7;
+constexpr bool FP8_KLINES = ATOMA_FP8_KLINES != 0;    // -DATOMA_FP8_KLINES=0: the half-line K fetch everywhere, kept for A/B
+constexpr int FP8_MMA_G = 16;                         // q heads per wavefront of the matrix-core kernel (p.group_tile)
+
+template <typename T, int P, bool NT>
+__device__ __forceinline__ void paged_decode_fp8_mma_item(const DecodeParams &p, const DecodeWork &wk) {
+    constexpr int D = 128, G = FP8_MMA_G;
+    const int lane = threadIdx.x & 63, grp = lane >> 4, col = lane & 15;
     const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
     const bool partial = wk.partial;
     const int hq0 = hk * p.g + gc * G;
     const int nq = min(G, p.g - gc * G);
     const float sl2 = p.scale_log2 * load_ro(p.k_scale + hk);
-    float m = -INFINITY, l = 0.f;        // head `col`, this lane group's 4 tokens per tile
-    float o[G][16];                      // O[head][d = 16.vc ..+15] over this lane's two rows per tile
+    float m = -INFINITY, l = 0.f;        // head `col`: running max over ALL tokens seen, sum over this lane group's 4 tokens per tile
+    f32x4_v o[8];                        // o[n][i] = O[head 4 grp + i][d = 8 col + n]
 #pragma unroll
-    for (int h = 0; h < G; ++h)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[h][e] = 0.f;
+    for (int n = 0; n < 8; ++n) o[n] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    // lane (grp, 4 grp + i) of this 16-lane row holds the state of head 4 grp + i
+    const int head_lane4 = ((lane & 48) + 4 * grp) << 2;     // ds_bpermute byte address of i = 0
 
     if (t0 < t1) {
         u32x4 qb[4];                     // Q^T operand of k-step s = 2j + u: q[head col][64 j + 16 grp + 8 u ..+7]
@@ -317,16 +348,11 @@ __device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p,
         const char *vbase = reinterpret_cast<const char *>(p.v) + (int64_t)hk * p.v_head_stride;
         const int64_t k_row_bytes = p.k_row_stride, v_row_bytes = p.v_row_stride;
         const int64_t k_page_bytes = p.k_batch_stride, v_page_bytes = p.v_batch_stride;
-        // K in FULL 128-byte lines: instruction jj fetches tokens 8 jj + (col & 7), the lane's 16 bytes are chunk grp + 4 (col >> 3) of
-        // the row -- 8 rows x 128 B per wave instruction.  Half lines (token col, bytes [64 j + 16 grp, +16)) cost a third of the CU's
-        // request slots when every wavefront walks its own sequence: 0.59 -> 0.67 of HBM on C2a (profiles/r03_fp8_decode_counters.json).
-        // On the balanced line the request format makes no difference (timing probe 0.65 either way) and the extra 4 MFMAs + 8 VALU per
-        // tile cost 6 %, so its pieces keep the half-line fetch (wave-uniform choice).
-        const bool klines = FP8_KLINES && !wk.balanced;
+        const bool klines = FP8_KLINES && (p.fp8_klines >= 2 || (p.fp8_klines == 1 && !wk.balanced && p.h_k > 1));
         const uint32_t k_lane_off = klines ? (uint32_t)((col & 7) * k_row_bytes + (grp + 4 * (col >> 3)) * 16)   // + 8 jj rows
                                            : (uint32_t)(col * k_row_bytes + grp * 16);                          // + 64 j
         const int k_step = klines ? (int)(8 * k_row_bytes) : 64;
-        const uint32_t v_lane_off = (uint32_t)((4 * grp + vhalf) * v_row_bytes + vc * 16);         // + 2 j rows
+        const uint32_t v_lane_off = (uint32_t)(4 * grp * v_row_bytes + col * 8);                                 // + i rows
         auto page_of = [&](int tile, uint32_t &tip) -> int {
             if (tpp == 1) { tip = 0; return tile; }
             const uint32_t pg = __umulhi((uint32_t)tile, tpp_magic);
@@ -339,7 +365,8 @@ __device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p,
             return load_ro(bt_row + pg);
         };
         constexpr int AUX = NT ? 2 : 0;
-        auto issue = [&](u32x4 (&kb)[2], u32x4 (&vb)[2], int tile, int pid) {
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        auto issue = [&](u32x4 (&kb)[2], u32x2 (&vb)[4], int tile, int pid) {
             uint32_t tip;
             (void)page_of(tile, tip);
             const char *kt = kbase + (int64_t)pid * k_page_bytes + (int64_t)(tip << 4) * k_row_bytes;
@@ -349,18 +376,14 @@ __device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p,
 #pragma unroll
             for (int j = 0; j < 2; ++j) kb[j] = __builtin_amdgcn_raw_buffer_load_b128(kr, k_lane_off, j * k_step, AUX);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) vb[j] = __builtin_amdgcn_raw_buffer_load_b128(vr, v_lane_off, (int)(2 * j * v_row_bytes), AUX);
+            for (int i = 0; i < 4; ++i) vb[i] = __builtin_amdgcn_raw_buffer_load_b64(vr, v_lane_off, (int)(i * v_row_bytes), AUX);
         };
-        auto compute = [&](const u32x4 (&kb)[2], const u32x4 (&vb)[2], int tile) {
+        auto compute = [&](const u32x4 (&kb)[2], const u32x2 (&vb)[4], int tile) {
             f32x4_v acc = {0.f, 0.f, 0.f, 0.f};
+            uint32_t k0[8], k1[8];
+            fp8x16_to_pairs<T>(kb[0], k0);
+            fp8x16_to_pairs<T>(kb[1], k1);
             if (klines) {
-                // MFMA row r < 8 holds the d < 64 half of token 8 jj + r, row r + 8 the other half of the SAME token: the product
-                // with the first half of Q^T is right in rows 0..7 (lanes 0..31), with the second half in rows 8..15 (lanes 32..63).
-                // Tokens 0..7 end in the low lanes, tokens 8..15 in the high lanes -- S^T[token 4 grp + i] as before: the halves that
-                // sit in the wrong lanes change sides with one v_permlane32_swap per register and enter the other product as C.
-                uint32_t k0[8], k1[8];
-                fp8x16_to_pairs<T>(kb[0], k0);
-                fp8x16_to_pairs<T>(kb[1], k1);
                 const f32x4_v zero = {0.f, 0.f, 0.f, 0.f};
                 f32x4_v hi0 = mfma16<T>(u32x4{k0[0], k0[1], k0[2], k0[3]}, qb[2], zero);     // high lanes: tokens 0..7, d >= 64
                 f32x4_v lo1 = mfma16<T>(u32x4{k1[0], k1[1], k1[2], k1[3]}, qb[0], zero);     // low lanes: tokens 8..15, d < 64
@@ -381,13 +404,10 @@ __device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p,
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = lane < 32 ? lo0[i] : hi1[i];
             } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    uint32_t kk[8];
-                    fp8x16_to_pairs<T>(kb[j], kk);
-                    acc = mfma16<T>(u32x4{kk[0], kk[1], kk[2], kk[3]}, qb[2 * j], acc);
-                    acc = mfma16<T>(u32x4{kk[4], kk[5], kk[6], kk[7]}, qb[2 * j + 1], acc);
-                }
+                acc = mfma16<T>(u32x4{k0[0], k0[1], k0[2], k0[3]}, qb[0], acc);
+                acc = mfma16<T>(u32x4{k0[4], k0[5], k0[6], k0[7]}, qb[1], acc);
+                acc = mfma16<T>(u32x4{k1[0], k1[1], k1[2], k1[3]}, qb[2], acc);
+                acc = mfma16<T>(u32x4{k1[4], k1[5], k1[6], k1[7]}, qb[3], acc);
             }
             float s[4];
             const int tok0 = (tile << 4) + 4 * grp;
@@ -398,47 +418,41 @@ __device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p,
                 for (int i = 0; i < 4; ++i)
                     if (tok0 + i >= L) s[i] = -INFINITY;
             }
-            const float mnew = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), m);
+            const float mnew = fmaxf(col_max4(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]))), m);
             if (__any(mnew > m)) {
                 const float ms = mnew == -INFINITY ? 0.f : mnew;
                 const float alpha = __builtin_amdgcn_exp2f(m - ms);
                 l *= alpha;
                 m = mnew;
-                decode_static_for<0, G>([&](auto Hc) {
-                    constexpr int h = decltype(Hc)::value;
-                    const float ah = row_bcastf<h>(alpha);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) o[h][e] *= ah;
-                });
+                for (int i = 0; i < 4; ++i) {
+                    const float ai = __uint_as_float(__builtin_amdgcn_ds_bpermute(head_lane4 + 4 * i, __float_as_uint(alpha)));
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) o[n][i] *= ai;
+                }
             }
             const float ms = m == -INFINITY ? 0.f : m;
             float pr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pr[i] = __builtin_amdgcn_exp2f(s[i] - ms);
             l += (pr[0] + pr[1]) + (pr[2] + pr[3]);
-            // token pairs of the V rows a lane holds: (4 grp + vhalf, 4 grp + 2 + vhalf)
-            const uint32_t pk_even = pack_pair<T>(pr[0], pr[2]), pk_odd = pack_pair<T>(pr[1], pr[3]);
-            uint32_t ph[G];
-            decode_static_for<0, G>([&](auto Hc) {
-                constexpr int h = decltype(Hc)::value;
-                const uint32_t e0 = row_bcast<h>(pk_even), e1 = row_bcast<h>(pk_odd);
-                ph[h] = vhalf ? e1 : e0;
-            });
-            uint32_t va[8], vc2[8];
-            fp8x16_to_pairs<T>(vb[0], va);
-            fp8x16_to_pairs<T>(vb[1], vc2);
+            const uint32_t pk01 = pack_pair<T>(pr[0], pr[1]), pk23 = pack_pair<T>(pr[2], pr[3]);   // A operand: P[head col][tokens 4 grp ..+3]
+            uint32_t c[4][4];            // c[i][q]: token 4 grp + i, the pair d = 8 col + 2q, + 1
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const uint32_t lo = __builtin_amdgcn_perm(vc2[w], va[w], 0x05040100u);
-                const uint32_t hi = __builtin_amdgcn_perm(vc2[w], va[w], 0x07060302u);
+            for (int i = 0; i < 4; ++i) {
+                c[i][0] = fp8x2_to_pair<T>(vb[i].x, false); c[i][1] = fp8x2_to_pair<T>(vb[i].x, true);
+                c[i][2] = fp8x2_to_pair<T>(vb[i].y, false); c[i][3] = fp8x2_to_pair<T>(vb[i].y, true);
+            }
 #pragma unroll
-                for (int h = 0; h < G; ++h) {
-                    o[h][2 * w] = dot2<T>(lo, ph[h], o[h][2 * w]);
-                    o[h][2 * w + 1] = dot2<T>(hi, ph[h], o[h][2 * w + 1]);
-                }
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t e01 = __builtin_amdgcn_perm(c[1][q], c[0][q], 0x05040100u), e23 = __builtin_amdgcn_perm(c[3][q], c[2][q], 0x05040100u);
+                const uint32_t o01 = __builtin_amdgcn_perm(c[1][q], c[0][q], 0x07060302u), o23 = __builtin_amdgcn_perm(c[3][q], c[2][q], 0x07060302u);
+                o[2 * q] = mfma16k16<T>(pk01, pk23, e01, e23, o[2 * q]);
+                o[2 * q + 1] = mfma16k16<T>(pk01, pk23, o01, o23, o[2 * q + 1]);
             }
         };
-        u32x4 kb[P][2], vb[P][2];
+        u32x4 kb[P][2];
+        u32x2 vb[P][4];
         int pid[P];
         int t = t0;
         if (t0 + 2 * P <= t1) {
@@ -480,95 +494,76 @@ __device__ __forceinline__ void paged_decode_fp8_mqk_item(const DecodeParams &p,
             }
         }
     }
-    // ---- merge: the 4 lane groups' (m, l) of head col; O over the 8 (grp, vhalf) row sets ----
-    float mt = m;
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float wgt = __builtin_amdgcn_exp2f(m - (mt == -INFINITY ? 0.f : mt));   // this lane group's weight for head col
-    float lt = l * wgt;
+    // ---- the max is already common; the row sums of head col over the 4 lane groups; then each lane fetches its 4 heads' (m, l) ----
+    float lt = l;
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
-    float mh[G], lh[G];
-    decode_static_for<0, G>([&](auto Hc) {
-        constexpr int h = decltype(Hc)::value;
-        const float wh = row_bcastf<h>(wgt);     // the group's weight for head h (same for both halves of the DPP row)
-        mh[h] = row_bcastf<h>(mt);
-        lh[h] = row_bcastf<h>(lt);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float x = o[h][e] * wh;
-            x += __shfl_xor(x, 8, 64);           // the other row of the pair set
-            x += __shfl_xor(x, 16, 64);
-            x += __shfl_xor(x, 32, 64);
-            o[h][e] = x;
-        }
-    });
-    if (lane >= 8) return;                       // lanes 0..7: d chunks 0..7
     const float vs = load_ro(p.v_scale + hk);
 #pragma unroll
-    for (int h = 0; h < G; ++h) {
+    for (int i = 0; i < 4; ++i) {
+        const float lh = __uint_as_float(__builtin_amdgcn_ds_bpermute(head_lane4 + 4 * i, __float_as_uint(lt)));
+        const float mh = __uint_as_float(__builtin_amdgcn_ds_bpermute(head_lane4 + 4 * i, __float_as_uint(m)));
+        const int h = 4 * grp + i;
         if (h >= nq) continue;
         const int hq = hq0 + h;
-        const bool empty = !(lh[h] > 0.f);
-        const float inv = empty ? 0.f : vs / lh[h];
-        const float lse = empty ? INFINITY : (mh[h] + __builtin_amdgcn_logf(lh[h])) * 0.6931471805599453f;
+        const bool empty = !(lh > 0.f);
+        const float inv = empty ? 0.f : vs / lh;
+        const float lse = empty ? INFINITY : (mh + __builtin_amdgcn_logf(lh)) * 0.6931471805599453f;
         if (!partial) {
-            uint4 w4[2];
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {
-                w4[hlf].x = pack2<T>(o[h][8 * hlf + 0] * inv, o[h][8 * hlf + 1] * inv);
-                w4[hlf].y = pack2<T>(o[h][8 * hlf + 2] * inv, o[h][8 * hlf + 3] * inv);
-                w4[hlf].z = pack2<T>(o[h][8 * hlf + 4] * inv, o[h][8 * hlf + 5] * inv);
-                w4[hlf].w = pack2<T>(o[h][8 * hlf + 6] * inv, o[h][8 * hlf + 7] * inv);
-            }
-            uint4 *dst = reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + vc * 16);
-            dst[0] = w4[0];
-            dst[1] = w4[1];
-            if (p.lse && vc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
+            uint4 w4;
+            w4.x = pack2<T>(o[0][i] * inv, o[1][i] * inv);
+            w4.y = pack2<T>(o[2][i] * inv, o[3][i] * inv);
+            w4.z = pack2<T>(o[4][i] * inv, o[5][i] * inv);
+            w4.w = pack2<T>(o[6][i] * inv, o[7][i] * inv);
+            *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + col * 8) = w4;
+            if (p.lse && col == 0) p.lse[(int64_t)b * p.h + hq] = lse;
         } else {
             const int64_t row = wk.prow + h;
-            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + vc * 16);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-                dst[q4] = make_float4(o[h][4 * q4] * inv, o[h][4 * q4 + 1] * inv, o[h][4 * q4 + 2] * inv, o[h][4 * q4 + 3] * inv);
-            if (vc == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
+            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + col * 8);
+            dst[0] = make_float4(o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
+            dst[1] = make_float4(o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
+            if (col == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
         }
     }
 }
 
-template <typename T, int G, int P, bool NT, bool STREAM, int NWG = 1>
-__global__ void __launch_bounds__(64 * NWG, 2) paged_decode_fp8_mqk_kernel(const DecodeParams p) {
-    decode_run_items<STREAM, NWG>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_mqk_item<T, G, P, NT>(pp, wk); });
+template <typename T, int P, bool NT, bool STREAM, int NWG = 1>
+__global__ void __launch_bounds__(64 * NWG, 2) paged_decode_fp8_mma_kernel(const DecodeParams p) {
+    decode_run_items<STREAM, NWG>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_mma_item<T, P, NT>(pp, wk); });
 }
-
 
 // ------------------------------------------------------------------------------------------
 // host side: the launches only (planning, scratch and the combine kernel: launch_decode_fp8 in paged_decode.hip)
 // ------------------------------------------------------------------------------------------
 #ifndef ATOMA_FP8_P
-#define ATOMA_FP8_P 3      // 16-token tiles (4 KiB) in flight per wavefront; -DATOMA_FP8_P=4/5 builds are probe variants (make fp8p)
+#define ATOMA_FP8_P 4      // 16-token tiles (4 KiB) in flight per wavefront; -DATOMA_FP8_P=4/5 builds are probe variants (make fp8p)
 #endif
 int decode_fp8_tiles_in_flight() { return ATOMA_FP8_P; }
+int decode_fp8_mma_group() { return FP8_MMA_G; }
 
 template <typename T, int G, bool NT, bool STREAM>
-static void launch_fp8_tgns(const DecodeParams &p, bool mqk, bool wg8, int64_t blocks, hipStream_t stream) {
-    if (wg8) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, ATOMA_FP8_P, NT, STREAM, 8>), dim3((unsigned)cdiv(blocks, 8)), dim3(512), 0, stream, p);
-    else if (mqk) hipLaunchKernelGGL((paged_decode_fp8_mqk_kernel<T, G, ATOMA_FP8_P, NT, STREAM>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
-    else hipLaunchKernelGGL((paged_decode_fp8_kernel<T, G, ATOMA_FP8_P, NT, STREAM>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+static void launch_fp8_dot2(const DecodeParams &p, int64_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL((paged_decode_fp8_kernel<T, G, ATOMA_FP8_P, NT, STREAM>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
 }
-template <typename T, int G>
-static void launch_fp8_tg(const DecodeParams &p, bool nt, bool mqk, bool wg8, int64_t blocks, hipStream_t stream) {
-    const bool balanced = p.stream_waves > 0;
-    if (nt) { if (balanced) launch_fp8_tgns<T, G, true, true>(p, mqk, wg8, blocks, stream); else launch_fp8_tgns<T, G, true, false>(p, mqk, wg8, blocks, stream); }
-    else { if (balanced) launch_fp8_tgns<T, G, false, true>(p, mqk, wg8, blocks, stream); else launch_fp8_tgns<T, G, false, false>(p, mqk, wg8, blocks, stream); }
+template <typename T, bool NT, bool STREAM>
+static void launch_fp8_mma(const DecodeParams &p, bool wg8, int64_t blocks, hipStream_t stream) {
+    if (wg8) hipLaunchKernelGGL((paged_decode_fp8_mma_kernel<T, ATOMA_FP8_P, NT, STREAM, 8>), dim3((unsigned)cdiv(blocks, 8)), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((paged_decode_fp8_mma_kernel<T, ATOMA_FP8_P, NT, STREAM>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+}
+template <typename T, bool NT, bool STREAM>
+static void launch_fp8_tns(const DecodeParams &p, int G, bool mqk, bool wg8, int64_t blocks, hipStream_t stream) {
+    if (mqk) return launch_fp8_mma<T, NT, STREAM>(p, wg8, blocks, stream);
+    switch (G) {
+        case 1: launch_fp8_dot2<T, 1, NT, STREAM>(p, blocks, stream); break;
+        case 2: launch_fp8_dot2<T, 2, NT, STREAM>(p, blocks, stream); break;
+        default: launch_fp8_dot2<T, 4, NT, STREAM>(p, blocks, stream); break;
+    }
 }
 template <typename T>
 static void launch_fp8_t(const DecodeParams &p, int G, bool nt, bool mqk, bool wg8, int64_t blocks, hipStream_t stream) {
-    switch (G) {
-        case 1: launch_fp8_tg<T, 1>(p, nt, mqk, wg8, blocks, stream); break;
-        case 2: launch_fp8_tg<T, 2>(p, nt, mqk, wg8, blocks, stream); break;
-        default: launch_fp8_tg<T, 4>(p, nt, mqk, wg8, blocks, stream); break;
-    }
+    const bool balanced = p.stream_waves > 0;
+    if (nt) { if (balanced) launch_fp8_tns<T, true, true>(p, G, mqk, wg8, blocks, stream); else launch_fp8_tns<T, true, false>(p, G, mqk, wg8, blocks, stream); }
+    else { if (balanced) launch_fp8_tns<T, false, true>(p, G, mqk, wg8, blocks, stream); else launch_fp8_tns<T, false, false>(p, G, mqk, wg8, blocks, stream); }
 }
 void launch_fp8_kernels(const DecodeParams &p, int G, bool is_bf16, bool nt, bool mqk, bool wg8, int64_t blocks, hipStream_t stream) {
     if (is_bf16) launch_fp8_t<bf16_t>(p, G, nt, mqk, wg8, blocks, stream);
