@@ -1055,20 +1055,22 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
     p.gchunks = (int)cdiv(g, G);
     if (p.num_splits <= 0) {
         const int64_t waves = (int64_t)p.b * p.h_k * p.gchunks;
-        const int cap = (G >= 8 && D >= 128 && !use_mqk) ? 4 : 8;   // resident wavefronts per CU of the variant that will run
+        const int cap = (!fp8 && G >= 8 && D >= 128 && !use_mqk) ? 4 : 8;   // wavefronts per CU to split for: the 512-register dot2 variant keeps 4 resident, all others 8+
         const int wpc_opt = decode_options().waves_per_cu;
         const int wpc = wpc_opt > 0 ? wpc_opt : cap;
         p.num_splits = decode_num_splits(waves, p.seqlen_k, wpc, std::max(1, decode_options().min_tiles.load()));
     }
     p.group_tile = G;
-    // The balanced line also for uniform batches that are resident at once (option decode_stream: 0 = no balanced mode at all, 1 = ragged batches and, where measured
-    // faster, uniform ones, 2 = always, 3 = ragged batches only): the line is kv-head major, so the wavefronts an XCD receives back to back are the SAME head of 32 sequences and the 8
-    // wavefronts that land on one CU are the 8 kv heads of ONE sequence -- they walk the same token rows together.  Kernels whose K
-    // operand layout asks for half lines gain most (fp8: C2a 0.400 -> 0.347 ms; bf16 matrix-core kernel at 8 q heads per kv head, the
-    // 70B shape: 0.746 -> 0.677 ms); the dot2 kernels, whose requests are whole lines, are level (d = 128) or lose (d = 64):
-    // tools/probes/fp8_modes.sh, stream_force_ab.sh.
+    // The balanced line also for uniform batches that are resident at once (option decode_stream: 0 = no balanced mode at all, 1 = ragged
+    // batches and, where measured faster, uniform ones, 2 = always, 3 = ragged batches only).  The line is kv-head major: the wavefronts an
+    // XCD receives back to back are the SAME head of 32 sequences, so the 8 wavefronts that land on one CU are the 8 kv heads of ONE
+    // sequence and walk the same token rows together (with the kv head fastest, a CU holds 8 unrelated sequences of one head).  Measured
+    // (tools/probes/fp8_modes.sh, stream_force_ab.sh, bench.py): the headline workload 6.12 -> 6.41 TB/s (0.77 -> 0.81 of HBM); fp8 C2a
+    // 0.400 -> 0.347 ms; the bf16 matrix-core kernel on the 70B shape 0.746 -> 0.677 ms; MHA (32 kv heads) level; d = 64 loses 8 %
+    // (0.385 -> 0.42 ms), so d = 64 keeps the old order.  Neither rotating the kv head by the sequence index nor dealing the sequences
+    // of a block of 8 to the 8 XCDs (all heads of a sequence behind one L2) reproduces it: it is the CU, not the XCD, that matters.
     const int st_opt = decode_options().stream;
-    p.stream_force = st_opt == 2 || (st_opt == 1 && p.h_k > 1 && (fp8 || use_mqk));
+    p.stream_force = st_opt == 2 || (st_opt == 1 && p.h_k > 1 && D == 128);
     p.fp8_klines = decode_options().fp8_klines;
     p.stream_waves = 0;
     const int64_t hk_chunks = (int64_t)p.h_k * p.gchunks, max_tiles = cdiv(p.seqlen_k, 16);

@@ -13,8 +13,9 @@ namespace atoma {
 //   * fp8 -> bf16 is exact: v_cvt_scalef32_pk_bf16_fp8 with scale 1.0 turns two bytes into one packed bf16 pair (8 per
 //     16-byte load), after which q.k and P.V are the same v_dot2c streams as in the 16-bit kernel;
 //   * the K scale folds into the softmax scale (scores = k_scale * q.k_q), the V scale into the final 1/l -- nothing per element.
-// Same work mapping, split-KV / balanced modes and combine kernel as the 16-bit path.  Groups of more than 4 q heads run
-// in chunks of 4 (K/V re-read per chunk).
+// Same work mapping, split-KV / balanced modes and combine kernel as the 16-bit path.  This first kernel (v_dot2c for both products,
+// option decode_fp8_mqk = 0) runs groups of more than 4 q heads in chunks of 4 (K/V re-read per chunk); the default is the matrix-core
+// kernel further down (paged_decode_fp8_mma_kernel), which takes up to 16 q heads in one pass.
 // ------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ uint32_t fp8x2_to_pair(uint32_t word, bool hi);
 template <> __device__ __forceinline__ uint32_t fp8x2_to_pair<bf16_t>(uint32_t word, bool hi) {

@@ -190,7 +190,7 @@ int atoma_linear_decode_qkv_rope_cache(const void *x, const void *w_qkv, void *q
  * atoma_paged_decode_fp8: flash_attn_kv_cache_full (csrc/src/lib.rs:1521-1855) for seqlen_q = 1 over such a cache:
  *   q [batch, h, 128] / o in f16 / bf16 (strides in elements), block_table int32 [batch, max_blocks], seqlens_k int32 [batch]
  *   on the device; cache strides in bytes; scores = softmax_scale * k_scale[hk] * (q . k_q), O = v_scale[hk] * softmax . v_q.
- *   head_dim 128 only; groups of more than 4 q heads per kv head run in chunks of 4. */
+ *   head_dim 128 only; up to 16 q heads per kv head in one pass over K / V (larger groups in chunks of 16). */
 int atoma_reshape_and_cache_flash_fp8(const void *key, const void *value, void *key_cache, void *value_cache, const int64_t *slot_mapping,
                                       const float *k_scale, const float *v_scale, int64_t block_stride, int64_t num_tokens, int64_t num_heads,
                                       int64_t head_size, int64_t block_size, int64_t key_stride, int64_t value_stride, int src_dtype, void *stream);

@@ -125,7 +125,7 @@ def bench_decode_fp8():
     rng = np.random.default_rng(0)
     for name, B, S, h, hk, ragged in (("C2a over fp8 KV: B=256 h=32 hk=8 S=4096", 256, 4096, 32, 8, False),
                                       ("C2c over fp8 KV: ragged U[2048,4096]", 256, 4096, 32, 8, True),
-                                      ("fp8 KV, 70B TP=8 shard: B=64 h=8 hk=1 S=4096 (two chunks of 4 heads)", 64, 4096, 8, 1, False),
+                                      ("fp8 KV, 70B TP=8 shard: B=64 h=8 hk=1 S=4096 (8 q heads in one pass)", 64, 4096, 8, 1, False),
                                       ("fp8 KV, B=16 S=8192", 16, 8192, 32, 8, False)):
         if os.environ.get("ATOMA_FP8_SHAPE") and os.environ["ATOMA_FP8_SHAPE"] not in name:   # one shape, for counter passes
             continue
