@@ -869,7 +869,7 @@ struct DecodeOptions {
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
     opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
     opt_int fp8_klines{env_int("ATOMA_DECODE_FP8_KLINES", 1)};   // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays, 2 always
-    opt_int mqk{env_int("ATOMA_DECODE_MQK", 5)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches
+    opt_int mqk{env_int("ATOMA_DECODE_MQK", 13)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches, bit 3 = groups of 2..4 on the balanced line
 };
 static DecodeOptions &decode_options() {
     static DecodeOptions o;
@@ -1079,7 +1079,13 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
         // enough wavefronts without splitting and the lengths are on the device: the kernel balances ragged batches itself
         p.stream_waves = (int)std::min<int64_t>(p.b * hk_chunks, (int64_t)device_num_cus() * DECODE_STREAM_MAX_WAVES_PER_CU);   // upper bound, set per kernel at launch
     }
-    DecodeLaunchPlan lp{G, use_mqk, 0, 0};
+    // bit 3 of decode_mqk: groups of 2..4 q heads take the matrix-core kernel when the launch runs on the balanced line.  In the
+    // per-sequence order the two kernels tied (or dot2 won by 2-3 %); on the line the matrix-core kernel's shorter instruction stream
+    // shows: headline 6.35 -> 6.6 TB/s, C2a 0.703 -> 0.662 ms, ragged 0.567 -> 0.535, B = 256 x 1024 0.190 -> 0.175; split-KV launches
+    // (+3 %) and MHA (+17 %) keep dot2 (tools/probes/mqk_ab.sh).  Same G, same scratch: only the kernel changes.
+    bool mqk_line = false;
+    if (!fp8 && !use_mqk && D == 128 && g >= 2 && g <= 4 && p.stream_waves > 0 && (mqk_opt & 8)) mqk_line = true;
+    DecodeLaunchPlan lp{G, use_mqk || mqk_line, 0, 0};
     if (p.num_splits > 1 || p.stream_waves > 0) {
         lp.rows = p.stream_waves > 0 ? (size_t)p.stream_waves * 2 * G : (size_t)p.num_splits * p.b * p.h;
         // plan: [0], [1], then b + 1 prefix entries (decode_run_items writes plan[2 + i] for i = 0..b, the combine kernel reads plan[3 + b])

@@ -188,6 +188,37 @@ def test_decode_large_batch_balanced_mode(gpu, kind):
     np.testing.assert_allclose(lse[~empty], lse2[~empty], rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("uniform", [False, True], ids=["ragged", "uniform"])
+@pytest.mark.parametrize("mqk", [13, 5], ids=["mfma-on-the-line", "dot2"])
+@pytest.mark.parametrize("dtype,h,hk", [(BF16, 32, 8), (F16, 6, 2), (BF16, 4, 2)])
+def test_decode_small_groups_on_the_balanced_line(gpu, dtype, h, hk, mqk, uniform):
+    """Groups of 2..4 q heads at d = 128 with several kv heads: every resident launch takes the kv-head-major line (uniform batches
+    too), by default with the matrix-core kernel (bit 3 of decode_mqk), with the dot2 kernel when that bit is off.  Both against the
+    oracle; the dispatcher's choice is read back."""
+    rng = np.random.default_rng(17 + h)
+    d, page = 128, 16
+    B = 1100 // hk + 3
+    lens = np.full(B, 300, np.int32) if uniform else rng.integers(1, 400, B).astype(np.int32)
+    if not uniform:
+        lens[5], lens[B // 2] = 0, 3000
+    nb = int(sum((int(x) + page - 1) // page for x in lens)) + 1
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+    q = rand_half(rng, (B, 1, h, d), dtype)
+    ref = _oracle_decode(q, kc, vc, bt, lens, dtype)
+    with _options(gpu, decode_mqk=mqk):
+        out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+        name = gpu.lib.atoma_last_decode_kernel().decode()
+    assert ("paged_decode_mqk_kernel" in name) == (mqk == 13) and "balanced" in name, name
+    for i, L in enumerate(lens):
+        assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"seq {i} (L={L})")
+    if not uniform:
+        assert not out[5].any() and np.isposinf(lse[5]).all()
+    with _options(gpu, decode_mqk=mqk, decode_stream=3):      # the per-sequence order for uniform batches: same numbers up to the tolerance
+        out3, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+    for i, L in enumerate(lens):
+        assert_close(out3[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"decode_stream=3 seq {i} (L={L})")
+
+
 @pytest.mark.parametrize("dtype,h,hk", [(BF16, 16, 2), (F16, 8, 8), (BF16, 12, 2)])
 def test_decode_balanced_mode_head_layouts(gpu, dtype, h, hk):
     """Balanced mode with the matrix-core kernel (groups of 8 and 6), MHA, f16, d = 128, page 32, ALiBi off."""
@@ -395,7 +426,7 @@ def test_decode_large_groups_both_kernels_agree(gpu):
         for mqk in (1, 0):
             assert gpu.lib.atoma_set_option(b"decode_mqk", mqk) == 0
             res[mqk] = gpu_decode(gpu, q, c["kc"], c["vc"], c["bt"], c["lens"], 0.088, BF16, alibi=c["alibi"])
-        gpu.lib.atoma_set_option(b"decode_mqk", 5)
+        gpu.lib.atoma_set_option(b"decode_mqk", 13)
         assert_close(res[1][0], res[0][0], BF16, atol=ATOL_VS_F32[BF16], what=f"{name}: matrix-core vs dot2 kernel")
         assert np.allclose(res[1][1], res[0][1], rtol=1e-5, atol=1e-5), name
         ref = A.flash_attn_kv_cache(q, c["kc"], c["vc"], 0.088, BF16, c["bt"], c["lens"], causal=True, alibi_slopes=c["alibi"])
@@ -430,7 +461,7 @@ def test_decode_full_size_70b_shape_properties(gpu):
 
 class _options:
     """atoma_set_option for the duration of a test (defaults restored afterwards)."""
-    DEFAULTS = {"decode_mqk": 5, "decode_min_tiles": 8, "decode_stream": 1}
+    DEFAULTS = {"decode_mqk": 13, "decode_min_tiles": 8, "decode_stream": 1}
 
     def __init__(self, gpu, **kw):
         self.gpu, self.kw = gpu, kw
