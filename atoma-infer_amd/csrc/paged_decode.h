@@ -41,6 +41,7 @@ struct DecodeParams {
     const float *k_scale, *v_scale;   // fp8 (e4m3fn) KV cache: per-kv-head dequantisation scales [h_k]; null for 16-bit caches
     int wg_splits;         // > 0: workgroup-merged split mode (paged_decode_wg_kernel): KV pieces per sequence = wg_splits x wavefronts per workgroup
     unsigned *counters;    // ... and its arrival counter per (sequence, kv head, q-head chunk), zero between launches
+    int head_major;        // 1: workgroup id -> (kv head, chunk) slowest, (split, sequence) fastest (decode_map_work)
     int stream_force;      // the balanced line also for uniform resident batches (decode_plan_launch says when)
     int fp8_klines;        // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays (not on the balanced line, not with a single kv head: contiguous rows), 2 always
     int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
@@ -98,10 +99,19 @@ struct DecodeWork {
     bool balanced;     // this piece is a range of the balanced line (the fp8 kernel fetches K differently there)
     float *sink_o, *sink_lse;   // SINK variants of the item functions: this wavefront's normalised O [heads][D] and LSE [heads] go here (LDS)
 };
-__device__ __forceinline__ void decode_map_work(const DecodeParams &p, int id, DecodeWork &w) {
+__device__ __forceinline__ void decode_map_work(const DecodeParams &p, int id, DecodeWork &w, bool allow_head_major = true) {
     const int hk_chunks = p.h_k * p.gchunks;
-    const int hkc = id % hk_chunks;
-    id /= hk_chunks;
+    int hkc;
+    if (allow_head_major && p.head_major) {
+        // kv-head major, as the balanced line: the workgroups an XCD receives back to back are the same head of consecutive pieces, so
+        // the wavefronts that share a CU are the kv heads of ONE piece (exactly so when pieces / 8 is a multiple of the 32 CUs of an XCD)
+        const int pieces = p.b * p.num_splits;
+        hkc = id / pieces;
+        id -= hkc * pieces;
+    } else {
+        hkc = id % hk_chunks;
+        id /= hk_chunks;
+    }
     w.b = id % p.b;
     w.split = id / p.b;
     w.hk = hkc / p.gchunks;
@@ -190,7 +200,7 @@ template <bool STREAM, int NWG = 1, typename F> __device__ __forceinline__ void 
     const int wid = NWG == 1 ? (int)blockIdx.x : (int)blockIdx.x * NWG + (int)(threadIdx.x >> 6);
     if (NWG > 1 && (int64_t)wid >= (int64_t)p0.b * p0.num_splits * p0.h_k * p0.gchunks) return;
     if constexpr (!STREAM) {
-        decode_map_work(p0, wid, wk);
+        decode_map_work(p0, wid, wk, NWG == 1);
         item(p0, wk);
     } else {
         __shared__ int cum[DECODE_STREAM_MAX_B + 1];
@@ -243,7 +253,7 @@ template <bool STREAM, int NWG = 1, typename F> __device__ __forceinline__ void 
                 wk.balanced = true;
                 wk.prow = ((int64_t)lw * 2 + (first ? 0 : 1)) * p.group_tile;
             } else {
-                decode_map_work(p, wid, wk);   // one wavefront per (sequence, kv head), final output
+                decode_map_work(p, wid, wk, NWG == 1);   // one wavefront per (sequence, kv head), final output
             }
             item(p, wk);
             if (!stream) break;

@@ -865,10 +865,11 @@ struct DecodeOptions {
     opt_int stream_waves_per_cu{env_int("ATOMA_DECODE_STREAM_WAVES_PER_CU", 0)};   // 0 = resident capacity
     opt_int waves_per_cu{env_int("ATOMA_DECODE_WAVES_PER_CU", 0)};   // 0 = resident capacity
     opt_int min_tiles{env_int("ATOMA_DECODE_MIN_TILES", 8)};
-    opt_int fp8_wg{env_int("ATOMA_DECODE_FP8_WG", 1)};     // fp8 KV cache: 8 wavefronts (the kv heads of a sequence) per workgroup: 0 never, 1 split-KV launches, 2 always
+    opt_int fp8_wg{env_int("ATOMA_DECODE_FP8_WG", 0)};     // fp8 KV cache: 8 wavefronts (the kv heads of a sequence) per workgroup: 0 never (default since the kv-head-major order does the same for free), 1 split-KV launches, 2 always
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
     opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
     opt_int fp8_klines{env_int("ATOMA_DECODE_FP8_KLINES", 1)};   // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays, 2 always
+    opt_int head_major{env_int("ATOMA_DECODE_HEAD_MAJOR", 1)};   // workgroup order of the non-balanced launches: kv head slowest (1) or fastest (0)
     opt_int mqk{env_int("ATOMA_DECODE_MQK", 13)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches, bit 3 = groups of 2..4 on the balanced line
 };
 static DecodeOptions &decode_options() {
@@ -891,6 +892,7 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_wg_merge") o.wg_merge = value;
     else if (name == "decode_fp8_mqk") o.fp8_mqk = value;
     else if (name == "decode_fp8_wg") o.fp8_wg = value;
+    else if (name == "decode_head_major") o.head_major = value;
     else if (name == "decode_fp8_klines") o.fp8_klines = value;
     else return false;
     return true;
@@ -1072,6 +1074,7 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
     const int st_opt = decode_options().stream;
     p.stream_force = st_opt == 2 || (st_opt == 1 && p.h_k > 1 && D == 128);
     p.fp8_klines = decode_options().fp8_klines;
+    p.head_major = decode_options().head_major != 0 && p.h_k > 1;
     p.stream_waves = 0;
     const int64_t hk_chunks = (int64_t)p.h_k * p.gchunks, max_tiles = cdiv(p.seqlen_k, 16);
     if (p.num_splits == 1 && st_opt != 0 && (p.cu_seqlens_k || p.seqused_k) && p.b <= DECODE_STREAM_MAX_B &&
@@ -1084,7 +1087,9 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
     // shows: headline 6.35 -> 6.6 TB/s, C2a 0.703 -> 0.662 ms, ragged 0.567 -> 0.535, B = 256 x 1024 0.190 -> 0.175; split-KV launches
     // (+3 %) and MHA (+17 %) keep dot2 (tools/probes/mqk_ab.sh).  Same G, same scratch: only the kernel changes.
     bool mqk_line = false;
-    if (!fp8 && !use_mqk && D == 128 && g >= 2 && g <= 4 && p.stream_waves > 0 && (mqk_opt & 8)) mqk_line = true;
+    // (only when uniform batches take the line too -- stream_force: in the per-sequence order the matrix-core kernel's half-line K
+    // requests cost 6 %: 0.744 against 0.702 ms)
+    if (!fp8 && !use_mqk && D == 128 && g >= 2 && g <= 4 && p.stream_waves > 0 && p.stream_force && (mqk_opt & 8)) mqk_line = true;
     DecodeLaunchPlan lp{G, use_mqk || mqk_line, 0, 0};
     if (p.num_splits > 1 || p.stream_waves > 0) {
         lp.rows = p.stream_waves > 0 ? (size_t)p.stream_waves * 2 * G : (size_t)p.num_splits * p.b * p.h;
@@ -1150,9 +1155,9 @@ static void launch_decode_fp8_g(DecodeParams &p, int G, hipStream_t stream) {
     if (p.stream_waves > 0) set_stream_waves(p, 8);   // __launch_bounds__(64, 2)
     const bool nt = decode_options().nt != 0;
     const bool mqk = decode_options().fp8_mqk != 0;
-    // 8 wavefronts per workgroup = the 8 kv-head slices (128 B each) of every token row read from one CU: whole 1 KiB rows
-    // (measured: uniform resident batches +7 %, split-KV batches +20 %; ragged batches in the balanced mode -15 %, where a
-    // workgroup's 8 wavefronts walk unrelated ranges -- so by default only launches that cannot take the balanced mode)
+    // 8 wavefronts per workgroup = the 8 kv-head slices (128 B each) of every token row read from one CU (round 2: +20 % on split-KV
+    // launches).  Round 3's kv-head-major workgroup order puts the same 8 wavefronts on one CU without tying them into a workgroup and
+    // is 4 % faster still (16 x 8192: 0.0503 -> 0.0483 ms), so this is opt-in now (decode_fp8_wg).
     const int wg_opt = decode_options().fp8_wg;
     const bool wg8 = mqk && ((int64_t)p.h_k * p.gchunks) % 8 == 0 && (wg_opt >= 2 || (wg_opt == 1 && p.stream_waves == 0));
     note_decode_kernel(mqk ? "paged_decode_fp8_mma_kernel" : "paged_decode_fp8_kernel", decode_tname<T>(), 128, G, decode_fp8_tiles_in_flight(), nt,

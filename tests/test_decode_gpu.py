@@ -213,10 +213,29 @@ def test_decode_small_groups_on_the_balanced_line(gpu, dtype, h, hk, mqk, unifor
         assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"seq {i} (L={L})")
     if not uniform:
         assert not out[5].any() and np.isposinf(lse[5]).all()
-    with _options(gpu, decode_mqk=mqk, decode_stream=3):      # the per-sequence order for uniform batches: same numbers up to the tolerance
+    with _options(gpu, decode_mqk=mqk, decode_stream=3):      # the per-sequence order for uniform batches (dot2 kernel): same numbers up to the tolerance
         out3, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
     for i, L in enumerate(lens):
         assert_close(out3[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"decode_stream=3 seq {i} (L={L})")
+
+
+@pytest.mark.parametrize("B,L,h,hk,d", [(16, 3000, 32, 8, 128), (3, 5000, 16, 2, 128), (40, 900, 8, 8, 64), (7, 2000, 64, 8, 128)])
+def test_decode_workgroup_order_does_not_change_the_bits(gpu, B, L, h, hk, d):
+    """Split-KV and small resident launches: kv head slowest (default: the wavefronts that share a CU are the kv heads of one piece)
+    against kv head fastest -- the same pieces, computed somewhere else."""
+    rng = np.random.default_rng(B + L)
+    page = 16
+    lens = rng.integers(L // 2, L + 1, B).astype(np.int32)
+    nb = int(sum((int(x) + page - 1) // page for x in lens)) + 1
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
+    with _options(gpu, decode_head_major=0):
+        out0, lse0 = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
+    assert np.array_equal(out, out0) and np.array_equal(lse, lse0)
+    ref = _oracle_decode(q, kc, vc, bt, lens, BF16)
+    for i, Li in enumerate(lens):
+        assert_close(out[i], ref[i], BF16, atol=attn_atol(BF16, Li), what=f"seq {i} (L={Li})")
 
 
 @pytest.mark.parametrize("dtype,h,hk", [(BF16, 16, 2), (F16, 8, 8), (BF16, 12, 2)])
@@ -461,7 +480,7 @@ def test_decode_full_size_70b_shape_properties(gpu):
 
 class _options:
     """atoma_set_option for the duration of a test (defaults restored afterwards)."""
-    DEFAULTS = {"decode_mqk": 13, "decode_min_tiles": 8, "decode_stream": 1}
+    DEFAULTS = {"decode_mqk": 13, "decode_min_tiles": 8, "decode_stream": 1, "decode_head_major": 1}
 
     def __init__(self, gpu, **kw):
         self.gpu, self.kw = gpu, kw

@@ -197,6 +197,27 @@ def test_decode_fp8_other_page_layouts_bit_identical(gpu, qk_variant, h, hk):
         assert np.array_equal(out, base), "padded rows"
 
 
+def test_decode_fp8_launch_orders_bit_identical(gpu):
+    """The workgroup order (kv head slowest, the default; kv head fastest; 8 wavefronts = the 8 kv heads of a sequence per workgroup,
+    option decode_fp8_wg) changes where a piece runs, never what it computes: same bits for a split sequence, a small resident batch
+    and a ragged batch on the balanced line."""
+    rng = np.random.default_rng(77)
+    h, hk, d, page = 32, 8, 128, 16
+    sc = np.float32(d ** -0.5)
+    for lens in (np.array([5000, 4000], np.int32), np.array([0, 1, 17, 64, 333, 600] * 3, np.int32), rng.integers(1, 700, 160).astype(np.int32)):
+        nb = int(sum((L + page - 1) // page for L in lens)) + 2
+        kc8, vc8, ks, vs, bt = make_fp8_cache(rng, nb, page, hk, d, lens)
+        q = rand_half(rng, (len(lens), h, d), BF16)
+        base = gpu_decode_fp8(gpu, q, kc8, vc8, ks, vs, bt, lens, sc, BF16)
+        for opt, val, restore in ((b"decode_head_major", 0, 1), (b"decode_fp8_wg", 2, 0)):
+            assert gpu.lib.atoma_set_option(opt, val) == 0
+            try:
+                out = gpu_decode_fp8(gpu, q, kc8, vc8, ks, vs, bt, lens, sc, BF16)
+            finally:
+                gpu.lib.atoma_set_option(opt, restore)
+            assert np.array_equal(out, base), opt
+
+
 def test_decode_fp8_rejects_bad_arguments(gpu):
     d = gpu.DeviceBuffer(4096)
     args = lambda **kw: [d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, d.ptr, kw.get("b", 1), kw.get("h", 8), kw.get("hk", 2), kw.get("d", 128), 4,

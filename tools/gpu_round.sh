@@ -25,6 +25,8 @@ cd $REPO
 # the decode kernels' launch orders / K fetch formats (fp8: uniform and ragged batches x balanced line x full-line K; bf16: uniform batches through the balanced line)
 (timeout 300 bash tools/probes/fp8_modes.sh 2>&1 | grep "==\|ms" | cut -c1-150) > $OUT/fp8_modes_$TAG.txt
 (timeout 300 bash tools/probes/stream_force_ab.sh 2>&1 | grep "==\|ms" | cut -c1-150) > $OUT/stream_force_ab_$TAG.txt
+(timeout 300 bash tools/probes/mqk_ab.sh 2>&1 | grep "==\|ms" | cut -c1-150) > $OUT/mqk_ab_$TAG.txt
+(timeout 400 bash tools/probes/headline_knobs.sh 2>&1) > $OUT/headline_knobs_$TAG.txt
 (timeout 1500 python tools/bench_kernels.py decode decode_fp8 prefill prefill_paged cache norm sampling linear linear_mid linear_big graph step swap prep 2>&1) > $OUT/kernels_$TAG.jsonl
 (timeout 400 python tools/engine_trace.py 2>&1 | tail -1) > $OUT/trace_$TAG.json
 (timeout 400 python tools/engine_trace.py --model 70b-tp8-shard --requests 64 --prompt 4096 --decode-steps 256 2>&1 | tail -1) > $OUT/trace_70b_tp8_rank_$TAG.json

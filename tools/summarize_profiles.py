@@ -57,7 +57,8 @@ for src, dst in ((f"bench_{tag}.log", f"{tag}_bench.json"), (f"kernels_{tag}.jso
                  (f"trace_70b_tp8_rank_{tag}.json", f"{tag}_trace_70b_tp8_rank.json"), (f"tp_step_n1_{tag}.json", f"{tag}_tp_step_n1.json"),
                  (f"rank_step_{tag}.json", f"{tag}_rank_step.json"), (f"rank_step_r02route_{tag}.json", f"{tag}_rank_step_r02_route.json"),
                  (f"linear64_ab_{tag}.jsonl", f"{tag}_linear64_ab.jsonl"), (f"gemm64_probe_{tag}.txt", f"{tag}_gemm64_probe.txt"),
-                 (f"fp8_modes_{tag}.txt", f"{tag}_fp8_modes.txt"), (f"stream_force_ab_{tag}.txt", f"{tag}_stream_force_ab.txt")):
+                 (f"fp8_modes_{tag}.txt", f"{tag}_fp8_modes.txt"), (f"stream_force_ab_{tag}.txt", f"{tag}_stream_force_ab.txt"),
+                 (f"mqk_ab_{tag}.txt", f"{tag}_mqk_ab.txt"), (f"headline_knobs_{tag}.txt", f"{tag}_headline_knobs.txt")):
     p = os.path.join(root, "gpurun_out", src)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(out, dst))
