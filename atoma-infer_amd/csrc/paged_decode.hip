@@ -1112,6 +1112,11 @@ size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k
         p.cu_seqlens_k = &dummy;   // lengths on the device: the balanced mode is reachable
         p.num_splits = 0;
         worst = std::max(worst, decode_plan_launch(p, d).bytes);
+        if (d == 128) {   // the same heads over an fp8 cache: up to 16 q heads per wavefront, so more partial rows on the balanced line
+            DecodeParams p8 = p;
+            p8.num_splits = 0;
+            worst = std::max(worst, decode_plan_launch(p8, d, true).bytes);
+        }
     }
     return worst;
 }

@@ -139,6 +139,48 @@ def test_warmup_makes_first_call_capturable(gpu):
     assert gpu.lib.atoma_warmup(st.s, 0, 8, 2, 128, 4096, 0) == -1 and "invalid" in gpu.last_error()
 
 
+def test_warmup_covers_the_balanced_line_of_both_caches(gpu):
+    """A resident batch (uniform, d = 128, 4 kv heads) takes the balanced line -- partial slots for every wavefront, 16 q heads wide over
+    an fp8 cache: atoma_warmup must have reserved them, for the 16-bit and the fp8 cache alike, so that the FIRST call can be a capture."""
+    from oracle import fp8_oracle as F8
+    assert gpu.lib.atoma_release_workspaces() == 0
+    rng = np.random.default_rng(12)
+    B, L, h, hk, d, page = 300, 200, 16, 4, 128, 16
+    st = gpu.Stream()
+    assert gpu.lib.atoma_warmup(st.s, B, h, hk, d, 4096, 0) == 0, gpu.last_error()
+    call, do, shape, ref, keep = _decode_case(gpu, rng, B, L, h=h, hk=hk)
+    with gpu.Graph.capture(st) as g:
+        call(st)
+    g.launch()
+    st.synchronize()
+    assert "balanced" in gpu.lib.atoma_last_decode_kernel().decode()
+    assert_close(do.numpy(np.uint16, shape), ref, BF16, atol=ATOL_VS_F32[BF16], what="16-bit cache, captured without an eager call")
+    # the same heads over an fp8 cache
+    lens = np.full(B, L, np.int32)
+    nb = B * ((L + page - 1) // page) + 1
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens)
+    ks, vs = np.full(hk, 0.02, np.float32), np.full(hk, 0.02, np.float32)
+    kc8 = F8.quantize(kc.reshape(-1, hk, d), BF16, ks).reshape(nb, page, hk, d)
+    vc8 = F8.quantize(vc.reshape(-1, hk, d), BF16, vs).reshape(nb, page, hk, d)
+    q = rand_half(rng, (B, h, d), BF16)
+    dq, dk, dv, dbt, dl, dks, dvs = (gpu.DeviceBuffer.from_numpy(a) for a in (q, kc8, vc8, np.ascontiguousarray(bt, np.int32), lens, ks, vs))
+    do8 = gpu.DeviceBuffer(q.nbytes)
+
+    def call8(stream):
+        rc = gpu.lib.atoma_paged_decode_fp8(dq.ptr, dk.ptr, dv.ptr, do8.ptr, dks.ptr, dvs.ptr, dbt.ptr, dl.ptr, B, h, hk, d, bt.shape[1], page,
+                                            h * d, d, h * d, d, page * hk * d, hk * d, d, float(d ** -0.5), BF16, stream)
+        assert rc == 0, gpu.last_error()
+    with gpu.Graph.capture(st) as g8:
+        call8(st.s)
+    g8.launch()
+    st.synchronize()
+    got = do8.numpy(np.uint16, q.shape).copy()
+    do8.fill_bytes(0)
+    call8(st.s)
+    st.synchronize()
+    assert np.array_equal(got, do8.numpy(np.uint16, q.shape)), "fp8 cache: replay of a first-call capture equals the eager call"
+
+
 def test_warmup_makes_projection_with_in_launch_merge_capturable(gpu):
     """The 17..64-row projection kernel merges its K splits inside the launch: arrival counters, fp32 tiles in the stream's scratch and a
     raised LDS limit.  After atoma_warmup (counters + the limit for every variant; extra_bytes covers the tiles) a CAPTURE may be the
