@@ -237,7 +237,7 @@ def main():
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json"))):
             for kern, e in json.load(open(f)).items():
-                if "paged_decode_kernel" in kern and "hbm_traffic_bytes_per_launch" in e:
+                if "atoma::paged_decode" in kern and "fp8" not in kern and "hbm_traffic_bytes_per_launch" in e:
                     out["roofline"]["traffic"] = int(e["hbm_traffic_bytes_per_launch"])
                     out["roofline"]["traffic_source"] = os.path.relpath(f, ROOT)
 
@@ -362,7 +362,8 @@ def measure_traffic(argv):
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "paged_decode_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                    # the decode kernel the dispatcher took (paged_decode_kernel / paged_decode_mqk_kernel / ...), not the combine kernel
+                    if "atoma::paged_decode" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
                         vals.append(float(r["Counter_Value"]))
             shutil.rmtree(d, ignore_errors=True)
             if not vals:
