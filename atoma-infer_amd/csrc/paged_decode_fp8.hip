@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(64 * NWG, 2) paged_decode_fp8_mma_kernel(const
 // host side: the launches only (planning, scratch and the combine kernel: launch_decode_fp8 in paged_decode.hip)
 // ------------------------------------------------------------------------------------------
 #ifndef ATOMA_FP8_P
-#define ATOMA_FP8_P 4      // 16-token tiles (4 KiB) in flight per wavefront; -DATOMA_FP8_P=4/5 builds are probe variants (make fp8p)
+#define ATOMA_FP8_P 4      // 16-token tiles (4 KiB) in flight per wavefront (3: ragged batches -8 %; 5, 6, 8: level); -DATOMA_FP8_P=.. builds are probe variants (make fp8p)
 #endif
 int decode_fp8_tiles_in_flight() { return ATOMA_FP8_P; }
 int decode_fp8_mma_group() { return FP8_MMA_G; }

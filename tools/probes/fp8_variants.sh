@@ -5,7 +5,7 @@ OUT=$REPO/gpurun_out/fp8var
 mkdir -p $OUT
 cd $REPO
 for rep in 1 2; do
-for v in "" p4 p5 p6 p8 kl0; do
+for v in "" p3 p6 kl0; do
   lib=$REPO/atoma-infer_amd/lib/libatoma_hip.so
   [ -n "$v" ] && lib=$REPO/tools/probes/libatoma_hip_fp8$v.so
   ATOMA_HIP_LIB=$lib python tools/bench_kernels.py decode_fp8 2>&1 | sed "s/\"workload\": \"/\"workload\": \"[${v:-default}] /" >> $OUT/variants.jsonl
