@@ -118,9 +118,9 @@ def qk_variant(gpu, request):
 
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
-@pytest.mark.parametrize("h,hk,page", [(32, 8, 16), (8, 8, 16), (16, 8, 32), (6, 2, 16), (16, 2, 64)])
+@pytest.mark.parametrize("h,hk,page", [(32, 8, 16), (8, 8, 16), (16, 8, 32), (6, 2, 16), (16, 2, 64), (16, 1, 16), (40, 2, 16), (5, 1, 32), (13, 1, 16)])
 def test_decode_fp8_matches_oracle_ragged(gpu, qk_variant, dtype, h, hk, page):
-    """group sizes 1, 2, 3, 4 and 8 (one pass on the matrix cores, two chunks of 4 in the dot2 kernel), pages of 16 / 32 / 64, ragged lengths incl. the empty sequence"""
+    """group sizes 1, 2, 3, 4, 5, 8, 13, 16 and 20 (= 16 + 4: two passes of the matrix-core kernel) (one pass on the matrix cores, two chunks of 4 in the dot2 kernel), pages of 16 / 32 / 64, ragged lengths incl. the empty sequence"""
     rng = np.random.default_rng(h * 3 + hk + page)
     d = 128
     lens = np.array([0, 1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 200, 333, 600], np.int32)
