@@ -377,12 +377,11 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
     const int nq = min(G, p.g - gc * G);
 
     const float sl2 = p.scale_log2;
-    float m = -INFINITY, l = 0.f;        // online softmax state of head `col` over this lane group's tokens
-    float o[G][8];                       // O[head][d = 8.col ..+7] over this lane group's tokens
+    float m = -INFINITY, l = 0.f;        // head `col`: running max over ALL tokens seen (common to its 4 lane groups), sum over this lane group's tokens
+    f32x4_v o[8];                        // o[n][i] = O[head 4 grp + i][d = 8 col + n]  (P.V on the matrix cores: 32 registers for any group size)
 #pragma unroll
-    for (int h = 0; h < G; ++h)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[h][e] = 0.f;
+    for (int n = 0; n < 8; ++n) o[n] = f32x4_v{0.f, 0.f, 0.f, 0.f};
+    const int head_lane4 = ((lane & 48) + 4 * grp) << 2;     // ds_bpermute address of lane (grp, 4 grp): the state of head 4 grp + i sits in lane (grp, 4 grp + i)
 
     if (t0 < t1) {
         u32x4 qb[4];                     // Q^T operand, k-step s: q[head col][d = 32s + 8.grp ..+7]
@@ -480,42 +479,38 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
                 for (int i = 0; i < 4; ++i)
                     if (tok0 + i >= L) s[i] = -INFINITY;
             }
-            const float mnew = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), m);
+            // all 16 tokens of the tile enter ONE accumulator, so the max of head col is taken over its four lane groups
+            const float mnew = fmaxf(col_max4(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]))), m);
             if (__any(mnew > m)) {  // rescale only when some running max moved
                 const float ms = mnew == -INFINITY ? 0.f : mnew;
                 const float alpha = __builtin_amdgcn_exp2f(m - ms);
                 l *= alpha;
                 m = mnew;
-                decode_static_for<0, G>([&](auto Hc) {
-                    constexpr int h = decltype(Hc)::value;
-                    const float ah = row_bcastf<h>(alpha);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[h][e] *= ah;
-                });
+                for (int i = 0; i < 4; ++i) {
+                    const float ai = __uint_as_float(__builtin_amdgcn_ds_bpermute(head_lane4 + 4 * i, __float_as_uint(alpha)));
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) o[n][i] *= ai;
+                }
             }
             const float ms = m == -INFINITY ? 0.f : m;
             float pr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pr[i] = __builtin_amdgcn_exp2f(s[i] - ms);
             l += (pr[0] + pr[1]) + (pr[2] + pr[3]);
-            const uint32_t pk[2] = {pack_pair<T>(pr[0], pr[1]), pack_pair<T>(pr[2], pr[3])};   // head col, token pairs
-            // P.V on token pairs: (V[r0][e], V[r1][e]) . (p[r0], p[r1]) for every head of the group
+            // P.V as O[head][d] = P[head][token] . V[token][d] on v_mfma_f32_16x16x16: the A operand of lane (grp, col) is P[head col][tokens
+            // 4 grp ..+3] -- the four probabilities this lane has just computed; the B operand is V[tokens 4 grp ..+3][d = 8 col + n]: the
+            // lane's four V loads are exactly those rows and columns, paired along d, re-paired along the tokens with v_perm
+            // (16 instructions instead of 16 + 16 G v_dot2c and G row broadcasts)
+            const uint32_t pk01 = pack_pair<T>(pr[0], pr[1]), pk23 = pack_pair<T>(pr[2], pr[3]);
+            const uint32_t x0[4] = {vb[0].x, vb[0].y, vb[0].z, vb[0].w}, x1[4] = {vb[1].x, vb[1].y, vb[1].z, vb[1].w};
+            const uint32_t x2[4] = {vb[2].x, vb[2].y, vb[2].z, vb[2].w}, x3[4] = {vb[3].x, vb[3].y, vb[3].z, vb[3].w};
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                uint32_t ph[G];
-                decode_static_for<0, G>([&](auto Hc) { ph[decltype(Hc)::value] = row_bcast<decltype(Hc)::value>(pk[c]); });
-                const uint32_t a[4] = {vb[2 * c].x, vb[2 * c].y, vb[2 * c].z, vb[2 * c].w};
-                const uint32_t bb[4] = {vb[2 * c + 1].x, vb[2 * c + 1].y, vb[2 * c + 1].z, vb[2 * c + 1].w};
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint32_t lo = __builtin_amdgcn_perm(bb[w], a[w], 0x05040100u);  // (a.lo, b.lo)
-                    const uint32_t hi = __builtin_amdgcn_perm(bb[w], a[w], 0x07060302u);  // (a.hi, b.hi)
-#pragma unroll
-                    for (int h = 0; h < G; ++h) {
-                        o[h][2 * w] = dot2<T>(lo, ph[h], o[h][2 * w]);
-                        o[h][2 * w + 1] = dot2<T>(hi, ph[h], o[h][2 * w + 1]);
-                    }
-                }
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t e01 = __builtin_amdgcn_perm(x1[q], x0[q], 0x05040100u), e23 = __builtin_amdgcn_perm(x3[q], x2[q], 0x05040100u);
+                const uint32_t o01 = __builtin_amdgcn_perm(x1[q], x0[q], 0x07060302u), o23 = __builtin_amdgcn_perm(x3[q], x2[q], 0x07060302u);
+                o[2 * q] = mfma16k16<T>(pk01, pk23, e01, e23, o[2 * q]);
+                o[2 * q + 1] = mfma16k16<T>(pk01, pk23, o01, o23, o[2 * q + 1]);
             }
         };
 
@@ -564,55 +559,38 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
         }
     }
 
-    // ---- merge the four lane groups (each has its own m, l for head col and its own O) ----
-    float mt = m;
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float wgt = __builtin_amdgcn_exp2f(m - (mt == -INFINITY ? 0.f : mt));   // this group's weight for head col
-    float lt = l * wgt;
+    // ---- the max is already common; the row sums of head col over the 4 lane groups; then each lane fetches its 4 heads' (m, l) ----
+    float lt = l;
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
-    float mh[G], lh[G];
-    decode_static_for<0, G>([&](auto Hc) {
-        constexpr int h = decltype(Hc)::value;
-        const float wh = row_bcastf<h>(wgt);
-        mh[h] = row_bcastf<h>(mt);
-        lh[h] = row_bcastf<h>(lt);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = o[h][e] * wh;
-            x += __shfl_xor(x, 16, 64);
-            x += __shfl_xor(x, 32, 64);
-            o[h][e] = x;
-        }
-    });
-
-    if (grp != 0) return;
-#pragma unroll
-    for (int h = 0; h < G; ++h) {
+    for (int i = 0; i < 4; ++i) {
+        const float lh = __uint_as_float(__builtin_amdgcn_ds_bpermute(head_lane4 + 4 * i, __float_as_uint(lt)));
+        const float mh = __uint_as_float(__builtin_amdgcn_ds_bpermute(head_lane4 + 4 * i, __float_as_uint(m)));
+        const int h = 4 * grp + i;
         if (h >= nq) continue;
         const int hq = hq0 + h;
-        const bool empty = !(lh[h] > 0.f);
-        const float inv = empty ? 0.f : 1.f / lh[h];
-        const float lse = empty ? INFINITY : (mh[h] + __builtin_amdgcn_logf(lh[h])) * 0.6931471805599453f;
+        const bool empty = !(lh > 0.f);
+        const float inv = empty ? 0.f : 1.f / lh;
+        const float lse = empty ? INFINITY : (mh + __builtin_amdgcn_logf(lh)) * 0.6931471805599453f;
         if constexpr (SINK) {   // workgroup-merged split mode: the piece's result stays on the CU
             float4 *dst = reinterpret_cast<float4 *>(wk.sink_o + h * D + col * 8);
-            dst[0] = make_float4(o[h][0] * inv, o[h][1] * inv, o[h][2] * inv, o[h][3] * inv);
-            dst[1] = make_float4(o[h][4] * inv, o[h][5] * inv, o[h][6] * inv, o[h][7] * inv);
+            dst[0] = make_float4(o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
+            dst[1] = make_float4(o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
             if (col == 0) wk.sink_lse[h] = empty ? -INFINITY : lse;
         } else if (!partial) {
             uint4 w4;
-            w4.x = pack2<T>(o[h][0] * inv, o[h][1] * inv);
-            w4.y = pack2<T>(o[h][2] * inv, o[h][3] * inv);
-            w4.z = pack2<T>(o[h][4] * inv, o[h][5] * inv);
-            w4.w = pack2<T>(o[h][6] * inv, o[h][7] * inv);
+            w4.x = pack2<T>(o[0][i] * inv, o[1][i] * inv);
+            w4.y = pack2<T>(o[2][i] * inv, o[3][i] * inv);
+            w4.z = pack2<T>(o[4][i] * inv, o[5][i] * inv);
+            w4.w = pack2<T>(o[6][i] * inv, o[7][i] * inv);
             *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + col * 8) = w4;
             if (p.lse && col == 0) p.lse[(int64_t)b * p.h + hq] = lse;
         } else {
             const int64_t row = wk.prow + h;
             float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + col * 8);
-            dst[0] = make_float4(o[h][0] * inv, o[h][1] * inv, o[h][2] * inv, o[h][3] * inv);
-            dst[1] = make_float4(o[h][4] * inv, o[h][5] * inv, o[h][6] * inv, o[h][7] * inv);
+            dst[0] = make_float4(o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
+            dst[1] = make_float4(o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
             if (col == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
         }
     }
@@ -981,7 +959,10 @@ static bool launch_decode_wg(DecodeParams &p, hipStream_t stream) {
 // d = 128: scores on the matrix cores (paged_decode_mqk_kernel), any G at two wavefronts per SIMD
 template <typename T, int G>
 static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
-    const bool p3 = decode_options().p >= 3 && G <= 4, nt = decode_options().nt != 0;
+    // 3 tiles in flight for every group size since P.V runs on the matrix cores (32 accumulator registers whatever G; option decode_mqk_p8:
+    // tiles in flight at 8 q heads per wavefront, A/B)
+    static const int p8 = env_int("ATOMA_DECODE_MQK_P8", 3);
+    const bool p3 = decode_options().p >= 3 && (G <= 4 || p8 >= 3), nt = decode_options().nt != 0;
     if (decode_wg_applicable(p)) {
         if (nt) { if (p3) launch_decode_wg<T, 128, G, 3, true, true>(p, stream); else launch_decode_wg<T, 128, G, 2, true, true>(p, stream); }
         else { if (p3) launch_decode_wg<T, 128, G, 3, false, true>(p, stream); else launch_decode_wg<T, 128, G, 2, false, true>(p, stream); }

@@ -291,25 +291,6 @@ __global__ void __launch_bounds__(64, 2) paged_decode_fp8_kernel(const DecodePar
 //     and are added once at the end; the rare rescale fetches the heads' factors with ds_bpermute.
 //   * Any group size up to 16 q heads runs in ONE pass with the same 32 accumulator registers (the dot2 layouts needed 16 per head:
 //     groups of 8 took two passes over K / V).
-template <typename T> __device__ __forceinline__ f32x4_v mfma16k16(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, f32x4_v c);
-template <> __device__ __forceinline__ f32x4_v mfma16k16<bf16_t>(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, f32x4_v c) {
-    typedef __attribute__((ext_vector_type(4))) short s16x4;
-    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u2{a0, a1}), __builtin_bit_cast(s16x4, u2{b0, b1}), c, 0, 0, 0);
-}
-template <> __device__ __forceinline__ f32x4_v mfma16k16<f16_t>(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, f32x4_v c) {
-    typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
-    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, u2{a0, a1}), __builtin_bit_cast(h16x4, u2{b0, b1}), c, 0, 0, 0);
-}
-// max over the four lanes (grp = 0..3) that share `col`
-__device__ __forceinline__ float col_max4(float x) {
-    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
-    u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
 #ifndef ATOMA_FP8_KLINES
 #define ATOMA_FP8_KLINES 1
 #endif

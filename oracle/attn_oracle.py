@@ -94,7 +94,7 @@ def attend_decode_online(qf, kf, vf, scale, dtype, tile=16, ngroups=4, group_of=
     kernels with different schedules differ by up to 2^-9 * |v| on rows with few keys (tests/test_oracle_golden.py shows
     it on the CPU).  ``mode="kernel"`` of attend_rows is the one-tile / one-group schedule (global max); the reference's
     split-KV kernel is (tile = 128 or 64, one group); libatoma_hip's decode kernels are (16, 4 groups, j % 4) for d = 128,
-    (16, 8 groups, j % 8) for d = 64 and (16, 4 groups, j // 4) for the matrix-core variant.  Given the kernel's own
+    (16, 8 groups, j % 8) for d = 64 and (16, one group) for the matrix-core variant.  Given the kernel's own
     schedule the comparison is tight (1e-3 + 1 ulp at every row length).  Returns out f32 [h,d] (not yet rounded)."""
     h, d = qf.shape
     L, hk, _ = kf.shape
@@ -184,7 +184,8 @@ def attend_prefill_online(qf, kf, vf, scale, causal, dtype, tile=64, defer=8.0):
 DECODE_SCHEDULES = {            # (head_dim, variant) -> (ngroups, group_of): row ownership of libatoma_hip's decode kernels
     (128, "dot2"): (4, lambda j: j % 4),      # paged_decode_item: 16 lanes per row, lane group `sub` loads rows sub + 4r
     (64, "dot2"): (8, lambda j: j % 8),       # 8 lanes per row, 8 rows per load instruction
-    (128, "mqk"): (4, lambda j: j // 4),      # paged_decode_mqk_item: lane group grp holds S^T[token 4.grp + i]
+    (128, "mqk"): (1, lambda j: 0),           # paged_decode_mqk_item since P.V runs on the matrix cores: all 16 tokens of a tile enter one
+                                              # accumulator, so the running max is common to the tile (round 2: 4 groups, j // 4)
 }
 
 
