@@ -27,6 +27,9 @@
 //    bf16 MMA) and P.V is again v_dot2c on token pairs;
 //  * KV splits write fp32 partial O / LSE to a workspace and a small combine kernel merges
 //    them (same math as the reference's combine kernel).
+// (That is the first kernel, paged_decode_kernel -- today it serves MHA, d = 64 and split-KV launches of small groups.  GQA groups at
+// d = 128 run on paged_decode_mqk_kernel further down: both products on the matrix cores; and WHICH wavefronts share a CU -- the
+// launch order, decode_plan_launch / decode_run_items -- turned out to be worth more than either kernel's inner loop: DESIGN.md 4.1.)
 //
 // Algorithmic HBM bytes per call: 2*B*S*h_k*D*2 (K,V once) + 2*B*h*D*2 + 4*B*ceil(S/page) + 4*B.
 #include "paged_decode.h"
@@ -359,11 +362,17 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
 //     4 x 1 KiB wave loads per tile as before, rows and chunks assigned differently;
 //   * Q^T operand (B): lane holds q[head col][d chunk 4s + grp] (zero for col >= heads), loaded once;
 //   * result: lane holds S^T[token 4.grp + i][head col], i = 0..3 -- one head per lane, so the online
-//     softmax state is two scalars per lane (per 4-token group, merged at the end);
-//   * P.V stays on v_dot2c over token pairs: lane (grp, col) loads V rows 4.grp + r, 16-byte d chunk `col`,
-//     accumulates O[head][8 d] for every head, and gets each head's packed probabilities from lane
-//     (grp, head) with one DPP row_newbcast per head and token pair.
-// VALU work per tile: ~100 + 16.G instead of ~70.G; 2 wavefronts per SIMD at any G.
+//     softmax state is two scalars per lane;
+//   * P.V (round 3; until then v_dot2c over token pairs with one DPP row_newbcast per head): O[head][d] = P[head][token] . V[token][d]
+//     as eight v_mfma_f32_16x16x16 per tile.  The A operand of lane (grp, col) is P[head col][tokens 4.grp ..+3] -- the four
+//     probabilities the lane has just computed, packed; the B operand is V[tokens 4.grp ..+3][d = 8.col + n], which is what the
+//     lane's four V loads (rows 4.grp + r, 16-byte d chunk `col`) hold, re-paired along the tokens with v_perm; MFMA n accumulates
+//     O[head 4.grp + i][d = 8.col + n] -- 32 accumulator registers for ANY group size.  All 16 tokens of a tile enter one
+//     accumulator, so the running max of a head is common to its 4 lane groups (v_permlane16_swap + v_permlane32_swap per tile);
+//     the row sums stay per lane group and are added at the end; the rare rescale fetches the heads' factors with ds_bpermute.
+//     Why: at one wavefront per SIMD (the TP rank's split-KV launches) the kernel was issue-bound -- 50 % of its cycles issuing, 11 %
+//     waiting for memory, 306 VALU instructions per tile at 8 heads (tools/probes/headline_counters.sh).
+// VALU work per tile: ~120 at any G (round 2: ~100 + 16.G; the dot2 kernel: ~70.G); 2 wavefronts per SIMD with 3 tiles in flight.
 // ------------------------------------------------------------------------------------------
 template <typename T, int G, int P, bool NT, bool SINK = false>
 __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, const DecodeWork &wk) {
