@@ -857,7 +857,7 @@ struct DecodeOptions {
     opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
     opt_int fp8_klines{env_int("ATOMA_DECODE_FP8_KLINES", 1)};   // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays, 2 always
     opt_int head_major{env_int("ATOMA_DECODE_HEAD_MAJOR", 1)};   // workgroup order of the non-balanced launches: kv head slowest (1) or fastest (0)
-    opt_int mqk{env_int("ATOMA_DECODE_MQK", 13)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches, bit 3 = groups of 2..4 on the balanced line
+    opt_int mqk{env_int("ATOMA_DECODE_MQK", 29)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches, bit 3 = groups of 2..4 on the balanced line, bit 4 = groups of 2..4 on split-KV launches
 };
 static DecodeOptions &decode_options() {
     static DecodeOptions o;
@@ -1080,6 +1080,8 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
     // (only when uniform batches take the line too -- stream_force: in the per-sequence order the matrix-core kernel's half-line K
     // requests cost 6 %: 0.744 against 0.702 ms)
     if (!fp8 && !use_mqk && D == 128 && g >= 2 && g <= 4 && p.stream_waves > 0 && p.stream_force && (mqk_opt & 8)) mqk_line = true;
+    // bit 4: ... and on split-KV launches (since P.V moved to the matrix cores: 16 x 8192 tokens 0.0958 -> 0.0893 ms)
+    if (!fp8 && !use_mqk && D == 128 && g >= 2 && g <= 4 && p.num_splits > 1 && (mqk_opt & 16)) mqk_line = true;
     DecodeLaunchPlan lp{G, use_mqk || mqk_line, 0, 0};
     if (p.num_splits > 1 || p.stream_waves > 0) {
         lp.rows = p.stream_waves > 0 ? (size_t)p.stream_waves * 2 * G : (size_t)p.num_splits * p.b * p.h;

@@ -189,7 +189,7 @@ def test_decode_large_batch_balanced_mode(gpu, kind):
 
 
 @pytest.mark.parametrize("uniform", [False, True], ids=["ragged", "uniform"])
-@pytest.mark.parametrize("mqk", [13, 5], ids=["mfma-on-the-line", "dot2"])
+@pytest.mark.parametrize("mqk", [29, 5], ids=["mfma-on-the-line", "dot2"])
 @pytest.mark.parametrize("dtype,h,hk", [(BF16, 32, 8), (F16, 6, 2), (BF16, 4, 2)])
 def test_decode_small_groups_on_the_balanced_line(gpu, dtype, h, hk, mqk, uniform):
     """Groups of 2..4 q heads at d = 128 with several kv heads: every resident launch takes the kv-head-major line (uniform batches
@@ -208,7 +208,7 @@ def test_decode_small_groups_on_the_balanced_line(gpu, dtype, h, hk, mqk, unifor
     with _options(gpu, decode_mqk=mqk):
         out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
         name = gpu.lib.atoma_last_decode_kernel().decode()
-    assert ("paged_decode_mqk_kernel" in name) == (mqk == 13) and "balanced" in name, name
+    assert ("paged_decode_mqk_kernel" in name) == (mqk == 29) and "balanced" in name, name
     for i, L in enumerate(lens):
         assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"seq {i} (L={L})")
     if not uniform:
@@ -445,7 +445,7 @@ def test_decode_large_groups_both_kernels_agree(gpu):
         for mqk in (1, 0):
             assert gpu.lib.atoma_set_option(b"decode_mqk", mqk) == 0
             res[mqk] = gpu_decode(gpu, q, c["kc"], c["vc"], c["bt"], c["lens"], 0.088, BF16, alibi=c["alibi"])
-        gpu.lib.atoma_set_option(b"decode_mqk", 13)
+        gpu.lib.atoma_set_option(b"decode_mqk", 29)
         assert_close(res[1][0], res[0][0], BF16, atol=ATOL_VS_F32[BF16], what=f"{name}: matrix-core vs dot2 kernel")
         assert np.allclose(res[1][1], res[0][1], rtol=1e-5, atol=1e-5), name
         ref = A.flash_attn_kv_cache(q, c["kc"], c["vc"], 0.088, BF16, c["bt"], c["lens"], causal=True, alibi_slopes=c["alibi"])
@@ -480,7 +480,7 @@ def test_decode_full_size_70b_shape_properties(gpu):
 
 class _options:
     """atoma_set_option for the duration of a test (defaults restored afterwards)."""
-    DEFAULTS = {"decode_mqk": 13, "decode_min_tiles": 8, "decode_stream": 1, "decode_head_major": 1}
+    DEFAULTS = {"decode_mqk": 29, "decode_min_tiles": 8, "decode_stream": 1, "decode_head_major": 1}
 
     def __init__(self, gpu, **kw):
         self.gpu, self.kw = gpu, kw
