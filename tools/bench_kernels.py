@@ -113,6 +113,8 @@ def bench_decode():
     decode_case("C4 decode Llama-70B shape TP=1: B=256 h=64 hk=8 S=4096", 256, 4096, 64, 8)
     decode_case("C4 decode 70B TP=8 shard: B=256 h=8 hk=1 S=4096", 256, 4096, 8, 1)
     decode_case("decode 70B TP=8 shard: B=64 h=8 hk=1 S=4096 (split-KV)", 64, 4096, 8, 1)
+    decode_case("decode 8B TP=2 shard: B=256 h=16 hk=4 S=4096 (one rank of bench.py --gpus 2)", 256, 4096, 16, 4)
+    decode_case("decode 8B TP=4 shard: B=256 h=8 hk=2 S=4096 (one rank of bench.py --gpus 4)", 256, 4096, 8, 2)
     decode_case("decode 8B TP=8 shard: B=256 h=4 hk=1 S=4096 (split-KV; one rank of bench.py --gpus 8)", 256, 4096, 4, 1)
     decode_case("decode B=1 S=4096 (split-KV)", 1, 4096, 32, 8)
     decode_case("decode B=16 S=8192", 16, 8192, 32, 8)
