@@ -389,13 +389,16 @@ int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int6
                          int64_t device_capacity, atoma_batch_layout *layout, void *stream);
 
 /* Tuning knobs for A/B measurements and tests (returns 0, or -1 for an unknown name).  Decode: "decode_p" (K/V tiles
- * in flight per wavefront, 2..4), "decode_nt" (0/1 non-temporal K/V loads), "decode_stream" (0/1, default 1: large batches
- * with device-side lengths share the batch's tiles evenly between the resident wavefronts; 0 = one wavefront per
- * (sequence, kv head)), "decode_stream_waves_per_cu", "decode_waves_per_cu" / "decode_min_tiles" (KV split
- * heuristic), "decode_mqk" (q.K^T on the matrix cores at head_dim 128: bit 0 = groups of more than 4 q heads per kv
- * head, bit 1 = smaller groups, bit 2 = groups of 2..4 when b * h_k <= 64; default 5), "decode_fp8_mqk" (fp8 KV cache: 1 = q.K^T of
- * the converted K on the matrix cores [default], 0 = v_dot2c), "decode_fp8_wg" (fp8: the 8 kv-head wavefronts of a sequence in one
- * workgroup: 0 never, 1 split-KV launches [default], 2 always).  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
+ * in flight per wavefront, 2..4), "decode_nt" (0/1 non-temporal K/V loads), "decode_stream" (the balanced, kv-head-major line for
+ * batches with device-side lengths that fill the chip: 0 = never (one wavefront per (sequence, kv head)), 1 = ragged batches and
+ * uniform head_dim-128 GQA batches [default], 2 = every such batch, 3 = ragged batches only), "decode_head_major" (workgroup order of
+ * the other launches: kv head slowest 1 [default] / fastest 0), "decode_stream_waves_per_cu", "decode_waves_per_cu" /
+ * "decode_min_tiles" (KV split heuristic), "decode_wg_merge" (split-KV merged inside the launch), "decode_mqk" (both products on the
+ * matrix cores at head_dim 128: bit 0 = groups of more than 4 q heads per kv head, bit 1 = all smaller groups, bit 2 = groups of 2..4
+ * when b * h_k <= 64, bit 3 = groups of 2..4 on the line, bit 4 = groups of 2..4 on split-KV launches; default 29), "decode_fp8_mqk"
+ * (fp8 KV cache: 1 = the matrix-core kernel [default], 0 = v_dot2c), "decode_fp8_klines" (fp8: K fetched in full 128-byte lines: 0
+ * never, 1 where it pays [default], 2 always), "decode_fp8_wg" (fp8: the 8 kv-head wavefronts of a sequence in one workgroup: 0 never
+ * [default], 1 split-KV launches, 2 always).  None of them changes a result bit except through the choice of kernel.  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
  * software-pipelined one-wave-per-SIMD kernel).  RoPE: "rope_table_rows" (rows of the caller's cos / sin tables; positions beyond
  * them then read the last row instead of memory behind the table -- the FFI carries no table length; 0 = unchecked [default]).
  * Defaults also come from ATOMA_DECODE_{P,NT,STREAM,WAVES_PER_CU,
