@@ -866,10 +866,13 @@ static DecodeOptions &decode_options() {
     return o;
 }
 extern std::atomic<int> prefill_cfg;  // prefill_mfma.hip
+extern std::atomic<int> prefill_exact_keys, prefill_simple;  // prefill_asm.hip
 extern std::atomic<int64_t> rope_table_rows;  // norm_rope.hip
 bool set_decode_option(const std::string &name, int value) {
     DecodeOptions &o = decode_options();
     if (name == "prefill_cfg") { prefill_cfg = value; return true; }
+    if (name == "prefill_exact_keys") { prefill_exact_keys = value; return true; }
+    if (name == "prefill_simple") { prefill_simple = value; return true; }
     if (name == "rope_table_rows") { rope_table_rows = value < 0 ? 0 : value; return true; }
     if (name == "decode_p") o.p = value;
     else if (name == "decode_nt") o.nt = value;

@@ -135,7 +135,7 @@ def attend_decode_online(qf, kf, vf, scale, dtype, tile=16, ngroups=4, group_of=
     return np.where(lt[:, None] > 0, ot / np.where(lt > 0, lt, np.float32(1))[:, None], np.float32(0)).astype(np.float32)
 
 
-def attend_prefill_online(qf, kf, vf, scale, causal, dtype, tile=64, defer=8.0):
+def attend_prefill_online(qf, kf, vf, scale, causal, dtype, tile=64, defer=8.0, prescale=False):
     """Prefill rows under the schedule of libatoma_hip's MFMA prefill kernel (csrc/prefill_mfma.hip, prefill_cfg = 0), with the
     reference's arithmetic (softmax.h:65-91,135-185): keys arrive in tiles of ``tile`` (64); per row, the running max (exp2
     domain) is raised to max(m, tile max) only when that exceeds m + ``defer`` (the deferred raise: p <= 2^defer), O and the row
@@ -143,6 +143,9 @@ def attend_prefill_online(qf, kf, vf, scale, causal, dtype, tile=64, defer=8.0):
     UNROUNDED p, P.V takes p rounded to the storage dtype, f32 accumulation, one division at the end.  Why: rounding p to bf16
     depends on which running max it is taken against, so against the f32 definition rows with few keys can only be held to
     2^-9.|v| (tests/test_oracle_schedules.py); against the kernel's OWN schedule every row is held to 1e-3 + 1 ulp.
+    ``prescale``: the schedule of the hand-scheduled kernel's fast variant (csrc/prefill_asm.hip, tools/pfasm/kernel.py): q is
+    multiplied by scale.log2(e) and rounded to the storage dtype ONCE, the scores leave the matrix pipe in the exp2 domain and
+    p = exp2(s~ - m) needs no multiply.
     ``qf [Lq,h,d]``, ``kf, vf [Lk,hk,d]`` float32; returns out f32 [Lq,h,d] (not yet rounded)."""
     Lq, h, d = qf.shape
     Lk, hk, _ = kf.shape
@@ -160,10 +163,14 @@ def attend_prefill_online(qf, kf, vf, scale, causal, dtype, tile=64, defer=8.0):
         o = np.zeros((Lq, d), np.float32)
         for kv0 in range(0, Lk, tile):
             cols = np.arange(kv0, min(kv0 + tile, Lk))[None, :]
-            s = (qf[:, head].astype(np.float32) @ kh[kv0:kv0 + tile].T).astype(np.float32)
+            if prescale:
+                qs = round_through((qf[:, head].astype(np.float32) * sl2).astype(np.float32), dtype)
+                s = (qs @ kh[kv0:kv0 + tile].T).astype(np.float32)
+            else:
+                s = (qf[:, head].astype(np.float32) @ kh[kv0:kv0 + tile].T).astype(np.float32)
             if causal:
                 s = np.where(cols <= rows + shift, s, -np.inf).astype(np.float32)
-            mx = (s.max(1) * sl2).astype(np.float32)                 # raw max, then the scale (as the kernel)
+            mx = s.max(1).astype(np.float32) if prescale else (s.max(1) * sl2).astype(np.float32)   # raw max, then the scale (as the kernel)
             m_cand = np.maximum(m, mx)
             with np.errstate(invalid="ignore"):
                 raise_it = m_cand > m + np.float32(defer)            # m = -inf: any finite candidate raises
@@ -172,7 +179,7 @@ def attend_prefill_online(qf, kf, vf, scale, causal, dtype, tile=64, defer=8.0):
             with np.errstate(invalid="ignore"):
                 alpha = np.where(np.isfinite(m), np.exp2(m - ms), np.float32(0)).astype(np.float32)
                 alpha = np.where(np.isfinite(m) | np.isfinite(m_new), alpha, np.float32(1))
-            pexp = (s.astype(np.float64) * np.float64(sl2) - ms[:, None].astype(np.float64)).astype(np.float32)   # one rounding: v_pk_fma_f32
+            pexp = (s.astype(np.float64) * np.float64(1.0 if prescale else sl2) - ms[:, None].astype(np.float64)).astype(np.float32)   # one rounding: v_pk_fma_f32
             p = np.exp2(pexp).astype(np.float32)
             l = (l * alpha + p.sum(1, dtype=np.float32)).astype(np.float32)
             o = (o * alpha[:, None] + round_through(p, dtype) @ vh[kv0:kv0 + tile]).astype(np.float32)

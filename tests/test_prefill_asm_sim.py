@@ -1,0 +1,129 @@
+"""The hand-scheduled prefill kernel (csrc/prefill_asm.hip) without a GPU: the generated instruction list (tools/pfasm/kernel.py)
+is executed by the functional simulator (tools/pfasm/sim.py -- adversarial load timing, MFMA hazard distances) one workgroup at
+a time and compared with the oracle's own-schedule restatement (oracle/attn_oracle.py attend_prefill_online; `prescale` = the fast
+variant's one rounding of scale.log2(e).Q) at 1e-3 + 1 ulp, and with the f32 definition at the tolerance of tests/util.py.  What
+the simulator accepts is, instruction for instruction, what hipcc assembles into libatoma_hip.so."""
+import numpy as np
+import pytest
+
+from oracle import attn_oracle as A
+from oracle.halfs import BF16, F16, to_f32, from_f32
+from tools.pfasm import harness as H
+from tools.pfasm import kernel as K
+from util import rand_half, assert_close, make_paged_cache, ATOL_VS_F32
+
+D = 128
+
+
+def run_case(lens, h, hk, causal, dtype=BF16, lens_k=None, exact=False, seed=1, spike=None, **kw):
+    rng = np.random.default_rng(seed)
+    lens = np.array(lens, np.int32)
+    lk = lens if lens_k is None else np.array(lens_k, np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cuk = np.concatenate([[0], np.cumsum(lk)]).astype(np.int32)
+    q = rand_half(rng, (int(cu[-1]), h, D), dtype)
+    k, v = rand_half(rng, (int(cuk[-1]), hk, D), dtype), rand_half(rng, (int(cuk[-1]), hk, D), dtype)
+    if spike is not None:                      # key `spike[0]` = the query of row `spike[1]`: a score ~ d far above the others
+        k[spike[0]] = q[spike[1], ::(h // hk)][:hk]
+    out, lse, stats = H.prefill_varlen(q, k, v, cu, cuk, D ** -0.5, causal, "bf16" if dtype == BF16 else "f16", want_lse=True, exact=exact, **kw)
+    qf, kf, vf = to_f32(q, dtype), to_f32(k, dtype), to_f32(v, dtype)
+    for b in range(len(lens)):
+        s0, s1, k0, k1 = int(cu[b]), int(cu[b + 1]), int(cuk[b]), int(cuk[b + 1])
+        if s1 == s0:
+            continue
+        own = from_f32(A.attend_prefill_online(qf[s0:s1], kf[k0:k1], vf[k0:k1], np.float32(D ** -0.5), causal, dtype, prescale=not exact), dtype)
+        assert_close(out[s0:s1], own, dtype, atol=1e-3, what=f"sequence {b} vs the kernel's own schedule")
+        if exact and k1 > k0:
+            ref, want_lse = A.attend_rows(qf[s0:s1], kf[k0:k1], vf[k0:k1], np.float32(D ** -0.5), causal=causal)
+            assert_close(out[s0:s1], from_f32(ref, dtype), dtype, atol=ATOL_VS_F32[dtype], what=f"sequence {b} vs the f32 definition")
+            fin = np.isfinite(want_lse)
+            assert np.allclose(lse[:, s0:s1][fin], want_lse[fin], rtol=1e-4, atol=1e-4)
+            assert np.all(np.isposinf(lse[:, s0:s1][~fin]))
+    return stats
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["fast", "exact"])
+@pytest.mark.parametrize("causal", [True, False])
+def test_ragged_lengths_around_every_boundary(exact, causal):
+    """1, 31..33, 63..65 tokens, a 256-row block with a ragged tail, GQA group 2: masked / single-slot / idle variants all run"""
+    run_case([1, 31, 33, 64, 65, 290], 2, 1, causal, exact=exact)
+
+
+@pytest.mark.parametrize("late,reverse", [(True, False), (False, True)], ids=["dma-lands-late", "dma-lands-early-waves-reversed"])
+def test_three_blocks_both_dma_timings(late, reverse):
+    """700 rows = three 256-row blocks (1, 8 and 11 K/V tiles): the steady-state loop, ring wrap-around, every barrier; the
+    LDS-DMA lands at the latest / earliest legal time"""
+    run_case([700], 1, 1, True, late_dma=late, reverse=reverse)
+
+
+def test_f16_and_more_queries_than_keys_and_empty():
+    run_case([513], 1, 1, True, dtype=F16)
+    run_case([100, 40, 70], 1, 1, True, lens_k=[400, 10, 0], exact=True)
+    run_case([100, 40], 1, 1, False, lens_k=[400, 10], exact=True)
+
+
+def test_forced_late_raise_of_the_reference():
+    """a key far above the others in the 4th tile of the last row (cdna guide T13 / rule 26): the rescale block with alpha != 1"""
+    for exact in (False, True):
+        base = run_case([300], 2, 1, True, exact=exact)
+        st = run_case([300], 2, 1, True, exact=exact, spike=(200, 299))
+        assert st["v_accvgpr_read_b32"] >= base["v_accvgpr_read_b32"] + 64     # O of a slot was read back for a rescale, not only by the epilogue
+
+
+@pytest.mark.parametrize("page", [16, 64])
+def test_paged_prefix(page):
+    """prefix / chunked prefill over the paged cache: 90 new rows over 333 cached + new keys, random block table"""
+    rng = np.random.default_rng(page)
+    h, hk = 2, 1
+    lens_q, lens_k = np.array([90, 17], np.int32), np.array([333, 81], np.int32)
+    nb = int(sum((x + page - 1) // page for x in lens_k)) + 3
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, D, BF16, lens_k)
+    # unwritten slots of the last pages hold NaN patterns: they must not reach the output (P = 0 times NaN)
+    for b, L in enumerate(lens_k):
+        last = bt[b, (L - 1) // page]
+        kc[last, (L - 1) % page + 1:] = 0x7FC0
+        vc[last, (L - 1) % page + 1:] = 0x7FC0
+    cu = np.concatenate([[0], np.cumsum(lens_q)]).astype(np.int32)
+    cuk = np.concatenate([[0], np.cumsum(lens_k)]).astype(np.int32)
+    q = rand_half(rng, (int(cu[-1]), h, D), BF16)
+    out, _, _ = H.prefill_varlen(q, kc, vc, cu, cuk, D ** -0.5, True, "bf16", block_table=bt, page_size=page, exact=True)
+    qf = to_f32(q, BF16)
+    for b in range(2):
+        rows = [bt[b, i // page] * page + i % page for i in range(lens_k[b])]
+        kf, vf = to_f32(kc.reshape(-1, hk, D)[rows], BF16), to_f32(vc.reshape(-1, hk, D)[rows], BF16)
+        own = from_f32(A.attend_prefill_online(qf[cu[b]:cu[b + 1]], kf, vf, np.float32(D ** -0.5), True, BF16), BF16)
+        assert_close(out[cu[b]:cu[b + 1]], own, BF16, atol=1e-3, what=f"paged, page {page}, sequence {b}")
+
+
+def test_every_iteration_variant_is_reached():
+    """the 15 iteration blocks + the idle one: each is entered by at least one of the shapes above (label coverage by simulation)"""
+    prog, _ = K.build("bf16", False)
+    labels = {i.ops[0]: n for n, i in enumerate(prog.ins) if i.op == "label"}
+    its = sorted(l for l in labels if l.startswith("IT_"))
+    assert len(its) == 17
+    from tools.pfasm.sim import Workgroup
+    seen = set()
+    orig = Workgroup.step
+
+    def step(self, w):
+        i = self.ins[w.pc] if w.pc < len(self.ins) else None
+        if i is not None and i.op == "label" and i.ops[0].startswith("IT_"):
+            seen.add(i.ops[0])
+        return orig(self, w)
+    Workgroup.step = step
+    try:
+        run_case([1, 33, 65, 290, 700], 1, 1, True)
+        run_case([200], 1, 1, False, lens_k=[130])
+    finally:
+        Workgroup.step = orig
+    assert seen == set(its), sorted(set(its) - seen)
+
+
+def test_schedule_density_of_the_plain_iteration():
+    """the plain iteration (both slots, no mask): 64 MFMAs, at most 5 fillers in any MFMA gap, under 4.7 on average"""
+    for exact, bound in ((False, 4.7), (True, 5.7)):
+        _, b = K.build("bf16", False, exact=exact)
+        l1, l2 = b.sched_log["IT_0_220"]
+        assert len(l1) == 33 and len(l2) == 33
+        assert max(l1 + l2) <= (7 if exact else 6)
+        assert sum(l1 + l2) / 64.0 <= bound
