@@ -113,7 +113,9 @@ def test_every_iteration_variant_is_reached():
     Workgroup.step = step
     try:
         run_case([1, 33, 65, 290, 700], 1, 1, True)
-        run_case([200], 1, 1, False, lens_k=[130])
+        run_case([200, 200], 1, 1, False, lens_k=[130, 100])         # both slots end together, after an even / odd number of tiles
+        run_case([160], 1, 1, True, lens_k=[96])                      # fewer keys than rows: slot 0 ends on an even tile, the next is masked
+        run_case([256], 1, 1, True, lens_k=[288])                     # slot 0 ends on an odd tile, the next tile is plain
     finally:
         Workgroup.step = orig
     assert seen == set(its), sorted(set(its) - seen)
