@@ -87,11 +87,13 @@ __global__ void __launch_bounds__(256) prefill_asm_kernel(const AttnParams p, co
             put64(PFA_q0_lo + 2 * s, (uint64_t)(uintptr_t)(p.q + q_off + (int64_t)sl[s].r0 * p.q_row_stride));
             put64(PFA_o0_lo + 2 * s, (uint64_t)(uintptr_t)(p.o + o_off + (int64_t)sl[s].r0 * p.o_row_stride));
             uint64_t lse = 0;
+#ifndef PFA_TIMING
             if (p.lse) {
                 const float *l = (p.unpadded_lse && p.cu_seqlens_q) ? p.lse + (int64_t)hq * p.cu_seqlens_q[p.b] + si.sum_q
                                                                      : p.lse + ((int64_t)b * p.h + hq) * p.seqlen_q;
                 lse = (uint64_t)(uintptr_t)(l + sl[s].r0);
             }
+#endif
             put64(PFA_lse0_lo + 2 * s, lse);
             par[PFA_rows0 + s] = (uint32_t)sl[s].rows;
             const int lim = causal ? sl[s].r0 + shift : len_k - 1;
@@ -129,6 +131,11 @@ __global__ void __launch_bounds__(256) prefill_asm_kernel(const AttnParams p, co
         par[PFA_scale_log2] = __float_as_uint(p.scale_log2);
         par[PFA_wave] = (uint32_t)wave;
         par[PFA_thr] = __float_as_uint(exact ? 8.0f / p.scale_log2 : 8.0f);
+#ifdef PFA_TIMING   // phase timers (make timing; tools/probes/pfa_phases.py): 8 dwords per wavefront into the LSE array
+        put64(PFA_dbg_lo, p.lse ? (uint64_t)(uintptr_t)(p.lse + ((int64_t)blockIdx.x * 4 + wave) * 8) : 0);
+#else
+        put64(PFA_dbg_lo, 0);
+#endif
     }
     // the wavefront reads its own block back (LDS operations of one wavefront stay in order): no barrier
     const uint32_t paddr = __builtin_amdgcn_readfirstlane((uint32_t)(PFA_LDS_PARAMS + wave * PFA_PARAM_DWORDS * 4));
@@ -141,12 +148,21 @@ __global__ void __launch_bounds__(256) prefill_asm_kernel(const AttnParams p, co
 #include "pfa_bf16_paged_fast.inc"
                 : : "s"(paddr) : PFA_CLOBBERS);
     } else if constexpr (BF16) {
+#ifdef PFA_TIMING
+        if (exact) asm volatile(
+#include "pfa_bf16_contig_exact_timing.inc"
+                : : "s"(paddr) : PFA_CLOBBERS);
+        else asm volatile(
+#include "pfa_bf16_contig_fast_timing.inc"
+                : : "s"(paddr) : PFA_CLOBBERS);
+#else
         if (exact) asm volatile(
 #include "pfa_bf16_contig_exact.inc"
                 : : "s"(paddr) : PFA_CLOBBERS);
         else asm volatile(
 #include "pfa_bf16_contig_fast.inc"
                 : : "s"(paddr) : PFA_CLOBBERS);
+#endif
     } else if constexpr (PAGED) {
         if (exact) asm volatile(
 #include "pfa_f16_paged_exact.inc"

@@ -48,6 +48,7 @@ PARAMS = [
     "k_page_bytes", "v_page_bytes",                 # paged: page strides, bytes
     "wave",                                         # 0 .. 3
     "thr",                                          # f32 bits: the deferred-raise threshold in the domain S' lives in (8, or 8 / scale_log2 when exact)
+    "dbg_lo", "dbg_hi",                             # timing builds: 32 bytes per wavefront for the phase timers
 ]
 PIDX = {n: i for i, n in enumerate(PARAMS)}
 PARAM_DWORDS = 64
@@ -143,6 +144,10 @@ S_VBASE = _salloc(2, 2)
 S_KVT = _salloc()               # paged: first key of the next K tile to request
 S_VVT = _salloc()
 SGPR_FIRST, SGPR_LAST = 36, _snext[0] - 1
+# timing builds (contiguous K/V only) reuse the paged-addressing registers
+S_TACC = [S_BT[0], S_BT[1], S_PSHIFT, S_KPAGE, S_VPAGE, S_KBASE[0], S_KBASE[1], S_KVT]
+S_TNOW = S_VBASE
+S_TLAST, S_TT = S_VVT, S_PTR[0]
 
 
 class Item:
@@ -243,12 +248,13 @@ def insert_lds_waits(ins_list):
 
 
 class Builder:
-    def __init__(self, dtype="bf16", paged=False, param_sgpr=S(4), exact=False):
+    def __init__(self, dtype="bf16", paged=False, param_sgpr=S(4), exact=False, timing=False):
         """exact = False: Q pre-multiplied by scale.log2(e) and rounded once (S' in the exp2 domain, 3 VALU per score);
         exact = True: Q as it is, S' = s - m in the raw domain and one v_mul_f32 by scale.log2(e) in front of every v_exp_f32 --
         the reference's arithmetic to the last rounding, for rows whose softmax mass sits on a few keys."""
         assert dtype in ("bf16", "f16")
-        self.dtype, self.paged, self.exact = dtype, paged, exact
+        assert not (timing and paged)
+        self.dtype, self.paged, self.exact, self.timing = dtype, paged, exact, timing
         self.mfma = "v_mfma_f32_32x32x16_" + dtype
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.param_sgpr = param_sgpr
@@ -259,6 +265,13 @@ class Builder:
     # ------------------------------------------------------------------------------------------------------------------------
     def e(self, op, *ops, **mods):
         return self.p.emit(op, *ops, **mods)
+
+    def stamp(self, k):
+        """timing builds: cycles since the previous stamp -> accumulator k (s_memtime: the wait drains the LDS queue too)"""
+        if not self.timing:
+            return []
+        return [Ins("s_memtime", S_TNOW), Ins("s_waitcnt", lgkmcnt=0), Ins("s_sub_u32", S_TT, S_TNOW[0], S_TLAST),
+                Ins("s_add_u32", S_TACC[k], S_TACC[k], S_TT), Ins("s_mov_b32", S_TLAST, S_TNOW[0])]
 
     def nop(self, states):
         """at least `states` wait states"""
@@ -471,15 +484,17 @@ class Builder:
         body1 = schedule(mf1, [exp_h0, vreads, e1_in_p1], cap=cap1, log=log1)
         body2 = schedule(mf2, [e1_in_p2, v2, mm, ring + kr + adv, dma, vadv], cap=cap2, log=log2)
         self.sched_log[name] = (log1, log2)
-        blk = []
+        blk = self.stamp(4)
         if mk:
             blk.append(Ins("s_lshl_b32", S_T1, S_T, 6))
             blk.append(Ins("s_add_u32", S_T1, S_T1, 64))       # kv1 = 64 (t + 1): LIMREL = LIM - kv1 - 4hi
         blk += body1
+        blk += self.stamp(0)
         if self.paged:
             blk.append(Ins("s_waitcnt", lgkmcnt=0))
             blk += self.paged_tile(S_KVT, False) + self.paged_tile(S_VVT, True)
         blk += body2
+        blk += self.stamp(1)
         blk, _ = insert_lds_waits(blk)
         P.extend(blk)
         # ---------------- decision, ring rotation, barrier ----------------
@@ -501,7 +516,11 @@ class Builder:
         self.e("s_add_u32", S_RBASE, S_RBASE, S_DELTA)
         self.e("s_add_u32", S_KDMA, S_DBASE, S_W1024)
         self.e("s_waitcnt", vmcnt=8, lgkmcnt=0)
+        P.extend(self.stamp(2))
         self.e("s_barrier")
+        P.extend(self.stamp(3))
+        if self.timing:
+            self.e("s_add_u32", S_TACC[7], S_TACC[7], 1)
         self.e("s_add_u32", S_T, S_T, 1)
         if (c, x, mk) == (2, 2, False):
             self.e("s_cmp_lt_u32", S_T, S_NST)
@@ -648,6 +667,12 @@ class Builder:
     def prologue(self):
         e = self.e
         P = self.p
+        if self.timing:
+            for a in S_TACC:
+                e("s_mov_b32", a, 0)
+            e("s_memtime", S_TNOW)
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_mov_b32", S_TLAST, S_TNOW[0])
         self.load_params()
         lane, hi = TMP[0], TMP[1]
         # ---- scalars ----
@@ -865,6 +890,7 @@ class Builder:
         P.label("PRO_ENTRY")
         e("s_waitcnt", vmcnt=8, lgkmcnt=0)
         e("s_barrier")
+        P.extend(self.stamp(5))
         e("s_branch", "DISP_0")
 
     def request_tile(self, kind, slot):
@@ -886,6 +912,7 @@ class Builder:
         P.label("DRAIN_EPILOGUE")          # n_tiles = 0: nothing was computed, requests still in flight must land before the wave ends
         e("s_waitcnt", vmcnt=0)
         P.label("EPILOGUE")
+        P.extend(self.stamp(4))
         self.nop(MFMA_SAFE)
         e("s_waitcnt", vmcnt=0, lgkmcnt=0)
         # parameters again (their VGPRs were reused)
@@ -960,6 +987,27 @@ class Builder:
             P.label(nolse)
             P.label(done)
         e("s_waitcnt", vmcnt=0)
+        if self.timing:
+            P.extend(self.stamp(6))
+            e("v_mov_b32", TMP[2], self.param_sgpr)
+            e("ds_read_b128", V(0, 4), TMP[2], offset=16 * (PIDX["dbg_lo"] // 4))
+            e("ds_read_b128", V(4, 4), TMP[2], offset=16 * (PIDX["dbg_lo"] // 4) + 16)
+            e("s_waitcnt", lgkmcnt=0)
+            e("v_readfirstlane_b32", S_ODESC[0], V(PIDX["dbg_lo"] % 4))
+            e("v_readfirstlane_b32", S_ODESC[1], V(PIDX["dbg_lo"] % 4 + 1))
+            e("s_mov_b32", S_ODESC[2], 32)
+            e("s_or_b32", S_TT, S_ODESC[0], S_ODESC[1])
+            e("s_cmp_eq_u32", S_TT, 0)
+            e("s_cbranch_scc1", "TIMING_DONE")
+            e("v_mbcnt_lo_u32_b32", TMP[0], -1, 0)
+            e("v_mbcnt_hi_u32_b32", TMP[0], -1, TMP[0])
+            e("v_lshlrev_b32", TMP[0], 16, TMP[0])                # only lane 0 is inside the 32-byte window
+            for k in range(8):
+                e("v_mov_b32", TMP[8 + k], S_TACC[k])
+            e("buffer_store_dwordx4", V(TMP[8].idx, 4), TMP[0], S_ODESC, 0, offen=True)
+            e("buffer_store_dwordx4", V(TMP[12].idx, 4), TMP[0], S_ODESC, 0, offen=True, offset=16)
+            e("s_waitcnt", vmcnt=0)
+            P.label("TIMING_DONE")
 
     # ---- the whole program ------------------------------------------------------------------------------------------------------------------
     def build(self):
@@ -989,8 +1037,8 @@ MFMA_SAFE = 20
 MFMA_SRCC_SAFE = 4
 
 
-def build(dtype="bf16", paged=False, param_sgpr=S(4), exact=False):
-    b = Builder(dtype, paged, param_sgpr, exact)
+def build(dtype="bf16", paged=False, param_sgpr=S(4), exact=False, timing=False):
+    b = Builder(dtype, paged, param_sgpr, exact, timing)
     prog = b.build()
     return prog, b
 

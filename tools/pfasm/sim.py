@@ -382,6 +382,17 @@ class Workgroup:
                 w.s[dst.idx + k] = data[k]
         w.lgq.append(("smem", done, regs))
 
+    def op_s_memtime(self, w, i):
+        dst = i.ops[0]
+        regs = [("s", dst.idx), ("s", dst.idx + 1)]
+        for r in regs:
+            w.pending[r] = f"s_memtime pc {w.pc}"
+        now = w.issue
+
+        def done():
+            w.s[dst.idx], w.s[dst.idx + 1] = now & 0xFFFFFFFF, 0
+        w.lgq.append(("smem", done, regs))
+
     def op_s_load_dword(self, w, i):
         self._s_load(w, i, 1)
 

@@ -10,19 +10,20 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "prefill_asm_kernel"      # or prefill_mfma_kernel
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 dur = None
 for f in glob.glob(os.path.join(root, "gpurun_out", f"pfprof_{tag}", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(out, f"{tag}_prefill_kernel_stats.csv"))
     for r in csv.DictReader(open(f)):
-        if "prefill_mfma_kernel" in r["Name"]:
+        if KERNEL in r["Name"]:
             dur, name = float(r["AverageNs"]), r["Name"]
 ctr = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, "gpurun_out", f"pfpmc_{tag}_*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "prefill_mfma_kernel" in r["Kernel_Name"]:
+        if KERNEL in r["Kernel_Name"]:
             ctr[r["Counter_Name"]].append(float(r["Counter_Value"]))
 c = {k: sum(v) / len(v) for k, v in ctr.items()}
 S, nseq, h, d = 2048, 16, 32, 128
@@ -35,7 +36,15 @@ if "GRBM_GUI_ACTIVE" in c:
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
         res["mfma_pipe_busy_frac_at_actual_clock"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * gui), 4)
 if c.get("SQ_INSTS_MFMA"):
-    res["valu_insts_per_mfma"] = round(c.get("SQ_INSTS_VALU", 0) / c["SQ_INSTS_MFMA"], 2)
+    res["valu_insts_per_mfma"] = round(c.get("SQ_INSTS_VALU", 0) / c["SQ_INSTS_MFMA"] - 1, 2)    # SQ_INSTS_VALU counts the MFMAs too
+    for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"):
+        if k in c:
+            res[k.lower()[3:] + "_per_mfma"] = round(c[k] / c["SQ_INSTS_MFMA"], 3)
+if c.get("SQ_WAVE_CYCLES"):
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA",
+              "SQ_ACTIVE_INST_VMEM"):
+        if k in c:
+            res[k.lower()[3:] + "_frac_of_wave_cycles"] = round(c[k] / c["SQ_WAVE_CYCLES"], 4)
 res["note"] = "counter passes run slower than un-profiled launches (lower clock under the profiler); duration_ns is from the --kernel-trace --stats pass"
 json.dump(res, open(os.path.join(out, f"{tag}_prefill_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
