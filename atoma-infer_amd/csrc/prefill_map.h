@@ -18,8 +18,8 @@ constexpr int PF_SGU = 8;              // (sequence, q head) units scheduled tog
 struct PfWork {
     int b, hq, mblk;
 };
-__device__ __forceinline__ bool pf_map_workgroup(const AttnParams &p, int block_rows, PfWork &w) {
-    const int L = (int)blockIdx.x, xcd = L & 7, i = L >> 3;
+__device__ __forceinline__ bool pf_map_index(const AttnParams &p, int block_rows, int L, PfWork &w) {
+    const int xcd = L & 7, i = L >> 3;
     const int m_blocks = (p.seqlen_q + block_rows - 1) / block_rows;
     const int n_units = p.b * p.h, uq = n_units >> 3, ur = n_units & 7;
     const int nu_x = uq + (xcd < ur ? 1 : 0);                                  // units of this XCD
@@ -39,6 +39,10 @@ __device__ __forceinline__ bool pf_map_workgroup(const AttnParams &p, int block_
     w.hq = unit - w.b * p.h;                                                     // q heads of a kv group are adjacent
     w.mblk = m_blocks - 1 - mpos;                                                // longest (most keys) first
     return true;
+}
+
+__device__ __forceinline__ bool pf_map_workgroup(const AttnParams &p, int block_rows, PfWork &w) {
+    return pf_map_index(p, block_rows, (int)blockIdx.x, w);
 }
 
 }  // namespace atoma

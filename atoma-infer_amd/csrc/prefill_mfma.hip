@@ -72,7 +72,7 @@ template <> __device__ __forceinline__ uint32_t cvt_pk<f16_t>(float lo, float hi
 }
 
 #ifndef PREFILL_DEFAULT_CFG
-#define PREFILL_DEFAULT_CFG 0
+#define PREFILL_DEFAULT_CFG 4
 #endif
 constexpr int PF_BN = 64;              // keys per K/V tile
 // The running row max is only raised when the new tile's max exceeds it by more than PF_DEFER (log2 units):
@@ -1171,8 +1171,9 @@ static void launch_pf_pipe(const AttnParams &p, hipStream_t stream) {
     ATOMA_CHECK_LAUNCH("prefill_pipe_kernel");
 }
 
-// atoma_set_option("prefill_cfg", n): 0 = tile-sequential loop (4 waves x 32 rows, two workgroups per CU), the
-// default; 2 = software-pipelined loop, 4 waves x 64 rows, one wave per SIMD (experimental: correct, but its
+// atoma_set_option("prefill_cfg", n): 4 = the hand-scheduled kernel of prefill_asm.hip (head_dim 128: persistent, 4 waves x 64
+// rows, one wave per SIMD), the default -- shapes it does not take (head_dim 64, ALiBi, ..) run on 0; 0 = tile-sequential loop
+// (4 waves x 32 rows, two workgroups per CU); 2 = software-pipelined loop, 4 waves x 64 rows, one wave per SIMD (experimental: correct, but its
 // un-overlapped barrier / LDS-DMA issue time makes it slower than 0 -- DESIGN.md).  RB = 1 of the pipelined
 // kernel is not instantiated: hipcc splits a 256-register budget 128 / 128 between the two register files
 // and the arch half spills.  The environment variable ATOMA_PREFILL_CFG overrides the option.

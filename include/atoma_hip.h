@@ -398,8 +398,12 @@ int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int6
  * when b * h_k <= 64, bit 3 = groups of 2..4 on the line, bit 4 = groups of 2..4 on split-KV launches; default 29), "decode_fp8_mqk"
  * (fp8 KV cache: 1 = the matrix-core kernel [default], 0 = v_dot2c), "decode_fp8_klines" (fp8: K fetched in full 128-byte lines: 0
  * never, 1 where it pays [default], 2 always), "decode_fp8_wg" (fp8: the 8 kv-head wavefronts of a sequence in one workgroup: 0 never
- * [default], 1 split-KV launches, 2 always).  None of them changes a result bit except through the choice of kernel.  Prefill: "prefill_cfg" (0 = tile-sequential kernel [default], 2 = the
- * software-pipelined one-wave-per-SIMD kernel).  RoPE: "rope_table_rows" (rows of the caller's cos / sin tables; positions beyond
+ * [default], 1 split-KV launches, 2 always).  None of them changes a result bit except through the choice of kernel.  Prefill: "prefill_cfg" (4 = the hand-scheduled persistent
+ * kernel of csrc/prefill_asm.hip [default; head_dim 128 -- other shapes run on 0], 0 = tile-sequential kernel, 2 = the
+ * software-pipelined one-wave-per-SIMD kernel), "prefill_exact_keys" (kernel 4: query blocks whose first row sees fewer keys take the
+ * arithmetic that leaves Q unrounded; default 512, 0 = never, 0x7fffffff = always), "prefill_simple" (A/B knob, default 0).  The
+ * persistent kernel keeps its plan table (256 bytes per 256-row query block and wavefront = 1 KiB per block) in the stream's workspace:
+ * count it in atoma_warmup's extra_bytes before capturing a graph.  RoPE: "rope_table_rows" (rows of the caller's cos / sin tables; positions beyond
  * them then read the last row instead of memory behind the table -- the FFI carries no table length; 0 = unchecked [default]).
  * Defaults also come from ATOMA_DECODE_{P,NT,STREAM,WAVES_PER_CU,
  * MIN_TILES,MQK}; ATOMA_PREFILL_CFG overrides "prefill_cfg". */

@@ -15,7 +15,8 @@ from util import rand_half, assert_close, make_paged_cache, ATOL_VS_F32
 D = 128
 
 
-def run_case(lens, h, hk, causal, dtype=BF16, lens_k=None, exact=False, seed=1, spike=None, **kw):
+def run_case(lens, h, hk, causal, dtype=BF16, lens_k=None, exact=False, seed=1, spike=None, auto=False, **kw):
+    """exact = True / False: every block on that arithmetic; auto: the kernel's rule (first row of the block sees < 512 keys -> exact)"""
     rng = np.random.default_rng(seed)
     lens = np.array(lens, np.int32)
     lk = lens if lens_k is None else np.array(lens_k, np.int32)
@@ -25,19 +26,22 @@ def run_case(lens, h, hk, causal, dtype=BF16, lens_k=None, exact=False, seed=1, 
     k, v = rand_half(rng, (int(cuk[-1]), hk, D), dtype), rand_half(rng, (int(cuk[-1]), hk, D), dtype)
     if spike is not None:                      # key `spike[0]` = the query of row `spike[1]`: a score ~ d far above the others
         k[spike[0]] = q[spike[1], ::(h // hk)][:hk]
-    out, lse, stats = H.prefill_varlen(q, k, v, cu, cuk, D ** -0.5, causal, "bf16" if dtype == BF16 else "f16", want_lse=True, exact=exact, **kw)
+    out, lse, stats = H.prefill_varlen(q, k, v, cu, cuk, D ** -0.5, causal, "bf16" if dtype == BF16 else "f16", want_lse=True,
+                                       exact=None if auto else exact, **kw)
     qf, kf, vf = to_f32(q, dtype), to_f32(k, dtype), to_f32(v, dtype)
     for b in range(len(lens)):
         s0, s1, k0, k1 = int(cu[b]), int(cu[b + 1]), int(cuk[b]), int(cuk[b + 1])
         if s1 == s0:
             continue
-        own = from_f32(A.attend_prefill_online(qf[s0:s1], kf[k0:k1], vf[k0:k1], np.float32(D ** -0.5), causal, dtype, prescale=not exact), dtype)
-        assert_close(out[s0:s1], own, dtype, atol=1e-3, what=f"sequence {b} vs the kernel's own schedule")
-        if exact and k1 > k0:
+        if not auto:
+            own = from_f32(A.attend_prefill_online(qf[s0:s1], kf[k0:k1], vf[k0:k1], np.float32(D ** -0.5), causal, dtype, prescale=not exact), dtype)
+            assert_close(out[s0:s1], own, dtype, atol=1e-3, what=f"sequence {b} vs the kernel's own schedule")
+        if (exact or auto) and k1 > k0:
             ref, want_lse = A.attend_rows(qf[s0:s1], kf[k0:k1], vf[k0:k1], np.float32(D ** -0.5), causal=causal)
             assert_close(out[s0:s1], from_f32(ref, dtype), dtype, atol=ATOL_VS_F32[dtype], what=f"sequence {b} vs the f32 definition")
             fin = np.isfinite(want_lse)
-            assert np.allclose(lse[:, s0:s1][fin], want_lse[fin], rtol=1e-4, atol=1e-4)
+            # the fast arithmetic's one rounding of scale.log2(e).Q moves the log-sum-exp by ~1e-3 (no caller reads it: SURVEY Q4)
+            assert np.allclose(lse[:, s0:s1][fin], want_lse[fin], rtol=1e-4, atol=2.5e-3 if auto else 1e-4)
             assert np.all(np.isposinf(lse[:, s0:s1][~fin]))
     return stats
 
@@ -54,6 +58,13 @@ def test_three_blocks_both_dma_timings(late, reverse):
     """700 rows = three 256-row blocks (1, 8 and 11 K/V tiles): the steady-state loop, ring wrap-around, every barrier; the
     LDS-DMA lands at the latest / earliest legal time"""
     run_case([700], 1, 1, True, late_dma=late, reverse=reverse)
+
+
+def test_two_persistent_workgroups_and_the_kernels_own_choice_of_arithmetic():
+    """two workgroups share the plan table round-robin; per block the entry's flag picks the arithmetic (first row sees < 512 keys ->
+    exact, else fast): 700 rows = two exact blocks and a fast one walked by the same workgroups"""
+    run_case([700, 300, 64], 1, 1, True, auto=True, g=2)
+    run_case([600], 2, 1, False, auto=True, g=3)
 
 
 def test_f16_and_more_queries_than_keys_and_empty():
@@ -100,7 +111,7 @@ def test_every_iteration_variant_is_reached():
     prog, _ = K.build("bf16", False)
     labels = {i.ops[0]: n for n, i in enumerate(prog.ins) if i.op == "label"}
     its = sorted(l for l in labels if l.startswith("IT_"))
-    assert len(its) == 17
+    assert len(its) == 17 and len([l for l in labels if l.startswith("ITX_")]) == 16
     from tools.pfasm.sim import Workgroup
     seen = set()
     orig = Workgroup.step
@@ -123,9 +134,9 @@ def test_every_iteration_variant_is_reached():
 
 def test_schedule_density_of_the_plain_iteration():
     """the plain iteration (both slots, no mask): 64 MFMAs, at most 5 fillers in any MFMA gap, under 4.7 on average"""
+    _, b = K.build("bf16", False)
     for exact, bound in ((False, 4.7), (True, 5.7)):
-        _, b = K.build("bf16", False, exact=exact)
-        l1, l2 = b.sched_log["IT_0_220"]
+        l1, l2 = b.sched_log["ITX_0_220" if exact else "IT_0_220"]
         assert len(l1) == 33 and len(l2) == 33
         assert max(l1 + l2) <= (7 if exact else 6)
         assert sum(l1 + l2) / 64.0 <= bound

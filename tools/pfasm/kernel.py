@@ -26,35 +26,38 @@ scheduler (`schedule`) with at most CAP fillers per MFMA gap:
 K/V tiles travel by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per instruction, bounds-checked by the descriptor: rows
 past the sequence read as zeros) into two 3-slot rings (96 KiB); one s_waitcnt vmcnt(8) + s_barrier per tile.
 """
+import os
+
 from .isa import Program, Ins, Reg, V, A, S, VCC, M0, f32_bits
 
 NEG_INF = float("-inf")
 
-# ---- parameter block: 64 dwords per wavefront, written by csrc/prefill_asm.hip (PfaWaveParams) -------------------------------
+# ---- parameter entry: 64 dwords per (query block, wavefront).  Contiguous K/V: an entry of the plan table in global memory
+# (csrc/prefill_asm.hip pfa_plan_kernel), fetched with three s_load_dwordx16 straight into s48..: descriptors and scalars sit in
+# the registers the code uses.  Paged K/V: the same layout in LDS, written by the launching kernel's C++ preamble. --------------
 PARAMS = [
-    "q0_lo", "q0_hi", "q1_lo", "q1_hi",             # address of row 0 of the slot's q block (this head)
-    "o0_lo", "o0_hi", "o1_lo", "o1_hi",             # same for the output
+    "k_lo", "k_hi", "k_bytes", "k_flags",           # K descriptor (contiguous: row 0 of this sequence / kv head, bytes to the end of its last row)
+    "v_lo", "v_hi", "v_bytes", "v_flags",           #   paged: lo / hi = cache base + head offset, bytes / flags rebuilt per piece
+    "o0_lo", "o0_hi", "o0_bytes", "o0_flags",       # O descriptor of slot 0: its row 0 for this head; bytes = (rows - 1) * stride + 256
+    "o1_lo", "o1_hi", "o1_bytes", "o1_flags",
+    "q0_lo", "q0_hi", "q1_lo", "q1_hi",             # row 0 of the slot's q block (this head)
     "lse0_lo", "lse0_hi", "lse1_lo", "lse1_hi",     # row 0 of the slot in the LSE array (4-byte row stride), 0 = none
-    "q_stride", "o_stride",                         # row strides, bytes
-    "rows0", "rows1",                               # valid rows of the slot (0 .. 32)
-    "k_lo", "k_hi", "v_lo", "v_hi",                 # contiguous: row 0 of this sequence and kv head; paged: cache base + head offset
-    "k_stride", "v_stride",                         # K/V row strides, bytes
-    "k_bytes", "v_bytes",                           # contiguous: bytes from row 0 to the end of the sequence's last row; paged: unused
+    "q_stride", "o_stride", "rows0", "rows1",       # row strides (bytes); valid rows of the slot (0 .. 32)
+    "k_tile", "v_tile", "k_stride", "v_stride",     # 64 * stride; K/V row strides, bytes
     "len_k", "n_tiles", "n0", "n1",                 # keys; K/V tiles of the workgroup; tiles slot 0 / slot 1 take part in
     "n_steady", "tm0", "tm1", "tmm",                # leading iterations of the plain variant; first tile that needs a mask (slot 0, 1, min)
-    "lim0", "lim1", "lim_step",                     # last visible key of the slot's row 0; +lim_step per row (1 causal, 0 not)
-    "scale_log2",                                   # f32 bits
-    "bt_lo", "bt_hi", "page_shift",                 # paged: this sequence's block table, log2(page size)
-    "k_page_bytes", "v_page_bytes",                 # paged: page strides, bytes
-    "wave",                                         # 0 .. 3
-    "thr",                                          # f32 bits: the deferred-raise threshold in the domain S' lives in (8, or 8 / scale_log2 when exact)
-    "dbg_lo", "dbg_hi",                             # timing builds: 32 bytes per wavefront for the phase timers
+    "lim0", "lim1", "lim_step", "scale_log2",       # last visible key of the slot's row 0; +lim_step per row (1 causal, 0 not); f32 bits
+    "thr", "flags", "mscale", "pad0",               # deferred-raise threshold in the domain of S' (8, or 8 / scale_log2 when exact); bit 0 exact, bit 1 valid; LSE: m * mscale
+    "bt_lo", "bt_hi", "page_shift", "k_page",       # paged: this sequence's block table, log2(page size), page strides (bytes)
+    "v_page", "wave", "dbg_lo", "dbg_hi",           # wave: 0 .. 3 (LDS entries only); timing builds: 32 bytes per wavefront
 ]
 PIDX = {n: i for i, n in enumerate(PARAMS)}
 PARAM_DWORDS = 64
+FLAG_EXACT, FLAG_VALID = 1, 2
 LDS_RING = 96 * 1024            # K slots at 0 / 16K / 32K, V slots at 48K / 64K / 80K
-LDS_PARAMS = LDS_RING           # 4 x 256 bytes
-LDS_TOTAL = LDS_RING + 4 * PARAM_DWORDS * 4
+LDS_STAGE = LDS_RING            # 4 x 16 KiB: O^T -> O transposition in the epilogue; the paged kernels' parameter entries
+LDS_PARAMS = LDS_RING           #   (4 x 256 bytes, read before the first barrier) share the first KiB
+LDS_TOTAL = 160 * 1024
 SLOT = 16384
 CAP = 5                         # fillers per MFMA gap the scheduler aims for
 
@@ -103,51 +106,39 @@ MREF = [V(224), V(225)]
 LIM = [V(226), V(227)]
 V_NEGINF = V(228)
 LIMREL = [V(229), V(230)]
+V_EPW = V(231)          # epilogue: LDS write address of this lane's row (staging region, swizzle folded in)
 TMP = [V(232 + i) for i in range(24)]
+EPR = [TMP[20], TMP[21], TMP[22], TMP[23]]      # epilogue: LDS read addresses (4 row groups); timing builds keep their timers in TMP[12..19]
+TACC = [TMP[14 + i] for i in range(6)]        # phase 1, phase 2, waits + barrier, loop control, prologue, epilogue
 
-_snext = [36]
+# scalar registers: s16 .. s99 belong to the asm statement, except s32 (the compiler's stack pointer; s100 / s101 are reserved too)
+S_T, S_T1, S_RBASE, S_DBASE, S_DELTA, S_KDMA, S_W1024, S_RET = (S(16 + i) for i in range(8))
+S_TMP = [S(24 + i) for i in range(8)]
+S_TLAST = S(33)
+S_PAIR = S(34, 2)
+S_KSOFF, S_VSOFF = S(36), S(37)                 # contiguous: byte offset of the next K / V tile to request
+S_BLK, S_NENT = S(38), S(39)
+S_SAVE = [S(40 + i) for i in range(8)]          # slot 1's epilogue parameters while the next block's entry is loaded (descriptor: 4-aligned)
+S_G, S_G2, S_TAB = S(96), S(97), S(98, 2)       # persistent: s96..s99 (the paged fields of the entry) are not loaded
+S_TNOW, S_TT = S(30, 2), S(29)
+S_HASNEXT = S_RET
+# paged kernels (not persistent): the registers of the block loop hold the paging state; the entry's paged fields sit in s96..s99
+S_KVT, S_VVT, S_VPAGE = S(36), S(37), S(33)
+S_KBASE, S_VBASE = S(40, 2), S(42, 2)
+S_BT, S_PSHIFT, S_KPAGE = S(96, 2), S(98), S(99)
+WIN = 48                        # the entry's first 52 dwords live in s48 .. s99
 
 
-def _salloc(n=1, align=1):
-    i = (_snext[0] + align - 1) // align * align
-    _snext[0] = i + n
-    assert _snext[0] <= 100, "out of SGPRs"
-    return S(i, n) if n > 1 else S(i)
+def W(name, n=1):
+    return S(WIN + PIDX[name], n)
 
 
-S_KDESC = _salloc(4, 4)
-S_VDESC = _salloc(4, 4)
-S_ODESC = _salloc(4, 4)
-S_PAIR = _salloc(2, 2)          # 64-bit scratch (compare results, addresses)
-S_VSTRIDE = _salloc()
-S_KSTRIDE = _salloc()
-S_KTILE = _salloc()             # 64 * k_stride
-S_VTILE = _salloc()
-S_KREC = _salloc()              # signed bytes left from the descriptor base to the end of the sequence
-S_VREC = _salloc()
-S_NT, S_N0, S_N1, S_NST, S_TM0, S_TM1, S_TMM = (_salloc() for _ in range(7))
-S_T, S_T1 = _salloc(), _salloc()
-S_RBASE, S_DBASE, S_DELTA, S_KDMA = (_salloc() for _ in range(4))
-S_W1024 = _salloc()
-S_LENK = _salloc()
-S_RET = _salloc()
-S_ROWS = [_salloc(), _salloc()]
-S_TMP = [_salloc() for _ in range(8)]
-S_SCALE = _salloc()
-S_THRV = _salloc()
-S_QST, S_OST = _salloc(), _salloc()
-S_PTR = _salloc(2, 2)           # parameter reload scratch
-S_BT = _salloc(2, 2)
-S_PSHIFT, S_KPAGE, S_VPAGE = _salloc(), _salloc(), _salloc()
-S_KBASE = _salloc(2, 2)
-S_VBASE = _salloc(2, 2)
-S_KVT = _salloc()               # paged: first key of the next K tile to request
-S_VVT = _salloc()
-SGPR_FIRST, SGPR_LAST = 36, _snext[0] - 1
-# timing builds (contiguous K/V only) reuse the paged-addressing registers
-S_TACC = [S_BT[0], S_BT[1], S_PSHIFT, S_KPAGE, S_VPAGE, S_KBASE[0], S_KBASE[1], S_KVT]
-S_TNOW = S_VBASE
-S_TLAST, S_TT = S_VVT, S_PTR[0]
+S_KDESC, S_VDESC, S_ODESC = W("k_lo", 4), W("v_lo", 4), [W("o0_lo", 4), W("o1_lo", 4)]
+S_LENK, S_NT, S_N0, S_N1, S_NST, S_TM0, S_TM1, S_TMM = (W(n) for n in ("len_k", "n_tiles", "n0", "n1", "n_steady", "tm0", "tm1", "tmm"))
+S_KTILE, S_VTILE, S_KSTRIDE, S_VSTRIDE = W("k_tile"), W("v_tile"), W("k_stride"), W("v_stride")
+S_SCALE, S_THRV, S_QST, S_OST = W("scale_log2"), W("thr"), W("q_stride"), W("o_stride")
+S_ROWS = [W("rows0"), W("rows1")]
+SGPR_FIRST, SGPR_LAST = 16, 99
 
 
 class Item:
@@ -248,30 +239,36 @@ def insert_lds_waits(ins_list):
 
 
 class Builder:
-    def __init__(self, dtype="bf16", paged=False, param_sgpr=S(4), exact=False, timing=False):
-        """exact = False: Q pre-multiplied by scale.log2(e) and rounded once (S' in the exp2 domain, 3 VALU per score);
-        exact = True: Q as it is, S' = s - m in the raw domain and one v_mul_f32 by scale.log2(e) in front of every v_exp_f32 --
-        the reference's arithmetic to the last rounding, for rows whose softmax mass sits on a few keys."""
+    def __init__(self, dtype="bf16", paged=False, inputs=None, timing=False):
+        """paged = False: the persistent kernel (one workgroup per CU walks the plan table); inputs = dict(tab, first, n, g, wave[, dbg])
+        of scalar operands.  paged = True: one workgroup per query block, parameters in LDS; inputs = dict(param).
+        Both carry the two arithmetic variants (label suffix "" = fast, "X" = exact), chosen per query block by the entry's flags:
+          fast  -- Q pre-multiplied by scale.log2(e) and rounded once (S' in the exp2 domain, 3 VALU per score);
+          exact -- Q as it is, S' = s - m in the raw domain and one v_mul_f32 by scale.log2(e) in front of every v_exp_f32: the
+                   reference's arithmetic to the last rounding, for rows whose softmax mass sits on a few keys."""
         assert dtype in ("bf16", "f16")
         assert not (timing and paged)
-        self.dtype, self.paged, self.exact, self.timing = dtype, paged, exact, timing
+        self.dtype, self.paged, self.timing = dtype, paged, timing
+        self.persistent = not paged
+        self.inp = inputs or (dict(param=S(4)) if paged else dict(tab=S(4, 2), first=S(6), n=S(7), g=S(8), wave=S(9), dbg=S(10, 2), g2=S(12)))
+        self.exact, self.sfx = False, ""
         self.mfma = "v_mfma_f32_32x32x16_" + dtype
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
-        self.param_sgpr = param_sgpr
         self.p = Program()
         self.sched_log = {}
-        self.ret_sites = []       # (id, label) of RESC call sites
+        self.ret_sites = []       # RESC call sites: (id, return label, stub label, bank, slots, suffix)
 
     # ------------------------------------------------------------------------------------------------------------------------
     def e(self, op, *ops, **mods):
         return self.p.emit(op, *ops, **mods)
 
-    def stamp(self, k):
-        """timing builds: cycles since the previous stamp -> accumulator k (s_memtime: the wait drains the LDS queue too)"""
-        if not self.timing:
+    def stamp(self, k, mode="phases"):
+        """timing builds ("phases": the loop's phases and the per-block sums; "block": the regions between two blocks' loops): cycles
+        since the previous stamp -> timer k; k = None only restarts the clock (s_memtime: the wait drains the LDS queue too)"""
+        if self.timing != mode:
             return []
-        return [Ins("s_memtime", S_TNOW), Ins("s_waitcnt", lgkmcnt=0), Ins("s_sub_u32", S_TT, S_TNOW[0], S_TLAST),
-                Ins("s_add_u32", S_TACC[k], S_TACC[k], S_TT), Ins("s_mov_b32", S_TLAST, S_TNOW[0])]
+        out = [Ins("s_memtime", S_TNOW), Ins("s_waitcnt", lgkmcnt=0), Ins("s_sub_u32", S_TT, S_TNOW[0], S_TLAST), Ins("s_mov_b32", S_TLAST, S_TNOW[0])]
+        return out + ([Ins("v_add_u32", TACC[k], S_TT, TACC[k])] if k is not None else [])
 
     def nop(self, states):
         """at least `states` wait states"""
@@ -311,13 +308,12 @@ class Builder:
 
             def cv(c):
                 return Ins(self.cvt, pos[c], e[2 * c], e[2 * c + 1])
+            x2 = lambda x: Ins("v_exp_f32", x, x)
             if self.exact:     # the multiplies run one pair ahead of their v_exp_f32
                 m = lambda x: Ins("v_mul_f32", x, S_SCALE, x)
-                x2 = lambda x: Ins("v_exp_f32", x, x)
                 seq += [m(e[0]), m(e[1]), m(e[2]), m(e[3]), x2(e[0]), x2(e[1]), x2(e[2]), x2(e[3]), m(e[4]), m(e[5]), ad(0), ad(1), cv(0),
                         x2(e[4]), x2(e[5]), m(e[6]), m(e[7]), ad(2), ad(3), cv(1), x2(e[6]), x2(e[7]), ad(4), ad(5), cv(2), ad(6), ad(7), cv(3)]
             else:
-                x2 = lambda x: Ins("v_exp_f32", x, x)
                 seq += [x2(e[0]), x2(e[1]), x2(e[2]), x2(e[3]), ad(0), ad(1), cv(0), x2(e[4]), x2(e[5]), ad(2), ad(3), cv(1),
                         x2(e[6]), x2(e[7]), ad(4), ad(5), cv(2), ad(6), ad(7), cv(3)]
         return [Item(i, release, deadline) for i in seq]
@@ -328,8 +324,8 @@ class Builder:
         dst = VV(o % 8)
         return [Ins("ds_read_b64_tr_b16", dst[0:2], VAD[db], offset=off), Ins("ds_read_b64_tr_b16", dst[2:4], VAD[db], offset=off + 2048)]
 
-    def k_reads(self):
-        return [Ins("ds_read_b128", KA(h, j), KAD[j], offset=h * 8192) for h in range(2) for j in range(8)]
+    def k_reads(self, extra=0):
+        return [Ins("ds_read_b128", KA(h, j), KAD[j], offset=h * 8192 + extra) for h in range(2) for j in range(8)]
 
     def max_items(self, bank_n, s, release):
         out = []
@@ -339,15 +335,13 @@ class Builder:
             for k in range(6):
                 out.append(Ins("v_max3_f32", acc, acc, t[3 + 2 * k], t[4 + 2 * k]))
             out.append(Ins("v_max_f32", acc, acc, t[15]))
-        # interleave the two chains, then combine
         a, b = out[:8], out[8:]
         seq = [x for pair in zip(a, b) for x in pair] + [Ins("v_max_f32", MX[s], MX[s], MXB[s])]
         return [Item(i, release) for i in seq]
 
     def mask_items(self, bank_n, s, release):
-        """keys beyond the lane's limit -> -inf: key(r, h) = kv1 + 32h + (r&3) + 8(r>>2) + 4hi > LIM  <=>  const > LIMREL"""
-        seq = [Ins("v_subrev_u32", LIMREL[s], S_T1, LIM[s]),          # LIM - 64 (t+1) ... S_T1 holds kv1 here (see iteration)
-               Ins("v_sub_u32", LIMREL[s], LIMREL[s], V_HI4)]
+        """keys beyond the lane's limit -> -inf: key(r, h) = kv1 + 32h + (r&3) + 8(r>>2) + 4hi > LIM  <=>  const > LIMREL (S_T1 = kv1)"""
+        seq = [Ins("v_subrev_u32", LIMREL[s], S_T1, LIM[s]), Ins("v_sub_u32", LIMREL[s], LIMREL[s], V_HI4)]
         for h in range(2):
             t = T(bank_n, s, h)
             for r in range(16):
@@ -359,17 +353,27 @@ class Builder:
             items.append(Item([seq[k], seq[k + 1]], release))       # the compare and its select stay together (VCC)
         return items
 
-    def dma_tile(self, desc, voffs, lds_extra):
-        """four 1 KiB pieces of this wavefront: rows 16u + 4w .. +3 of the tile -> ring slot S_KDMA (+ lds_extra for V)"""
+    def dma_tile(self, is_v):
+        """contiguous K/V: the four 1 KiB pieces of this wavefront (rows 16u + 4w .. +3 of the tile) -> ring slot S_KDMA; the tile's byte
+        offset rides in soffset (it takes part in the descriptor's range check: rows past the sequence arrive as zeros)"""
+        desc, voffs, soff, tile, extra = (S_VDESC, VOFV, S_VSOFF, S_VTILE, 3 * SLOT) if is_v else (S_KDESC, VOFK, S_KSOFF, S_KTILE, 0)
         items = []
+        exp = os.environ.get("PFA_EXP", "")
+        if exp in ("regload", "regload_write", "nodma") and getattr(self, "in_loop", False):
+            # TIMING EXPERIMENTS ONLY (results are wrong): the pieces as plain loads into registers [+ a 16-byte LDS write each] / no request at all
+            for u in range(4):
+                dst = V(TMP[0].idx + 4 * ((u + 4 * is_v) % 3), 4)
+                if exp != "nodma":
+                    items.append(Item([Ins("buffer_load_dwordx4", dst, voffs[u], desc, soff, offen=True)]))
+                if exp == "regload_write":
+                    items.append(Item([Ins("ds_write_b128", VAD[0], V(TMP[12].idx, 4), offset=0)]))
+            items.append(Item(Ins("s_add_u32", soff, soff, tile)))
+            return items
         for u in range(4):
-            items.append(Item([Ins("s_add_u32", M0, S_KDMA, lds_extra + u * 4096), Ins("s_nop", 0),
-                               Ins("buffer_load_dwordx4", voffs[u], desc, 0, offen=True, lds=True)]))
+            items.append(Item([Ins("s_add_u32", M0, S_KDMA, extra + u * 4096), Ins("s_nop", 0),
+                               Ins("buffer_load_dwordx4", voffs[u], desc, soff, offen=True, lds=True)]))
+        items.append(Item(Ins("s_add_u32", soff, soff, tile)))
         return items
-
-    def desc_advance(self, desc, tile, rec):
-        return [Item(Ins("s_add_u32", desc[0], desc[0], tile)), Item(Ins("s_addc_u32", desc[1], desc[1], 0)),
-                Item(Ins("s_sub_i32", rec, rec, tile)), Item(Ins("s_max_i32", desc[2], rec, 0))]
 
     # ---- paged K/V: the descriptor of every piece comes from the block table -------------------------------------------------------
     def paged_piece_setup(self, u, key0, base, page_bytes, stride, desc, pg):
@@ -409,10 +413,24 @@ class Builder:
         seq.append(Ins("s_add_u32", key0, key0, 64))
         return seq
 
+    def request_tile(self, is_v, slot=None):
+        """the four pieces of the next K (or V) tile, as straight code; slot: ring slot index (prologue), None: S_KDMA is set"""
+        if slot is not None:
+            self.e("s_add_u32", S_KDMA, S_W1024, slot * SLOT)
+        if self.paged:
+            self.p.extend(self.paged_tile(S_VVT if is_v else S_KVT, is_v))
+        else:
+            for it in self.dma_tile(is_v):
+                self.p.extend(it.ins)
+
+    def ring_rotate(self):
+        return [Ins("s_mov_b32", S_DBASE, S_RBASE), Ins("s_add_u32", S_RBASE, S_RBASE, S_DELTA), Ins("s_add_u32", S_KDMA, S_DBASE, S_W1024)]
+
     # ---- one iteration -----------------------------------------------------------------------------------------------------------
     def iteration(self, p, c, x, mk):
         """tile t in bank p: cur slots (c = 2: both, 1: slot 1, 0: none) exponentiate + P.V; next slots (x) get S(t+1)."""
-        name = f"IT_{p}_{c}{x}{'m' if mk else '0'}"
+        sfx = self.sfx
+        name = f"IT{sfx}_{p}_{c}{x}{'m' if mk else '0'}"
         cur = {2: [0, 1], 1: [1], 0: []}[c]
         nxt = {2: [0, 1], 1: [1], 0: []}[x]
         bank_c, bank_n = p, p ^ 1
@@ -421,14 +439,13 @@ class Builder:
         # ---------------- phase 1 ----------------
         mf1 = self.qk_mfmas(bank_n, nxt)
         n1 = len(mf1)
-        exp_h0 = [it for s in cur for it in self.exp_items(bank_c, s, 0)]
-        # interleave the slots' streams so that both finish early (P of half 0 is needed first by P.V)
-        if len(cur) == 2:
+        if len(cur) == 2:      # interleave the slots' streams so that both finish early (P of half 0 is needed first by P.V)
             a, b = self.exp_items(bank_c, 0, 0), self.exp_items(bank_c, 1, 0)
             exp_h0 = [y for pair in zip(a, b) for y in pair]
             a, b = self.exp_items(bank_c, 0, 1), self.exp_items(bank_c, 1, 1)
             exp_h1 = [y for pair in zip(a, b) for y in pair]
         else:
+            exp_h0 = [it for s in cur for it in self.exp_items(bank_c, s, 0)]
             exp_h1 = [it for s in cur for it in self.exp_items(bank_c, s, 1)]
         vreads = []
         if cur:
@@ -452,18 +469,14 @@ class Builder:
             if mk:
                 mm += self.mask_items(bank_n, s, rel_m)
             mm += self.max_items(bank_n, s, rel_m)
-        kr = []
-        if nxt:
-            kr = [Item(i, 1 if n2 else -1) for i in self.k_reads()]
+        kr = [Item(i, 1 if n2 else -1) for i in self.k_reads()] if nxt else []
         ring = [Item(Ins("s_mov_b32", S_TMP[0], SLOT), -1, 1), Item(Ins("s_cmp_eq_u32", S_RBASE, 2 * SLOT), -1, 1),
                 Item(Ins("s_cselect_b32", S_DELTA, -2 * SLOT, S_TMP[0]), -1, 1)]
         adv = [Item(Ins("v_add_u32", KAD[j], S_DELTA, KAD[j])) for j in range(8)]
         vadv = [Item(Ins("v_add_u32", VAD[db], S_DELTA, VAD[db]), release=max(15 * per - 1, -1)) for db in range(4)]
-        if self.paged:
-            dma = []           # issued as a scalar block in front of phase 2 (see below)
-        else:
-            dma = self.dma_tile(S_KDESC, VOFK, 0) + self.desc_advance(S_KDESC, S_KTILE, S_KREC) + \
-                self.dma_tile(S_VDESC, VOFV, 3 * SLOT) + self.desc_advance(S_VDESC, S_VTILE, S_VREC)
+        self.in_loop = True
+        dma = [] if self.paged else self.dma_tile(False) + self.dma_tile(True)      # paged: a scalar block in front of phase 2
+        self.in_loop = False
         for it in dma:
             it.release = max(it.release, 2 if n2 else -1)
         # ---- how much of the second half's softmax rides in phase 1: the same filler density in both phases ----
@@ -481,10 +494,15 @@ class Builder:
         cap1 = max(dens, -(-(f1 + move) // max(n1, 1)))
         cap2 = max(dens, -(-(f2 + n_e1 - move) // max(n2, 1)))
         log1, log2 = [], []
+        exp_knob = os.environ.get("PFA_EXP", "")
+        if exp_knob.startswith("drop:"):      # TIMING EXPERIMENTS ONLY (wrong results): drop every filler with this mnemonic from the loop
+            ops = exp_knob[5:].split(",")
+            flt = lambda items: [it for it in items if not any(i.op in ops for i in it.ins)]
+            exp_h0, vreads, e1_in_p1, e1_in_p2, v2, mm, kr, adv, vadv = (flt(x) for x in (exp_h0, vreads, e1_in_p1, e1_in_p2, v2, mm, kr, adv, vadv))
         body1 = schedule(mf1, [exp_h0, vreads, e1_in_p1], cap=cap1, log=log1)
         body2 = schedule(mf2, [e1_in_p2, v2, mm, ring + kr + adv, dma, vadv], cap=cap2, log=log2)
         self.sched_log[name] = (log1, log2)
-        blk = self.stamp(4)
+        blk = self.stamp(3)
         if mk:
             blk.append(Ins("s_lshl_b32", S_T1, S_T, 6))
             blk.append(Ins("s_add_u32", S_T1, S_T1, 64))       # kv1 = 64 (t + 1): LIMREL = LIM - kv1 - 4hi
@@ -500,8 +518,7 @@ class Builder:
         # ---------------- decision, ring rotation, barrier ----------------
         if nxt:
             site = len(self.ret_sites)
-            ret = f"RET_{site}"
-            stub = f"STUB_{site}"
+            ret, stub = f"RET_{site}", f"STUB_{site}"
             if len(nxt) == 2:
                 self.e("v_cmp_gt_f32", S_PAIR, MX[0], THR[0])
                 self.e("v_cmp_gt_f32", VCC, MX[1], THR[1])
@@ -511,87 +528,79 @@ class Builder:
                 self.e("s_or_b64", S_PAIR, S_PAIR, S_PAIR)
             self.e("s_cbranch_scc1", stub)
             P.label(ret)
-            self.ret_sites.append((site, ret, stub, bank_n, x))
-        self.e("s_mov_b32", S_DBASE, S_RBASE)
-        self.e("s_add_u32", S_RBASE, S_RBASE, S_DELTA)
-        self.e("s_add_u32", S_KDMA, S_DBASE, S_W1024)
+            self.ret_sites.append((site, ret, stub, bank_n, x, sfx))
+        P.extend(self.ring_rotate())
         self.e("s_waitcnt", vmcnt=8, lgkmcnt=0)
-        P.extend(self.stamp(2))
         self.e("s_barrier")
-        P.extend(self.stamp(3))
-        if self.timing:
-            self.e("s_add_u32", S_TACC[7], S_TACC[7], 1)
+        P.extend(self.stamp(2))
         self.e("s_add_u32", S_T, S_T, 1)
         if (c, x, mk) == (2, 2, False):
             self.e("s_cmp_lt_u32", S_T, S_NST)
-            self.e("s_cbranch_scc1", f"IT_{p ^ 1}_220")
-        self.e("s_branch", f"DISP_{p ^ 1}")
+            self.e("s_cbranch_scc1", f"IT{sfx}_{p ^ 1}_220")
+        self.e("s_branch", f"DISP{sfx}_{p ^ 1}")
 
     def idle_iteration(self):
-        """a wavefront with no active slot: its share of the LDS-DMA, the barrier"""
+        """a wavefront with no active slot: its share of the LDS-DMA, the barrier (the read addresses keep following the ring: the
+        next block of a persistent workgroup starts from them)"""
         P = self.p
         P.label("IT_00")
-        if self.paged:
-            P.extend(self.paged_tile(S_KVT, False) + self.paged_tile(S_VVT, True))
-        else:
-            for it in self.dma_tile(S_KDESC, VOFK, 0) + self.desc_advance(S_KDESC, S_KTILE, S_KREC) + \
-                    self.dma_tile(S_VDESC, VOFV, 3 * SLOT) + self.desc_advance(S_VDESC, S_VTILE, S_VREC):
-                P.extend(it.ins)
+        self.request_tile(False)
+        self.request_tile(True)
         self.e("s_mov_b32", S_TMP[0], SLOT)
         self.e("s_cmp_eq_u32", S_RBASE, 2 * SLOT)
         self.e("s_cselect_b32", S_DELTA, -2 * SLOT, S_TMP[0])
-        self.e("s_mov_b32", S_DBASE, S_RBASE)
-        self.e("s_add_u32", S_RBASE, S_RBASE, S_DELTA)
-        self.e("s_add_u32", S_KDMA, S_DBASE, S_W1024)
+        for r in KAD + VAD:
+            self.e("v_add_u32", r, S_DELTA, r)
+        P.extend(self.ring_rotate())
         self.e("s_waitcnt", vmcnt=8, lgkmcnt=0)
         self.e("s_barrier")
         self.e("s_add_u32", S_T, S_T, 1)
         self.e("s_cmp_lt_u32", S_T, S_NT)
         self.e("s_cbranch_scc1", "IT_00")
-        self.e("s_branch", "EPILOGUE")
+        self.e("s_branch", "BLOCK_END")
 
     def dispatcher(self, p):
-        P = self.p
-        e = self.e
-        P.label(f"DISP_{p}")
+        P, e, x = self.p, self.e, self.sfx
+        P.label(f"DISP{x}_{p}")
         e("s_cmp_ge_u32", S_T, S_NT)
-        e("s_cbranch_scc1", "EPILOGUE")
+        e("s_cbranch_scc1", "BLOCK_END")
         e("s_cmp_lt_u32", S_T, S_NST)
-        e("s_cbranch_scc1", f"IT_{p}_220")
+        e("s_cbranch_scc1", f"IT{x}_{p}_220")
         e("s_add_u32", S_T1, S_T, 1)
         e("s_cmp_lt_u32", S_T, S_N0)
-        e("s_cbranch_scc0", f"D{p}_CNOT2")
+        e("s_cbranch_scc0", f"D{x}{p}_CNOT2")
         e("s_cmp_lt_u32", S_T1, S_N0)
-        e("s_cbranch_scc0", f"D{p}_C2XN2")
+        e("s_cbranch_scc0", f"D{x}{p}_C2XN2")
         e("s_cmp_ge_u32", S_T1, S_TMM)
-        e("s_cbranch_scc1", f"IT_{p}_22m")
-        e("s_branch", f"IT_{p}_220")
-        P.label(f"D{p}_C2XN2")
+        e("s_cbranch_scc1", f"IT{x}_{p}_22m")
+        e("s_branch", f"IT{x}_{p}_220")
+        P.label(f"D{x}{p}_C2XN2")
         e("s_cmp_lt_u32", S_T1, S_N1)
-        e("s_cbranch_scc0", f"IT_{p}_200")
+        e("s_cbranch_scc0", f"IT{x}_{p}_200")
         e("s_cmp_ge_u32", S_T1, S_TM1)
-        e("s_cbranch_scc1", f"IT_{p}_21m")
-        e("s_branch", f"IT_{p}_210")
-        P.label(f"D{p}_CNOT2")
+        e("s_cbranch_scc1", f"IT{x}_{p}_21m")
+        e("s_branch", f"IT{x}_{p}_210")
+        P.label(f"D{x}{p}_CNOT2")
         e("s_cmp_lt_u32", S_T, S_N1)
         e("s_cbranch_scc0", "IT_00")
         e("s_cmp_lt_u32", S_T1, S_N1)
-        e("s_cbranch_scc0", f"IT_{p}_100")
+        e("s_cbranch_scc0", f"IT{x}_{p}_100")
         e("s_cmp_ge_u32", S_T1, S_TM1)
-        e("s_cbranch_scc1", f"IT_{p}_11m")
-        e("s_branch", f"IT_{p}_110")
+        e("s_cbranch_scc1", f"IT{x}_{p}_11m")
+        e("s_branch", f"IT{x}_{p}_110")
 
     # ---- the rare block: raise the rows' reference --------------------------------------------------------------------------------
     def rescale(self, bank_n, x):
         """S'(t+1) of the slots in x sits in bank_n relative to the OLD references.  Per row (both lanes of a pair agree):
-        r = row max';  raise = r > THR (THR = -inf while the row has no reference yet, 8 afterwards);  delta = raise ? r : 0;
+        r = row max';  raise = r > THR (THR = -inf while the row has no reference yet, S_THRV afterwards);  delta = raise ? r : 0;
         m += delta;  C-init = -m;  S' -= delta;  alpha = had a reference ? 2^-delta : 1;  O *= alpha;  l *= alpha."""
         e = self.e
         slots = {2: [0, 1], 1: [1]}[x]
-        self.p.label(f"RESC_{bank_n}_{x}")
+        self.p.label(f"RESC{self.sfx}_{bank_n}_{x}")
         self.nop(MFMA_SAFE)
         for s in slots:
-            r, r2, dl, al, one = TMP[0], TMP[1], TMP[2], TMP[3], TMP[4]
+            r, r2, dl, al, one = VV(0)[0], VV(0)[1], VV(0)[2], VV(0)[3], VV(1)[0]     # the V^T window is dead here (all P.V MFMAs issued)
+            tmp8 = [VV(2 + k // 4)[k % 4] for k in range(8)]
             e("v_mov_b32", r, MX[s])
             e("v_mov_b32", r2, MX[s])
             self.nop(2)
@@ -609,8 +618,8 @@ class Builder:
             e("v_mov_b32", one, 1.0)
             e("v_cmp_gt_f32", S_PAIR, THR[s], 0)                   # the row already had a reference
             e("v_cndmask_b32", al, one, al, S_PAIR)                # alpha
-            e("v_mov_b32", TMP[5], S_THRV)
-            e("v_cndmask_b32", THR[s], THR[s], TMP[5], VCC)        # raised rows have a reference from now on
+            e("v_mov_b32", VV(1)[1], S_THRV)
+            e("v_cndmask_b32", THR[s], THR[s], VV(1)[1], VCC)      # raised rows have a reference from now on
             e("v_add_f32", MREF[s], MREF[s], dl)
             for k in range(16):
                 e("v_sub_f32", CI(s)[k], 0, MREF[s])
@@ -620,117 +629,93 @@ class Builder:
                     e("v_sub_f32", t[k], t[k], dl)
             e("v_mul_f32", LS(s, 0), LS(s, 0), al)
             e("v_mul_f32", LS(s, 1), LS(s, 1), al)
-            # O *= alpha unless alpha == 1 everywhere (always so at the first tile)
+            # O *= alpha unless alpha == 1 everywhere
             skip = self.p.uniq("RESC_SKIP")
             e("v_cmp_neq_f32", VCC, al, one)
             e("s_cbranch_vccz", skip)
             for db in range(4):
                 o = OA(s, db)
                 for k0 in range(0, 16, 8):
-                    for k in range(k0, k0 + 8):
-                        e("v_accvgpr_read_b32", TMP[8 + k - k0], o[k])
-                    for k in range(k0, k0 + 8):
-                        e("v_mul_f32", TMP[8 + k - k0], TMP[8 + k - k0], al)
-                    for k in range(k0, k0 + 8):
-                        e("v_accvgpr_write_b32", o[k], TMP[8 + k - k0])
+                    for k in range(8):
+                        e("v_accvgpr_read_b32", tmp8[k], o[k0 + k])
+                    for k in range(8):
+                        e("v_mul_f32", tmp8[k], tmp8[k], al)
+                    for k in range(8):
+                        e("v_accvgpr_write_b32", o[k0 + k], tmp8[k])
             self.p.label(skip)
         self.nop(MFMA_SRCC_SAFE)
-        # return to the call site
-        sites = [st for st in self.ret_sites if st[3] == bank_n and st[4] == x]
-        for site, ret, stub, _, _ in sites:
+        sites = [st for st in self.ret_sites if st[3] == bank_n and st[4] == x and st[5] == self.sfx]
+        for site, ret, stub, _, _, _ in sites:
             e("s_cmp_eq_u32", S_RET, site)
             e("s_cbranch_scc1", ret)
-        e("s_branch", sites[0][1] if sites else "EPILOGUE")
+        e("s_branch", sites[0][1])
 
-    # ---- prologue ---------------------------------------------------------------------------------------------------------------------
-    def load_params(self):
+    def first_reference(self, bank, s):
+        """tile 0 of a block: the row's first reference is its maximum over the tile (rows that see no key yet keep none)"""
         e = self.e
-        # lane ids
-        e("v_mbcnt_lo_u32_b32", TMP[0], -1, 0)
-        e("v_mbcnt_hi_u32_b32", TMP[0], -1, TMP[0])               # lane
-        e("v_and_b32", V_LQ, 31, TMP[0])
-        e("v_lshrrev_b32", TMP[1], 5, TMP[0])                     # hi
-        e("v_lshlrev_b32", V_HI4, 2, TMP[1])
-        # the parameter block: every lane reads the same 16 dwords x 4
-        e("v_mov_b32", TMP[2], self.param_sgpr)
-        for k in range(len(PARAMS) // 4 + (1 if len(PARAMS) % 4 else 0)):
-            e("ds_read_b128", V(4 * k, 4), TMP[2], offset=16 * k)
-        e("s_waitcnt", lgkmcnt=0)
+        r, r2, dl = TMP[8], TMP[9], TMP[10]
+        e("v_mov_b32", r, MX[s])
+        e("v_mov_b32", r2, MX[s])
+        self.nop(2)
+        e("v_permlane32_swap_b32", r, r2)
+        e("v_max_f32", r, r, r2)                                   # the row's max in both lanes of the pair
+        e("v_cmp_gt_f32", VCC, r, V_NEGINF)                        # the row sees a key
+        e("v_mov_b32", dl, 0)
+        e("v_cndmask_b32", dl, dl, r, VCC)
+        e("v_mov_b32", r2, S_THRV)
+        e("v_cndmask_b32", THR[s], THR[s], r2, VCC)
+        e("v_mov_b32", MREF[s], dl)
+        for k in range(16):
+            e("v_sub_f32", CI(s)[k], 0, dl)
+        for h in range(2):
+            t = T(bank, s, h)
+            for k in range(16):
+                e("v_sub_f32", t[k], t[k], dl)
 
-    def P(self, name):
-        """VGPR that holds parameter `name` right after load_params (all lanes equal)"""
-        return V(PIDX[name])
-
-    def rfl(self, dst, name):
-        self.e("v_readfirstlane_b32", dst, self.P(name))
-
-    def prologue(self):
-        e = self.e
-        P = self.p
+    # ---- entry: lane constants that hold for the whole launch ----------------------------------------------------------------------
+    def entry(self):
+        e, P = self.e, self.p
+        lane, hi = TMP[0], TMP[1]
+        e("v_mbcnt_lo_u32_b32", lane, -1, 0)
+        e("v_mbcnt_hi_u32_b32", lane, -1, lane)
+        e("v_and_b32", V_LQ, 31, lane)
+        e("v_lshrrev_b32", hi, 5, lane)
+        e("v_lshlrev_b32", V_HI4, 2, hi)
         if self.timing:
-            for a in S_TACC:
-                e("s_mov_b32", a, 0)
+            for a in TACC:
+                e("v_mov_b32", a, 0)
             e("s_memtime", S_TNOW)
             e("s_waitcnt", lgkmcnt=0)
             e("s_mov_b32", S_TLAST, S_TNOW[0])
-        self.load_params()
-        lane, hi = TMP[0], TMP[1]
-        # ---- scalars ----
-        for dst, name in ((S_NT, "n_tiles"), (S_N0, "n0"), (S_N1, "n1"), (S_NST, "n_steady"), (S_TM0, "tm0"), (S_TM1, "tm1"),
-                          (S_TMM, "tmm"), (S_LENK, "len_k"), (S_SCALE, "scale_log2"), (S_THRV, "thr"), (S_ROWS[0], "rows0"), (S_ROWS[1], "rows1"),
-                          (S_QST, "q_stride"), (S_OST, "o_stride"), (S_KSTRIDE, "k_stride"), (S_VSTRIDE, "v_stride"),
-                          (S_TMP[7], "wave")):
-            self.rfl(dst, name)
-        e("s_lshl_b32", S_W1024, S_TMP[7], 10)
-        e("s_lshl_b32", S_KTILE, S_KSTRIDE, 6)
-        e("s_lshl_b32", S_VTILE, S_VSTRIDE, 6)
-        # ---- descriptors ----
-        if self.paged:
-            for dst, name in ((S_KBASE[0], "k_lo"), (S_KBASE[1], "k_hi"), (S_VBASE[0], "v_lo"), (S_VBASE[1], "v_hi"), (S_BT[0], "bt_lo"),
-                              (S_BT[1], "bt_hi"), (S_PSHIFT, "page_shift"), (S_KPAGE, "k_page_bytes"), (S_VPAGE, "v_page_bytes")):
-                self.rfl(dst, name)
-            e("s_mov_b32", S_KVT, 0)
-            e("s_mov_b32", S_VVT, 0)
+        if self.persistent:
+            e("s_lshl_b32", S_W1024, self.inp["wave"], 10)
+            e("s_mov_b32", S_BLK, self.inp["first"])
+            e("s_mov_b32", S_NENT, self.inp["n"])
+            e("s_mov_b32", S_G, self.inp["g"])                   # the workgroup's stride through the table alternates (snake order: a
+            e("s_mov_b32", S_G2, self.inp["g2"])                 #  workgroup that took an early = long block of a round takes a late one next)
+            e("s_mov_b64", S_TAB, self.inp["tab"])
+            e("s_cmp_ge_u32", S_BLK, S_NENT)
+            e("s_cbranch_scc1", "KERNEL_END")
+            self.load_entry()                                     # strides are filled in every entry, valid or not
+            e("s_waitcnt", lgkmcnt=0)
         else:
-            for desc, rec, lo, hi_, nb in ((S_KDESC, S_KREC, "k_lo", "k_hi", "k_bytes"), (S_VDESC, S_VREC, "v_lo", "v_hi", "v_bytes")):
-                self.rfl(desc[0], lo)
-                self.rfl(desc[1], hi_)
-                self.rfl(rec, nb)
-                e("s_max_i32", desc[2], rec, 0)
-        e("s_mov_b32", S_KDESC[3], 0x00020000)
-        e("s_mov_b32", S_VDESC[3], 0x00020000)
-        e("s_mov_b32", S_ODESC[3], 0x00020000)
-        # ---- per-lane constants ----
-        # K reads: row lq, 16-byte chunk (2j + hi) ^ (lq & 15)
-        e("v_and_b32", TMP[3], 15, V_LQ)
-        e("v_lshlrev_b32", TMP[4], 8, V_LQ)                       # lq * 256
-        for j in range(8):
-            e("v_xor_b32", TMP[5], 2 * j, TMP[3])                 # (2j) ^ (lq & 15) ... + hi below: hi only flips bit 0 and 2j is even
-            e("v_xor_b32", TMP[5], TMP[5], hi)
-            e("v_lshl_add_u32", KAD[j], TMP[5], 4, TMP[4])
-        # V^T reads: vrow = 4hi + ((lane & 15) >> 2); dcol = 32db + 16((lane >> 4) & 1) + 4(lane & 3)
-        e("v_and_b32", TMP[3], 15, lane)
-        e("v_lshrrev_b32", TMP[3], 2, TMP[3])                     # jrow
-        e("v_add_u32", TMP[4], V_HI4, TMP[3])                     # vrow
-        e("v_lshlrev_b32", TMP[5], 2, TMP[3])                     # (vrow & 3) << 2 = jrow << 2
-        e("v_lshrrev_b32", TMP[6], 4, lane)
-        e("v_and_b32", TMP[6], 1, TMP[6])                         # (lane >> 4) & 1
-        e("v_and_b32", TMP[7], 3, lane)                           # cc
-        for db in range(4):
-            # chunk = (dcol >> 3) = 4db + 2 g + (cc >> 1);  (dcol & 7) * 2 = (cc & 1) * 8
-            e("v_lshrrev_b32", TMP[8], 1, TMP[7])
-            e("v_lshl_add_u32", TMP[8], TMP[6], 1, TMP[8])
-            e("v_add_u32", TMP[8], 4 * db, TMP[8])
-            e("v_xor_b32", TMP[8], TMP[8], TMP[5])
-            e("v_lshlrev_b32", TMP[8], 4, TMP[8])
-            e("v_and_b32", TMP[9], 1, TMP[7])
-            e("v_lshl_add_u32", TMP[8], TMP[9], 3, TMP[8])
-            e("v_lshl_add_u32", VAD[db], TMP[4], 8, TMP[8])
-            e("v_add_u32", VAD[db], 3 * SLOT + 2 * SLOT, VAD[db])   # V(0) lives in V slot (0 + 2) % 3
-        # the K read addresses start at slot 1 (K(1) is fetched in the prologue with an explicit -SLOT: see below)
+            e("v_mov_b32", TMP[2], self.inp["param"])
+            for k in range(14):
+                e("ds_read_b128", V(4 * k, 4), TMP[2], offset=16 * k)
+            e("s_waitcnt", lgkmcnt=0)
+            for i in range(52):
+                e("v_readfirstlane_b32", S(WIN + i), V(i))
+            for dst, name in ((S_VPAGE, "v_page"), (S_TMP[7], "wave")):
+                e("v_readfirstlane_b32", dst, V(PIDX[name]))
+            e("s_lshl_b32", S_W1024, S_TMP[7], 10)
+            e("s_mov_b64", S_KBASE, S(S_KDESC.idx, 2))
+            e("s_mov_b64", S_VBASE, S(S_VDESC.idx, 2))
+            e("s_mov_b32", S_KDESC[3], 0x00020000)
+            e("s_mov_b32", S_VDESC[3], 0x00020000)
         # LDS-DMA: lane -> row 4w + lane/16 of a 16-row group, 16-byte slot lane%16; source chunk = slot ^ swizzle(row)
+        e("s_lshr_b32", S_TMP[7], S_W1024, 10)                    # wave
         e("v_lshrrev_b32", TMP[3], 4, lane)                       # lane / 16
-        e("v_lshl_add_u32", TMP[3], S_TMP[7], 2, TMP[3])          # row16 = 4w + lane/16   (wave in S_TMP[7])
+        e("v_lshl_add_u32", TMP[3], S_TMP[7], 2, TMP[3])          # row16 = 4w + lane/16
         e("v_and_b32", TMP[4], 15, lane)                          # slot
         e("v_xor_b32", TMP[5], TMP[4], TMP[3])                    # K: slot ^ (row & 15)   (row16 < 16)
         e("v_and_b32", TMP[6], 3, TMP[3])
@@ -744,7 +729,7 @@ class Builder:
         e("v_mov_b32", TMP[7], S_VSTRIDE)
         e("v_mul_lo_u32", TMP[8], TMP[3], TMP[7])
         e("v_add_u32", VOFV[0], TMP[8], TMP[6])
-        e("s_lshl_b32", S_TMP[0], S_KSTRIDE, 4)                  # 16 rows
+        e("s_lshl_b32", S_TMP[0], S_KSTRIDE, 4)                   # 16 rows
         e("s_lshl_b32", S_TMP[1], S_VSTRIDE, 4)
         for u in range(1, 4):
             if self.paged:                                        # every piece has its own descriptor base: same offset
@@ -753,283 +738,433 @@ class Builder:
             else:
                 e("v_add_u32", VOFK[u], S_TMP[0], VOFK[u - 1])
                 e("v_add_u32", VOFV[u], S_TMP[1], VOFV[u - 1])
-        # masks: last visible key of this lane's row, per slot
+        # K reads: row lq, 16-byte chunk (2j + hi) ^ (lq & 15); the addresses start at ring slot 0
+        e("v_and_b32", TMP[3], 15, V_LQ)
+        e("v_lshlrev_b32", TMP[4], 8, V_LQ)                       # lq * 256
+        for j in range(8):
+            e("v_xor_b32", TMP[5], 2 * j, TMP[3])
+            e("v_xor_b32", TMP[5], TMP[5], hi)                    # 2j is even: xor with hi = + hi
+            e("v_lshl_add_u32", KAD[j], TMP[5], 4, TMP[4])
+        # V^T reads: vrow = 4hi + ((lane & 15) >> 2); dcol = 32db + 16((lane >> 4) & 1) + 4(lane & 3); new_block() moves them to V slot 2
+        e("v_and_b32", TMP[3], 15, lane)
+        e("v_lshrrev_b32", TMP[3], 2, TMP[3])                     # jrow
+        e("v_add_u32", TMP[4], V_HI4, TMP[3])                     # vrow
+        e("v_lshlrev_b32", TMP[5], 2, TMP[3])                     # (vrow & 3) << 2 = jrow << 2
+        e("v_lshrrev_b32", TMP[6], 4, lane)
+        e("v_and_b32", TMP[6], 1, TMP[6])                         # (lane >> 4) & 1
+        e("v_and_b32", TMP[7], 3, lane)                           # cc
+        for db in range(4):
+            e("v_lshrrev_b32", TMP[8], 1, TMP[7])                 # chunk = (dcol >> 3) = 4db + 2 g + (cc >> 1);  (dcol & 7) * 2 = (cc & 1) * 8
+            e("v_lshl_add_u32", TMP[8], TMP[6], 1, TMP[8])
+            e("v_add_u32", TMP[8], 4 * db, TMP[8])
+            e("v_xor_b32", TMP[8], TMP[8], TMP[5])
+            e("v_lshlrev_b32", TMP[8], 4, TMP[8])
+            e("v_and_b32", TMP[9], 1, TMP[7])
+            e("v_lshl_add_u32", TMP[8], TMP[9], 3, TMP[8])
+            e("v_lshl_add_u32", VAD[db], TMP[4], 8, TMP[8])
+            e("v_add_u32", VAD[db], 3 * SLOT, VAD[db])
         e("v_mov_b32", V_NEGINF, NEG_INF)
-        self.rfl(S_TMP[2], "lim_step")
-        self.rfl(S_TMP[3], "lim0")
-        self.rfl(S_TMP[4], "lim1")
-        e("s_sub_u32", S_TMP[5], S_LENK, 1)
-        e("v_mul_lo_u32", TMP[3], V_LQ, V(PIDX["lim_step"]))
-        for s in range(2):
-            e("v_add_u32", LIM[s], S_TMP[3 + s], TMP[3])
-            e("v_min_i32", LIM[s], S_TMP[5], LIM[s])
-        # ---- Q loads (in flight while the rings are set up) ----
-        for s in range(2):
-            skip = f"PRO_NOQ_{s}"
-            e("s_cmp_eq_u32", S_ROWS[s], 0)
+        # epilogue staging (this wavefront's 16 KiB at LDS_STAGE + 16K w): write address of the lane's row, 16-byte chunk index xor (row & 15)
+        e("s_lshl_b32", S_TMP[0], S_TMP[7], 14)
+        e("s_add_u32", S_TMP[0], S_TMP[0], LDS_STAGE)
+        e("v_lshlrev_b32", TMP[3], 8, V_LQ)
+        e("v_lshl_add_u32", TMP[3], hi, 3, TMP[3])                # lq * 256 + 8 hi
+        e("v_and_b32", TMP[4], 15, V_LQ)
+        e("v_lshlrev_b32", TMP[4], 4, TMP[4])
+        e("v_xor_b32", TMP[3], TMP[3], TMP[4])
+        e("v_add_u32", V_EPW, S_TMP[0], TMP[3])
+        # ... and the read addresses: instruction k reads rows 4k + lane/16, chunk lane%16 (de-swizzled); 4 row groups (k & 3)
+        e("v_lshrrev_b32", TMP[3], 4, lane)                       # rowl
+        e("v_and_b32", TMP[4], 15, lane)                          # c
+        for kk in range(4):
+            e("v_add_u32", TMP[5], 4 * kk, TMP[3])
+            e("v_xor_b32", TMP[5], TMP[5], TMP[4])                # c ^ (4 kk + rowl)
+            e("v_lshlrev_b32", TMP[5], 4, TMP[5])
+            e("v_lshl_add_u32", TMP[5], TMP[3], 8, TMP[5])        # + rowl * 256
+            e("v_add_u32", TMP[5], kk * 1024, TMP[5])             # + 4 kk rows
+            e("v_add_u32", EPR[kk], S_TMP[0], TMP[5])
+
+    def load_entry(self):
+        """persistent: the plan table's entry of (S_BLK, this wavefront) -> s48 .. s99 (asynchronous: s_waitcnt lgkmcnt(0) before use)"""
+        e = self.e
+        e("s_lshl_b32", S_TMP[0], S_BLK, 10)                      # 4 wavefronts x 256 bytes
+        e("s_lshr_b32", S_TMP[1], S_W1024, 2)                     # wave * 256
+        e("s_add_u32", S_TMP[0], S_TMP[0], S_TMP[1])
+        e("s_lshr_b32", S_TMP[1], S_BLK, 22)
+        e("s_add_u32", S_PAIR[0], S_TAB[0], S_TMP[0])
+        e("s_addc_u32", S_PAIR[1], S_TAB[1], S_TMP[1])
+        for k in range(3):
+            e("s_load_dwordx16", S(WIN + 16 * k, 16), S_PAIR, 64 * k)
+
+    def new_block(self):
+        """A valid entry sits in s48..: read addresses back to K slot 0 / V slot 2 (they followed the ring: address = base + S_RBASE;
+        S_RBASE = 0 before the first block), then the requests.  Persistent: entered at CHECK_ENTRY with the entry in flight; empty
+        entries (a query block past the end of a short sequence, the padded tail of an XCD's list) are skipped; S_HASNEXT = 1 while
+        the previous block's epilogue is still to come (block_end), S_T = 1 when a block has been set up."""
+        e, P = self.e, self.p
+        if self.persistent:
+            P.label("CHECK_ENTRY")
+            e("s_waitcnt", lgkmcnt=0)
+            e("s_bitcmp1_b32", W("flags"), 1)
+            e("s_cbranch_scc1", "NEW_BLOCK")
+            P.extend(self.advance())
+            e("s_cmp_lt_u32", S_BLK, S_NENT)
+            e("s_cbranch_scc1", "FETCH_ENTRY")
+            e("s_mov_b32", S_T, 0)                                # the table is exhausted
+            e("s_cmp_eq_u32", S_HASNEXT, 0)
+            e("s_cbranch_scc1", "KERNEL_END")
+            e("s_branch", "EPI_BOTH")
+            P.label("FETCH_ENTRY")
+            self.load_entry()
+            e("s_branch", "CHECK_ENTRY")
+        P.label("NEW_BLOCK")
+        P.extend(self.stamp(1, "block"))
+        for j in range(8):
+            e("v_subrev_u32", KAD[j], S_RBASE, KAD[j])
+        e("s_sub_u32", S_TMP[0], S_RBASE, 2 * SLOT)
+        for db in range(4):
+            e("v_subrev_u32", VAD[db], S_TMP[0], VAD[db])
+        self.pro_issue("A")
+        if self.persistent:
+            e("s_mov_b32", S_T, 1)
+            e("s_cmp_eq_u32", S_HASNEXT, 1)
+            e("s_cbranch_scc1", "EPI_BOTH")
+
+    def advance(self):
+        return [Ins("s_add_u32", S_BLK, S_BLK, S_G), Ins("s_mov_b32", S_TMP[3], S_G), Ins("s_mov_b32", S_G, S_G2), Ins("s_mov_b32", S_G2, S_TMP[3])]
+
+    # ---- per block: requests first ----------------------------------------------------------------------------------------------------
+    def pro_issue(self, tag):
+        """Q of the slots that see keys, then the first five K/V tiles.  K tile i lives in K slot i % 3, V tile i in V slot
+        (i + 2) % 3; K(3) takes K(0)'s slot and is requested once every wavefront has fetched its K(0) fragments (pro_compute)."""
+        e, P = self.e, self.p
+        hi = TMP[1]
+        e("v_lshrrev_b32", hi, 2, V_HI4)
+        for s, sn in ((0, S_N0), (1, S_N1)):
+            skip = f"PRO_NOQ_{tag}{s}"
+            e("s_cmp_eq_u32", sn, 0)
             e("s_cbranch_scc1", skip)
             e("s_sub_u32", S_TMP[0], S_ROWS[s], 1)
             e("v_min_u32", TMP[10], S_TMP[0], V_LQ)               # clamp to the slot's last valid row
-            e("v_mov_b32", TMP[11], S_QST)
-            e("v_mul_lo_u32", TMP[10], TMP[10], TMP[11])
-            e("v_lshl_add_u32", TMP[10 + 2 + s], hi, 4, TMP[10])  # + hi * 16 bytes
-            P.label(skip)
-        # the loads themselves come after every use of the parameter VGPRs v0..v63 (fast: they land in the S bank v64..v127 and
-        # are pre-multiplied below; exact: straight into the accumulator file)
-        for s in range(2):
-            self.rfl(S_PAIR[0], f"q{s}_lo")
-            self.rfl(S_PAIR[1], f"q{s}_hi")
-            skip = f"PRO_NOQL_{s}"
-            e("s_cmp_eq_u32", S_ROWS[s], 0)
-            e("s_cbranch_scc1", skip)
+            e("v_mul_lo_u32", TMP[10], TMP[10], S_QST)
+            e("v_lshl_add_u32", TMP[12], hi, 4, TMP[10])          # + hi * 16 bytes
             for j in range(8):
-                e("global_load_dwordx4", QA(s, j) if self.exact else V(64 + 32 * s + 4 * j, 4), TMP[12 + s], S_PAIR, offset=32 * j)
+                e("global_load_dwordx4", V(64 + 32 * s + 4 * j, 4), TMP[12], W(f"q{s}_lo", 2), offset=32 * j)
             P.label(skip)
-        # ---- zero the V ring (rows the DMA never writes must not hold NaN patterns: P = 0 times NaN) ----
-        e("v_mov_b32", TMP[16], 0)
-        e("v_mov_b32", TMP[17], 0)
-        e("v_mov_b32", TMP[18], 0)
-        e("v_mov_b32", TMP[19], 0)
-        e("v_lshlrev_b32", TMP[3], 4, lane)
-        e("v_add_u32", TMP[3], S_W1024, TMP[3])
-        e("v_add_u32", TMP[3], 3 * SLOT, TMP[3])
-        for k in range(12):
-            e("ds_write_b128", TMP[3], V(TMP[16].idx, 4), offset=k * 4096)
-        e("s_waitcnt", lgkmcnt=0)
-        e("s_barrier")
-        # ---- ring state and the first six tiles: K0 K1 V0 K2 V1 K3 ----
-        e("s_mov_b32", S_T, 0)
-        # K tile i lives in K slot i % 3, V tile i in V slot (i + 2) % 3.  K(3) takes K(0)'s slot: it is requested below, once
-        # every wavefront has fetched its K(0) fragments.
-        for kind, slot in (("k", 0), ("k", 1), ("v", 2), ("k", 2), ("v", 0)):
-            self.request_tile(kind, slot)
-        # ---- softmax state, O = 0 ----
+        P.extend(self.stamp(2, "block"))
+        if self.paged:
+            e("s_mov_b32", S_KVT, 0)
+            e("s_mov_b32", S_VVT, 0)
+        else:
+            e("s_mov_b32", S_KSOFF, 0)
+            e("s_mov_b32", S_VSOFF, 0)
+        self.request_tile(False, 0)
+        self.request_tile(False, 1)
+        self.request_tile(True, 2)
+        self.request_tile(False, 2)
+        self.request_tile(True, 0)
+
+    # ---- per block: S(0), the rows' first reference ----------------------------------------------------------------------------------------
+    def pro_compute(self):
+        """Barriers: K(0) landed, K(1) landed, entry -- the same count on every path."""
+        e, P = self.e, self.p
+        P.label("PRO_COMPUTE")
+        # masks: last visible key of this lane's row, per slot
+        e("s_sub_u32", S_TMP[5], S_LENK, 1)
+        e("v_mul_lo_u32", TMP[3], V_LQ, W("lim_step"))
+        for s in range(2):
+            e("v_add_u32", LIM[s], W(f"lim{s}"), TMP[3])
+            e("v_min_i32", LIM[s], S_TMP[5], LIM[s])
+        # softmax state; O = 0 and C-init = 0 through the matrix pipe (0 x 0 + 0: 10 instructions instead of 160)
         for s in range(2):
             e("v_mov_b32", LS(s, 0), 0)
             e("v_mov_b32", LS(s, 1), 0)
             e("v_mov_b32", MREF[s], 0)
             e("v_mov_b32", THR[s], NEG_INF)
             e("v_mov_b32", MX[s], NEG_INF)
-            for k in range(16):
-                e("v_mov_b32", CI(s)[k], 0)
-        for k in range(128):
-            e("v_accvgpr_write_b32", A(k), 0)
+        z = VV(0)
+        for k in range(4):
+            e("v_mov_b32", z[k], 0)
+        self.nop(2)
+        for s in range(2):
+            for db in range(4):
+                e(self.mfma, OA(s, db), z, z, 0)
+        for s in range(2):
+            e(self.mfma, CI(s), z, z, 0)
+        e("s_mov_b32", S_T, 0)
         e("s_cmp_eq_u32", S_NT, 0)
-        e("s_cbranch_scc1", "DRAIN_EPILOGUE")
-        # ---- Q arrives: pre-multiply by scale.log2(e), round once, park in the accumulator file ----
-        e("s_waitcnt", vmcnt=20)
+        e("s_cbranch_scc1", "BLOCK_DRAIN")
+        e("s_cmp_eq_u32", S_N1, 0)
+        e("s_cbranch_scc1", "PRO_IDLE")
         e("v_mov_b32", TMP[3], S_SCALE)
-        for s in range(0 if self.exact else 2):
-            skip = f"PRO_NOQS_{s}"
-            e("s_cmp_eq_u32", S_ROWS[s], 0)
-            e("s_cbranch_scc1", skip)
-            for j in range(8):
+
+        def q_to_acc(s, exact, js=range(8)):
+            """Q of slot s, d-steps js -> accumulator file; fast: pre-multiplied by scale.log2(e) and rounded once"""
+            out = []
+            for j in js:
                 for k in range(4):
                     x = V(64 + 32 * s + 4 * j + k)
+                    if exact:
+                        out.append(Ins("v_accvgpr_write_b32", QA(s, j)[k], x))
+                        continue
                     lo, hi2 = TMP[4 + 2 * (k & 1)], TMP[5 + 2 * (k & 1)]
                     if self.dtype == "bf16":
-                        e("v_lshlrev_b32", lo, 16, x)
-                        e("v_and_b32", hi2, 0xFFFF0000, x)
+                        out += [Ins("v_lshlrev_b32", lo, 16, x), Ins("v_and_b32", hi2, 0xFFFF0000, x)]
                     else:
-                        e("v_cvt_f32_f16", lo, x)
-                        e("v_lshrrev_b32", hi2, 16, x)
-                        e("v_cvt_f32_f16", hi2, hi2)
-                    e("v_mul_f32", lo, lo, TMP[3])
-                    e("v_mul_f32", hi2, hi2, TMP[3])
-                    e(self.cvt, lo, lo, hi2)
-                    e("v_accvgpr_write_b32", QA(s, j)[k], lo)
-            P.label(skip)
-        # ---- K(0): fragments, S(0) ----
-        e("s_waitcnt", vmcnt=16)
-        e("s_barrier")
-        for i in self.k_reads():                                   # KAD points at slot 0 here
-            P.ins.append(i)
-        e("s_waitcnt", lgkmcnt=0)
-        self.nop(2)
-        e("s_cmp_eq_u32", S_N1, 0)
-        e("s_cbranch_scc1", "PRO_K1")                              # no row of this wavefront sees a key
-        e("s_cmp_eq_u32", S_N0, 0)
-        e("s_cbranch_scc1", "PRO_QK1")
-        P.extend(self.qk_mfmas(0, [0, 1]))
-        e("s_branch", "PRO_K1")
-        P.label("PRO_QK1")
-        P.extend(self.qk_mfmas(0, [1]))
+                        out += [Ins("v_cvt_f32_f16", lo, x), Ins("v_lshrrev_b32", hi2, 16, x), Ins("v_cvt_f32_f16", hi2, hi2)]
+                    out += [Ins("v_mul_f32", lo, lo, TMP[3]), Ins("v_mul_f32", hi2, hi2, TMP[3]), Ins(self.cvt, lo, lo, hi2),
+                            Ins("v_accvgpr_write_b32", QA(s, j)[k], lo)]
+            return out
+
+        def k0_fragments():
+            e("s_waitcnt", vmcnt=16)
+            e("s_barrier")                                         # K(0) landed
+            P.extend(self.stamp(4, "block"))
+            P.extend(self.k_reads())                               # KAD points at slot 0 here
+            e("s_waitcnt", lgkmcnt=0)
+            self.nop(2)
+        e("s_waitcnt", vmcnt=20)                                   # Q arrived (first on the queue: 20 K/V pieces were issued after it)
+        for exact, tag in ((False, "F"), (True, "X")):
+            if not exact:
+                e("s_bitcmp1_b32", W("flags"), 0)
+                e("s_cbranch_scc1", "PRO_QX")
+            else:
+                P.label("PRO_QX")
+            one = f"PRO_ONE_{tag}"
+            e("s_cmp_eq_u32", S_N0, 0)
+            e("s_cbranch_scc1", one)
+            # ---- both slots see keys: the d-steps of Q are converted just ahead of the S(0) MFMAs that take them (MFMA 2j of slot 0,
+            # 16 + 2j of slot 1, with a margin of two instructions for the accumulator-write -> MFMA hazard) ----
+            P.extend(q_to_acc(0, exact, (0, 1)))
+            k0_fragments()
+            a = [Item(i, -1, max(2 * j - 3, -1)) for j in range(2, 8) for i in q_to_acc(0, exact, (j,))]
+            b = [Item(i, -1, 13 + 2 * j) for j in range(8) for i in q_to_acc(1, exact, (j,))]
+            P.extend(schedule(self.qk_mfmas(0, [0]) + self.qk_mfmas(0, [1]), [a, b], cap=12))
+            e("s_branch", "PRO_K1")
+            # ---- slot 1 only ----
+            P.label(one)
+            P.extend(q_to_acc(1, exact, (0, 1)))
+            k0_fragments()
+            a = [Item(i, -1, max(2 * j - 3, -1)) for j in range(2, 8) for i in q_to_acc(1, exact, (j,))]
+            P.extend(schedule(self.qk_mfmas(0, [1]), [a], cap=12))
+            if not exact:
+                e("s_branch", "PRO_K1")
         # ---- K(1) fragments (K(1) sits in slot 1); K(3) may now replace K(0) ----
         P.label("PRO_K1")
         e("s_waitcnt", vmcnt=12)
         e("s_barrier")
-        for i in self.k_reads():
-            i.mods["offset"] = i.mods.get("offset", 0) + SLOT
-            P.ins.append(i)
+        P.extend(self.k_reads(extra=SLOT))
         for j in range(8):
             e("v_add_u32", KAD[j], 2 * SLOT, KAD[j])               # next K read: K(2) in slot 2
-        self.request_tile("k", 0)
+        self.request_tile(False, 0)
+        # ---- [mask] + row max of tile 0, the rows' first reference ----
+        e("s_mov_b32", S_T1, 0)                                    # kv1 = 0 for the mask code
+        self.nop(MFMA_SAFE)
+        for s, sn, stm in ((0, S_N0, S_TM0), (1, S_N1, S_TM1)):
+            skip, nomask = f"PRO_NOMAX_{s}", f"PRO_NOMASK_{s}"
+            if s == 0:
+                e("s_cmp_eq_u32", sn, 0)
+                e("s_cbranch_scc1", skip)
+            e("s_cmp_eq_u32", stm, 0)                              # tile 0 needs the mask only when the slot's first masked tile is tile 0
+            e("s_cbranch_scc0", nomask)
+            for it in self.mask_items(0, s, -1):
+                P.extend(it.ins)
+            P.label(nomask)
+            for it in self.max_items(0, s, -1):
+                P.extend(it.ins)
+            self.first_reference(0, s)
+            P.label(skip)
+        self.nop(MFMA_SRCC_SAFE)
+        e("s_branch", "PRO_ENTRY")
+        # ---- no row of this wavefront sees a key: only the barriers and its share of the DMA ----
+        P.label("PRO_IDLE")
+        e("s_waitcnt", vmcnt=16)
+        e("s_barrier")
+        e("s_waitcnt", vmcnt=12)
+        e("s_barrier")
+        for j in range(8):
+            e("v_add_u32", KAD[j], 2 * SLOT, KAD[j])
+        self.request_tile(False, 0)
+        P.label("PRO_ENTRY")
         # state at the entry of iteration 0: read slot r = 2 (K(2) and V(0) live in slot 2), DMA slot d = 1
         e("s_mov_b32", S_RBASE, 2 * SLOT)
         e("s_mov_b32", S_DBASE, 1 * SLOT)
         e("s_add_u32", S_KDMA, S_DBASE, S_W1024)
         e("s_mov_b32", S_DELTA, 0)
-        # ---- mask + row max of tile 0 (always through the masking code), then the rows' first reference ----
-        e("s_mov_b32", S_T1, 0)                                    # kv1 = 0
-        e("s_cmp_eq_u32", S_N1, 0)
-        e("s_cbranch_scc1", "PRO_ENTRY")
-        self.nop(MFMA_SAFE)
-        e("s_cmp_eq_u32", S_N0, 0)
-        e("s_cbranch_scc1", "PRO_M1")
-        for x0, lab in ((2, None), (1, "PRO_M1")):
-            if lab:
-                P.label(lab)
-            for s in {2: [0, 1], 1: [1]}[x0]:
-                for it in self.mask_items(0, s, -1) + self.max_items(0, s, -1):
-                    P.extend(it.ins)
-            site = len(self.ret_sites)
-            self.ret_sites.append((site, f"RET_{site}", f"STUB_{site}", 0, x0))
-            e("s_branch", f"STUB_{site}")
-            P.label(f"RET_{site}")
-            e("s_branch", "PRO_ENTRY")
-        P.label("PRO_ENTRY")
         e("s_waitcnt", vmcnt=8, lgkmcnt=0)
         e("s_barrier")
-        P.extend(self.stamp(5))
+        P.extend(self.stamp(4))
+        P.extend(self.stamp(5, "block"))
+        e("s_bitcmp1_b32", W("flags"), 0)
+        e("s_cbranch_scc1", "DISPX_0")
         e("s_branch", "DISP_0")
 
-    def request_tile(self, kind, slot):
-        """prologue: the four pieces of the next K (or V) tile -> ring slot `slot`"""
-        e = self.e
-        e("s_add_u32", S_KDMA, S_W1024, slot * SLOT)
-        if self.paged:
-            self.p.extend(self.paged_tile(S_VVT if kind == "v" else S_KVT, kind == "v"))
-        else:
-            desc, voffs, tile, rec, extra = ((S_VDESC, VOFV, S_VTILE, S_VREC, 3 * SLOT) if kind == "v"
-                                             else (S_KDESC, VOFK, S_KTILE, S_KREC, 0))
-            for it in self.dma_tile(desc, voffs, extra) + self.desc_advance(desc, tile, rec):
-                self.p.extend(it.ins)
+    # ---- per block: normalise, transpose through LDS, store -----------------------------------------------------------------------------------
+    def epi_slot(self, s, tag, odesc, lse, rows, ost, mscale):
+        """O^T of slot s (accumulators) -> 1/l -> storage type -> this wavefront's LDS staging rows (swizzled) -> whole 256-byte rows
+        to memory, 4 rows per store instruction (a per-lane row-strided store would touch 32 partial lines per instruction)"""
+        e, P = self.e, self.p
+        done = f"EPI_DONE_{tag}{s}"
+        e("s_cmp_eq_u32", rows, 0)
+        e("s_cbranch_scc1", done)
+        ltot, inv, t0, t1 = TMP[3], TMP[4], TMP[5], TMP[6]
+        e("v_add_f32", t0, LS(s, 0), LS(s, 1))
+        e("v_mov_b32", t1, t0)
+        self.nop(2)
+        e("v_permlane32_swap_b32", t0, t1)
+        e("v_add_f32", ltot, t0, t1)
+        e("v_rcp_f32", inv, ltot)
+        e("v_cmp_gt_f32", VCC, ltot, 0)
+        e("v_mov_b32", t0, 0)
+        e("v_cndmask_b32", inv, t0, inv, VCC)                      # rows that saw no key: 0
+        f = [TMP[0], TMP[2], TMP[7], TMP[8]]
+        for db in range(4):
+            o = OA(s, db)
+            for r4 in range(4):
+                w = [TMP[10 + 2 * (r4 & 1)], TMP[11 + 2 * (r4 & 1)]]
+                for k in range(4):
+                    e("v_accvgpr_read_b32", f[k], o[4 * r4 + k])
+                for k in range(4):
+                    e("v_mul_f32", f[k], f[k], inv)
+                e(self.cvt, w[0], f[0], f[1])
+                e(self.cvt, w[1], f[2], f[3])
+                e("v_xor_b32", t1, (4 * db + r4) * 16, V_EPW)      # 16-byte chunk 4db + r4 of the row, swizzled; + 8 hi is in V_EPW
+                e("ds_write_b64", t1, V(w[0].idx, 2), offset=s * 8192)
+        e("s_waitcnt", lgkmcnt=0)
+        # rows 4k + lane/16 of the slot, 16 bytes per lane
+        e("v_lshrrev_b32", t0, 4, TMP[9])                          # TMP[9] = lane (set by the caller)
+        e("v_mul_lo_u32", t0, t0, ost)
+        e("v_and_b32", t1, 15, TMP[9])
+        e("v_lshl_add_u32", t0, t1, 4, t0)                         # (lane / 16) * stride + (lane % 16) * 16
+        e("s_mov_b32", S_TMP[0], 0)
+        e("s_lshl_b32", S_TMP[1], ost, 2)
+        for k in range(8):                                         # the V^T window (32 registers) is dead here: all reads, one wait, all stores
+            e("ds_read_b128", VV(k), EPR[k & 3], offset=s * 8192 + (k >> 2) * 4096)
+        for k in range(8):
+            e("s_waitcnt", lgkmcnt=7 - k)
+            e("buffer_store_dwordx4", VV(k), t0, odesc, S_TMP[0], offen=True)
+            e("s_add_u32", S_TMP[0], S_TMP[0], S_TMP[1])
+        # log-sum-exp (natural log), rows without keys: +inf
+        nolse = f"EPI_NOLSE_{tag}{s}"
+        e("s_or_b32", S_TMP[0], lse[0], lse[1])
+        e("s_cmp_eq_u32", S_TMP[0], 0)
+        e("s_cbranch_scc1", nolse)
+        e("s_mov_b64", S_PAIR, S(lse[0].idx, 2))
+        e("s_mov_b32", S_TMP[4], S_PAIR[0])
+        e("s_mov_b32", S_TMP[5], S_PAIR[1])
+        e("s_lshl_b32", S_TMP[6], rows, 2)
+        e("s_mov_b32", S_TMP[7], 0x00020000)
+        e("v_log_f32", t0, ltot)
+        e("v_mul_f32", t1, mscale, MREF[s])
+        e("v_add_f32", t0, t0, t1)
+        e("v_mul_f32", t0, 0.6931471805599453, t0)
+        e("v_mov_b32", t1, float("inf"))
+        e("v_cndmask_b32", t0, t1, t0, VCC)
+        e("v_lshlrev_b32", t1, 2, V_LQ)
+        e("v_cmp_eq_u32", S_PAIR, 0, V_HI4)                        # one lane of each pair stores
+        e("v_mov_b32", TMP[0], 0x7FFFFFF0)
+        e("v_cndmask_b32", t1, TMP[0], t1, S_PAIR)
+        e("buffer_store_dword", t0, t1, S(S_TMP[4].idx, 4), 0, offen=True)
+        P.label(nolse)
+        P.label(done)
 
-    # ---- epilogue -----------------------------------------------------------------------------------------------------------------------
-    def epilogue(self):
-        e = self.e
-        P = self.p
-        P.label("DRAIN_EPILOGUE")          # n_tiles = 0: nothing was computed, requests still in flight must land before the wave ends
-        e("s_waitcnt", vmcnt=0)
-        P.label("EPILOGUE")
-        P.extend(self.stamp(4))
+    def block_end(self):
+        """Non-persistent: wait, barrier, both epilogues.  Persistent: the epilogue's parameters move to accumulator registers that
+        are dead by now (the K fragments), the NEXT block's entry is fetched and its Q rows and first K/V tiles requested
+        (new_block), and only then this block's O is normalised and stored: the requests' round trips ride under the stores."""
+        e, P = self.e, self.p
+        P.label("BLOCK_DRAIN")             # no K/V tile at all: the requests in flight must land before the ring is reused
+        P.label("BLOCK_END")
+        P.extend(self.stamp(3))
+        P.extend(self.stamp(None, "block"))
         self.nop(MFMA_SAFE)
         e("s_waitcnt", vmcnt=0, lgkmcnt=0)
-        # parameters again (their VGPRs were reused)
-        e("v_mov_b32", TMP[2], self.param_sgpr)
-        for k in range(4):
-            e("ds_read_b128", V(4 * k, 4), TMP[2], offset=16 * k)
-        e("s_waitcnt", lgkmcnt=0)
-        e("v_lshrrev_b32", TMP[1], 2, V_HI4)                     # hi
-        for s in range(2):
-            done = f"EPI_DONE_{s}"
-            e("s_cmp_eq_u32", S_ROWS[s], 0)
-            e("s_cbranch_scc1", done)
-            self.rfl(S_ODESC[0], f"o{s}_lo")
-            self.rfl(S_ODESC[1], f"o{s}_hi")
-            e("s_sub_u32", S_TMP[0], S_ROWS[s], 1)
-            e("s_mul_i32", S_TMP[0], S_TMP[0], S_OST)
-            e("s_add_u32", S_ODESC[2], S_TMP[0], 256)            # rows past the slot's last valid row are out of range: dropped
-            ltot, inv, t0, t1 = TMP[3], TMP[4], TMP[5], TMP[6]
-            e("v_add_f32", t0, LS(s, 0), LS(s, 1))
-            e("v_mov_b32", t1, t0)
-            self.nop(2)
-            e("v_permlane32_swap_b32", t0, t1)
-            e("v_add_f32", ltot, t0, t1)
-            e("v_rcp_f32", inv, ltot)
-            e("v_cmp_gt_f32", VCC, ltot, 0)
-            e("v_mov_b32", t0, 0)
-            e("v_cndmask_b32", inv, t0, inv, VCC)                # rows that saw no key: 0
-            e("v_mov_b32", t0, S_OST)
-            e("v_mul_lo_u32", t0, V_LQ, t0)
-            e("v_lshl_add_u32", TMP[7], TMP[1], 4, t0)           # row * stride + hi * 16
-            for db in range(4):
-                o = OA(s, db)
-                for pr in range(2):                               # pairs of 8-column groups (r4 = 2pr, 2pr + 1)
-                    w = [TMP[8 + 4 * ((2 * db + pr) % 4) + k] for k in range(4)]
-                    f = [TMP[0], TMP[2]]
-                    for half in range(2):
-                        r4 = 2 * pr + half
-                        for k2 in range(2):
-                            e("v_accvgpr_read_b32", f[0], o[4 * r4 + 2 * k2])
-                            e("v_accvgpr_read_b32", f[1], o[4 * r4 + 2 * k2 + 1])
-                            e("v_mul_f32", f[0], f[0], inv)
-                            e("v_mul_f32", f[1], f[1], inv)
-                            e(self.cvt, w[2 * half + k2], f[0], f[1])
-                    self.nop(2)
-                    e("v_permlane32_swap_b32", w[0], w[2])
-                    e("v_permlane32_swap_b32", w[1], w[3])
-                    e("buffer_store_dwordx4", V(w[0].idx, 4), TMP[7], S_ODESC, 0, offen=True, offset=(32 * db + 16 * pr) * 2)
-            # log-sum-exp (natural log), rows without keys: +inf
-            nolse = f"EPI_NOLSE_{s}"
-            self.rfl(S_PAIR[0], f"lse{s}_lo")
-            self.rfl(S_PAIR[1], f"lse{s}_hi")
-            e("s_or_b32", S_TMP[0], S_PAIR[0], S_PAIR[1])
-            e("s_cmp_eq_u32", S_TMP[0], 0)
-            e("s_cbranch_scc1", nolse)
-            e("s_mov_b32", S_ODESC[0], S_PAIR[0])
-            e("s_mov_b32", S_ODESC[1], S_PAIR[1])
-            e("s_lshl_b32", S_ODESC[2], S_ROWS[s], 2)
-            e("v_log_f32", t0, ltot)
-            if self.exact:
-                e("v_mul_f32", t1, S_SCALE, MREF[s])
-                e("v_add_f32", t0, t0, t1)
-            else:
-                e("v_add_f32", t0, t0, MREF[s])
-            e("v_mul_f32", t0, 0.6931471805599453, t0)
-            e("v_mov_b32", t1, float("inf"))
-            e("v_cndmask_b32", t0, t1, t0, VCC)
-            e("v_lshlrev_b32", t1, 2, V_LQ)
-            e("v_cmp_eq_u32", S_PAIR, 0, V_HI4)                  # one lane of each pair stores
-            e("v_mov_b32", TMP[0], 0x7FFFFFF0)
-            e("v_cndmask_b32", t1, TMP[0], t1, S_PAIR)
-            e("buffer_store_dword", t0, t1, S_ODESC, 0, offen=True)
-            P.label(nolse)
-            P.label(done)
-        e("s_waitcnt", vmcnt=0)
+        e("s_barrier")                     # every wavefront is done with the ring and with its requests
+        P.extend(self.stamp(0, "block"))
+        if not self.persistent:
+            e("v_mbcnt_lo_u32_b32", TMP[9], -1, 0)
+            e("v_mbcnt_hi_u32_b32", TMP[9], -1, TMP[9])
+            self.epi_slot(0, "A", S_ODESC[0], [W("lse0_lo"), W("lse0_hi")], S_ROWS[0], S_OST, W("mscale"))
+            self.epi_slot(1, "A", S_ODESC[1], [W("lse1_lo"), W("lse1_hi")], S_ROWS[1], S_OST, W("mscale"))
+            P.label("KERNEL_END")
+            return
+        stash = ["o0_lo", "o0_hi", "o0_bytes", "o0_flags", "lse0_lo", "lse0_hi", "rows0", "mscale",
+                 "o1_lo", "o1_hi", "o1_bytes", "o1_flags", "lse1_lo", "lse1_hi", "rows1", "o_stride"]
+        for k, name in enumerate(stash):
+            e("v_accvgpr_write_b32", A(192 + k), W(name))
+        e("s_mov_b32", S_HASNEXT, 1)
+        e("s_mov_b32", S_T, 0)
+        P.extend(self.advance())
+        e("s_cmp_lt_u32", S_BLK, S_NENT)
+        e("s_cbranch_scc1", "FETCH_ENTRY")
+        P.label("EPI_BOTH")
+        P.extend(self.stamp(3, "block"))
+        e("s_mov_b32", S_HASNEXT, 0)
+        e("v_mbcnt_lo_u32_b32", TMP[9], -1, 0)
+        e("v_mbcnt_hi_u32_b32", TMP[9], -1, TMP[9])
+        for s_ in range(2):
+            for k in range(8):
+                e("v_accvgpr_read_b32", TMP[k], A(192 + 8 * s_ + k))
+            e("v_accvgpr_read_b32", TMP[8], A(192 + 15))
+            e("v_accvgpr_read_b32", TMP[10], A(192 + 7))
+            self.nop(1)
+            for k in range(8):
+                e("v_readfirstlane_b32", S_SAVE[k], TMP[k])
+            e("v_readfirstlane_b32", S_TMP[2], TMP[8])              # o_stride
+            e("v_readfirstlane_b32", S_TMP[3], TMP[10])             # mscale (slot 0's stash holds it; slot 1's has the stride instead)
+            self.epi_slot(s_, "B", S(S_SAVE[0].idx, 4), [S_SAVE[4], S_SAVE[5]], S_SAVE[6], S_TMP[2], S_TMP[3])
+        P.extend(self.stamp(None, "block"))
+        P.extend(self.stamp(5))
+        e("s_cmp_eq_u32", S_T, 1)
+        e("s_cbranch_scc1", "PRO_COMPUTE")
+        P.label("KERNEL_END")
         if self.timing:
-            P.extend(self.stamp(6))
-            e("v_mov_b32", TMP[2], self.param_sgpr)
-            e("ds_read_b128", V(0, 4), TMP[2], offset=16 * (PIDX["dbg_lo"] // 4))
-            e("ds_read_b128", V(4, 4), TMP[2], offset=16 * (PIDX["dbg_lo"] // 4) + 16)
-            e("s_waitcnt", lgkmcnt=0)
-            e("v_readfirstlane_b32", S_ODESC[0], V(PIDX["dbg_lo"] % 4))
-            e("v_readfirstlane_b32", S_ODESC[1], V(PIDX["dbg_lo"] % 4 + 1))
-            e("s_mov_b32", S_ODESC[2], 32)
-            e("s_or_b32", S_TT, S_ODESC[0], S_ODESC[1])
-            e("s_cmp_eq_u32", S_TT, 0)
+            e("s_waitcnt", vmcnt=0)
+            e("s_mov_b64", S(S_TMP[4].idx, 2), self.inp["dbg"])
+            e("s_mov_b32", S_TMP[6], 32)
+            e("s_mov_b32", S_TMP[7], 0x00020000)
+            e("s_or_b32", S_T1, S_TMP[4], S_TMP[5])
+            e("s_cmp_eq_u32", S_T1, 0)
             e("s_cbranch_scc1", "TIMING_DONE")
             e("v_mbcnt_lo_u32_b32", TMP[0], -1, 0)
             e("v_mbcnt_hi_u32_b32", TMP[0], -1, TMP[0])
             e("v_lshlrev_b32", TMP[0], 16, TMP[0])                # only lane 0 is inside the 32-byte window
-            for k in range(8):
-                e("v_mov_b32", TMP[8 + k], S_TACC[k])
-            e("buffer_store_dwordx4", V(TMP[8].idx, 4), TMP[0], S_ODESC, 0, offen=True)
-            e("buffer_store_dwordx4", V(TMP[12].idx, 4), TMP[0], S_ODESC, 0, offen=True, offset=16)
+            e("buffer_store_dwordx4", V(TACC[0].idx, 4), TMP[0], S(S_TMP[4].idx, 4), 0, offen=True)
+            e("v_mov_b32", TMP[20], 0)
+            e("v_mov_b32", TMP[21], 0)
+            e("buffer_store_dwordx4", V(TACC[4].idx, 4), TMP[0], S(S_TMP[4].idx, 4), 0, offen=True, offset=16)
             e("s_waitcnt", vmcnt=0)
             P.label("TIMING_DONE")
 
     # ---- the whole program ------------------------------------------------------------------------------------------------------------------
     def build(self):
-        self.prologue()
-        for p in (0, 1):
-            self.dispatcher(p)
-        for p in (0, 1):
-            self.p.emit("p2align", 6)
-            self.iteration(p, 2, 2, False)
-        for p in (0, 1):
-            for c, x, mk in ((2, 2, True), (2, 1, False), (2, 1, True), (2, 0, False), (1, 1, False), (1, 1, True), (1, 0, False)):
-                self.iteration(p, c, x, mk)
+        self.entry()
+        self.e("s_mov_b32", S_RBASE, 0)
+        self.e("s_mov_b32", S_HASNEXT, 0)
+        self.new_block()
+        self.pro_compute()
+        for exact in (False, True):
+            self.exact, self.sfx = exact, "X" if exact else ""
+            for p in (0, 1):
+                self.dispatcher(p)
+            for p in (0, 1):
+                self.p.emit("p2align", 6)
+                self.iteration(p, 2, 2, False)
+            for p in (0, 1):
+                for c, x, mk in ((2, 2, True), (2, 1, False), (2, 1, True), (2, 0, False), (1, 1, False), (1, 1, True), (1, 0, False)):
+                    self.iteration(p, c, x, mk)
         self.idle_iteration()
-        # call stubs, rescale blocks
-        for site, ret, stub, bank_n, x in self.ret_sites:
+        for site, ret, stub, bank_n, x, sfx in self.ret_sites:
             self.p.label(stub)
             self.e("s_mov_b32", S_RET, site)
-            self.e("s_branch", f"RESC_{bank_n}_{x}")
-        for bank_n in (0, 1):
-            for x in (2, 1):
-                self.rescale(bank_n, x)
-        self.epilogue()
+            self.e("s_branch", f"RESC{sfx}_{bank_n}_{x}")
+        for exact in (False, True):
+            self.exact, self.sfx = exact, "X" if exact else ""
+            for bank_n in (0, 1):
+                for x in (2, 1):
+                    self.rescale(bank_n, x)
+        self.exact, self.sfx = False, ""
+        self.block_end()
         return self.p
 
 
@@ -1037,12 +1172,12 @@ MFMA_SAFE = 20
 MFMA_SRCC_SAFE = 4
 
 
-def build(dtype="bf16", paged=False, param_sgpr=S(4), exact=False, timing=False):
-    b = Builder(dtype, paged, param_sgpr, exact, timing)
+def build(dtype="bf16", paged=False, inputs=None, timing=False):
+    b = Builder(dtype, paged, inputs, timing)
     prog = b.build()
     return prog, b
 
 
 def clobbers():
     """registers the asm statement owns (csrc/prefill_asm.hip lists them as clobbered)"""
-    return [f"v{i}" for i in range(256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(SGPR_FIRST, SGPR_LAST + 1)] + ["vcc", "scc", "memory"]
+    return [f"v{i}" for i in range(256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(SGPR_FIRST, SGPR_LAST + 1) if i != 32] + ["vcc", "scc", "memory"]

@@ -402,6 +402,12 @@ class Workgroup:
     def op_s_load_dwordx4(self, w, i):
         self._s_load(w, i, 4)
 
+    def op_s_load_dwordx16(self, w, i):
+        self._s_load(w, i, 16)
+
+    def op_s_bitcmp1_b32(self, w, i):
+        w.scc = bool((w.rs(i.ops[0]) >> (w.rs(i.ops[1]) & 31)) & 1)
+
     # ---- vector: special cases -----------------------------------------------------------------------------------
     def op_v_cndmask_b32(self, w, i):
         sel = i.ops[3]
@@ -566,6 +572,16 @@ class Workgroup:
             self.lds[a[l]:a[l] + 16] = data[l]
         w.lgq.append(("lds", None, []))
 
+    def op_ds_write_b64(self, w, i):
+        addr, src = i.ops[0], i.ops[1]
+        a = w.rd_vec(addr).astype(np.int64) + int(i.mods.get("offset", 0))
+        if (a % 8 != 0).any():
+            raise SimError(f"wave {w.wid} pc {w.pc}: misaligned ds_write_b64")
+        data = np.ascontiguousarray(w.rd_tuple(src).T).view(np.uint8).reshape(64, 8)
+        for l in range(64):
+            self.lds[a[l]:a[l] + 8] = data[l]
+        w.lgq.append(("lds", None, []))
+
     def op_ds_write_b32(self, w, i):
         addr, src = i.ops[0], i.ops[1]
         a = w.rd_vec(addr).astype(np.int64) + int(i.mods.get("offset", 0))
@@ -590,15 +606,11 @@ class Workgroup:
         dst_or_off = i.ops
         if i.mods.get("lds"):
             voff, rs, soff = i.ops
-            if getattr(w, "m0_set_at", -9) == w.issue - 0 and False:
-                pass
-            if w.issue - getattr(w, "m0_set_at", -9) < 1:
+            if w.issue - getattr(w, "m0_set_at", -9) < 2:      # one wait state between the SALU write of M0 and its use
                 raise SimError(f"wave {w.wid} pc {w.pc}: LDS-DMA right behind the SALU write of M0")
             base, nrec = self._desc(w, rs)
-            so = w.rs(soff)
-            if so != 0:
-                raise SimError("soffset != 0: whether it takes part in the range check is not modelled; keep it 0")
-            off = w.rd_vec(voff).astype(np.int64) + int(i.mods.get("offset", 0))
+            so = w.rs(soff)          # soffset takes part in the range check (measured on gfx950: tools/probes/lds_dma_oob_probe.hip)
+            off = w.rd_vec(voff).astype(np.int64) + int(i.mods.get("offset", 0)) + so
             lds_base = int(w.m0) + int(i.mods.get("offset", 0))
             if lds_base % 16 or lds_base + 1024 > len(self.lds):
                 raise SimError(f"wave {w.wid} pc {w.pc}: LDS-DMA destination {lds_base:#x}")
@@ -619,9 +631,7 @@ class Workgroup:
             return
         dst, voff, rs, soff = i.ops
         base, nrec = self._desc(w, rs)
-        if w.rs(soff) != 0:
-            raise SimError("soffset != 0 not modelled")
-        off = w.rd_vec(voff).astype(np.int64) + int(i.mods.get("offset", 0))
+        off = w.rd_vec(voff).astype(np.int64) + int(i.mods.get("offset", 0)) + w.rs(soff)
         inr = off + 16 <= nrec
         regs = dst.regs()
         for r in regs:
@@ -656,9 +666,7 @@ class Workgroup:
     def _buffer_store(self, w, i, n):
         src, voff, rs, soff = i.ops
         base, nrec = self._desc(w, rs)
-        if w.rs(soff) != 0:
-            raise SimError("soffset != 0 not modelled")
-        off = w.rd_vec(voff).astype(np.int64) + int(i.mods.get("offset", 0))
+        off = w.rd_vec(voff).astype(np.int64) + int(i.mods.get("offset", 0)) + w.rs(soff)
         data = np.ascontiguousarray(w.rd_tuple(src).T if n > 1 else w.rd_vec(src)[:, None]).view(np.uint8).reshape(64, 4 * n)
         for l in range(64):
             if off[l] + 4 * n <= nrec:

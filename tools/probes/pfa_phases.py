@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "atoma-infer_amd", "bindings")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import atoma_hip as ah
 import tp_step as TS
-lib = C.CDLL(os.path.join(ROOT, "tools", "probes", "libatoma_hip_timing.so"))
+BLOCK = os.environ.get("PFA_TIMING_BLOCK", "0") == "1"      # libatoma_hip_timing2.so: the regions between two blocks' loops
+lib = C.CDLL(os.path.join(ROOT, "tools", "probes", os.environ.get("PFA_TIMING_LIB", "libatoma_hip_timing2.so" if BLOCK else "libatoma_hip_timing.so")))
 lib.run_mha.argtypes = ah._RUN_MHA_ARGS
 lib.atoma_set_option.argtypes = [C.c_char_p, C.c_int]
 ah.set_device(0)
@@ -25,7 +26,8 @@ for S, nseq, causal, ek in shapes:
     q, k, v = (TS.rand_dev(rng, T * n * d * 2) for n in (h, hk, hk))
     o = ah.DeviceBuffer(T * h * d * 2)
     cu = ah.DeviceBuffer.from_numpy((np.arange(nseq + 1) * S).astype(np.int32))
-    nwg = 8 * ((nseq * h + 7) // 8) * ((S + 255) // 256)
+    nblk = nseq * h * ((S + 255) // 256)
+    nwg = min(256, 8 * ((nseq * h + 7) // 8) * ((S + 255) // 256))       # persistent: one workgroup per CU
     dbg = ah.DeviceBuffer.zeros((nwg * 4, 8), np.uint32)
     rnd = lambda x, m: (x + m - 1) // m * m
     args = [q.ptr, k.ptr, v.ptr, o.ptr, dbg.ptr, None, cu.ptr, cu.ptr, True, 0, 0, 0, 0, 0, h * d, hk * d, hk * d, h * d, d, d, d, d,
@@ -35,15 +37,18 @@ for S, nseq, causal, ek in shapes:
         lib.run_mha(*args)
     ah.synchronize()
     t = dbg.numpy().astype(np.float64)
-    t = t[t[:, 7] > 0]
-    it = t[:, 7].sum()
-    names = ["phase1", "phase2", "waitcnt", "barrier", "control"]
-    per_tile = {n: int(t[:, i].sum() / it) for i, n in enumerate(names)}
-    print(f"S={S} x{nseq} causal={causal} exact_keys={ek}: wavefronts {len(t)}, iterations/wave {t[:, 7].mean():.1f}; cycles per iteration {per_tile} "
-          f"sum {sum(per_tile.values())}; per block: prologue {int(t[:, 5].mean())} epilogue {int(t[:, 6].mean())} loop {int(t[:, :5].sum(1).mean())}", flush=True)
-    # by number of iterations (blocks near the diagonal vs long ones)
-    for lo, hi in ((1, 8), (9, 16), (17, 24), (25, 64)):
-        m = (t[:, 7] >= lo) & (t[:, 7] <= hi)
-        if m.any():
-            print(f"   waves with {lo}-{hi} iterations: n={int(m.sum())} per-iteration", {n: int(t[m, i].sum() / t[m, 7].sum()) for i, n in enumerate(names)},
-                  f"prologue {int(t[m, 5].mean())} epilogue {int(t[m, 6].mean())}", flush=True)
+    t = t[t[:, :6].sum(1) > 0]
+    nt = [(4 * (i + 1) if causal else (S + 63) // 64) for i in range((S + 255) // 256)]      # K/V tiles of the blocks of one (sequence, head)
+    nt = [min(x, (S + 63) // 64) for x in nt]
+    it = nseq * h * sum(nt) / nwg                                        # iterations per wavefront
+    bpw = nblk / nwg                                                     # blocks per workgroup
+    if BLOCK:
+        names = ["drain+barrier", "next entry fetched", "Q addresses + loads issued", "5 K/V tiles requested", "Q wait + first d-steps + K(0) barrier", "S(0) .. loop entry"]
+        print(f"S={S} x{nseq} causal={causal} exact_keys={ek}: cycles per block:", {n: int(t[:, i].mean() / bpw) for i, n in enumerate(names)}, flush=True)
+        continue
+    names = ["phase1", "phase2", "wait+barrier", "control", "prologue", "epilogue"]
+    per_tile = {n: int(t[:, i].mean() / it) for i, n in enumerate(names[:4])}
+    tot = t[:, :6].sum(1)
+    print(f"S={S} x{nseq} causal={causal} exact_keys={ek}: wavefronts {len(t)}, {bpw:.1f} blocks and {it:.0f} iterations per workgroup; cycles per iteration "
+          f"{per_tile} sum {sum(per_tile.values())}; per block: prologue {int(t[:, 4].mean() / bpw)} epilogue {int(t[:, 5].mean() / bpw)} "
+          f"loop {int(t[:, :4].sum(1).mean() / bpw)}; per wavefront total {int(tot.mean())} (min {int(tot.min())} max {int(tot.max())})", flush=True)
