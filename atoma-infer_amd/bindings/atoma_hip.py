@@ -69,6 +69,10 @@ lib.atoma_host_alloc.argtypes = [C.c_size_t]
 lib.atoma_host_alloc.restype = _vp
 lib.atoma_host_free.argtypes = [_vp]
 lib.atoma_host_free.restype = None
+lib.atoma_host_register.argtypes = [_vp, C.c_size_t]
+lib.atoma_host_register.restype = C.c_int
+lib.atoma_host_unregister.argtypes = [_vp]
+lib.atoma_host_unregister.restype = C.c_int
 lib.atoma_device_count.restype = _int
 lib.atoma_set_option.argtypes = [C.c_char_p, _int]
 lib.atoma_set_option.restype = _int

@@ -8,6 +8,11 @@
 // contiguous, a page is block_size such rows), falling back to 2-byte moves only when the
 // caller's pointers/strides are not 16-byte aligned.  HBM-bound: bytes = 2x what is moved.
 #include "common.h"
+#include <algorithm>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <string.h>
 
 namespace atoma {
 
@@ -186,6 +191,127 @@ static void *device_alias(const void *host_ptr) {
     return dev;
 }
 
+// Pageable host memory (the reference's CPU cache is ordinary Candle tensors: backends/vllm/src/worker.rs:570-598; its swap is one
+// cudaMemcpyAsync per page, csrc/src/ops.rs:158-166,205-216 -- which the runtime stages page by page: 3 GB/s here).  Pages travel
+// through a pinned, device-addressable bounce ring instead: two 8 MiB slots per device; the gather / scatter kernel moves up to a
+// slot's worth of pages between the cache and a slot in one launch, a small team of host threads copies between the slot and the
+// caller's pages, and the two slots alternate so that the PCIe transfer of one chunk runs beside the host copy of the other.  Like
+// a pageable hipMemcpy, the call returns when the host side is done (GPU -> CPU: the data is in the caller's pages; CPU -> GPU: the
+// caller's pages have been read); the device side stays ordered on `stream`.
+namespace {
+constexpr size_t BOUNCE_SLOT = 8u << 20;
+struct Bounce {
+    int device = -1;
+    char *host[2] = {nullptr, nullptr};
+    char *dev[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};     // the kernel that last touched the slot
+    bool busy[2] = {false, false};
+};
+std::mutex g_bounce_mu;
+std::vector<Bounce> g_bounce;
+
+Bounce *bounce_for_device() {
+    int dev = 0;
+    if (!check_hip(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
+    for (auto &b : g_bounce)
+        if (b.device == dev) return &b;
+    Bounce b;
+    b.device = dev;
+    for (int i = 0; i < 2; ++i) {
+        void *h = nullptr, *d = nullptr;
+        if (!check_hip(hipHostMalloc(&h, BOUNCE_SLOT, hipHostMallocMapped | hipHostMallocPortable), "swap_blocks bounce hipHostMalloc") ||
+            !check_hip(hipHostGetDevicePointer(&d, h, 0), "swap_blocks bounce alias") ||
+            !check_hip(hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming), "swap_blocks bounce event"))
+            return nullptr;
+        b.host[i] = static_cast<char *>(h);
+        b.dev[i] = static_cast<char *>(d);
+    }
+    g_bounce.push_back(b);
+    return &g_bounce.back();
+}
+
+// n pages between a packed slot and the caller's pageable pages, split over a few threads (one memcpy stream does ~10 GB/s)
+void host_copy_pages(char *slot, char *tensor, const int64_t *pages, int64_t n, int64_t block_bytes, bool to_slot) {
+    const int64_t bytes = n * block_bytes;
+    const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(4, bytes >> 20));
+    auto work = [&](int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k) {
+            char *pg = tensor + pages[k] * block_bytes, *sl = slot + k * block_bytes;
+            if (to_slot) memcpy(sl, pg, (size_t)block_bytes); else memcpy(pg, sl, (size_t)block_bytes);
+        }
+    };
+    if (nthreads == 1) { work(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, n * t / nthreads, n * (t + 1) / nthreads);
+    work(0, n / nthreads);
+    for (auto &t : th) t.join();
+}
+}  // namespace
+
+static int swap_blocks_pageable(const void *const *srcs, void *const *dsts, int64_t num_tensors, const int64_t *mapping, int64_t num_pairs,
+                                int64_t block_bytes, int kind, hipStream_t stream) {
+    if ((size_t)block_bytes > BOUNCE_SLOT) {     // pages larger than a slot: the plain per-page copy
+        const hipMemcpyKind mk = kind == ATOMA_SWAP_CPU_TO_GPU ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+        for (int64_t t = 0; t < num_tensors; ++t)
+            for (int64_t p = 0; p < num_pairs; ++p) {
+                const char *sp = static_cast<const char *>(srcs[t]) + mapping[2 * p] * block_bytes;
+                char *dp = static_cast<char *>(dsts[t]) + mapping[2 * p + 1] * block_bytes;
+                if (!check_hip(hipMemcpyAsync(dp, sp, (size_t)block_bytes, mk, stream), "swap_blocks memcpy")) return -1;
+            }
+        return 0;
+    }
+    std::lock_guard<std::mutex> lock(g_bounce_mu);
+    Bounce *bn = bounce_for_device();
+    if (!bn) return -1;
+    const bool out = kind == ATOMA_SWAP_GPU_TO_CPU;
+    const int64_t per_slot = std::min<int64_t>((int64_t)(BOUNCE_SLOT / (size_t)block_bytes), SWAP_MAX_PAIRS);
+    const int64_t spans = cdiv(block_bytes, (int64_t)COPY_SPAN_VECS * 16);
+    std::vector<int64_t> host_pages((size_t)per_slot);
+    struct Pending { int slot; int64_t t, p0, n; };
+    Pending pend{-1, 0, 0, 0};                   // GPU -> CPU: the chunk whose gather is in flight
+    auto drain = [&](const Pending &c) -> bool {  // wait for its gather, copy the slot out to the caller's pages
+        if (!check_hip(hipEventSynchronize(bn->done[c.slot]), "swap_blocks bounce wait")) return false;
+        bn->busy[c.slot] = false;
+        for (int64_t k = 0; k < c.n; ++k) host_pages[(size_t)k] = mapping[2 * (c.p0 + k) + 1];
+        host_copy_pages(bn->host[c.slot], static_cast<char *>(dsts[c.t]), host_pages.data(), c.n, block_bytes, false);
+        return true;
+    };
+    int slot = 0;
+    for (int64_t t = 0; t < num_tensors; ++t)
+        for (int64_t p0 = 0; p0 < num_pairs; p0 += per_slot, slot ^= 1) {
+            const int64_t n = std::min(per_slot, num_pairs - p0);
+            if (bn->busy[slot]) {                 // the kernel that last read / wrote this slot (this call or an earlier one)
+                if (out && pend.slot == slot) { if (!drain(pend)) return -1; pend.slot = -1; }
+                else if (!check_hip(hipEventSynchronize(bn->done[slot]), "swap_blocks bounce wait")) return -1;
+                bn->busy[slot] = false;
+            }
+            SwapArgs a;
+            for (int64_t k = 0; k < n; ++k) {
+                a.pairs[k][0] = out ? (int32_t)mapping[2 * (p0 + k)] : (int32_t)k;
+                a.pairs[k][1] = out ? (int32_t)k : (int32_t)mapping[2 * (p0 + k) + 1];
+            }
+            if (out) {
+                a.src[0] = static_cast<const char *>(srcs[t]);
+                a.dst[0] = bn->dev[slot];
+            } else {
+                for (int64_t k = 0; k < n; ++k) host_pages[(size_t)k] = mapping[2 * (p0 + k)];
+                host_copy_pages(bn->host[slot], const_cast<char *>(static_cast<const char *>(srcs[t])), host_pages.data(), n, block_bytes, true);
+                a.src[0] = bn->dev[slot];
+                a.dst[0] = static_cast<char *>(dsts[t]);
+            }
+            hipLaunchKernelGGL(swap_blocks_kernel, dim3((unsigned)n, 1, (unsigned)spans), dim3(COPY_THREADS), 0, stream, a, block_bytes);
+            if (!ATOMA_CHECK_LAUNCH("swap_blocks (bounce)")) return -1;
+            if (!check_hip(hipEventRecord(bn->done[slot], stream), "swap_blocks bounce record")) return -1;
+            bn->busy[slot] = true;
+            if (out) {                            // the previous chunk's host copy runs beside this chunk's gather
+                if (pend.slot >= 0 && !drain(pend)) return -1;
+                pend = Pending{slot, t, p0, n};
+            }
+        }
+    if (out && pend.slot >= 0 && !drain(pend)) return -1;
+    return 0;
+}
+
 int swap_blocks_multi(const void *const *srcs, void *const *dsts, int64_t num_tensors, const int64_t *mapping,
                       int64_t num_pairs, int64_t block_bytes, int kind, hipStream_t stream) {
     if (kind < ATOMA_SWAP_GPU_TO_GPU || kind > ATOMA_SWAP_GPU_TO_CPU) {
@@ -215,18 +341,7 @@ int swap_blocks_multi(const void *const *srcs, void *const *dsts, int64_t num_te
             if (!a) kernel_path = false; else d[t] = static_cast<char *>(a);
         }
     }
-    if (!kernel_path) {
-        // Pageable host memory: the reference's own shape, one async copy per page
-        // (csrc/src/ops.rs:158-166,205-216), but on the caller's stream.
-        const hipMemcpyKind mk = kind == ATOMA_SWAP_CPU_TO_GPU ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
-        for (int64_t t = 0; t < num_tensors; ++t)
-            for (int64_t p = 0; p < num_pairs; ++p) {
-                const char *sp = static_cast<const char *>(srcs[t]) + mapping[2 * p] * block_bytes;
-                char *dp = static_cast<char *>(dsts[t]) + mapping[2 * p + 1] * block_bytes;
-                if (!check_hip(hipMemcpyAsync(dp, sp, (size_t)block_bytes, mk, stream), "swap_blocks memcpy")) return -1;
-            }
-        return 0;
-    }
+    if (!kernel_path) return swap_blocks_pageable(srcs, dsts, num_tensors, mapping, num_pairs, block_bytes, kind, stream);
     const int64_t spans = cdiv(block_bytes, (int64_t)COPY_SPAN_VECS * 16);
     for (int64_t t0 = 0; t0 < num_tensors; t0 += SWAP_MAX_TENSORS) {
         const int nt = (int)((num_tensors - t0) < SWAP_MAX_TENSORS ? (num_tensors - t0) : SWAP_MAX_TENSORS);
@@ -302,6 +417,16 @@ void *atoma_host_alloc(size_t bytes) {
 }
 void atoma_host_free(void *p) {
     if (p) atoma::check_hip(hipHostFree(p), "atoma_host_free");
+}
+// Pin an allocation the caller already owns (the reference's CPU cache tensors, worker.rs:570-598) and map it into the device's
+// address space: swap_blocks then moves its pages with the gather / scatter kernel at the PCIe rate instead of through the bounce ring.
+int atoma_host_register(void *p, size_t bytes) {
+    atoma::clear_error();
+    return atoma::check_hip(hipHostRegister(p, bytes, hipHostRegisterMapped | hipHostRegisterPortable), "atoma_host_register") ? 0 : -1;
+}
+int atoma_host_unregister(void *p) {
+    atoma::clear_error();
+    return atoma::check_hip(hipHostUnregister(p), "atoma_host_unregister") ? 0 : -1;
 }
 
 }  // extern "C"

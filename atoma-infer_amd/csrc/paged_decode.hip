@@ -45,7 +45,7 @@ __device__ __forceinline__ void paged_decode_item(const DecodeParams &p, const D
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, dc = lane % LPR;
 
-    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
+    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
     const int64_t kv_row0 = wk.kv_row0;
     const bool partial = wk.partial;
     const int hq0 = hk * p.g + gc * G;
@@ -143,13 +143,14 @@ __device__ __forceinline__ void paged_decode_item(const DecodeParams &p, const D
             for (int r = 0; r < IPP; ++r)
                 vb[r] = __builtin_amdgcn_raw_buffer_load_b128(vr, v_lane_off, (int)(r * RPI * v_row_bytes), AUX);
         };
-        // any tile: rows clamped to the last row of the sequence, so a contiguous (non-paged)
-        // cache is never read past its end; paged tiles always have their 16 rows
+        // any tile: rows clamped to the last row of the sequence: a contiguous (non-paged) cache is never read past its end, and the
+        // never-written slots of a paged cache's last page (NaN patterns included) never meet p = 0 in P.V (the reference zero-fills
+        // out-of-range V rows, flash_fwd_kernel.h:903)
         auto issue_tail = [&](u32x4 (&kb)[IPP], u32x4 (&vb)[IPP], int tile, int pid) {
             const char *kt, *vt;
             tile_bases(tile, pid, kt, vt);
             const __amdgpu_buffer_rsrc_t kr = tile_rsrc(kt), vr = tile_rsrc(vt);
-            const int lastrow = paged ? 15 : min(15, L - 1 - (tile << 4));
+            const int lastrow = min(15, L - 1 - (tile << 4));
 #pragma unroll
             for (int r = 0; r < IPP; ++r) {
                 const int row = min(r * RPI + sub, lastrow);
@@ -251,7 +252,7 @@ __device__ __forceinline__ void paged_decode_item(const DecodeParams &p, const D
         u32x4 kb[P][IPP], vb[P][IPP];
         int pid[P];
         int t = t0;
-        const int steady_end = min(t1, paged ? n_tiles : (L >> 4));  // tiles below this load without clamping
+        const int steady_end = min(t1, L >> 4);  // full tiles load without clamping; a ragged last tile goes through the clamped tail (paged too: never-written slots)
         if (t0 + 2 * P <= steady_end) {
             // long sequence: unconditional prologue, so the loop header sees ONE load history
 #pragma unroll
@@ -379,7 +380,7 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
     constexpr int D = 128;
     const int lane = threadIdx.x & 63, grp = lane >> 4, col = lane & 15;
 
-    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, n_tiles = wk.n_tiles, t0 = wk.t0, t1 = wk.t1;
+    const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
     const int64_t kv_row0 = wk.kv_row0;
     const bool partial = wk.partial;
     const int hq0 = hk * p.g + gc * G;
@@ -462,7 +463,7 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
             const char *kt, *vt;
             tile_bases(tile, pid, kt, vt);
             const __amdgpu_buffer_rsrc_t kr = tile_rsrc(kt), vr = tile_rsrc(vt);
-            const int lastrow = paged ? 15 : min(15, L - 1 - (tile << 4));
+            const int lastrow = min(15, L - 1 - (tile << 4));
             const uint32_t koff = (uint32_t)(min(col, lastrow) * k_row_bytes + grp * 16);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) kb[s4] = __builtin_amdgcn_raw_buffer_load_b128(kr, koff, s4 * 64, AUX);
@@ -527,7 +528,7 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
         u32x4 kb[P][4], vb[P][4];
         int pid[P];
         int t = t0;
-        const int steady_end = min(t1, paged ? n_tiles : (L >> 4));
+        const int steady_end = min(t1, L >> 4);   // a ragged last tile takes the clamped loads (see paged_decode_item)
         if (t0 + 2 * P <= steady_end) {
 #pragma unroll
             for (int s = 0; s < P; ++s) pid[s] = fetch_pid(t0 + s);

@@ -157,6 +157,14 @@ __device__ __forceinline__ void paged_decode_fp8_item(const DecodeParams &p, con
             uint32_t va[8], vc[8];
             fp8x16_to_pairs<T>(vb[0], va);
             fp8x16_to_pairs<T>(vb[1], vc);
+            if ((tile << 4) + 16 > L) {   // wave-uniform: slots of the last page behind the sequence were never written -- whatever they hold
+                                          // (NaN codes 0x7f / 0xff included) must not meet p = 0 in the products (flash_fwd_kernel.h:903 zero-fills them)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    va[w] = tok0 >= L ? 0u : va[w];
+                    vc[w] = tok0 + RPI >= L ? 0u : vc[w];
+                }
+            }
 #pragma unroll
             for (int w = 0; w < 8; ++w) {
                 const uint32_t lo = __builtin_amdgcn_perm(vc[w], va[w], 0x05040100u);  // (row sub, row 8 + sub) of element 2w
@@ -424,6 +432,11 @@ __device__ __forceinline__ void paged_decode_fp8_mma_item(const DecodeParams &p,
             for (int i = 0; i < 4; ++i) {
                 c[i][0] = fp8x2_to_pair<T>(vb[i].x, false); c[i][1] = fp8x2_to_pair<T>(vb[i].x, true);
                 c[i][2] = fp8x2_to_pair<T>(vb[i].y, false); c[i][3] = fp8x2_to_pair<T>(vb[i].y, true);
+            }
+            if ((tile << 4) + 16 > L) {  // wave-uniform: never-written slots behind the sequence (NaN codes included) must not meet p = 0
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (tok0 + i >= L) c[i][0] = c[i][1] = c[i][2] = c[i][3] = 0u;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

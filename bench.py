@@ -187,6 +187,7 @@ def main():
         wall = float(t.item())
     launch_ms = [a.elapsed_ms(b_) for a, b_ in ev]
     kern_ms = float(np.mean(launch_ms))
+    gpu_out = do.numpy(np.uint16, q.shape)                  # what the timed region wrote (checked below against the CPU leg's output)
 
     ms_per_step = wall * 1e3 / args.steps
     total_bytes = algorithmic_bytes(B, S, h, hk, d, page)           # whole job (all ranks)
@@ -244,6 +245,7 @@ def main():
     # ---- end-to-end numbers beside the headline, each timed with HIP events in this same run (tools/bench_extra.py) ----
     # N = 1: the 8B decode step of configs[2], the prefill kernel, the configs[4] swap.  N > 1: the tensor-parallel decode step
     # of configs[3] (70B-shaped shard per rank, 2 all-reduces of [64, 8192] per layer) with RCCL and with the direct xGMI kernels.
+    prefill_smp = None
     if not args.no_extra:
         for b_ in (dkc, dvc, dq, do):
             b_.free()
@@ -270,7 +272,7 @@ def main():
         try:
             if world == 1 and not force_comm:
                 import bench_extra
-                extra.update(bench_extra.collect())
+                extra.update(bench_extra.collect(prefill_sample=not args.no_cpu_baseline))
                 if args.tp_step:
                     import tp_step
                     extra["tp_step"] = tp_step.run(steps=10)
@@ -286,12 +288,27 @@ def main():
             extra["error"] = repr(e)
         if watchdog is not None:
             watchdog.cancel()
+        if isinstance(extra.get("prefill"), dict):
+            prefill_smp = extra["prefill"].pop("sample", None)      # host copies of sampled rows: checked below, not part of the line
         out["extra"] = extra
         if world > 1:
             out["tp_step"] = tp_summary(extra.get("tp_step") or tp_progress, extra.get("error"))
 
+    failed = False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU baseline is an N = 1 leg
-        out["cpu_baseline"] = cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk_l, h_l)
+        out["cpu_baseline"], o_cpu = cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk_l, h_l)
+        # ---- the timed region's output against the CPU leg's (the oracle's C restatement, here as the checker): the sequences the
+        # baseline computed anyway, BASELINE.json's tolerance (1e-3 + one unit in the last place of bf16)
+        from halfs import to_f32
+        got, want = to_f32(gpu_out[:o_cpu.shape[0]], BF16), to_f32(o_cpu, BF16)
+        err = np.abs(got - want)
+        ok = bool(np.isfinite(got).all() and (err <= 1e-3 + 2.0 ** -7 * np.abs(want)).all())
+        out["verified"] = {"ok": ok, "sequences": int(o_cpu.shape[0]), "max_err": float(err.max()), "tolerance": "1e-3 + 2^-7 |ref| (bf16)",
+                           "against": "oracle/c/oracle.c oracle_decode_grouped (f32) on the same tensors"}
+        failed = failed or not ok
+        if prefill_smp is not None:
+            out["verified"]["prefill"] = verify_prefill_sample(prefill_smp)
+            failed = failed or not out["verified"]["prefill"]["ok"]
     if comm is not None or xgmi is not None:
         if dist is not None:
             dist.barrier()
@@ -307,6 +324,27 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stderr.flush()
         print(json.dumps(out), flush=True)
+    if failed:
+        sys.exit(3)                                          # a line whose numbers come from wrong results must not pass for a measurement
+
+
+def verify_prefill_sample(smp):
+    """extra.prefill: sampled query rows of two (sequence, head) pairs against the f32 definition (oracle/attn_oracle.py attend_rows, the
+    checker); rows that see >= 512 keys at 1e-3 + 1 ulp, the first rows of a sequence at the P-rounding bound (tests/util.py)."""
+    from oracle import attn_oracle as A
+    from halfs import to_f32, BF16
+    worst, ok, n = 0.0, True, 0
+    for it in smp:
+        kf, vf = to_f32(it["k"], BF16)[:, None, :], to_f32(it["v"], BF16)[:, None, :]
+        for r, qrow, orow in zip(it["rows"], it["q"], it["o"]):
+            ref, _ = A.attend_rows(to_f32(qrow, BF16)[None, None, :], kf[:r + 1], vf[:r + 1], np.float32(it["scale"]), causal=False)
+            got = to_f32(orow, BF16)
+            err = np.abs(got - ref[0, 0])
+            tol = (1e-3 if r + 1 >= 512 else 4e-3) + 2.0 ** -7 * np.abs(ref[0, 0])
+            ok = ok and bool(np.isfinite(got).all() and (err <= tol).all())
+            worst = max(worst, float(err.max()))
+            n += 1
+    return {"ok": ok, "rows": n, "max_err": worst, "against": "oracle/attn_oracle.py attend_rows (f32 definition)"}
 
 
 def tp_summary(res, note=None):
@@ -383,7 +421,9 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     os.environ.setdefault("OMP_PLACES", "cores")
     from util import oracle_c
     lib = oracle_c()
-    Bs = min(args.cpu_sample_seqs, args.batch)
+    avail = len(os.sched_getaffinity(0)) or 1
+    few = avail < 8                                             # a cpuset of a few hardware threads (the driver's box): a short leg
+    Bs = min(16 if few else args.cpu_sample_seqs, args.batch)
     d, page, S = args.head_dim, args.block_size, args.seq
     # host copy of the cache: the same slab tiling as on the device
     reps = -(-n_pages // slab_k.shape[0])
@@ -396,7 +436,6 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     i64 = C.c_int64
     lib.oracle_decode_grouped.argtypes = [C.c_void_p] * 6 + [i64, C.c_int, i64, i64, i64] + [C.c_int] * 4 + [C.c_float, C.c_int]
     lib.oracle_max_threads.restype = C.c_int
-    avail = len(os.sched_getaffinity(0)) or 1
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
 
     def run(cores):       # one task per (sequence, kv head): K / V rows converted once for the whole query group, vectorised inner loops
@@ -419,7 +458,8 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     cores = best[1]
     t0 = time.perf_counter()
     reps_done = 0
-    while reps_done < 3 or (time.perf_counter() - t0 < 10.0 and reps_done < 50):
+    budget = 3.0 if few else 10.0
+    while reps_done < 3 or (time.perf_counter() - t0 < budget and reps_done < 50):
         run(cores)
         reps_done += 1
     dt = (time.perf_counter() - t0) / reps_done
@@ -439,7 +479,7 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
                       "fa_acausal f32 restatement, one task per (sequence, kv head), K/V rows converted once per query group, "
                       "vectorised inner loops (oracle/c/oracle.c oracle_decode_grouped, gcc -O3 -march=x86-64-v3 -fopenmp); thread count = the "
                       "fastest of 4/8/16/32/64/128/all (thread_sweep_GBps), threads bound to cores and spread (placement)" % (Bs, args.batch, reps_done, dt),
-            "decode_tokens_per_s": round(Bs / dt, 1)}
+            "decode_tokens_per_s": round(Bs / dt, 1)}, o
 
 
 if __name__ == "__main__":

@@ -117,9 +117,12 @@ int atoma_compute_num_splits(int64_t batch_size, int64_t num_heads, int64_t head
 /* swap_blocks (csrc/src/cache_manager.rs:18-128 + csrc/src/ops.rs:14-220: one async memcpy per
  * page there).  dst[page d] = src[page s] for every (s,d) in `mapping` (HOST int64 [n][2]),
  * whole pages of block_size_in_bytes.  kind: 0 = gpu->gpu (same device), 1 = cpu->gpu,
- * 2 = gpu->cpu.  Host pointers that the device can address (atoma_host_alloc or
- * hipHostRegister'ed) are moved by one gather/scatter kernel over PCIe; pageable host memory
- * falls back to per-page hipMemcpyAsync.  Stream-ordered; the caller syncs the stream. */
+ * 2 = gpu->cpu.  Host pointers that the device can address (atoma_host_alloc, atoma_host_register
+ * or hipHostRegister'ed) are moved by one gather/scatter kernel over PCIe.  Pageable host memory
+ * (what the unchanged reference passes) travels through a pinned bounce ring owned by the library:
+ * two 8 MiB slots, the same kernel between cache and slot, host threads between slot and the
+ * caller's pages, the two overlapped; like a pageable hipMemcpy the call then returns when the
+ * host side is done.  Device side stream-ordered; the caller syncs the stream. */
 enum { ATOMA_SWAP_GPU_TO_GPU = 0, ATOMA_SWAP_CPU_TO_GPU = 1, ATOMA_SWAP_GPU_TO_CPU = 2 };
 int atoma_swap_blocks(const void *src, void *dst, const int64_t *mapping, int64_t num_pairs,
                       int64_t block_size_in_bytes, int kind, void *stream);
@@ -131,6 +134,10 @@ int atoma_swap_blocks_multi(const void *const *srcs, void *const *dsts, int64_t 
  * Candle CPU tensors, backends/vllm/src/worker.rs:570-598). */
 void *atoma_host_alloc(size_t bytes);
 void atoma_host_free(void *p);
+/* Pin and map an allocation the caller already owns (one call per CPU cache tensor after it is
+ * allocated): its pages then move at the PCIe rate without the bounce ring.  0 on success. */
+int atoma_host_register(void *p, size_t bytes);
+int atoma_host_unregister(void *p);
 
 /* RMSNorm (models/src/llama.rs:402,408,474 -> candle_nn::ops::rms_norm): per row
  * y = T(rsqrt(mean(x^2) + eps) * x * w), f32 arithmetic, one rounding. */

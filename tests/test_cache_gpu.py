@@ -148,22 +148,25 @@ def test_swap_blocks_gpu_to_gpu_reference_case(gpu, dtype, mapping):
     assert np.array_equal(dd.numpy(), dst) and np.array_equal(ds.numpy(), src)
 
 
-@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("pinned", [False, True, "registered"])
 def test_swap_blocks_cpu_gpu_round_trip(gpu, pinned):
-    """cache_manager_tests.rs:104-186 both directions, pageable (memcpy path) and pinned
-    (one gather/scatter kernel over PCIe); swap-out then swap-in restores the pages."""
+    """cache_manager_tests.rs:104-186 both directions: pageable host memory (the library's pinned bounce ring), atoma_host_alloc and
+    a caller-owned allocation pinned in place with atoma_host_register (one gather/scatter kernel over PCIe); swap-out then swap-in
+    restores the pages."""
     rng = np.random.default_rng(4)
     shape = (40, 16, 8, 128)                                   # 32 KiB pages (Llama-3.1-8B)
     nbytes = int(np.prod(shape)) * 2
     gpu_cache = rand_half(rng, shape, F16)
     dg = gpu.DeviceBuffer.from_numpy(gpu_cache)
-    if pinned:
+    if pinned is True:
         hptr = gpu.lib.atoma_host_alloc(nbytes)
         assert hptr
         host = np.ctypeslib.as_array(C.cast(hptr, C.POINTER(C.c_uint16)), shape=(nbytes // 2,)).reshape(shape)
     else:
         host = np.empty(shape, np.uint16)
         hptr = host.ctypes.data
+        if pinned == "registered":
+            assert gpu.lib.atoma_host_register(hptr, nbytes) == 0, gpu.last_error()
     host[...] = rand_half(rng, shape, F16)
     want_host = host.copy()
     out_map = {int(s): int(d) for s, d in zip(rng.permutation(40)[:17], rng.permutation(40)[:17])}
@@ -178,8 +181,10 @@ def test_swap_blocks_cpu_gpu_round_trip(gpu, pinned):
         assert np.array_equal(back[s], gpu_cache[s])
     untouched = [i for i in range(40) if i not in out_map]
     assert not back[untouched].any()
-    if pinned:
+    if pinned is True:
         gpu.lib.atoma_host_free(hptr)
+    elif pinned == "registered":
+        assert gpu.lib.atoma_host_unregister(hptr) == 0, gpu.last_error()
 
 
 def test_swap_blocks_multi_all_layers(gpu):

@@ -6,7 +6,7 @@ import pytest
 
 from oracle import attn_oracle as A
 from oracle.halfs import F16, BF16, to_f32
-from util import rand_half, make_paged_cache, assert_close, c_attention, ATOL_VS_F32, attn_atol
+from util import rand_half, make_paged_cache, assert_close, c_attention, ATOL_VS_F32, attn_atol, poison_unwritten_slots
 
 pytestmark = pytest.mark.gpu
 CASES = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_cases.npz"))
@@ -515,3 +515,20 @@ def test_decode_matches_own_schedule_tightly(gpu, dtype, d, h, hk, variant):
     # and it is far tighter than that almost everywhere: at most a handful of outputs differ at all (a p on a rounding
     # boundary where v_exp_f32 and numpy's exp2 differ in the last f32 bit)
     assert (out != ref).mean() < 0.01
+
+
+@pytest.mark.parametrize("dtype,nan", [(BF16, 0x7FC0), (F16, 0x7E00)])
+@pytest.mark.parametrize("d,h,hk,page", [(128, 32, 8, 16), (128, 8, 8, 16), (128, 64, 8, 32), (64, 32, 8, 16), (128, 8, 1, 64)])
+def test_decode_never_written_slots_do_not_reach_the_output(gpu, dtype, nan, d, h, hk, page):
+    """rows >= L of the last page get p = 0 but still enter P.V (matrix-core and dot2 kernels alike): NaN patterns in
+    those never-written slots -- and in pages no sequence owns -- must leave every output bit where it was."""
+    rng = np.random.default_rng(d + h + hk + page)
+    lens = np.array([1, 2, 15, 17, 31, 33, 100, 333, 1000, 2049], np.int32)
+    nb = int(sum((L + page - 1) // page for L in lens)) + 5
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+    q = rand_half(rng, (len(lens), 1, h, d), dtype)
+    clean, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+    kp, vp = poison_unwritten_slots(kc, vc, bt, lens, nan)
+    got, lse = gpu_decode(gpu, q, kp, vp, bt, lens, d ** -0.5, dtype)
+    assert np.isfinite(to_f32(got, dtype)).all() and np.isfinite(lse).all()
+    assert np.array_equal(got, clean)

@@ -227,3 +227,23 @@ def test_decode_fp8_rejects_bad_arguments(gpu):
     assert gpu.lib.atoma_paged_decode_fp8(*args(page=8)) == -1 and "page_size" in gpu.last_error()
     assert gpu.lib.atoma_paged_decode_fp8(*args(dtype=2)) == -1 and "dtype" in gpu.last_error()
     assert gpu.lib.atoma_paged_decode_fp8(*args(b=0)) == 0
+
+
+@pytest.mark.parametrize("code", [0x7F, 0xFF], ids=["+nan", "-nan"])
+@pytest.mark.parametrize("h,hk,page", [(32, 8, 16), (8, 8, 32), (16, 1, 16)])
+def test_decode_fp8_never_written_slots_do_not_reach_the_output(gpu, qk_variant, h, hk, page, code):
+    """e4m3fn NaN codes in the slots of the last page behind the sequence (p = 0 there, but the products still run) and in pages
+    nobody owns: every output bit stays where it was"""
+    from util import poison_unwritten_slots
+    rng = np.random.default_rng(h + hk + page + code)
+    d = 128
+    lens = np.array([1, 2, 15, 17, 31, 33, 100, 333, 1000], np.int32)
+    nb = int(sum((L + page - 1) // page for L in lens)) + 4
+    kc8, vc8, ks, vs, bt = make_fp8_cache(rng, nb, page, hk, d, lens)
+    q = rand_half(rng, (len(lens), h, d), BF16)
+    scale = np.float32(d ** -0.5)
+    clean = gpu_decode_fp8(gpu, q, kc8, vc8, ks, vs, bt, lens, scale, BF16)
+    kp, vp = poison_unwritten_slots(kc8, vc8, bt, lens, code)
+    got = gpu_decode_fp8(gpu, q, kp, vp, ks, vs, bt, lens, scale, BF16)
+    assert np.isfinite(to_f32(got, BF16)).all()
+    assert np.array_equal(got, clean)

@@ -231,3 +231,23 @@ def test_prefill_4096_sampled_rows_vs_f32_definition(gpu, prefill_variant):
             ref, _ = A.attend_rows(qf[r:r + 1], kf[:r + 1], vf[:r + 1], np.float32(d ** -0.5), causal=False)
             from oracle.halfs import from_f32
             assert_close(out[r:r + 1], from_f32(ref, BF16), BF16, atol=1e-3 if r + 1 >= 512 else ATOL_VS_F32[BF16], what=f"S=4096 h={h} row {r}")
+
+
+@pytest.mark.parametrize("page", [16, 64])
+def test_prefill_paged_never_written_slots_do_not_reach_the_output(gpu, page):
+    """prefix prefill over a paged cache whose never-written slots (behind each sequence in its last page, and every page nobody
+    owns) hold NaN patterns: rows past the sequence must arrive as zeros in the V tiles (P = 0 times NaN would poison O)"""
+    from util import poison_unwritten_slots
+    rng = np.random.default_rng(page)
+    h, hk, d = 8, 2, 128
+    lens_q, lens_k = np.array([90, 17, 300], np.int32), np.array([333, 81, 700], np.int32)
+    nb = int(sum((x + page - 1) // page for x in lens_k)) + 3
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, BF16, lens_k)
+    cu = np.concatenate([[0], np.cumsum(lens_q)]).astype(np.int32)
+    cuk = np.concatenate([[0], np.cumsum(lens_k)]).astype(np.int32)
+    q = rand_half(rng, (int(cu[-1]), h, d), BF16)
+    clean, _ = gpu_varlen(gpu, q, kc, vc, cu, cuk, d ** -0.5, True, BF16, bt=bt)
+    kp, vp = poison_unwritten_slots(kc, vc, bt, lens_k, 0x7FC0)
+    got, _ = gpu_varlen(gpu, q, kp, vp, cu, cuk, d ** -0.5, True, BF16, bt=bt)
+    assert np.isfinite(to_f32(got, BF16)).all()
+    assert np.array_equal(got, clean)

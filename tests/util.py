@@ -52,6 +52,26 @@ def assert_close(got_bits, ref_bits, dtype, atol=1e-3, what=""):
                            f"at {np.unravel_index(err.argmax(), err.shape)} (ref {ref.flat[err.argmax()]:.5f})")
 
 
+def poison_unwritten_slots(kc, vc, bt, lens, pattern):
+    """The slots of every sequence's last page behind its length were never written by reshape_and_cache: whatever they hold must
+    not reach an output (the reference zero-fills out-of-range V rows, flash_fwd_kernel.h:903).  Fills them -- and every page no
+    sequence owns -- with `pattern` (a NaN code of the cache's element type); returns poisoned copies."""
+    page = kc.shape[1]
+    kc2, vc2 = kc.copy(), vc.copy()
+    owned = set()
+    for b, L in enumerate(lens):
+        n = (int(L) + page - 1) // page
+        owned.update(int(x) for x in bt[b, :n])
+        if n and int(L) % page:
+            kc2[bt[b, n - 1], int(L) % page:] = pattern
+            vc2[bt[b, n - 1], int(L) % page:] = pattern
+    for pg in range(kc.shape[0]):
+        if pg not in owned:
+            kc2[pg] = pattern
+            vc2[pg] = pattern
+    return kc2, vc2
+
+
 _oracle_lib = None
 
 

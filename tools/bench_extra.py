@@ -74,7 +74,7 @@ def c3_decode_step_fp8_kv(iters=10):
     return c3_decode_step(iters=iters, kv_fp8=True)
 
 
-def prefill(iters=10, S=2048, nseq=16, h=32, hk=8, d=128, seed=1):
+def prefill(iters=10, S=2048, nseq=16, h=32, hk=8, d=128, seed=1, with_sample=False):
     rng = np.random.default_rng(seed)
     T = S * nseq
     q, k, v = (TS.rand_dev(rng, T * n * d * 2) for n in (h, hk, hk))
@@ -88,7 +88,16 @@ def prefill(iters=10, S=2048, nseq=16, h=32, hk=8, d=128, seed=1):
                    is_causal=1, cu_seqlens_q=cu, cu_seqlens_k=cu, stream=st.s)
     ms = _timed(st, run, iters)
     flops = 4 * S * S * h * d / 2 * nseq
-    return {"workload": f"FlashAttention-2 prefill, causal varlen, {nseq} x {S} tokens, {h} q / {hk} kv heads, d = {d}, bf16", "ms": round(ms, 4),
+    # a small host-side sample of what the timed calls wrote, for bench.py's check against the oracle (rows near both ends and at tile / block seams)
+    sample = []
+    rows = [0, 1, 63, 64, 255, 256, 511, 512, 1023, S - 2, S - 1] if with_sample else []
+    qh, kh, vh, oh = (b_.numpy(np.uint16, (T, n, d)) for b_, n in ((q, h), (k, hk), (v, hk), (o, h))) if with_sample else (None,) * 4
+    for b_, hq in ((0, 0), (nseq - 1, h - 1)) if with_sample else ():
+        s0 = b_ * S
+        sample.append({"rows": rows, "scale": d ** -0.5, "q": qh[s0 + np.array(rows), hq].copy(), "o": oh[s0 + np.array(rows), hq].copy(),
+                       "k": kh[s0:s0 + S, hq // (h // hk)].copy(), "v": vh[s0:s0 + S, hq // (h // hk)].copy()})
+    return {**({"sample": sample} if with_sample else {}),
+            "workload": f"FlashAttention-2 prefill, causal varlen, {nseq} x {S} tokens, {h} q / {hk} kv heads, d = {d}, bf16", "ms": round(ms, 4),
             "flops": int(flops), "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1), "frac_mfma": round(flops / (ms * 1e-3) / MFMA_PEAK_BF16, 4),
             "prompt_tokens_per_s_attention_only": round(T / (ms * 1e-3))}
 
@@ -131,11 +140,11 @@ def c4_rank_step(iters=10):
     return rank_step.run(iters=iters)
 
 
-def collect(which=("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "swap")):
+def collect(which=("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "swap"), prefill_sample=False):
     out = {}
     for name in which:
         try:
-            out[name] = globals()[name]()
+            out[name] = globals()[name](with_sample=True) if (name == "prefill" and prefill_sample) else globals()[name]()
         except Exception as e:          # an extra must never take the headline down with it
             out[name] = {"error": repr(e)}
     return out
