@@ -423,7 +423,7 @@ def cpu_baseline(args, bt, lens, slab_k, slab_v, q, n_pages, page_elems, hk, h):
     lib = oracle_c()
     avail = len(os.sched_getaffinity(0)) or 1
     few = avail < 8                                             # a cpuset of a few hardware threads (the driver's box): a short leg
-    Bs = min(16 if few else args.cpu_sample_seqs, args.batch)
+    Bs = min(args.cpu_sample_seqs, 16 if few else args.cpu_sample_seqs, args.batch)
     d, page, S = args.head_dim, args.block_size, args.seq
     # host copy of the cache: the same slab tiling as on the device
     reps = -(-n_pages // slab_k.shape[0])
