@@ -477,12 +477,17 @@ class Builder:
         self.in_loop = True
         dma = [] if self.paged else self.dma_tile(False) + self.dma_tile(True)      # paged: a scalar block in front of phase 2
         self.in_loop = False
+        qpre = []
+        if self.persistent and x == 0 and c > 0:         # the wavefront's last active iteration of the block: the NEXT block's Q rows
+            v, loads = self.qpre_code()
+            qpre1 = [Item(i) for i in v + loads[:8]]          # phase 1 of a draining iteration has no MFMAs at all: half of the loads there
+            qpre = [Item(i, 2) for i in loads[8:]]
         for it in dma:
             it.release = max(it.release, 2 if n2 else -1)
         # ---- how much of the second half's softmax rides in phase 1: the same filler density in both phases ----
         cnt = lambda items: sum(len(it.ins) for it in items)
         f1 = cnt(exp_h0) + cnt(vreads)
-        f2 = cnt(v2) + cnt(mm) + cnt(ring) + cnt(kr) + cnt(adv) + cnt(vadv) + cnt(dma)
+        f2 = cnt(v2) + cnt(mm) + cnt(ring) + cnt(kr) + cnt(adv) + cnt(vadv) + cnt(dma) + cnt(qpre)
         n_e1 = len(exp_h1)
         dens = -(-(f1 + f2 + n_e1) // max(n1 + n2, 1))                # fillers per MFMA gap over the whole iteration
         move = max(0, min(n_e1, dens * n1 - f1)) if (n1 and cur) else 0
@@ -499,8 +504,8 @@ class Builder:
             ops = exp_knob[5:].split(",")
             flt = lambda items: [it for it in items if not any(i.op in ops for i in it.ins)]
             exp_h0, vreads, e1_in_p1, e1_in_p2, v2, mm, kr, adv, vadv = (flt(x) for x in (exp_h0, vreads, e1_in_p1, e1_in_p2, v2, mm, kr, adv, vadv))
-        body1 = schedule(mf1, [exp_h0, vreads, e1_in_p1], cap=cap1, log=log1)
-        body2 = schedule(mf2, [e1_in_p2, v2, mm, ring + kr + adv, dma, vadv], cap=cap2, log=log2)
+        body1 = schedule(mf1, [exp_h0, vreads, e1_in_p1] + ([qpre1] if qpre else []), cap=cap1, log=log1)
+        body2 = schedule(mf2, [e1_in_p2, v2, mm, ring + kr + adv, dma + qpre, vadv], cap=cap2, log=log2)
         self.sched_log[name] = (log1, log2)
         blk = self.stamp(3)
         if mk:
@@ -530,13 +535,16 @@ class Builder:
             P.label(ret)
             self.ret_sites.append((site, ret, stub, bank_n, x, sfx))
         P.extend(self.ring_rotate())
-        self.e("s_waitcnt", vmcnt=8, lgkmcnt=0)
+        self.e("s_waitcnt", vmcnt=8 + (16 if qpre else 0), lgkmcnt=0)
         self.e("s_barrier")
         P.extend(self.stamp(2))
         self.e("s_add_u32", S_T, S_T, 1)
         if (c, x, mk) == (2, 2, False):
             self.e("s_cmp_lt_u32", S_T, S_NST)
             self.e("s_cbranch_scc1", f"IT{sfx}_{p ^ 1}_220")
+        if qpre:                                               # the block ends here for most wavefronts: the Q loads stay in flight across its epilogue
+            self.e("s_cmp_ge_u32", S_T, S_NT)
+            self.e("s_cbranch_scc1", "BLOCK_END_Q")
         self.e("s_branch", f"DISP{sfx}_{p ^ 1}")
 
     def idle_iteration(self):
@@ -808,6 +816,7 @@ class Builder:
             e("s_bitcmp1_b32", W("flags"), 1)
             e("s_cbranch_scc1", "NEW_BLOCK")
             P.extend(self.advance())
+            e("s_mov_b32", S_T1, 0)                               # (the prefetched Q rows were this empty entry's: not the block that follows)
             e("s_cmp_lt_u32", S_BLK, S_NENT)
             e("s_cbranch_scc1", "FETCH_ENTRY")
             e("s_mov_b32", S_T, 0)                                # the table is exhausted
@@ -824,11 +833,15 @@ class Builder:
         e("s_sub_u32", S_TMP[0], S_RBASE, 2 * SLOT)
         for db in range(4):
             e("v_subrev_u32", VAD[db], S_TMP[0], VAD[db])
-        self.pro_issue("A")
         if self.persistent:
             e("s_mov_b32", S_T, 1)
             e("s_cmp_eq_u32", S_HASNEXT, 1)
-            e("s_cbranch_scc1", "EPI_BOTH")
+            e("s_cbranch_scc0", "COLD_START")
+            e("s_cmp_eq_u32", S_T1, 1)                          # the requests ride inside the previous block's epilogue (block_end);
+            e("s_cbranch_scc1", "EPI_WOVEN_NOQ")                #  the Q rows, usually, already went out with its last iteration
+            e("s_branch", "EPI_WOVEN")
+            P.label("COLD_START")
+        self.pro_issue("A")
 
     def advance(self):
         return [Ins("s_add_u32", S_BLK, S_BLK, S_G), Ins("s_mov_b32", S_TMP[3], S_G), Ins("s_mov_b32", S_G, S_G2), Ins("s_mov_b32", S_G2, S_TMP[3])]
@@ -849,7 +862,7 @@ class Builder:
             e("v_mul_lo_u32", TMP[10], TMP[10], S_QST)
             e("v_lshl_add_u32", TMP[12], hi, 4, TMP[10])          # + hi * 16 bytes
             for j in range(8):
-                e("global_load_dwordx4", V(64 + 32 * s + 4 * j, 4), TMP[12], W(f"q{s}_lo", 2), offset=32 * j)
+                e("global_load_dwordx4", QA(s, j), TMP[12], W(f"q{s}_lo", 2), offset=32 * j)
             P.label(skip)
         P.extend(self.stamp(2, "block"))
         if self.paged:
@@ -864,11 +877,84 @@ class Builder:
         self.request_tile(False, 2)
         self.request_tile(True, 0)
 
+    def q_offsets(self, regs, rows=None, ns=None, hi=None, tmp=None):
+        """per-lane byte offsets of the Q rows of both slots -> regs[0..1]; a slot that sees no key reads (harmlessly) the head of
+        the plan table instead: its base moves there and its offsets collapse to 0 -- no branch, so the loads can ride anywhere.
+        Returns the instruction list (rows / ns: the registers that hold the slots' valid rows / tile counts)."""
+        rows, ns = rows or S_ROWS, ns or (S_N0, S_N1)
+        hi, t0, t1 = hi or TMP[1], (tmp or S_TMP)[0], (tmp or S_TMP)[1]
+        out = [Ins("v_lshrrev_b32", hi, 2, V_HI4)]
+        for s in range(2):
+            q = W(f"q{s}_lo", 2)
+            out += [Ins("s_sub_u32", t0, rows[s], 1), Ins("s_max_i32", t0, t0, 0),
+                    Ins("v_min_u32", regs[s], t0, V_LQ),                        # clamp to the slot's last valid row
+                    Ins("v_mul_lo_u32", regs[s], regs[s], S_QST),
+                    Ins("v_lshl_add_u32", regs[s], hi, 4, regs[s]),             # + hi * 16 bytes
+                    Ins("s_cmp_eq_u32", ns[s], 0), Ins("s_cselect_b32", t1, 0, 1),
+                    Ins("v_mul_lo_u32", regs[s], regs[s], t1),
+                    Ins("s_cselect_b32", q[0], S_TAB[0], q[0]), Ins("s_cselect_b32", q[1], S_TAB[1], q[1])]
+        return out
+
+    # ---- persistent: the NEXT block's Q rows are requested by the CURRENT block's last active iteration ---------------------------------
+    # (16 row-strided loads cost ~230 cycles each when issued back to back between two blocks: 3.7k cycles per block, `profiles/r04_prefill_block_regions.txt`;
+    #  under the P.V MFMAs of a draining iteration they cost their issue slots.)  Q^T lives in accumulator registers that the draining iteration
+    #  no longer reads, so the loads land there directly.  The entry after this one is "peeked" at the start of the block: its Q pointers
+    #  replace this block's (dead after its own loads) in s64..s67, rows / tile counts / flags go to S_SAVE[0..4]; S_SAVE[5] = 1 once the loads are out.
+    def peek_next(self):
+        e = self.e
+        e("s_mov_b32", S_SAVE[4], 0)
+        e("s_mov_b32", S_SAVE[5], 0)
+        e("s_add_u32", S_TMP[2], S_BLK, S_G)
+        e("s_cmp_ge_u32", S_TMP[2], S_NENT)
+        e("s_cbranch_scc1", "PEEK_NONE")
+        e("s_lshl_b32", S_TMP[0], S_TMP[2], 10)
+        e("s_lshr_b32", S_TMP[1], S_W1024, 2)
+        e("s_add_u32", S_TMP[0], S_TMP[0], S_TMP[1])
+        e("s_lshr_b32", S_TMP[1], S_TMP[2], 22)
+        e("s_add_u32", S_PAIR[0], S_TAB[0], S_TMP[0])
+        e("s_addc_u32", S_PAIR[1], S_TAB[1], S_TMP[1])
+        e("s_load_dwordx4", W("q0_lo", 4), S_PAIR, 4 * PIDX["q0_lo"])
+        e("s_load_dwordx2", S(S_SAVE[0].idx, 2), S_PAIR, 4 * PIDX["rows0"])
+        e("s_load_dwordx2", S(S_SAVE[2].idx, 2), S_PAIR, 4 * PIDX["n0"])
+        e("s_load_dword", S_SAVE[4], S_PAIR, 4 * PIDX["flags"])
+        self.p.label("PEEK_NONE")
+
+    def qpre_code(self):
+        """requests of the peeked entry's Q rows -> QA; an invalid / empty entry turns them into harmless reads of the table's head"""
+        v = [Ins("s_bitcmp1_b32", S_SAVE[4], 1),                               # valid entry?
+             Ins("s_cselect_b32", S_SAVE[2], S_SAVE[2], 0), Ins("s_cselect_b32", S_SAVE[3], S_SAVE[3], 0),
+             Ins("s_cselect_b32", S_SAVE[5], 1, 0)]
+        v += self.q_offsets(LIMREL, rows=(S_SAVE[0], S_SAVE[1]), ns=(S_SAVE[2], S_SAVE[3]), hi=MXB[0], tmp=(S_SAVE[6], S_SAVE[7]))
+        loads = [Ins("global_load_dwordx4", QA(s, j), LIMREL[s], W(f"q{s}_lo", 2), offset=32 * j) for s in range(2) for j in range(8)]
+        return v, loads
+
+
+    def request_groups(self, regs, with_q=True):
+        """the next block's requests as instruction groups (block_end weaves them into the epilogue): [16 Q loads,] K(0) K(1) V(0) K(2) V(1)"""
+        groups = []
+        for s in range(2 if with_q else 0):
+            for j in range(8):
+                groups.append([Ins("global_load_dwordx4", QA(s, j), regs[s], W(f"q{s}_lo", 2), offset=32 * j)])
+        first = True
+        if os.environ.get("PFA_EXP", "") == "noreq":          # TIMING EXPERIMENT ONLY (wrong results): what the K/V requests between two blocks cost
+            return groups
+        for is_v, slot in ((False, 0), (False, 1), (True, 2), (False, 2), (True, 0)):
+            items = self.dma_tile(is_v)
+            head = [Ins("s_add_u32", S_KDMA, S_W1024, slot * SLOT)]
+            if first:
+                head = [Ins("s_mov_b32", S_KSOFF, 0), Ins("s_mov_b32", S_VSOFF, 0)] + head
+                first = False
+            for k, it in enumerate(items):
+                groups.append((head if k == 0 else []) + it.ins)
+        return groups
+
     # ---- per block: S(0), the rows' first reference ----------------------------------------------------------------------------------------
     def pro_compute(self):
         """Barriers: K(0) landed, K(1) landed, entry -- the same count on every path."""
         e, P = self.e, self.p
         P.label("PRO_COMPUTE")
+        if self.persistent:
+            self.peek_next()
         # masks: last visible key of this lane's row, per slot
         e("s_sub_u32", S_TMP[5], S_LENK, 1)
         e("v_mul_lo_u32", TMP[3], V_LQ, W("lim_step"))
@@ -899,14 +985,14 @@ class Builder:
         e("v_mov_b32", TMP[3], S_SCALE)
 
         def q_to_acc(s, exact, js=range(8)):
-            """Q of slot s, d-steps js -> accumulator file; fast: pre-multiplied by scale.log2(e) and rounded once"""
+            """Q^T of slot s, d-steps js, in the accumulator file; fast: pre-multiplied by scale.log2(e) and rounded once, in place"""
             out = []
             for j in js:
                 for k in range(4):
-                    x = V(64 + 32 * s + 4 * j + k)
                     if exact:
-                        out.append(Ins("v_accvgpr_write_b32", QA(s, j)[k], x))
-                        continue
+                        continue                                  # Q^T is already where the MFMAs read it
+                    x = TMP[8 + (k & 1)]
+                    out.append(Ins("v_accvgpr_read_b32", x, QA(s, j)[k]))
                     lo, hi2 = TMP[4 + 2 * (k & 1)], TMP[5 + 2 * (k & 1)]
                     if self.dtype == "bf16":
                         out += [Ins("v_lshlrev_b32", lo, 16, x), Ins("v_and_b32", hi2, 0xFFFF0000, x)]
@@ -978,20 +1064,28 @@ class Builder:
         e("s_branch", "PRO_ENTRY")
         # ---- no row of this wavefront sees a key: only the barriers and its share of the DMA ----
         P.label("PRO_IDLE")
-        e("s_waitcnt", vmcnt=16)
+        if self.persistent:                                       # this wavefront has no draining iteration: its share of the next block's Q goes out here
+            e("s_waitcnt", vmcnt=20, lgkmcnt=0)                    # (behind this block's own -- unused -- Q loads: same registers)
+            v, loads = self.qpre_code()
+            P.extend(v + loads)
+        e("s_waitcnt", vmcnt=16 + (16 if self.persistent else 0))
         e("s_barrier")
-        e("s_waitcnt", vmcnt=12)
+        e("s_waitcnt", vmcnt=12 + (16 if self.persistent else 0))
         e("s_barrier")
         for j in range(8):
             e("v_add_u32", KAD[j], 2 * SLOT, KAD[j])
         self.request_tile(False, 0)
+        if self.persistent:
+            e("s_waitcnt", vmcnt=8 + 16, lgkmcnt=0)                # (the 16 prefetch loads are younger than V(0), K(2))
+            e("s_branch", "PRO_ENTRY_STATE")
         P.label("PRO_ENTRY")
+        e("s_waitcnt", vmcnt=8, lgkmcnt=0)
+        P.label("PRO_ENTRY_STATE")
         # state at the entry of iteration 0: read slot r = 2 (K(2) and V(0) live in slot 2), DMA slot d = 1
         e("s_mov_b32", S_RBASE, 2 * SLOT)
         e("s_mov_b32", S_DBASE, 1 * SLOT)
         e("s_add_u32", S_KDMA, S_DBASE, S_W1024)
         e("s_mov_b32", S_DELTA, 0)
-        e("s_waitcnt", vmcnt=8, lgkmcnt=0)
         e("s_barrier")
         P.extend(self.stamp(4))
         P.extend(self.stamp(5, "block"))
@@ -1000,13 +1094,13 @@ class Builder:
         e("s_branch", "DISP_0")
 
     # ---- per block: normalise, transpose through LDS, store -----------------------------------------------------------------------------------
-    def epi_slot(self, s, tag, odesc, lse, rows, ost, mscale):
+    def epi_slot(self, s, tag, odesc, lse, rows, ost, mscale, weave=()):
         """O^T of slot s (accumulators) -> 1/l -> storage type -> this wavefront's LDS staging rows (swizzled) -> whole 256-byte rows
         to memory, 4 rows per store instruction (a per-lane row-strided store would touch 32 partial lines per instruction)"""
         e, P = self.e, self.p
-        done = f"EPI_DONE_{tag}{s}"
+        done, norows = f"EPI_DONE_{tag}{s}", f"EPI_NOROWS_{tag}{s}"
         e("s_cmp_eq_u32", rows, 0)
-        e("s_cbranch_scc1", done)
+        e("s_cbranch_scc1", norows)
         ltot, inv, t0, t1 = TMP[3], TMP[4], TMP[5], TMP[6]
         e("v_add_f32", t0, LS(s, 0), LS(s, 1))
         e("v_mov_b32", t1, t0)
@@ -1018,18 +1112,25 @@ class Builder:
         e("v_mov_b32", t0, 0)
         e("v_cndmask_b32", inv, t0, inv, VCC)                      # rows that saw no key: 0
         f = [TMP[0], TMP[2], TMP[7], TMP[8]]
+        body = []
         for db in range(4):
             o = OA(s, db)
             for r4 in range(4):
                 w = [TMP[10 + 2 * (r4 & 1)], TMP[11 + 2 * (r4 & 1)]]
-                for k in range(4):
-                    e("v_accvgpr_read_b32", f[k], o[4 * r4 + k])
-                for k in range(4):
-                    e("v_mul_f32", f[k], f[k], inv)
-                e(self.cvt, w[0], f[0], f[1])
-                e(self.cvt, w[1], f[2], f[3])
-                e("v_xor_b32", t1, (4 * db + r4) * 16, V_EPW)      # 16-byte chunk 4db + r4 of the row, swizzled; + 8 hi is in V_EPW
-                e("ds_write_b64", t1, V(w[0].idx, 2), offset=s * 8192)
+                body += [Ins("v_accvgpr_read_b32", f[k], o[4 * r4 + k]) for k in range(4)]
+                body += [Ins("v_mul_f32", f[k], f[k], inv) for k in range(4)]
+                body += [Ins(self.cvt, w[0], f[0], f[1]), Ins(self.cvt, w[1], f[2], f[3]),
+                         Ins("v_xor_b32", t1, (4 * db + r4) * 16, V_EPW),      # 16-byte chunk 4db + r4 of the row, swizzled; + 8 hi is in V_EPW
+                         Ins("ds_write_b64", t1, V(w[0].idx, 2), offset=s * 8192)]
+        # the next block's requests, evenly between these instructions
+        n = len(weave)
+        cut = [round((i + 1) * len(body) / (n + 1)) for i in range(n)]
+        pos = 0
+        for i in range(n):
+            P.extend(body[pos:cut[i]])
+            P.extend(weave[i])
+            pos = cut[i]
+        P.extend(body[pos:])
         e("s_waitcnt", lgkmcnt=0)
         # rows 4k + lane/16 of the slot, 16 bytes per lane
         e("v_lshrrev_b32", t0, 4, TMP[9])                          # TMP[9] = lane (set by the caller)
@@ -1066,6 +1167,13 @@ class Builder:
         e("v_cndmask_b32", t1, TMP[0], t1, S_PAIR)
         e("buffer_store_dword", t0, t1, S(S_TMP[4].idx, 4), 0, offen=True)
         P.label(nolse)
+        if weave:
+            e("s_branch", done)
+            P.label(norows)                # no row of this slot exists: only the requests
+            for g in weave:
+                P.extend(g)
+        else:
+            P.label(norows)
         P.label(done)
 
     def block_end(self):
@@ -1074,11 +1182,19 @@ class Builder:
         (new_block), and only then this block's O is normalised and stored: the requests' round trips ride under the stores."""
         e, P = self.e, self.p
         P.label("BLOCK_DRAIN")             # no K/V tile at all: the requests in flight must land before the ring is reused
+        if self.persistent:
+            P.label("BLOCK_END_Q")         # the 16 youngest requests are the next block's Q rows (accumulator registers): only the ring's must have landed
+            P.extend(self.stamp(3))
+            P.extend(self.stamp(None, "block"))
+            self.nop(MFMA_SAFE)
+            e("s_waitcnt", vmcnt=16, lgkmcnt=0)
+            e("s_branch", "BLOCK_END_BAR")
         P.label("BLOCK_END")
         P.extend(self.stamp(3))
         P.extend(self.stamp(None, "block"))
         self.nop(MFMA_SAFE)
         e("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        P.label("BLOCK_END_BAR")
         e("s_barrier")                     # every wavefront is done with the ring and with its requests
         P.extend(self.stamp(0, "block"))
         if not self.persistent:
@@ -1094,29 +1210,50 @@ class Builder:
             e("v_accvgpr_write_b32", A(192 + k), W(name))
         e("s_mov_b32", S_HASNEXT, 1)
         e("s_mov_b32", S_T, 0)
+        e("s_mov_b32", S_T1, S_SAVE[5])                           # 1: the next entry's Q rows are already in (or on their way to) QA
         P.extend(self.advance())
         e("s_cmp_lt_u32", S_BLK, S_NENT)
         e("s_cbranch_scc1", "FETCH_ENTRY")
-        P.label("EPI_BOTH")
-        P.extend(self.stamp(3, "block"))
-        e("s_mov_b32", S_HASNEXT, 0)
-        e("v_mbcnt_lo_u32_b32", TMP[9], -1, 0)
-        e("v_mbcnt_hi_u32_b32", TMP[9], -1, TMP[9])
-        for s_ in range(2):
-            for k in range(8):
-                e("v_accvgpr_read_b32", TMP[k], A(192 + 8 * s_ + k))
-            e("v_accvgpr_read_b32", TMP[8], A(192 + 15))
-            e("v_accvgpr_read_b32", TMP[10], A(192 + 7))
-            self.nop(1)
-            for k in range(8):
-                e("v_readfirstlane_b32", S_SAVE[k], TMP[k])
-            e("v_readfirstlane_b32", S_TMP[2], TMP[8])              # o_stride
-            e("v_readfirstlane_b32", S_TMP[3], TMP[10])             # mscale (slot 0's stash holds it; slot 1's has the stride instead)
-            self.epi_slot(s_, "B", S(S_SAVE[0].idx, 4), [S_SAVE[4], S_SAVE[5]], S_SAVE[6], S_TMP[2], S_TMP[3])
+        def epilogue(tag, woven, with_q=True):
+            e("s_mov_b32", S_HASNEXT, 0)
+            e("v_mbcnt_lo_u32_b32", TMP[9], -1, 0)
+            e("v_mbcnt_hi_u32_b32", TMP[9], -1, TMP[9])
+            groups = []
+            if woven:
+                if with_q:
+                    P.extend(self.q_offsets(LIMREL))               # (LIMREL is rewritten by every masked tile: free between blocks)
+                groups = self.request_groups(LIMREL, with_q)
+            half = (len(groups) + 1) // 2
+            for s_ in range(2):
+                for k in range(8):
+                    e("v_accvgpr_read_b32", TMP[k], A(192 + 8 * s_ + k))
+                e("v_accvgpr_read_b32", TMP[8], A(192 + 15))
+                e("v_accvgpr_read_b32", TMP[10], A(192 + 7))
+                self.nop(1)
+                for k in range(8):
+                    e("v_readfirstlane_b32", S_SAVE[k], TMP[k])
+                e("v_readfirstlane_b32", S_TMP[2], TMP[8])              # o_stride
+                e("v_readfirstlane_b32", S_TMP[3], TMP[10])             # mscale (slot 0's stash holds it; slot 1's has the stride instead)
+                self.epi_slot(s_, tag, S(S_SAVE[0].idx, 4), [S_SAVE[4], S_SAVE[5]], S_SAVE[6], S_TMP[2], S_TMP[3],
+                              weave=groups[:half] if s_ == 0 else groups[half:])
+        P.label("EPI_BOTH")                    # no next block: the plain epilogue
+        P.extend(self.stamp(1, "block"))
+        epilogue("B", False)
+        P.extend(self.stamp(5))
+        e("s_branch", "KERNEL_END")
+        P.label("EPI_WOVEN")                   # the next block's entry is in s48..: its Q rows and first K/V tiles are requested between the epilogue's
+        P.extend(self.stamp(1, "block"))       #  instructions.  (Taken when the Q rows did not go out with the last iteration: an empty entry was
+        e("s_waitcnt", vmcnt=0)                #  skipped, or the block had no tile -- whatever that iteration requested into QA lands first.)
+        epilogue("C", True)
         P.extend(self.stamp(None, "block"))
         P.extend(self.stamp(5))
-        e("s_cmp_eq_u32", S_T, 1)
-        e("s_cbranch_scc1", "PRO_COMPUTE")
+        e("s_branch", "PRO_COMPUTE")
+        P.label("EPI_WOVEN_NOQ")
+        P.extend(self.stamp(1, "block"))
+        epilogue("D", True, with_q=False)
+        P.extend(self.stamp(None, "block"))
+        P.extend(self.stamp(5))
+        e("s_branch", "PRO_COMPUTE")
         P.label("KERNEL_END")
         if self.timing:
             e("s_waitcnt", vmcnt=0)
