@@ -11,7 +11,7 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
-KERNEL = sys.argv[2] if len(sys.argv) > 2 else "prefill_asm_kernel"      # or prefill_mfma_kernel
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "prefill_asm_persistent"      # or prefill_mfma_kernel
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 dur = None
