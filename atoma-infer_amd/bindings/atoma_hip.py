@@ -120,6 +120,7 @@ _opt("atoma_last_decode_kernel", [], C.c_char_p)
 _opt("atoma_warmup", [_vp, _i64, _i64, _i64, _i64, _i64, _i64])
 _opt("atoma_reserve_workspace", [_vp, _i64])
 _opt("atoma_release_workspaces", [])
+_opt("atoma_reset_sync_counters", [_vp])
 _opt("atoma_comm_unique_id", [_vp])
 _opt("atoma_comm_init", [C.POINTER(_vp), _int, _int, _vp, _int])
 _opt("atoma_allreduce_sum", [_vp, _vp, _vp, _i64, _int, _vp])

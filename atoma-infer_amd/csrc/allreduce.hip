@@ -77,6 +77,7 @@ struct Comm {
     std::string xgmi_note;       // why the direct path is unavailable, if it is
     bool xgmi_tried = false;     // comm_setup_xgmi ran (it is collective: once per communicator, on every rank)
     bool xgmi_allowed = true;    // ATOMA_XGMI_SETUP != 0
+    unsigned char *xchg = nullptr;   // 128 + world x 128 bytes of device memory for comm_setup_xgmi's two collectives, allocated by atoma_comm_init
 };
 
 }  // namespace atoma
@@ -113,21 +114,16 @@ static void comm_setup_xgmi(atoma::Rccl *r, atoma::Comm *c) {
     if (!r->AllGather) { c->xgmi_note = "ncclAllGather not found"; return; }
     // The two exchanges below are COLLECTIVE: every rank that got this far takes part in both, whatever happened to it locally --
     // a local failure travels in the payload (byte 127 of the handle / the agreement flag), never as a skipped call that would
-    // leave the peers blocked inside RCCL.  The exchange buffers therefore come first.
-    unsigned char *dsend = nullptr, *drecv = nullptr;
+    // leave the peers blocked inside RCCL.
+    // The buffers of the exchange were allocated by atoma_comm_init (a rank without them never gets here: its init failed), so nothing
+    // between here and the second collective can leave early.
+    unsigned char *dsend = c->xchg, *drecv = c->xchg + 128;
     std::vector<unsigned char> all((size_t)c->world * 128, 0);
-    if (hipMalloc(reinterpret_cast<void **>(&dsend), 128) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&drecv), all.size()) != hipSuccess ||
-        hipMemset(dsend, 0, 128) != hipSuccess) {
-        // no device memory for a 128-byte message: RCCL itself cannot work on this rank either
-        (void)hipGetLastError();
-        if (dsend) (void)hipFree(dsend);
-        if (drecv) (void)hipFree(drecv);
-        c->xgmi_note = "could not allocate the handle exchange buffers";
-        return;
-    }
+    const bool zeroed = hipMemset(dsend, 0, 128) == hipSuccess;
+    if (!zeroed) (void)hipGetLastError();
     void *xg = nullptr;
-    int ok = atoma_xgmi_create(&xg, c->rank, c->world, c->device, cap) == 0;
-    std::string why = ok ? "" : atoma_last_error();
+    int ok = zeroed && atoma_xgmi_create(&xg, c->rank, c->world, c->device, cap) == 0;
+    std::string why = ok ? "" : (zeroed ? atoma_last_error() : "could not clear the handle exchange buffer");
     unsigned char mine[128] = {0};
     if (ok && atoma_xgmi_handle(xg, mine) != 0) { ok = 0; why = atoma_last_error(); }
     // exchange the handles (and, in byte 127, whether this rank is still healthy) through RCCL; dsend holds zeros (= unhealthy)
@@ -149,8 +145,6 @@ static void comm_setup_xgmi(atoma::Rccl *r, atoma::Comm *c) {
     bool aok = r->AllReduce(dsend, drecv, 1, NCCL_FLOAT32, NCCL_SUM, c->comm, nullptr) == 0;
     aok = hipStreamSynchronize(nullptr) == hipSuccess && aok;
     aok = aok && hipMemcpy(&total, drecv, 4, hipMemcpyDeviceToHost) == hipSuccess;
-    if (dsend) (void)hipFree(dsend);
-    if (drecv) (void)hipFree(drecv);
     (void)hipGetLastError();
     if (!aok || (int)(total + 0.5f) != c->world) {
         if (why.empty()) why = "another rank could not map its peers";
@@ -173,6 +167,11 @@ int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128
     memcpy(id.internal, id128, 128);
     auto *c = new atoma::Comm{nullptr, rank, world_size, device};
     if (!atoma::check_nccl(r, r->CommInitRank(&c->comm, world_size, id, rank), "ncclCommInitRank")) {
+        delete c;
+        return -1;
+    }
+    if (!atoma::check_hip(hipMalloc(reinterpret_cast<void **>(&c->xchg), 128 + (size_t)world_size * 128), "atoma_comm_init: exchange buffers")) {
+        (void)r->CommDestroy(c->comm);
         delete c;
         return -1;
     }
@@ -250,6 +249,7 @@ int atoma_comm_destroy(void *comm) {
     auto *c = static_cast<atoma::Comm *>(comm);
     int rc = 0;
     if (c->xgmi) atoma_xgmi_destroy(c->xgmi);
+    if (c->xchg) (void)hipFree(c->xchg);
     if (r && !atoma::check_nccl(r, r->CommDestroy(c->comm), "ncclCommDestroy")) rc = -1;
     delete c;
     return rc;

@@ -452,7 +452,10 @@ int atoma_linear_decode_qkv_rope_cache(const void *x, const void *w_qkv, void *q
     const bool plain = (dtype == ATOMA_F16 || dtype == ATOMA_BF16) && batch > 16 && batch <= 64 && num_q_heads > 0 && num_kv_heads > 0 &&
                        head_dim > 0 && head_dim % 16 == 0 && in_features > 0 && in_features % 128 == 0 && page_size > 0 && !(ptrs & 15u) &&
                        x_row_stride >= in_features && w_row_stride >= in_features && out_row_stride >= width &&
-                       !(x_row_stride % 8 || w_row_stride % 8 || out_row_stride % 8 || block_stride % 8) && slot_mapping && positions;
+                       !(x_row_stride % 8 || w_row_stride % 8 || out_row_stride % 8 || block_stride % 8) && slot_mapping && positions &&
+                       // a null pointer passes the alignment test above: the two ops have the messages for those; the tile
+                       // kernel's cache write assumes the reference's page layout [page_size][heads_kv][head_dim]
+                       x && w_qkv && qkv_out && k_cache && v_cache && cos_table && sin_table && block_stride >= page_size * num_kv_heads * head_dim;
     if (!plain) return two_ops();
     LinearParams p{};
     p.x = static_cast<const uint16_t *>(x);

@@ -91,6 +91,11 @@ void *workspace(hipStream_t stream, size_t bytes) {
 // it): SYNC_COUNTERS zero-initialised words per (device, stream), allocated once and kept zero by the kernels themselves (the last
 // arriver of a tile puts its counter back to zero), so that a captured graph replays without a memset node.  Kernels of one stream
 // run one after the other and may share the words.
+// CONSTRAINTS (the same as for the scratch of `workspace`): the pointer is baked into captured graphs, so a graph must be
+// replayed on the stream it was captured on and never concurrently with eager calls on that stream (two launches counting on the same words
+// mis-merge silently); a launch that aborted half-way may leave a word non-zero -- atoma_reset_sync_counters(stream) re-zeroes them
+// (a memset on the stream; call it after any failed launch, outside capture); atoma_release_workspaces frees them and thereby invalidates
+// every graph captured before it.
 constexpr size_t SYNC_COUNTERS = 8192;
 struct SyncWords { int device; hipStream_t stream; unsigned *ptr; };
 static std::vector<SyncWords> g_sync;
@@ -113,6 +118,21 @@ unsigned *sync_counters(hipStream_t stream) {
     }
     g_sync.push_back(SyncWords{dev, stream, ptr});
     return ptr;
+}
+
+// 0 = ok (also when the stream has no counters yet)
+int reset_sync_counters(hipStream_t stream) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    unsigned *ptr = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(*g_ws_mu);
+        for (auto &w : g_sync)
+            if (w.device == dev && w.stream == stream) ptr = w.ptr;
+    }
+    if (!ptr) return 0;
+    if (stream_is_capturing(stream)) { set_error("atoma_reset_sync_counters: not inside a hipGraph capture"); return -1; }
+    return check_hip(hipMemsetAsync(ptr, 0, SYNC_COUNTERS * sizeof(unsigned), stream), "atoma_reset_sync_counters") ? 0 : -1;
 }
 
 size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k);   // paged_decode.hip
@@ -191,6 +211,11 @@ int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num
     if (!atoma::sync_counters(static_cast<hipStream_t>(stream)) || !atoma::linear_tile_prepare()) return -1;
     if (need == 0) return 0;
     return atoma::workspace(static_cast<hipStream_t>(stream), need) ? 0 : -1;
+}
+
+int atoma_reset_sync_counters(void *stream) {
+    atoma::clear_error();
+    return atoma::reset_sync_counters(static_cast<hipStream_t>(stream));
 }
 
 int atoma_release_workspaces(void) {

@@ -429,11 +429,17 @@ const char *atoma_last_decode_kernel(void);
  *     splits * batch * out_features * 4) -- call it once per stream before capturing, instead of relying on an eager call.
  *   - atoma_release_workspaces frees live and retired blocks of ALL streams: only when no graph that used them will be
  *     replayed and the streams are idle.
+ *   - The kernels that merge their own split-K / split-KV pieces count arrivals in 8192 words per (device, stream) that they keep at
+ *     zero themselves.  Like the scratch block the words are baked into captured graphs: replay a graph on the stream it was captured
+ *     on and never concurrently with eager calls on that stream.  After a launch that FAILED (an error from any entry point, a device
+ *     fault) call atoma_reset_sync_counters(stream) before the next call on that stream -- a word left non-zero makes later merges
+ *     silently wrong.  Not inside a capture.
  * The device is the calling thread's current device (hipSetDevice), as for every entry point. */
 int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, int64_t max_seqlen_k,
                  int64_t extra_bytes);
 int atoma_reserve_workspace(void *stream, int64_t bytes);
 int atoma_release_workspaces(void);
+int atoma_reset_sync_counters(void *stream);
 
 /* Device helpers used by the host layer, tests and bench (plain HIP runtime, no torch). */
 int atoma_device_count(void);
