@@ -13,7 +13,7 @@
 // ds_write; image [row][16-byte slot ^ (row & 15)]: the swizzle sits on the per-lane SOURCE address, fragment reads are
 // conflict-free), ring of 3-4 chunks of 128 inputs, one barrier per chunk, counted vmcnt so that the ring never drains;
 // v_mfma_f32_16x16x32 on ds_read_b128 fragments: wavefront w multiplies batch tile w >> 1 with half of the row groups.
-// K is split over 1, 2 or 4 workgroups so that the grid fills the CUs; a split is merged INSIDE the launch: every workgroup publishes
+// K is split over 1 .. 8 workgroups so that the grid fills the CUs; a split is merged INSIDE the launch: every workgroup publishes
 // its fp32 tile (write-through stores), the one that arrives LAST adds the others' in split order and runs the epilogue (arrival counter
 // per tile, agent scope; no spinning: the earlier arrivers just leave).  More splits (matrices with a handful of 64-row tiles) go to fp32
 // partials for the caller's reduce / RoPE kernel.  fp32 accumulation in K order (split 0 + split 1 + ..), one rounding, then the epilogue
@@ -61,7 +61,7 @@ struct TileParams {
     float *slabs;                // in-launch merge: [tile][split][wave][group][lane] float4
     unsigned *counters;          // arrival counter per tile (zero between launches)
     int chunks_per_split;        // chunks of 128 inputs
-    int merge_splits;            // 2..4: K split this many ways and merged here by the last workgroup to arrive; 0: no in-launch merge
+    int merge_splits;            // 2..8: K split this many ways and merged here by the last workgroup to arrive; 0: no in-launch merge
     TileRope rope;
 };
 constexpr int TILE_PLAIN = 0, TILE_GATE_UP = 1, TILE_ROPE = 2;
@@ -328,31 +328,33 @@ static int tile_env_or(const char *name, int dflt) { const char *v = getenv(name
 static std::atomic<int> linear_tile_on{tile_env_or("ATOMA_LINEAR_TILE", 1)};          // 0: the older kernels serve 17..64 rows
 static std::atomic<int> linear_tile_nw{tile_env_or("ATOMA_LINEAR_TILE_NW", 0)};       // weight rows per workgroup: 0 = by shape
 static std::atomic<int> linear_tile_splits{tile_env_or("ATOMA_LINEAR_TILE_SPLITS", 0)};   // K splits: 0 = by shape
+static std::atomic<int> linear_tile_max_splits{tile_env_or("ATOMA_LINEAR_TILE_MAX_SPLITS", 8)};   // largest split the plan considers (A/B: 4 = round 3's plans)
 bool set_linear_tile_option(const std::string &name, int value) {
     if (name == "linear_tile") linear_tile_on = value;
     else if (name == "linear_tile_nw") linear_tile_nw = value;
     else if (name == "linear_tile_splits") linear_tile_splits = value;
+    else if (name == "linear_tile_max_splits") linear_tile_max_splits = value;
     else return false;
     return true;
 }
 
 // Workgroup shape and K split from the SHAPE OF W alone (p.n rows, p.k inputs), so that the stacked gate / up launch with its SiLU.up
 // epilogue, the residual epilogue, the RoPE epilogue and the plain projection of the same matrix split K alike and stay bit-identical
-// to projection + separate op.  Candidates: 128 / 64 / 32 rows per workgroup x 1, 2 or 4 K splits (a split merges inside the launch),
+// to projection + separate op.  Candidates: 128 / 64 / 32 rows per workgroup x 1 .. 8 K splits (a split merges inside the launch),
 // priced with the measured model of DESIGN.md 4.8c -- a CU's time = (weight KB + 0.3 x KB of x) x 0.04 us, plus 1 us + 0.05 us per KB
 // the last arriver reads back for an in-launch merge, times the rounds of workgroups over the CUs -- e.g. (64 rows, 2 splits) for the
 // 70B shard's gate/up and down, (32 rows, 1 split) for its o projection, (32 rows, 4 splits) for its 1280-row q/k/v shard.  A matrix with
 // so few rows that even the best candidate leaves more than 40 % of the CUs idle is split further over K (powers of two) and leaves
 // fp32 partials for the caller's reduce / RoPE kernel.
-constexpr int TILE_MAX_MERGE = 4;
+constexpr int TILE_MAX_MERGE = 8;
 static void tile_plan(int64_t n, int64_t k, int cus, int *nw_out, int *splits_out) {
     const int64_t chunks = k / 128;
     int best_nw = 0, best_s = 1;
     int64_t best_wgs = 0;
     double best_t = 1e30;
-    for (int s : {1, 2, 4})
+    for (int s : {1, 2, 3, 4, 5, 6, 8})      // (uneven splits are fine: the last workgroup of a tile takes the remainder)
         for (int nw : {128, 64, 32}) {
-            if (n % nw || chunks / s < 4 || n / nw > 4096) continue;
+            if (n % nw || chunks / s < 4 || n / nw > 4096 || s > linear_tile_max_splits) continue;
             const int64_t wgs = n / nw * s;
             const double kb = (double)(k / s) * 2.0 / 1024.0;
             const double merge = s == 1 ? 0.0 : 1.0 + 0.05 * (nw * 64 * 4 / 1024.0) * (s - 1);

@@ -44,6 +44,7 @@ struct DecodeParams {
     int head_major;        // 1: workgroup id -> (kv head, chunk) slowest, (split, sequence) fastest (decode_map_work)
     int stream_force;      // the balanced line also for uniform resident batches (decode_plan_launch says when)
     int fp8_klines;        // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays (not on the balanced line, not with a single kv head: contiguous rows), 2 always
+    int line_merge;        // balanced mode: the cut pieces of a sequence are merged by the LAST wavefront to arrive at it (counters), no combine launch
     int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
     float scale, scale_log2;
 };
@@ -188,6 +189,115 @@ __device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, in
     return pl;
 }
 
+// fp32 partials (split-KV pieces, cut pieces of the balanced line) are published WRITE-THROUGH (agent-scope stores: past the XCD's
+// L2), so that a wavefront on another XCD -- the last arriver of decode_line_merge, or the combine kernel -- reads them with
+// agent-scope loads and no fence.
+__device__ __forceinline__ void partial_store(float *dst, float a, float b, float c, float d) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + 2), ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void partial_store(float *dst, float a) {
+    __hip_atomic_store(reinterpret_cast<unsigned *>(dst), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float partial_load(const float *src) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Balanced line, merge inside the launch (the uniform headline launched a combine kernel that found nothing to merge, a
+// ragged batch paid a second launch per layer).  A sequence cut between the wavefronts w0 .. w0 + nsp - 1 of the line has one arrival
+// counter, index w0 (a wavefront's range ends inside at most one sequence, so w0 names the sequence); every piece is published write-through, the wavefront takes a ticket, and the one that arrives LAST merges the pieces
+// in line order with decode_combine_kernel's arithmetic (flash_fwd_kernel.h:1204-1236) and writes the output.  Nobody waits; the result
+// does not depend on the order of arrival; the counter returns to zero.  Not inlined: the call sits in the segment loop, whose scalar
+// registers are the tight resource of these kernels.
+template <typename T, int D>
+__device__ __attribute__((noinline)) void decode_line_merge(const DecodeParams *pp, int b, int hkc, int w0, int nsp, int first_slot) {
+    const DecodeParams &p = *pp;
+    const int lane = threadIdx.x & 63;
+    const int hk = hkc / p.gchunks, gc = hkc - hk * p.gchunks;
+    const int nq = min(p.group_tile, p.g - gc * p.group_tile), hq0 = hk * p.g + gc * p.group_tile;
+    auto prow = [&](int gq, int s) -> int64_t { return ((int64_t)(w0 + s) * 2 + (s == 0 ? first_slot : 0)) * p.group_tile + gq; };
+    // The merge is three dependent trips to memory (ticket, LSEs, rows) on the critical path of the launch's last wavefronts, so every trip
+    // fetches as much as it can: four q heads at a time; LSEs: 16 lanes per head, one piece each; rows: D / 4 lanes per row (four floats
+    // each) and 64 / (D / 4) pieces side by side, summed in a fixed order (pieces sub, sub + PP, .. per lane group, then the groups).
+    constexpr int LPR = D / 4, PP = 64 / LPR;
+    const int col = lane % LPR, sub = lane / LPR;
+    for (int g0 = 0; g0 < nq; g0 += 4) {
+        const int gql = min(g0 + (lane >> 4), nq - 1), sl = lane & 15;
+        float mx = -INFINITY;
+        for (int s = sl; s < nsp; s += 16) mx = fmaxf(mx, partial_load(p.lse_accum + prow(gql, s)));
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float ms = mx == -INFINITY ? 0.f : mx;
+        float tot = 0.f;
+        for (int s = sl; s < nsp; s += 16) tot += __expf(partial_load(p.lse_accum + prow(gql, s)) - ms);
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) tot += __shfl_xor(tot, off, 64);
+        const float lse_l = tot > 0.f ? __logf(tot) + ms : INFINITY;
+        float lse[4], acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lse[u] = __shfl(lse_l, 16 * u, 64);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[u][e] = 0.f;
+        }
+        for (int s0 = 0; s0 < nsp; s0 += PP) {
+            const int sp = s0 + sub;
+            const bool on = sp < nsp;
+            float pl[4];
+            unsigned long long v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                                  // all twelve loads leave before the first is needed
+                const int64_t row = prow(min(g0 + u, nq - 1), on ? sp : 0);
+                pl[u] = partial_load(p.lse_accum + row);
+                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p.o_accum + row * D + col * 4);
+                v[u][0] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[u][1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float w = (on && lse[u] != INFINITY) ? __expf(pl[u] - lse[u]) : 0.f;
+                acc[u][0] += w * __uint_as_float((unsigned)v[u][0]);
+                acc[u][1] += w * __uint_as_float((unsigned)(v[u][0] >> 32));
+                acc[u][2] += w * __uint_as_float((unsigned)v[u][1]);
+                acc[u][3] += w * __uint_as_float((unsigned)(v[u][1] >> 32));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[u][e] += __shfl_xor(acc[u][e], off, 64);
+            if (g0 + u < nq && sub == 0) {
+                const int hq = hq0 + g0 + u;
+                uint2 o;
+                o.x = pack2<T>(acc[u][0], acc[u][1]);
+                o.y = pack2<T>(acc[u][2], acc[u][3]);
+                *reinterpret_cast<uint2 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + col * 4) = o;
+                if (p.lse && col == 0) p.lse[(int64_t)b * p.h + hq] = lse[u];
+            }
+        }
+    }
+}
+// ... and the sequences without a single tile, which no wavefront of the line ever sees (flash_fwd_kernel.h:543-582: O = 0, LSE = +inf)
+template <int D> __device__ __attribute__((noinline)) void decode_line_zero(const DecodeParams *pp, int b) {
+    const DecodeParams &p = *pp;
+    const int lane = threadIdx.x & 63;
+    for (int hq = 0; hq < p.h; ++hq) {
+        uint16_t *dst = p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride;
+        for (int e = lane; e < D; e += 64) dst[e] = 0;
+        if (p.lse && lane == 0) p.lse[(int64_t)b * p.h + hq] = INFINITY;
+    }
+}
+struct DecodeNoMerge {
+    __device__ __forceinline__ void merge(const DecodeParams *, int, int, int, int, int) const {}
+    __device__ __forceinline__ void zero(const DecodeParams *, int) const {}
+};
+template <typename T, int D> struct DecodeLineMerge {
+    __device__ __forceinline__ void merge(const DecodeParams *p, int b, int hkc, int w0, int nsp, int first_slot) const { decode_line_merge<T, D>(p, b, hkc, w0, nsp, first_slot); }
+    __device__ __forceinline__ void zero(const DecodeParams *p, int b) const { decode_line_zero<D>(p, b); }
+};
+
 // `item(p, wk)` is inlined exactly once.  In the balanced variant the kernel arguments are re-read through a pointer
 // the compiler cannot see through at the top of every segment: hoisting every field of DecodeParams out of the
 // segment loop costs ~20 SGPRs more than the 102 there are and the spills (v_readlane in the tile loop) cost 5 %.
@@ -195,7 +305,7 @@ __device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, in
 // of ONE sequence, so a workgroup of NWG wavefronts reads NWG adjacent head slices of every token row from one CU at about
 // the same time -- with 128-byte slices (fp8 cache, or d = 64 at 16 bits) a lone wavefront fetches half of a 256-byte
 // DRAM granule and its neighbour, dispatched to another XCD (block index % 8), fetches the other half some time later.
-template <bool STREAM, int NWG = 1, typename F> __device__ __forceinline__ void decode_run_items(const DecodeParams &p0, F &&item) {
+template <bool STREAM, int NWG = 1, typename F, typename M = DecodeNoMerge> __device__ __forceinline__ void decode_run_items(const DecodeParams &p0, F &&item, M merger = M{}) {
     DecodeWork wk;
     const int wid = NWG == 1 ? (int)blockIdx.x : (int)blockIdx.x * NWG + (int)(threadIdx.x >> 6);
     if (NWG > 1 && (int64_t)wid >= (int64_t)p0.b * p0.num_splits * p0.h_k * p0.gchunks) return;
@@ -213,6 +323,10 @@ template <bool STREAM, int NWG = 1, typename F> __device__ __forceinline__ void 
         // position of this wavefront on the line.  The line is kv-head major, so wavefronts w and w + W / 8 walk the same
         // sequences of adjacent heads: with 8 wavefronts per workgroup, give the 8 of a workgroup those ranges (W is a multiple of 8)
         if (stream && wid >= p0.stream_waves) return;      // the line is shared by stream_waves wavefronts; the grid may hold more
+        if (stream && p0.line_merge) {
+            for (int e = wid; e < p0.b; e += p0.stream_waves)
+                if (__builtin_amdgcn_readfirstlane(cum[e]) == __builtin_amdgcn_readfirstlane(cum[e + 1])) merger.zero(&p0, e);
+        }
         const int lw = NWG == 1 ? wid : (wid % NWG) * (p0.stream_waves / NWG) + wid / NWG;
         int pos = 0, end = 1, hkc = 0, r = 0, b = 0;       // host guarantees total < 2^31
         bool first = true;
@@ -257,6 +371,20 @@ template <bool STREAM, int NWG = 1, typename F> __device__ __forceinline__ void 
             }
             item(p, wk);
             if (!stream) break;
+            if (wk.partial && p.line_merge) {
+                // w0 / w1: the wavefronts of the line that hold the first / last tile of this sequence
+                const int c0 = __builtin_amdgcn_readfirstlane(cum[b]);
+                const int64_t s0 = (int64_t)hkc * pl.T + c0;
+                const int w0 = (int)(s0 / pl.share), w1 = (int)((s0 + wk.n_tiles - 1) / pl.share);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this piece is out
+                unsigned t = 0;
+                if ((threadIdx.x & 63) == 0) {
+                    t = __hip_atomic_fetch_add(p.counters + w0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (t == (unsigned)(w1 - w0)) __hip_atomic_store(p.counters + w0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t == (unsigned)(w1 - w0)) merger.merge(&p, b, hkc, w0, w1 - w0 + 1, s0 > (int64_t)w0 * pl.share ? 1 : 0);
+            }
             first = false;
             pos += seg;
             r += seg;

@@ -340,17 +340,17 @@ __device__ __forceinline__ void paged_decode_item(const DecodeParams &p, const D
             if (p.lse && dc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
         } else {
             const int64_t row = wk.prow + gq;
-            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + dc * 8);
-            dst[0] = make_float4(o[gq][0] * inv, o[gq][1] * inv, o[gq][2] * inv, o[gq][3] * inv);
-            dst[1] = make_float4(o[gq][4] * inv, o[gq][5] * inv, o[gq][6] * inv, o[gq][7] * inv);
-            if (dc == 0) p.lse_accum[row] = empty ? -INFINITY : lse;  // flash_fwd_kernel.h:543-582
+            float *dst = p.o_accum + row * D + dc * 8;
+            partial_store(dst, o[gq][0] * inv, o[gq][1] * inv, o[gq][2] * inv, o[gq][3] * inv);
+            partial_store(dst + 4, o[gq][4] * inv, o[gq][5] * inv, o[gq][6] * inv, o[gq][7] * inv);
+            if (dc == 0) partial_store(p.lse_accum + row, empty ? -INFINITY : lse);  // flash_fwd_kernel.h:543-582
         }
     }
 }
 
 template <typename T, int D, int G, int P, int MINW, bool NT, bool STREAM>
 __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodeParams p) {
-    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_item<T, D, G, P, NT>(pp, wk); });
+    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_item<T, D, G, P, NT>(pp, wk); }, DecodeLineMerge<T, D>{});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -598,17 +598,17 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
             if (p.lse && col == 0) p.lse[(int64_t)b * p.h + hq] = lse;
         } else {
             const int64_t row = wk.prow + h;
-            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + col * 8);
-            dst[0] = make_float4(o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
-            dst[1] = make_float4(o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
-            if (col == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
+            float *dst = p.o_accum + row * D + col * 8;
+            partial_store(dst, o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
+            partial_store(dst + 4, o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
+            if (col == 0) partial_store(p.lse_accum + row, empty ? -INFINITY : lse);
         }
     }
 }
 
 template <typename T, int G, int P, bool NT, bool STREAM>
 __global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodeParams p) {
-    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_mqk_item<T, G, P, NT>(pp, wk); });
+    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_mqk_item<T, G, P, NT>(pp, wk); }, DecodeLineMerge<T, 128>{});
 }
 
 // LSE-weighted merge of the split partials: /root/reference/csrc/kernels/flash_fwd_kernel.h:1204-1236.
@@ -858,6 +858,7 @@ struct DecodeOptions {
     opt_int fp8_wg{env_int("ATOMA_DECODE_FP8_WG", 0)};     // fp8 KV cache: 8 wavefronts (the kv heads of a sequence) per workgroup: 0 never (default since the kv-head-major order does the same for free), 1 split-KV launches, 2 always
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
     opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
+    opt_int line_merge{env_int("ATOMA_DECODE_LINE_MERGE", 1)};   // balanced line: cut sequences merged by the last wavefront to arrive (1) or by decode_combine_kernel (0)
     opt_int fp8_klines{env_int("ATOMA_DECODE_FP8_KLINES", 1)};   // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays, 2 always
     opt_int head_major{env_int("ATOMA_DECODE_HEAD_MAJOR", 1)};   // workgroup order of the non-balanced launches: kv head slowest (1) or fastest (0)
     opt_int mqk{env_int("ATOMA_DECODE_MQK", 29)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches, bit 3 = groups of 2..4 on the balanced line, bit 4 = groups of 2..4 on split-KV launches
@@ -883,6 +884,7 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_min_tiles") o.min_tiles = value;
     else if (name == "decode_mqk") o.mqk = value;
     else if (name == "decode_wg_merge") o.wg_merge = value;
+    else if (name == "decode_line_merge") o.line_merge = value;
     else if (name == "decode_fp8_mqk") o.fp8_mqk = value;
     else if (name == "decode_fp8_wg") o.fp8_wg = value;
     else if (name == "decode_head_major") o.head_major = value;
@@ -907,10 +909,17 @@ template <typename K> static int resident_waves_per_cu(K kernel) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 64, 0) != hipSuccess || n <= 0) n = 8;
     return std::min(n, DECODE_STREAM_MAX_WAVES_PER_CU);
 }
-static void set_stream_waves(DecodeParams &p, int occupancy) {
+// ... and, with the number of wavefronts on the line known, whether its cut sequences are merged inside the launch (decode_line_merge)
+static void set_stream_waves(DecodeParams &p, int occupancy, hipStream_t stream) {
     const int opt = decode_options().stream_waves_per_cu;
     const int wpc = opt > 0 ? std::min(opt, DECODE_STREAM_MAX_WAVES_PER_CU) : occupancy;
     p.stream_waves = (int)std::min<int64_t>((int64_t)p.b * p.h_k * p.gchunks, (int64_t)device_num_cus() * wpc);
+    p.line_merge = 0;
+    if (decode_options().line_merge && p.stream_waves <= DECODE_WG_MAX_COUNTERS) {
+        p.counters = sync_counters(stream);
+        p.line_merge = p.counters ? 1 : 0;
+        if (!p.counters) clear_error();           // (a capture without warm-up: the combine kernel serves)
+    }
 }
 
 // Which decode kernel the dispatcher took last on this thread (bench.py labels its roofline line with it instead of a literal)
@@ -926,7 +935,7 @@ static void launch_decode_cfg(DecodeParams &p, hipStream_t stream) {
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
     if (p.stream_waves > 0) {
         static const int occ = resident_waves_per_cu(paged_decode_kernel<T, D, G, P, MINW, NT, true>);
-        set_stream_waves(p, occ);
+        set_stream_waves(p, occ, stream);
     }
     note_decode_kernel("paged_decode_kernel", decode_tname<T>(), D, G, P, NT,
                        p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? (std::to_string(p.num_splits) + " KV splits + combine").c_str() : "one wavefront per (sequence, kv head)"));
@@ -984,7 +993,7 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
         return;
     }
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
-    if (p.stream_waves > 0) set_stream_waves(p, 8);   // __launch_bounds__(64, 2)
+    if (p.stream_waves > 0) set_stream_waves(p, 8, stream);   // __launch_bounds__(64, 2)
     note_decode_kernel("paged_decode_mqk_kernel", decode_tname<T>(), 128, G, p3 ? 3 : 2, nt,
                        p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? (std::to_string(p.num_splits) + " KV splits + combine").c_str() : "one wavefront per (sequence, kv head)"));
 #define ATOMA_MQK(P_, NT_, S_) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, P_, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p)
@@ -994,7 +1003,7 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
 #undef ATOMA_MQK_S
 #undef ATOMA_MQK
     if (!ATOMA_CHECK_LAUNCH("paged_decode_mqk_kernel")) return;
-    if (p.num_splits > 1 || p.stream_waves > 0) {
+    if (p.num_splits > 1 || (p.stream_waves > 0 && !p.line_merge)) {
         hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
@@ -1024,7 +1033,7 @@ static void launch_decode_tdg(DecodeParams &p, hipStream_t stream) {
         else launch_decode_cfg<T, D, G, 2, MINW, false>(p, stream);
     }
     if (!ATOMA_CHECK_LAUNCH("paged_decode_kernel")) return;
-    if (p.num_splits > 1 || p.stream_waves > 0) {
+    if (p.num_splits > 1 || (p.stream_waves > 0 && !p.line_merge)) {
         hipLaunchKernelGGL((decode_combine_kernel<T, D>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
@@ -1155,7 +1164,7 @@ int decode_fp8_tiles_in_flight();
 template <typename T>
 static void launch_decode_fp8_g(DecodeParams &p, int G, hipStream_t stream) {
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
-    if (p.stream_waves > 0) set_stream_waves(p, 8);   // __launch_bounds__(64, 2)
+    if (p.stream_waves > 0) set_stream_waves(p, 8, stream);   // __launch_bounds__(64, 2)
     const bool nt = decode_options().nt != 0;
     const bool mqk = decode_options().fp8_mqk != 0;
     // 8 wavefronts per workgroup = the 8 kv-head slices (128 B each) of every token row read from one CU (round 2: +20 % on split-KV
@@ -1167,7 +1176,7 @@ static void launch_decode_fp8_g(DecodeParams &p, int G, hipStream_t stream) {
                        p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? "KV splits + combine" : (wg8 ? "8 wavefronts per workgroup" : "one wavefront per (sequence, kv head)")));
     launch_fp8_kernels(p, G, std::is_same<T, bf16_t>::value, nt, mqk, wg8, blocks, stream);
     if (!ATOMA_CHECK_LAUNCH("paged_decode_fp8_kernel")) return;
-    if (p.num_splits > 1 || p.stream_waves > 0) {
+    if (p.num_splits > 1 || (p.stream_waves > 0 && !p.line_merge)) {
         hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }

@@ -265,18 +265,18 @@ __device__ __forceinline__ void paged_decode_fp8_item(const DecodeParams &p, con
             if (p.lse && dc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
         } else {
             const int64_t row = wk.prow + gq;
-            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + dc * 16);
+            float *dst = p.o_accum + row * D + dc * 16;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4)
-                dst[q4] = make_float4(o[gq][4 * q4] * inv, o[gq][4 * q4 + 1] * inv, o[gq][4 * q4 + 2] * inv, o[gq][4 * q4 + 3] * inv);
-            if (dc == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
+                partial_store(dst + 4 * q4, o[gq][4 * q4] * inv, o[gq][4 * q4 + 1] * inv, o[gq][4 * q4 + 2] * inv, o[gq][4 * q4 + 3] * inv);
+            if (dc == 0) partial_store(p.lse_accum + row, empty ? -INFINITY : lse);
         }
     }
 }
 
 template <typename T, int G, int P, bool NT, bool STREAM>
 __global__ void __launch_bounds__(64, 2) paged_decode_fp8_kernel(const DecodeParams p) {
-    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_item<T, G, P, NT>(pp, wk); });
+    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_item<T, G, P, NT>(pp, wk); }, DecodeLineMerge<T, 128>{});
 }
 
 // fp8 KV cache with BOTH products on the matrix cores (round 3; the v_dot2c variant above stays behind option decode_fp8_mqk = 0).
@@ -514,17 +514,17 @@ __device__ __forceinline__ void paged_decode_fp8_mma_item(const DecodeParams &p,
             if (p.lse && col == 0) p.lse[(int64_t)b * p.h + hq] = lse;
         } else {
             const int64_t row = wk.prow + h;
-            float4 *dst = reinterpret_cast<float4 *>(p.o_accum + row * D + col * 8);
-            dst[0] = make_float4(o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
-            dst[1] = make_float4(o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
-            if (col == 0) p.lse_accum[row] = empty ? -INFINITY : lse;
+            float *dst = p.o_accum + row * D + col * 8;
+            partial_store(dst, o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
+            partial_store(dst + 4, o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
+            if (col == 0) partial_store(p.lse_accum + row, empty ? -INFINITY : lse);
         }
     }
 }
 
 template <typename T, int P, bool NT, bool STREAM, int NWG = 1>
 __global__ void __launch_bounds__(64 * NWG, 2) paged_decode_fp8_mma_kernel(const DecodeParams p) {
-    decode_run_items<STREAM, NWG>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_mma_item<T, P, NT>(pp, wk); });
+    decode_run_items<STREAM, NWG>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_fp8_mma_item<T, P, NT>(pp, wk); }, DecodeLineMerge<T, 128>{});
 }
 
 // ------------------------------------------------------------------------------------------

@@ -147,8 +147,9 @@ def _oracle_decode(q, kc, vc, bt, lens, dtype):
 @pytest.mark.parametrize("kind", ["ragged", "straggler", "more_than_resident", "mostly_empty"])
 def test_decode_large_batch_balanced_mode(gpu, kind):
     """A batch big enough to fill the chip without KV splitting (B * h_k > 1024): the kernel lays all tiles of the
-    batch on one line and gives every wavefront the same share; sequences cut between wavefronts are merged by the
-    combine kernel, whole ones are written directly, empty ones by the combine kernel.  Same answer as the oracle,
+    batch on one line and gives every wavefront the same share; sequences cut between wavefronts are merged inside the
+    launch by the last wavefront to arrive (option decode_line_merge = 0: by the combine kernel), whole ones are written
+    directly, empty ones by the wavefronts of the line (or the combine kernel).  Same answer as the oracle,
     and as the one-wavefront-per-sequence route (option decode_stream = 0)."""
     rng = np.random.default_rng(99)
     h, hk, d, page = 4, 4, 64, 16
@@ -174,9 +175,22 @@ def test_decode_large_batch_balanced_mode(gpu, kind):
     out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
     out_again, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
     assert np.array_equal(out, out_again), "balanced mode is deterministic"
+    for _ in range(3):      # cut sequences are merged by the LAST wavefront to arrive: whoever that is, the bits are the same
+        again, lse_again = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
+        assert np.array_equal(out, again) and np.array_equal(lse, lse_again, equal_nan=True)
     for i, L in enumerate(lens):
         assert_close(out[i], ref[i], BF16, atol=attn_atol(BF16, L), what=f"{kind} batch seq {i} (L={L})")
     empty = lens == 0
+    assert gpu.lib.atoma_set_option(b"decode_line_merge", 0) == 0               # the same pieces merged by decode_combine_kernel
+    try:
+        out_ck, lse_ck = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, BF16)
+    finally:
+        assert gpu.lib.atoma_set_option(b"decode_line_merge", 1) == 0
+    assert np.array_equal(out[empty], out_ck[empty])
+    for i, L in enumerate(lens):
+        assert_close(out_ck[i], ref[i], BF16, atol=attn_atol(BF16, L), what=f"{kind} batch (combine kernel) seq {i} (L={L})")
+    assert (out != out_ck).mean() < 2e-3, "the two merges differ only in the summation order of three or more pieces"
+    np.testing.assert_allclose(lse[~empty], lse_ck[~empty], rtol=0, atol=1e-5)
     assert not out[empty].any() and np.isposinf(lse[empty]).all() and np.isfinite(lse[~empty]).all()
     assert gpu.lib.atoma_set_option(b"decode_stream", 0) == 0
     try:

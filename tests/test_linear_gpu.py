@@ -338,7 +338,7 @@ def test_qkv_projection_rope_cache_entry_is_the_two_ops_bit_for_bit(gpu, dtype, 
 def test_tile_kernel_strides_padding_exactness(gpu, dtype, B, K, N):
     """linear_tile_kernel (17..64 rows) with everything a caller may hand it: x rows that are slices of a wider buffer, weight rows with
     padding between them, y (and the residual) in wider buffers whose padding must stay untouched, batches that are not a multiple
-    of 16, both dtypes; K split merged in the launch (4096 x 2048: 2 splits), not split (8192 x 1024), split 4 ways (1280 x 8192) and
+    of 16, both dtypes; K split merged in the launch (4096 x 2048: 2 splits), not split (8192 x 1024), split 6 ways, unevenly (1280 x 8192) and
     a matrix of four 64-row tiles (fp32 partials + merge kernel).  Integer-valued inputs: every partial sum is exact in fp32, so the
     result must be bit-exact whatever the split and the order of arrival -- ten runs in a row must agree to the bit."""
     rng = np.random.default_rng(B + K + N + dtype)
