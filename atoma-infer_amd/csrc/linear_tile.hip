@@ -63,6 +63,7 @@ struct TileParams {
     int chunks_per_split;        // chunks of 128 inputs
     int merge_splits;            // 2..8: K split this many ways and merged here by the last workgroup to arrive; 0: no in-launch merge
     TileRope rope;
+    int w_plain;                 // probe (ATOMA_LINEAR_TILE_W_NT=0): weight pieces without the non-temporal hint
 };
 constexpr int TILE_PLAIN = 0, TILE_GATE_UP = 1, TILE_ROPE = 2;
 
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp
         const uint32_t sl = lds0 + slot * SLOT;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            if (isw[i]) tile_dma_nt(wb + (uint64_t)chunk * 256, voff[i], sl + dst[i]);
+            if (isw[i]) { if (tp.w_plain) tile_dma(wb + (uint64_t)chunk * 256, voff[i], sl + dst[i]); else tile_dma_nt(wb + (uint64_t)chunk * 256, voff[i], sl + dst[i]); }
             else tile_dma(xb + (uint64_t)chunk * 256, voff[i], sl + dst[i]);
         }
     };
@@ -424,6 +425,8 @@ template <typename T> static int launch_linear_tile_t(LinearParams &p, hipStream
         if (!p.partial) return -1;
     }
     tp.p = p;
+    static const int w_nt = tile_env_or("ATOMA_LINEAR_TILE_W_NT", 1);
+    tp.w_plain = w_nt ? 0 : 1;
     if (rope) tp.rope = *rope;
     const int mode = rope ? TILE_ROPE : (p.epilogue == 2 ? TILE_GATE_UP : TILE_PLAIN);
     const dim3 grid((unsigned)(tiles * splits)), block(512);

@@ -998,6 +998,8 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
                        p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? (std::to_string(p.num_splits) + " KV splits + combine").c_str() : "one wavefront per (sequence, kv head)"));
 #define ATOMA_MQK(P_, NT_, S_) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, P_, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p)
 #define ATOMA_MQK_S(P_, NT_) do { if (p.stream_waves > 0) ATOMA_MQK(P_, NT_, true); else ATOMA_MQK(P_, NT_, false); } while (0)
+    // (4 and 5 tiles in flight for the 8-head groups of split-KV launches, 8 / 16 / 32 splits, in-launch merge or combine kernel: all within
+    // 29.3-32 us on the 70B shard's B = 64 call -- profiles/r04_decode_b64_hk1_depth_probe.txt; launch, ramp and merge bound it, not depth)
     if (nt) { if (p3) ATOMA_MQK_S(3, true); else ATOMA_MQK_S(2, true); }
     else { if (p3) ATOMA_MQK_S(3, false); else ATOMA_MQK_S(2, false); }
 #undef ATOMA_MQK_S

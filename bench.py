@@ -219,6 +219,13 @@ def main():
     }
 
     if world > 1 or force_comm:
+        # every rank's own shard and kernel time (HIP events on its stream): a slow or mis-sharded rank shows here, not only in the max
+        mine = {"rank": rank, "q_heads": h_l, "kv_heads": hk_l, "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": rank_bytes,
+                "frac_of_hbm": round(rank_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel": (ah.lib.atoma_last_decode_kernel() or b"").decode()}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        out["per_rank"] = per_rank
         out["ranks_seen"] = ranks_seen                      # sum of ones over the communicator: must equal n_gpus
         out["ranks_expected"] = world
         out["rank_devices"] = rank_devices                  # one entry per rank: host, device ordinal, PCI bus id

@@ -25,6 +25,8 @@ def test_bench_two_ranks_on_one_device(gpu):
     assert out["ranks_seen"] == 2, out                         # counted through the communicator itself
     assert sorted(d["rank"] for d in out["rank_devices"]) == [0, 1] and all(d["pci_bus_id"] for d in out["rank_devices"])
     assert "tp2" in out["config"]["parallelism"] and out["scaling"] == "strong"
+    pr = out["per_rank"]                                        # every rank's own shard and kernel time
+    assert [r_["rank"] for r_ in pr] == [0, 1] and all(r_["q_heads"] == 16 and r_["kv_heads"] == 4 and r_["kernel_ms"] > 0 and "paged_decode" in r_["kernel"] for r_ in pr)
     assert "paged_decode" in out["roofline"]["kernel"]
     tps = out["tp_step"]
     assert tps["engines_available"].get("xgmi") is True and tps["xgmi_step_ms"] and tps["xgmi_allreduce_us"], tps
