@@ -375,9 +375,17 @@ __global__ void __launch_bounds__(64, MINW) paged_decode_kernel(const DecodePara
 //     waiting for memory, 306 VALU instructions per tile at 8 heads (tools/probes/headline_counters.sh).
 // VALU work per tile: ~120 at any G (round 2: ~100 + 16.G; the dot2 kernel: ~70.G); 2 wavefronts per SIMD with 3 tiles in flight.
 // ------------------------------------------------------------------------------------------
-template <typename T, int G, int P, bool NT, bool SINK = false>
+// PAIR64 (round 4): head_dim 64 through this kernel.  A kv head's slice of a token row is then 128 bytes -- half of what a wavefront fetches
+// per row here -- and its neighbour's half arrives from another wavefront some time later: the dot2 kernel stays at 0.63-0.73 of HBM on the
+// Llama-3.2-1B shape and loses on the kv-head-major line.  So ONE wavefront takes TWO adjacent kv heads: the launcher hands
+// over a view with h_k / 2 kv heads of 128 "dims" (the two heads' 64 + 64, contiguous in the reference's cache layout) and 2 g q heads per
+// group; the q heads of the first kv head carry zeros in the upper 64 dims of the Q^T operand, those of the second in the lower 64, so
+// S = K . Q^T is each head's own 64-dim product; O = P . V comes out 128 wide, of which a head keeps the half of its own kv head
+// (fp32 partial rows are 64 floats).  Half of the matrix-core work is wasted; the kernel waits for memory either way.
+template <typename T, int G, int P, bool NT, bool SINK = false, bool PAIR64 = false>
 __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, const DecodeWork &wk) {
     constexpr int D = 128;
+    static_assert(!(PAIR64 && SINK), "the workgroup-merged route does not take kv-head pairs");
     const int lane = threadIdx.x & 63, grp = lane >> 4, col = lane & 15;
 
     const int b = wk.b, hk = wk.hk, gc = wk.gc, L = wk.L, t0 = wk.t0, t1 = wk.t1;
@@ -398,7 +406,11 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             qb[s4] = u32x4{0, 0, 0, 0};
-            if (col < nq)
+            if constexpr (PAIR64) {      // chunk c = 4 s4 + grp of the 128-wide row: chunks 0..7 belong to the first kv head of the pair, 8..15 to the second
+                const int c = 4 * s4 + grp;
+                if (col < nq && (c >> 3) == (col >= (p.g >> 1) ? 1 : 0))
+                    qb[s4] = *reinterpret_cast<const u32x4 *>(p.q + (int64_t)b * p.q_batch_stride + (int64_t)(hq0 + col) * p.q_head_stride + (c & 7) * 8);
+            } else if (col < nq)
                 qb[s4] = *reinterpret_cast<const u32x4 *>(p.q + (int64_t)b * p.q_batch_stride +
                                                           (int64_t)(hq0 + col) * p.q_head_stride + (4 * s4 + grp) * 8);
         }
@@ -588,6 +600,25 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
             dst[0] = make_float4(o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
             dst[1] = make_float4(o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
             if (col == 0) wk.sink_lse[h] = empty ? -INFINITY : lse;
+        } else if constexpr (PAIR64) {
+            // this lane's eight outputs are dims 8 col ..+7 of the 128-wide row: the head's own when they lie in its kv head's half
+            if ((col >> 3) != (h >= (p.g >> 1) ? 1 : 0)) continue;
+            const int dc = (col & 7) * 8;
+            if (!partial) {
+                uint4 w4;
+                w4.x = pack2<T>(o[0][i] * inv, o[1][i] * inv);
+                w4.y = pack2<T>(o[2][i] * inv, o[3][i] * inv);
+                w4.z = pack2<T>(o[4][i] * inv, o[5][i] * inv);
+                w4.w = pack2<T>(o[6][i] * inv, o[7][i] * inv);
+                *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + dc) = w4;
+                if (p.lse && dc == 0) p.lse[(int64_t)b * p.h + hq] = lse;
+            } else {
+                const int64_t row = wk.prow + h;
+                float *dst = p.o_accum + row * 64 + dc;
+                partial_store(dst, o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
+                partial_store(dst + 4, o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
+                if (dc == 0) partial_store(p.lse_accum + row, empty ? -INFINITY : lse);
+            }
         } else if (!partial) {
             uint4 w4;
             w4.x = pack2<T>(o[0][i] * inv, o[1][i] * inv);
@@ -606,9 +637,10 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
     }
 }
 
-template <typename T, int G, int P, bool NT, bool STREAM>
+template <typename T, int G, int P, bool NT, bool STREAM, bool PAIR64 = false>
 __global__ void __launch_bounds__(64, 2) paged_decode_mqk_kernel(const DecodeParams p) {
-    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_mqk_item<T, G, P, NT>(pp, wk); }, DecodeLineMerge<T, 128>{});
+    decode_run_items<STREAM>(p, [](const DecodeParams &pp, const DecodeWork &wk) { paged_decode_mqk_item<T, G, P, NT, false, PAIR64>(pp, wk); },
+                             DecodeLineMerge<T, PAIR64 ? 64 : 128>{});
 }
 
 // LSE-weighted merge of the split partials: /root/reference/csrc/kernels/flash_fwd_kernel.h:1204-1236.
@@ -858,6 +890,7 @@ struct DecodeOptions {
     opt_int fp8_wg{env_int("ATOMA_DECODE_FP8_WG", 0)};     // fp8 KV cache: 8 wavefronts (the kv heads of a sequence) per workgroup: 0 never (default since the kv-head-major order does the same for free), 1 split-KV launches, 2 always
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
     opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
+    opt_int pair64{env_int("ATOMA_DECODE_PAIR64", 1)};   // head_dim 64 with an even number of kv heads and groups of 1 / 2 / 4 q heads: two kv heads per wavefront on the matrix-core kernel (1) or the dot2 kernel (0)
     opt_int line_merge{env_int("ATOMA_DECODE_LINE_MERGE", 1)};   // balanced line: cut sequences merged by the last wavefront to arrive (1) or by decode_combine_kernel (0)
     opt_int fp8_klines{env_int("ATOMA_DECODE_FP8_KLINES", 1)};   // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays, 2 always
     opt_int head_major{env_int("ATOMA_DECODE_HEAD_MAJOR", 1)};   // workgroup order of the non-balanced launches: kv head slowest (1) or fastest (0)
@@ -885,6 +918,7 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_mqk") o.mqk = value;
     else if (name == "decode_wg_merge") o.wg_merge = value;
     else if (name == "decode_line_merge") o.line_merge = value;
+    else if (name == "decode_pair64") o.pair64 = value;
     else if (name == "decode_fp8_mqk") o.fp8_mqk = value;
     else if (name == "decode_fp8_wg") o.fp8_wg = value;
     else if (name == "decode_head_major") o.head_major = value;
@@ -981,22 +1015,24 @@ static bool launch_decode_wg(DecodeParams &p, hipStream_t stream) {
 }
 
 // d = 128: scores on the matrix cores (paged_decode_mqk_kernel), any G at two wavefronts per SIMD
-template <typename T, int G>
+template <typename T, int G, bool PAIR64 = false>
 static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
     // 3 tiles in flight for every group size since P.V runs on the matrix cores (32 accumulator registers whatever G; option decode_mqk_p8:
     // tiles in flight at 8 q heads per wavefront, A/B)
     static const int p8 = env_int("ATOMA_DECODE_MQK_P8", 3);
     const bool p3 = decode_options().p >= 3 && (G <= 4 || p8 >= 3), nt = decode_options().nt != 0;
-    if (decode_wg_applicable(p)) {
-        if (nt) { if (p3) launch_decode_wg<T, 128, G, 3, true, true>(p, stream); else launch_decode_wg<T, 128, G, 2, true, true>(p, stream); }
-        else { if (p3) launch_decode_wg<T, 128, G, 3, false, true>(p, stream); else launch_decode_wg<T, 128, G, 2, false, true>(p, stream); }
-        return;
+    if constexpr (!PAIR64) {
+        if (decode_wg_applicable(p)) {
+            if (nt) { if (p3) launch_decode_wg<T, 128, G, 3, true, true>(p, stream); else launch_decode_wg<T, 128, G, 2, true, true>(p, stream); }
+            else { if (p3) launch_decode_wg<T, 128, G, 3, false, true>(p, stream); else launch_decode_wg<T, 128, G, 2, false, true>(p, stream); }
+            return;
+        }
     }
     const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
     if (p.stream_waves > 0) set_stream_waves(p, 8, stream);   // __launch_bounds__(64, 2)
-    note_decode_kernel("paged_decode_mqk_kernel", decode_tname<T>(), 128, G, p3 ? 3 : 2, nt,
+    note_decode_kernel(PAIR64 ? "paged_decode_mqk_kernel(kv-head pairs)" : "paged_decode_mqk_kernel", decode_tname<T>(), PAIR64 ? 64 : 128, G, p3 ? 3 : 2, nt,
                        p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? (std::to_string(p.num_splits) + " KV splits + combine").c_str() : "one wavefront per (sequence, kv head)"));
-#define ATOMA_MQK(P_, NT_, S_) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, P_, NT_, S_>), dim3((unsigned)blocks), dim3(64), 0, stream, p)
+#define ATOMA_MQK(P_, NT_, S_) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, P_, NT_, S_, PAIR64>), dim3((unsigned)blocks), dim3(64), 0, stream, p)
 #define ATOMA_MQK_S(P_, NT_) do { if (p.stream_waves > 0) ATOMA_MQK(P_, NT_, true); else ATOMA_MQK(P_, NT_, false); } while (0)
     // (4 and 5 tiles in flight for the 8-head groups of split-KV launches, 8 / 16 / 32 splits, in-launch merge or combine kernel: all within
     // 29.3-32 us on the 70B shard's B = 64 call -- profiles/r04_decode_b64_hk1_depth_probe.txt; launch, ramp and merge bound it, not depth)
@@ -1006,7 +1042,7 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
 #undef ATOMA_MQK
     if (!ATOMA_CHECK_LAUNCH("paged_decode_mqk_kernel")) return;
     if (p.num_splits > 1 || (p.stream_waves > 0 && !p.line_merge)) {
-        hipLaunchKernelGGL((decode_combine_kernel<T, 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((decode_combine_kernel<T, PAIR64 ? 64 : 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
 }
@@ -1108,6 +1144,7 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
     return lp;
 }
 
+static bool decode_pair64_view(const DecodeParams &p, DecodeParams &v);
 // Largest scratch any decode call with batch <= max_b, these head counts and contexts <= max_seqlen_k can ask for
 // (atoma_warmup reserves it up front, so that a hipGraph capture never meets a growing workspace).
 size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k) {
@@ -1121,6 +1158,11 @@ size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k
         p.cu_seqlens_k = &dummy;   // lengths on the device: the balanced mode is reachable
         p.num_splits = 0;
         worst = std::max(worst, decode_plan_launch(p, d).bytes);
+        if (d == 64) {    // the kv-head-pair view of the same call
+            DecodeParams v;
+            p.k_head_stride = p.v_head_stride = 64;
+            if (decode_pair64_view(p, v)) { v.num_splits = 0; worst = std::max(worst, decode_plan_launch(v, 128).bytes); }
+        }
         if (d == 128) {   // the same heads over an fp8 cache: up to 16 q heads per wavefront, so more partial rows on the balanced line
             DecodeParams p8 = p;
             p8.num_splits = 0;
@@ -1130,8 +1172,37 @@ size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k
     return worst;
 }
 
+// head_dim 64 as pairs of kv heads on the matrix-core kernel (paged_decode_mqk_item<.., PAIR64>): the view the kernel works on, or false
+static bool decode_pair64_view(const DecodeParams &p, DecodeParams &v) {
+    if (!decode_options().pair64 || p.k_scale || p.h_k % 2 || !(p.g == 1 || p.g == 2 || p.g == 4) || p.k_head_stride != 64 || p.v_head_stride != 64) return false;
+    v = p;
+    v.h_k = p.h_k / 2;
+    v.g = 2 * p.g;
+    v.k_head_stride = v.v_head_stride = 128;
+    return true;
+}
+template <typename T> static void launch_decode_pair64(DecodeParams &v, hipStream_t stream) {
+    const DecodeLaunchPlan lp = decode_plan_launch(v, 128);      // the decisions of a 128-wide launch with these head counts (its scratch bound covers the 64-float rows used here)
+    if (lp.rows) {
+        float *ws = static_cast<float *>(workspace(stream, lp.bytes));
+        if (!ws) return;
+        v.o_accum = ws;
+        v.lse_accum = ws + lp.rows * 64;
+        v.plan = reinterpret_cast<int *>(ws + lp.rows * 65);
+    }
+    switch (lp.G) {
+        case 2: launch_decode_mqk<T, 2, true>(v, stream); break;
+        case 4: launch_decode_mqk<T, 4, true>(v, stream); break;
+        default: launch_decode_mqk<T, 8, true>(v, stream); break;
+    }
+}
+
 template <typename T, int D>
 static void launch_decode_td(DecodeParams &p, hipStream_t stream) {
+    if constexpr (D == 64) {
+        DecodeParams v;
+        if (decode_pair64_view(p, v)) { launch_decode_pair64<T>(v, stream); return; }
+    }
     const DecodeLaunchPlan lp = decode_plan_launch(p, D);
     const int G = lp.G;
     const bool use_mqk = lp.use_mqk;

@@ -193,6 +193,7 @@ DECODE_SCHEDULES = {            # (head_dim, variant) -> (ngroups, group_of): ro
     (64, "dot2"): (8, lambda j: j % 8),       # 8 lanes per row, 8 rows per load instruction
     (128, "mqk"): (1, lambda j: 0),           # paged_decode_mqk_item since P.V runs on the matrix cores: all 16 tokens of a tile enter one
                                               # accumulator, so the running max is common to the tile (round 2: 4 groups, j // 4)
+    (64, "mqk"): (1, lambda j: 0),            # the same item on pairs of 64-dim kv heads (PAIR64): the other head's dims enter q.K^T as exact zeros
 }
 
 

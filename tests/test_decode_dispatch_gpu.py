@@ -19,8 +19,9 @@ EXPECT = [
     ((256, 1024, 32, 8, 128, False), ("paged_decode_mqk_kernel", 4, "balanced")),
     ((256, 4096, 32, 32, 128, False), ("paged_decode_kernel", 1, "balanced")),             # MHA keeps the dot2 kernel
     ((256, 4096, 64, 8, 128, False), ("paged_decode_mqk_kernel", 8, "balanced")),          # 8 q heads per kv head
-    ((256, 4096, 32, 8, 64, False), ("paged_decode_kernel", 4, "balanced")),               # head_dim 64: dot2 only
-    ((8, 2048, 32, 8, 64, False), ("paged_decode_kernel", 4, "KV splits + combine")),
+    ((256, 4096, 32, 8, 64, False), ("paged_decode_mqk_kernel(kv-head pairs)", 8, "balanced")),   # head_dim 64: two kv heads per wavefront (Llama-3.2-1B)
+    ((8, 2048, 32, 8, 64, False), ("paged_decode_mqk_kernel(kv-head pairs)", 8, "KV splits + combine")),
+    ((32, 1024, 9, 3, 64, False), ("paged_decode_kernel", 4, "KV splits + combine")),       # ... an odd number of kv heads: the dot2 kernel
     ((512, 512, 32, 8, 128, True), ("paged_decode_mqk_kernel", 4, "balanced")),            # configs[4]'s batch
     ((3, 257, 12, 2, 128, False), ("paged_decode_mqk_kernel", 8, "KV splits + combine")),   # 6 q heads per kv head -> one pass of 8
 ]

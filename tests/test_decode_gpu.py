@@ -494,7 +494,7 @@ def test_decode_full_size_70b_shape_properties(gpu):
 
 class _options:
     """atoma_set_option for the duration of a test (defaults restored afterwards)."""
-    DEFAULTS = {"decode_mqk": 29, "decode_min_tiles": 8, "decode_stream": 1, "decode_head_major": 1}
+    DEFAULTS = {"decode_mqk": 29, "decode_min_tiles": 8, "decode_stream": 1, "decode_head_major": 1, "decode_pair64": 1}
 
     def __init__(self, gpu, **kw):
         self.gpu, self.kw = gpu, kw
@@ -510,7 +510,9 @@ class _options:
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("d,h,hk,variant", [(128, 32, 8, "dot2"), (128, 8, 8, "dot2"), (128, 16, 2, "dot2"), (64, 32, 8, "dot2"),
-                                            (128, 32, 8, "mqk"), (128, 16, 2, "mqk"), (128, 6, 2, "mqk")])
+                                            (128, 32, 8, "mqk"), (128, 16, 2, "mqk"), (128, 6, 2, "mqk"),
+                                            # head_dim 64 as pairs of kv heads on the matrix-core kernel (round 4): groups of 4, 2 and 1 q heads
+                                            (64, 32, 8, "mqk"), (64, 8, 4, "mqk"), (64, 4, 4, "mqk")])
 def test_decode_matches_own_schedule_tightly(gpu, dtype, d, h, hk, variant):
     """1e-3 + 1 ulp at EVERY row length (no few-keys allowance) against the oracle evaluated under this kernel's own
     online-softmax schedule (oracle/attn_oracle.py attend_decode_online; tests/test_oracle_schedules.py shows on the CPU
@@ -522,8 +524,10 @@ def test_decode_matches_own_schedule_tightly(gpu, dtype, d, h, hk, variant):
     kc, vc, bt = make_paged_cache(rng, nb, 16, hk, d, dtype, lens)
     q = rand_half(rng, (len(lens), 1, h, d), dtype)
     scale = np.float32(d ** -0.5)
-    with _options(gpu, decode_mqk=7 if variant == "mqk" else 0, decode_min_tiles=1 << 20, decode_stream=0):
+    with _options(gpu, decode_mqk=7 if variant == "mqk" else 0, decode_min_tiles=1 << 20, decode_stream=0, decode_pair64=1 if variant == "mqk" else 0):
         out, _ = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype)
+        if d == 64:
+            assert ("kv-head pairs" in gpu.lib.atoma_last_decode_kernel().decode()) == (variant == "mqk")
     ref = A.flash_attn_kv_cache_online(q, kc, vc, scale, dtype, bt, lens, variant)
     assert_close(out, ref, dtype, atol=1e-3, what=f"decode vs own-schedule oracle ({variant}, d={d})")
     # and it is far tighter than that almost everywhere: at most a handful of outputs differ at all (a p on a rounding

@@ -120,6 +120,9 @@ def bench_decode():
     decode_case("decode B=16 S=8192", 16, 8192, 32, 8)
     decode_case("decode B=256 S=1024", 256, 1024, 32, 8)
     decode_case("decode Llama-3.2-1B shape d=64 B=256 S=4096", 256, 4096, 32, 8, d=64)
+    decode_case("decode d=64 ragged U[2048,4096] B=256 h=32 hk=8", 256, 4096, 32, 8, d=64, ragged=True)
+    decode_case("decode d=64 B=16 S=8192 h=32 hk=8 (split-KV)", 16, 8192, 32, 8, d=64)
+    decode_case("decode d=64 MHA B=256 S=2048 h=16 hk=16", 256, 2048, 16, 16, d=64)
 
 
 def bench_decode_fp8():
