@@ -515,9 +515,8 @@ def bench_prep():
 
 
 def BO_prepare(seqs, page):
-    sys.path.insert(0, ROOT)
-    from oracle import batch_prep_oracle as BO   # bench-only: builds the contents of the emulated reference copies
-    return BO.prepare_inputs(seqs, page)
+    """The contents of the emulated reference copies: the library's own host-side packing (nothing under tools/ imports oracle/)"""
+    return ah.prepare_inputs_host(seqs, page)[0]
 
 
 def bench_swap():

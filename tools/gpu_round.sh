@@ -3,7 +3,7 @@
 # per-kernel measurements, the C3-lite trace and the 70B step.  Run through gpurun:
 #   gpurun --timeout 2400 -- 'bash tools/gpu_round.sh r02'
 # then: python tools/summarize_profiles.py r02   (copies the summaries into profiles/)
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
@@ -19,14 +19,6 @@ ATOMA_BENCH_STEP_CASES=1 timeout 400 rocprofv3 --kernel-trace --output-format cs
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/prof_rank_$TAG -o step -- python $REPO/tools/rank_step.py --layers 8 --iters 3 > $OUT/prof_rank_$TAG.log 2>&1
 cd $REPO
 (timeout 400 python tools/rank_step.py --layers 80 --iters 20 2>&1 | tail -1) > $OUT/rank_step_$TAG.json
-(ATOMA_LINEAR_TILE=0 ATOMA_STEP_QKV_FUSED=0 timeout 400 python tools/rank_step.py --layers 80 --iters 20 2>&1 | tail -1) > $OUT/rank_step_r02route_$TAG.json
-(timeout 400 python tools/probes/linear64_ab.py 2>&1) > $OUT/linear64_ab_$TAG.jsonl
-(timeout 300 tools/probes/gemm64_probe 2>&1 | grep -v "^check") > $OUT/gemm64_probe_$TAG.txt
-# the decode kernels' launch orders / K fetch formats (fp8: uniform and ragged batches x balanced line x full-line K; bf16: uniform batches through the balanced line)
-(timeout 300 bash tools/probes/fp8_modes.sh 2>&1 | grep "==\|ms" | cut -c1-150) > $OUT/fp8_modes_$TAG.txt
-(timeout 300 bash tools/probes/stream_force_ab.sh 2>&1 | grep "==\|ms" | cut -c1-150) > $OUT/stream_force_ab_$TAG.txt
-(timeout 300 bash tools/probes/mqk_ab.sh 2>&1 | grep "==\|ms" | cut -c1-150) > $OUT/mqk_ab_$TAG.txt
-(timeout 400 bash tools/probes/headline_knobs.sh 2>&1) > $OUT/headline_knobs_$TAG.txt
 (timeout 1500 python tools/bench_kernels.py decode decode_fp8 prefill prefill_paged cache norm sampling linear linear_mid linear_big graph step swap prep 2>&1) > $OUT/kernels_$TAG.jsonl
 (timeout 400 python tools/engine_trace.py 2>&1 | tail -1) > $OUT/trace_$TAG.json
 (timeout 400 python tools/engine_trace.py --model 70b-tp8-shard --requests 64 --prompt 4096 --decode-steps 256 2>&1 | tail -1) > $OUT/trace_70b_tp8_rank_$TAG.json
