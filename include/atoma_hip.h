@@ -400,12 +400,17 @@ int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int6
  * batches with device-side lengths that fill the chip: 0 = never (one wavefront per (sequence, kv head)), 1 = ragged batches and
  * uniform head_dim-128 GQA batches [default], 2 = every such batch, 3 = ragged batches only), "decode_head_major" (workgroup order of
  * the other launches: kv head slowest 1 [default] / fastest 0), "decode_stream_waves_per_cu", "decode_waves_per_cu" /
- * "decode_min_tiles" (KV split heuristic), "decode_wg_merge" (split-KV merged inside the launch), "decode_mqk" (both products on the
+ * "decode_min_tiles" (KV split heuristic), "decode_wg_merge" (split-KV merged inside the launch), "decode_line_merge" (the balanced line
+ * merges the pieces of a cut sequence inside the launch, by the last wavefront to arrive: 1 [default]; 0 = a second launch of the combine
+ * kernel), "decode_pair64" (head_dim 64 with an even number of kv heads and 1 / 2 / 4 q heads per kv head: two kv heads per wavefront on
+ * the matrix-core kernel 1 [default] / the dot2 kernel 0), "decode_mqk" (both products on the
  * matrix cores at head_dim 128: bit 0 = groups of more than 4 q heads per kv head, bit 1 = all smaller groups, bit 2 = groups of 2..4
  * when b * h_k <= 64, bit 3 = groups of 2..4 on the line, bit 4 = groups of 2..4 on split-KV launches; default 29), "decode_fp8_mqk"
  * (fp8 KV cache: 1 = the matrix-core kernel [default], 0 = v_dot2c), "decode_fp8_klines" (fp8: K fetched in full 128-byte lines: 0
  * never, 1 where it pays [default], 2 always), "decode_fp8_wg" (fp8: the 8 kv-head wavefronts of a sequence in one workgroup: 0 never
- * [default], 1 split-KV launches, 2 always).  None of them changes a result bit except through the choice of kernel.  Prefill: "prefill_cfg" (4 = the hand-scheduled persistent
+ * [default], 1 split-KV launches, 2 always).  None of them changes a result bit except through the choice of kernel.  Projections at
+ * 17..64 rows: "linear_tile" (0 = the older kernels), "linear_tile_nw" / "linear_tile_splits" (force the tile height / the K split),
+ * "linear_tile_max_splits" (largest K split the plan considers, default 8; 4 = round 3's plans).  Prefill: "prefill_cfg" (4 = the hand-scheduled persistent
  * kernel of csrc/prefill_asm.hip [default; head_dim 128 -- other shapes run on 0], 0 = tile-sequential kernel, 2 = the
  * software-pipelined one-wave-per-SIMD kernel), "prefill_exact_keys" (kernel 4: query blocks whose first row sees fewer keys take the
  * arithmetic that leaves Q unrounded; default 512, 0 = never, 0x7fffffff = always), "prefill_simple" (A/B knob, default 0).  The
