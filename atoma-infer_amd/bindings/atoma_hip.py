@@ -392,6 +392,19 @@ _opt("atoma_flash_attn", [_TP, _TP, _TP, _f32, _int, _TP])
 _opt("atoma_flash_attn_varlen", [_TP, _TP, _TP, _TP, _TP, _i64, _i64, _f32, _int, _TP])
 _opt("atoma_flash_attn_varlen_with_block_table", [_TP, _TP, _TP, _TP, _TP, _TP, _i64, _i64, _f32, _i64, _i64, _TP, _TP])
 _opt("atoma_flash_attn_kv_cache_full", [_TP, _TP, _TP, _TP, _f32, _TP, _TP, _int, _TP])
+# the reference's other forms of the three ops (windows: negative = None)
+_opt("atoma_flash_attn_windowed", [_TP, _TP, _TP, _f32, _i64, _i64, _TP])
+_opt("atoma_flash_attn_alibi", [_TP, _TP, _TP, _TP, _f32, _int, _TP])
+_opt("atoma_flash_attn_alibi_windowed", [_TP, _TP, _TP, _TP, _f32, _i64, _i64, _TP])
+_opt("atoma_flash_attn_alibi_windowed_with_softcap", [_TP, _TP, _TP, _TP, _f32, _i64, _i64, _f32, _TP])
+_opt("atoma_flash_attn_varlen_windowed", [_TP, _TP, _TP, _TP, _TP, _i64, _i64, _f32, _i64, _i64, _TP])
+_opt("atoma_flash_attn_varlen_alibi", [_TP, _TP, _TP, _TP, _TP, _TP, _i64, _i64, _f32, _int, _TP])
+_opt("atoma_flash_attn_varlen_alibi_windowed", [_TP, _TP, _TP, _TP, _TP, _TP, _i64, _i64, _f32, _i64, _i64, _TP])
+_opt("atoma_flash_attn_varlen_full", [_TP, _TP, _TP, _TP, _TP, _TP, _i64, _i64, _f32, _i64, _i64, _TP, _TP, _f32, _TP])
+_opt("atoma_flash_attn_kv_cache", [_TP, _TP, _TP, _f32, _int, _TP])
+_opt("atoma_flash_attn_kv_cache_windowed", [_TP, _TP, _TP, _TP, _f32, _i64, _i64, _TP])
+_opt("atoma_flash_attn_kv_cache_alibi", [_TP, _TP, _TP, _TP, _TP, _f32, _int, _TP])
+_opt("atoma_flash_attn_kv_cache_alibi_windowed", [_TP, _TP, _TP, _TP, _f32, _i64, _i64, _TP])
 _opt("atoma_reshape_and_cache_flash", [_TP, _TP, _TP, _TP, _TP])
 _opt("atoma_copy_blocks", [C.POINTER(_TP), _i64, C.POINTER(_TP), _i64, _TP])
 _opt("atoma_swap_blocks_tensor", [_TP, _TP, C.POINTER(C.c_uint32), _i64])

@@ -76,7 +76,7 @@ static int64_t numel(const atoma_tensor *t) {
 struct MhaCall {  // the argument block the reference's wrappers assemble for ffi::run_mha
     const atoma_tensor *q, *k, *v;
     atoma_tensor *out;
-    const atoma_tensor *alibi = nullptr, *seqlens_q = nullptr, *seqlens_k = nullptr, *block_table = nullptr;
+    const atoma_tensor *alibi = nullptr, *seqlens_q = nullptr, *seqlens_k = nullptr, *block_table = nullptr, *seqused_k = nullptr;
     bool is_seqlens_k_cumulative = true;
     int64_t b = 0, h = 0, h_k = 0, d = 0, seqlen_q = 0, seqlen_k = 0, page = 0;
     uint32_t qs[3] = {0, 0, 0}, ks[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, os[3] = {0, 0, 0};  // batch,row,head
@@ -101,7 +101,7 @@ static int launch(const MhaCall &c) {
                    c.vs[2], c.os[2], c.num_splits, (uint32_t)c.b, (uint32_t)c.h, (uint32_t)c.h_k, (uint32_t)c.d,
                    (uint32_t)round_multiple(c.d, 32), c.scale, c.scale * LOG2E,
                    c.block_table ? static_cast<int *>(c.block_table->data) : nullptr,
-                   c.block_table ? (uint32_t)c.block_table->stride[0] : 0u, (int)c.page, nullptr, (uint32_t)c.seqlen_q,
+                   c.block_table ? (uint32_t)c.block_table->stride[0] : 0u, (int)c.page, c.seqused_k ? static_cast<int *>(c.seqused_k->data) : nullptr, (uint32_t)c.seqlen_q,
                    (uint32_t)c.seqlen_k, (uint32_t)round_multiple(c.seqlen_q, 128),
                    (uint32_t)round_multiple(c.seqlen_k, 128), c.q->dtype == ATOMA_BF16 ? 1 : 0, c.is_causal, c.wl, c.wr,
                    0.f, c.unpadded_lse, c.force_split, nullptr, nullptr, nullptr);
@@ -142,8 +142,9 @@ static int check_out(const atoma_tensor *out, const atoma_tensor *q) {
 }
 
 // csrc/src/lib.rs:31-343 (FlashAttention::cuda_fwd_t) behind csrc::flash_attn (:392-411)
-static int flash_attn(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, float scale, bool causal,
-                      atoma_tensor *out) {
+// window_left / window_right: the reference's Option<usize>, None = negative (causal = (None, Some(0)), lib.rs:399-400)
+static int flash_attn(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi, float scale,
+                      int64_t window_left, int64_t window_right, atoma_tensor *out) {
     if (int e = check_common(q, k, v, "flash-attn")) return e;
     if (q->rank != 4 || k->rank != 4 || v->rank != 4)
         return fail("flash-attn expects input tensors of rank 4 (q: " + std::to_string(q->rank) + ", k: " +
@@ -157,16 +158,21 @@ static int flash_attn(const atoma_tensor *q, const atoma_tensor *k, const atoma_
     if (memcmp(k->shape, want, sizeof(want))) return fail("shape mismatch q " + dims(q) + " and k " + dims(k));
     if (memcmp(v->shape, want, sizeof(want))) return fail("shape mismatch q " + dims(q) + " and v " + dims(v));
     if (int e = check_head(d, h, hk)) return e;
+    if (int e = check_alibi(alibi, h)) return e;
     if (int e = check_out(out, q)) return e;
     MhaCall c;
-    c.q = q; c.k = k; c.v = v; c.out = out;
+    c.q = q; c.k = k; c.v = v; c.out = out; c.alibi = alibi;
     c.b = b; c.h = h; c.h_k = hk; c.d = d; c.seqlen_q = sq; c.seqlen_k = sk;
     c.scale = scale;
-    // window (None, Some(0)) == causal; seqlen_q == 1 without alibi switches it off (lib.rs:207-216)
-    c.is_causal = causal ? 1 : 0;
-    if (sq == 1) c.is_causal = 0;
-    c.wl = -1; c.wr = causal ? 0 : -1;
-    if (c.wl < 0 && c.wr >= 0) c.wl = (int)sk;
+    // lib.rs:186-229: a window beyond seqlen_k (or None) -> -1; (None, Some(0)) == causal; seqlen_q == 1 without alibi switches it off;
+    // a one-sided window gets seqlen_k on the other side
+    int wl = (window_left >= 0 && window_left <= sk) ? (int)window_left : -1;
+    int wr = (window_right >= 0 && window_right <= sk) ? (int)window_right : -1;
+    c.is_causal = (wl < 0 && wr == 0) ? 1 : 0;
+    if (sq == 1 && !alibi) c.is_causal = 0;
+    if (wl < 0 && wr >= 0) wl = (int)sk;
+    if (wl >= 0 && wr < 0) wr = (int)sk;
+    c.wl = wl; c.wr = wr;
     c.qs[0] = (uint32_t)q->stride[0]; c.qs[1] = (uint32_t)q->stride[1]; c.qs[2] = (uint32_t)q->stride[2];
     c.ks[0] = (uint32_t)k->stride[0]; c.ks[1] = (uint32_t)k->stride[1]; c.ks[2] = (uint32_t)k->stride[2];
     c.vs[0] = (uint32_t)v->stride[0]; c.vs[1] = (uint32_t)v->stride[1]; c.vs[2] = (uint32_t)v->stride[2];
@@ -178,8 +184,12 @@ static int flash_attn(const atoma_tensor *q, const atoma_tensor *k, const atoma_
 static int flash_attn_varlen(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
                              const atoma_tensor *alibi, const atoma_tensor *seqlens_q, const atoma_tensor *seqlens_k,
                              int64_t max_seqlen_q, int64_t max_seqlen_k, float scale, int64_t window_left,
-                             int64_t window_right, const atoma_tensor *block_table, atoma_tensor *out) {
+                             int64_t window_right, const atoma_tensor *block_table, atoma_tensor *out, const atoma_tensor *seqused_k = nullptr) {
     if (int e = check_common(q, k, v, "flash-attn-varlen")) return e;
+    if (seqused_k) {   // lib.rs:775-791
+        if (seqused_k->device < 0 || !is_index32(seqused_k->dtype)) return fail("seqused_k must be a cuda tensor");
+        if (!contiguous(seqused_k)) return fail("seqused_k has to be contiguous");
+    }
     if (!seqlens_q || seqlens_q->device < 0 || !is_index32(seqlens_q->dtype)) return fail("seqlens_q must be a cuda tensor");
     if (!contiguous(seqlens_q)) return fail("seqlens_q has to be contiguous");
     if (!seqlens_k || seqlens_k->device < 0 || !is_index32(seqlens_k->dtype)) return fail("seqlens_k must be a cuda tensor");
@@ -249,7 +259,7 @@ static int flash_attn_varlen(const atoma_tensor *q, const atoma_tensor *k, const
     if (wl >= 0 && wr < 0) wr = (int)max_seqlen_k;
     c.wl = wl; c.wr = wr;
     c.q = q; c.k = k; c.v = v; c.out = out; c.alibi = alibi;
-    c.seqlens_q = seqlens_q; c.seqlens_k = seqlens_k; c.block_table = block_table;
+    c.seqlens_q = seqlens_q; c.seqlens_k = seqlens_k; c.block_table = block_table; c.seqused_k = seqused_k;
     c.b = batch; c.h = h; c.h_k = hk; c.d = d; c.seqlen_q = max_seqlen_q; c.seqlen_k = max_seqlen_k; c.page = page;
     c.scale = scale;
     c.qs[0] = 0; c.qs[1] = (uint32_t)q->stride[0]; c.qs[2] = (uint32_t)q->stride[1];
@@ -268,7 +278,7 @@ static int flash_attn_varlen(const atoma_tensor *q, const atoma_tensor *k, const
 // csrc/src/lib.rs:1521-1855 (FlashAttentionKvCache::cuda_fwd_t)
 static int flash_attn_kv_cache_full(const atoma_tensor *q, const atoma_tensor *kc, const atoma_tensor *vc,
                                     const atoma_tensor *alibi, float scale, const atoma_tensor *block_table,
-                                    const atoma_tensor *seqlens_k, bool causal, atoma_tensor *out) {
+                                    const atoma_tensor *seqlens_k, int64_t window_left, int64_t window_right, atoma_tensor *out) {
     if (int e = check_common(q, kc, vc, "flash-attn")) return e;
     if (block_table) {
         if (block_table->device < 0 || !is_index32(block_table->dtype)) return fail("block_table must be a cuda tensor");
@@ -312,12 +322,14 @@ static int flash_attn_kv_cache_full(const atoma_tensor *q, const atoma_tensor *k
     }
     if (int e = check_out(out, q)) return e;
     MhaCall c;
-    int wl = -1, wr = causal ? 0 : -1;           // window (None, Some(0)) for causal
-    if (wr >= seqlen_k) wr = -1;
+    // lib.rs:1606-1640: windows of seqlen_k or more -> none; causal = (None, Some(0)); one-sided windows get seqlen_k on the other side
+    int wl = (window_left >= 0 && window_left < seqlen_k) ? (int)window_left : -1;
+    int wr = (window_right >= 0 && window_right < seqlen_k) ? (int)window_right : -1;
     bool is_causal = wl < 0 && wr == 0;
     if (sq == 1 && !alibi) is_causal = false;      // lib.rs:1629-1631
     if (is_causal) wr = 0;
     if (wl < 0 && wr >= 0) wl = (int)seqlen_k;
+    if (wr < 0 && wl >= 0) wr = (int)seqlen_k;
     c.is_causal = is_causal ? 1 : 0;
     c.wl = wl; c.wr = wr;
     c.q = q; c.k = kc; c.v = vc; c.out = out; c.alibi = alibi;
@@ -383,7 +395,33 @@ extern "C" {
 int atoma_flash_attn(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, float softmax_scale, int causal,
                      atoma_tensor *out) {
     atoma::clear_error();
-    return atoma::flash_attn(q, k, v, softmax_scale, causal != 0, out);
+    return atoma::flash_attn(q, k, v, nullptr, softmax_scale, -1, causal ? 0 : -1, out);
+}
+// csrc/src/lib.rs:432-450, 464-487, 506-527, 552-572: the same op with windows (negative = None) and / or ALiBi slopes.  Sliding windows
+// and softcap are compiled out of the reference's kernels (csrc/kernels/static_switch.h:8-11,66-83): as there, only the causal
+// combination (None, Some(0)) acts, and softcap is accepted and ignored.
+int atoma_flash_attn_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, float softmax_scale, int64_t window_size_left,
+                              int64_t window_size_right, atoma_tensor *out) {
+    atoma::clear_error();
+    return atoma::flash_attn(q, k, v, nullptr, softmax_scale, window_size_left, window_size_right, out);
+}
+int atoma_flash_attn_alibi(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes, float softmax_scale,
+                           int causal, atoma_tensor *out) {
+    atoma::clear_error();
+    if (!alibi_slopes) return atoma::fail("alibi_slopes is required");
+    return atoma::flash_attn(q, k, v, alibi_slopes, softmax_scale, -1, causal ? 0 : -1, out);
+}
+int atoma_flash_attn_alibi_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                    float softmax_scale, int64_t window_size_left, int64_t window_size_right, atoma_tensor *out) {
+    atoma::clear_error();
+    if (!alibi_slopes) return atoma::fail("alibi_slopes is required");
+    return atoma::flash_attn(q, k, v, alibi_slopes, softmax_scale, window_size_left, window_size_right, out);
+}
+int atoma_flash_attn_alibi_windowed_with_softcap(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                                 float softmax_scale, int64_t window_size_left, int64_t window_size_right, float softcap,
+                                                 atoma_tensor *out) {
+    (void)softcap;
+    return atoma_flash_attn_alibi_windowed(q, k, v, alibi_slopes, softmax_scale, window_size_left, window_size_right, out);
 }
 
 // csrc/src/lib.rs:1160-1188
@@ -405,12 +443,68 @@ int atoma_flash_attn_varlen_with_block_table(const atoma_tensor *q, const atoma_
     return atoma::flash_attn_varlen(q, k, v, alibi_slopes, seqlens_q, seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale,
                                     window_size_left, window_size_right, block_table, out);
 }
+// csrc/src/lib.rs:1218-1248, 1268-1300, 1328-1360, 1464-1495: the other forms of the varlen op (windows: negative = None; softcap ignored as in
+// the reference's build; seqused_k u32 [B] or NULL)
+int atoma_flash_attn_varlen_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *seqlens_q,
+                                     const atoma_tensor *seqlens_k, int64_t max_seqlen_q, int64_t max_seqlen_k, float softmax_scale,
+                                     int64_t window_size_left, int64_t window_size_right, atoma_tensor *out) {
+    atoma::clear_error();
+    return atoma::flash_attn_varlen(q, k, v, nullptr, seqlens_q, seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, window_size_left,
+                                    window_size_right, nullptr, out);
+}
+int atoma_flash_attn_varlen_alibi(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                  const atoma_tensor *seqlens_q, const atoma_tensor *seqlens_k, int64_t max_seqlen_q, int64_t max_seqlen_k,
+                                  float softmax_scale, int causal, atoma_tensor *out) {
+    atoma::clear_error();
+    if (!alibi_slopes) return atoma::fail("alibi_slopes is required");
+    return atoma::flash_attn_varlen(q, k, v, alibi_slopes, seqlens_q, seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, -1, causal ? 0 : -1,
+                                    nullptr, out);
+}
+int atoma_flash_attn_varlen_alibi_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                           const atoma_tensor *seqlens_q, const atoma_tensor *seqlens_k, int64_t max_seqlen_q, int64_t max_seqlen_k,
+                                           float softmax_scale, int64_t window_size_left, int64_t window_size_right, atoma_tensor *out) {
+    atoma::clear_error();
+    if (!alibi_slopes) return atoma::fail("alibi_slopes is required");
+    return atoma::flash_attn_varlen(q, k, v, alibi_slopes, seqlens_q, seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, window_size_left,
+                                    window_size_right, nullptr, out);
+}
+int atoma_flash_attn_varlen_full(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                 const atoma_tensor *seqlens_q, const atoma_tensor *seqlens_k, int64_t max_seqlen_q, int64_t max_seqlen_k,
+                                 float softmax_scale, int64_t window_size_left, int64_t window_size_right, const atoma_tensor *block_table,
+                                 const atoma_tensor *seqused_k, float softcap, atoma_tensor *out) {
+    (void)softcap;
+    atoma::clear_error();
+    return atoma::flash_attn_varlen(q, k, v, alibi_slopes, seqlens_q, seqlens_k, max_seqlen_q, max_seqlen_k, softmax_scale, window_size_left,
+                                    window_size_right, block_table, out, seqused_k);
+}
 
 int atoma_flash_attn_kv_cache_full(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
                                    const atoma_tensor *alibi_slopes, float softmax_scale, const atoma_tensor *block_table,
                                    const atoma_tensor *seqlens_k, int causal, atoma_tensor *out) {
     atoma::clear_error();
-    return atoma::flash_attn_kv_cache_full(q, k, v, alibi_slopes, softmax_scale, block_table, seqlens_k, causal != 0, out);
+    return atoma::flash_attn_kv_cache_full(q, k, v, alibi_slopes, softmax_scale, block_table, seqlens_k, -1, causal ? 0 : -1, out);
+}
+// csrc/src/lib.rs:1907-1925, 1949-1966, 1989-2007, 2036-2053: the other forms of the kv-cache op (no block table)
+int atoma_flash_attn_kv_cache(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, float softmax_scale, int causal, atoma_tensor *out) {
+    atoma::clear_error();
+    return atoma::flash_attn_kv_cache_full(q, k, v, nullptr, softmax_scale, nullptr, nullptr, -1, causal ? 0 : -1, out);
+}
+int atoma_flash_attn_kv_cache_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *seqlens_k,
+                                       float softmax_scale, int64_t window_size_left, int64_t window_size_right, atoma_tensor *out) {
+    atoma::clear_error();
+    return atoma::flash_attn_kv_cache_full(q, k, v, nullptr, softmax_scale, nullptr, seqlens_k, window_size_left, window_size_right, out);
+}
+int atoma_flash_attn_kv_cache_alibi(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                    const atoma_tensor *seqlens_k, float softmax_scale, int causal, atoma_tensor *out) {
+    atoma::clear_error();
+    if (!alibi_slopes) return atoma::fail("alibi_slopes is required");
+    return atoma::flash_attn_kv_cache_full(q, k, v, alibi_slopes, softmax_scale, nullptr, seqlens_k, -1, causal ? 0 : -1, out);
+}
+int atoma_flash_attn_kv_cache_alibi_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                             float softmax_scale, int64_t window_size_left, int64_t window_size_right, atoma_tensor *out) {
+    atoma::clear_error();
+    if (!alibi_slopes) return atoma::fail("alibi_slopes is required");
+    return atoma::flash_attn_kv_cache_full(q, k, v, alibi_slopes, softmax_scale, nullptr, nullptr, window_size_left, window_size_right, out);
 }
 
 int atoma_reshape_and_cache_flash(const atoma_tensor *key, const atoma_tensor *value, const atoma_tensor *key_cache,
@@ -606,7 +700,7 @@ int atoma_flash_attention_forward(const atoma_flash_attention *self, const atoma
         o4.shape[0] = nd; o4.shape[1] = 1; o4.shape[2] = qH; o4.shape[3] = qD;
         o4.stride[0] = qH * qD; o4.stride[1] = qH * qD; o4.stride[2] = qD; o4.stride[3] = 1;
         if (atoma::flash_attn_kv_cache_full(&q4, &kc, &vc, self->alibi_slopes, self->softmax_scale, meta->decoding_block_tables,
-                                            meta->decoding_sequence_lengths, true, &o4))
+                                            meta->decoding_sequence_lengths, -1, 0, &o4))      // causal = (None, Some(0)), flash_attention.rs:459
             return -1;
     }
     return 0;

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm-ms", type=float, default=100.0, help="untimed load before the warm-up steps: brings the device from its idle power state to its sustained clocks (0 = off)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--seq", type=int, default=4096)
     ap.add_argument("--heads", type=int, default=32)
@@ -168,6 +169,13 @@ def main():
             dist.barrier()
         ah.synchronize()
 
+    # Power state first: after the uploads above the device has idled for seconds and needs ~30 ms of load to return to its sustained
+    # clocks (tools/probes/warm_probe.py, profiles/r04_clock_ramp_probe.txt: the same kernel reads 18 % slower in the first milliseconds).
+    # Untimed, like the W warm-up steps that follow; --prewarm-ms 0 switches it off.
+    t_pw = time.perf_counter()
+    while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+        step()
+        ah.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -197,7 +205,7 @@ def main():
 
     out = {
         "metric": "paged-attn decode HBM GB/s (decode tokens/s/GPU alongside), Llama-3.1-8B shape, TP=%d" % world,
-        "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "decode_tokens_per_s": round(B / (ms_per_step * 1e-3), 1),

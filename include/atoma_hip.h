@@ -471,6 +471,20 @@ typedef struct atoma_tensor {
  * atoma_last_error(). */
 int atoma_flash_attn(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
                      float softmax_scale, int causal, atoma_tensor *out);
+/* The reference's other forms of the same op: csrc::flash_attn_windowed (lib.rs:432-450), flash_attn_alibi (:464-487),
+ * flash_attn_alibi_windowed (:506-527), flash_attn_alibi_windowed_with_softcap (:552-572).  window_size_* are the reference's
+ * Option<usize>: negative = None; (None, Some(0)) is the causal mask.  Sliding windows and softcap are compiled OUT of the reference's
+ * kernels (csrc/kernels/static_switch.h:8-11,66-83): there as here only the causal combination acts and softcap is ignored.
+ * alibi_slopes f32 [h]. */
+int atoma_flash_attn_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, float softmax_scale,
+                              int64_t window_size_left, int64_t window_size_right, atoma_tensor *out);
+int atoma_flash_attn_alibi(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                           float softmax_scale, int causal, atoma_tensor *out);
+int atoma_flash_attn_alibi_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                    float softmax_scale, int64_t window_size_left, int64_t window_size_right, atoma_tensor *out);
+int atoma_flash_attn_alibi_windowed_with_softcap(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
+                                                 const atoma_tensor *alibi_slopes, float softmax_scale, int64_t window_size_left,
+                                                 int64_t window_size_right, float softcap, atoma_tensor *out);
 /* csrc::flash_attn_varlen (lib.rs:1160-1188). q [total_q,h,d], k,v [total_k,hk,d],
  * seqlens_q/k u32 cumulative [B+1]. */
 int atoma_flash_attn_varlen(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
@@ -486,6 +500,33 @@ int atoma_flash_attn_varlen_with_block_table(const atoma_tensor *q, const atoma_
                                              float softmax_scale, int64_t window_size_left,
                                              int64_t window_size_right, const atoma_tensor *block_table,
                                              atoma_tensor *out);
+/* csrc::flash_attn_varlen_windowed (lib.rs:1218-1248), _varlen_alibi (:1268-1300), _varlen_alibi_windowed (:1328-1360),
+ * flash_attn_varlen_full (:1464-1495; alibi_slopes, block_table, seqused_k [B] u32 may be NULL; softcap ignored as in the reference's build). */
+int atoma_flash_attn_varlen_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *seqlens_q,
+                                     const atoma_tensor *seqlens_k, int64_t max_seqlen_q, int64_t max_seqlen_k, float softmax_scale,
+                                     int64_t window_size_left, int64_t window_size_right, atoma_tensor *out);
+int atoma_flash_attn_varlen_alibi(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                  const atoma_tensor *seqlens_q, const atoma_tensor *seqlens_k, int64_t max_seqlen_q, int64_t max_seqlen_k,
+                                  float softmax_scale, int causal, atoma_tensor *out);
+int atoma_flash_attn_varlen_alibi_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
+                                           const atoma_tensor *alibi_slopes, const atoma_tensor *seqlens_q, const atoma_tensor *seqlens_k,
+                                           int64_t max_seqlen_q, int64_t max_seqlen_k, float softmax_scale, int64_t window_size_left,
+                                           int64_t window_size_right, atoma_tensor *out);
+int atoma_flash_attn_varlen_full(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                 const atoma_tensor *seqlens_q, const atoma_tensor *seqlens_k, int64_t max_seqlen_q, int64_t max_seqlen_k,
+                                 float softmax_scale, int64_t window_size_left, int64_t window_size_right, const atoma_tensor *block_table,
+                                 const atoma_tensor *seqused_k, float softcap, atoma_tensor *out);
+/* csrc::flash_attn_kv_cache (lib.rs:1907-1925), _kv_cache_windowed (:1949-1966), _kv_cache_alibi (:1989-2007),
+ * _kv_cache_alibi_windowed (:2036-2053): contiguous caches [B,sk,hk,d], seqlens_k u32 [B] or NULL. */
+int atoma_flash_attn_kv_cache(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, float softmax_scale, int causal,
+                              atoma_tensor *out);
+int atoma_flash_attn_kv_cache_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *seqlens_k,
+                                       float softmax_scale, int64_t window_size_left, int64_t window_size_right, atoma_tensor *out);
+int atoma_flash_attn_kv_cache_alibi(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v, const atoma_tensor *alibi_slopes,
+                                    const atoma_tensor *seqlens_k, float softmax_scale, int causal, atoma_tensor *out);
+int atoma_flash_attn_kv_cache_alibi_windowed(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,
+                                             const atoma_tensor *alibi_slopes, float softmax_scale, int64_t window_size_left,
+                                             int64_t window_size_right, atoma_tensor *out);
 /* csrc::flash_attn_kv_cache_full (lib.rs:2083-2105). q [B,sq,h,d]; caches [B_c,sk,hk,d] or
  * paged [nb,page,hk,d] with block_table [B,max_blocks] u32; seqlens_k u32 [B] or NULL. */
 int atoma_flash_attn_kv_cache_full(const atoma_tensor *q, const atoma_tensor *k, const atoma_tensor *v,

@@ -550,3 +550,37 @@ def test_decode_never_written_slots_do_not_reach_the_output(gpu, dtype, nan, d, 
     got, lse = gpu_decode(gpu, q, kp, vp, bt, lens, d ** -0.5, dtype)
     assert np.isfinite(to_f32(got, dtype)).all() and np.isfinite(lse).all()
     assert np.array_equal(got, clean)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_decode_random_shapes_through_the_default_dispatch(gpu, seed):
+    """Whatever the dispatcher picks by default (dot2 / matrix-core kernel, kv-head pairs at head_dim 64, the balanced line with its
+    in-launch merge, split-KV with the combine kernel or the workgroup merge) for a random batch -- random head counts and group sizes,
+    both head sizes, pages of 16 / 32 / 64 tokens, batch 1..320, lengths from empty to a few thousand with a few long stragglers,
+    a shuffled block table -- the answer is the C oracle's, twice in a row to the bit."""
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([64, 128]))
+    hk = int(rng.choice([1, 2, 3, 4, 8]))
+    g = int(rng.choice([1, 2, 3, 4, 6, 8]))
+    h = hk * g
+    page = int(rng.choice([16, 32, 64]))
+    dtype = BF16 if seed % 3 else F16
+    B = int(rng.choice([1, 3, 17, 64, 130, 257, 320]))
+    top = int(rng.choice([40, 300, 1500]))
+    top = max(20, min(top, (48 << 20) // (B * hk * d)))                                # (keeps the caches of the largest batches at ~100 MB)
+    lens = rng.integers(0, top + 1, B).astype(np.int32)
+    lens[rng.integers(0, B, max(1, B // 50))] = rng.integers(top, 4 * top + 50)       # stragglers
+    if seed % 4 == 0:
+        lens[:] = int(lens.max())                                                       # a uniform batch now and then
+    nb = int(sum((int(x) + page - 1) // page for x in lens)) + 2
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+    q = rand_half(rng, (B, 1, h, d), dtype)
+    ref = _oracle_decode(q, kc, vc, bt, lens, dtype)
+    out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+    name = gpu.lib.atoma_last_decode_kernel().decode()
+    again, lse2 = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+    assert np.array_equal(out, again) and np.array_equal(lse, lse2), name
+    for i, L in enumerate(lens):
+        assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"seed {seed} {name}: B={B} h={h}/{hk} d={d} page={page} seq {i} (L={L})")
+    empty = lens == 0
+    assert not out[empty].any() and np.isposinf(lse[empty]).all() and np.isfinite(lse[~empty]).all(), name

@@ -144,6 +144,95 @@ def test_wrappers_match_oracle(gpu):
     assert_close(do1.numpy(np.uint16, q1.shape), ref, F16, atol=ATOL_VS_F32[F16], what="kv_cache_full")
 
 
+def test_the_other_forms_of_the_three_ops(gpu):
+    """The twelve convenience forms of csrc/src/lib.rs (:432-572, :1218-1495, :1907-2053) through tensor descriptors: windows as
+    Option (negative = None; (None, Some(0)) is the causal mask -- sliding windows are compiled out of the reference's kernels, so any
+    other window is a no-op there and here), ALiBi slopes against the oracle, seqused_k of the varlen form, and every form bit for bit
+    the form it abbreviates."""
+    ah = gpu
+    rng = np.random.default_rng(31)
+    b, s, h, hk, d = 2, 48, 4, 2, 64
+    q, k, v = rand_half(rng, (b, s, h, d), F16), rand_half(rng, (b, s, hk, d), F16), rand_half(rng, (b, s, hk, d), F16)
+    slopes = (2.0 ** -np.arange(1, h + 1)).astype(np.float32)
+    dq, dk, dv, ds = dev(ah, q), dev(ah, k), dev(ah, v), dev(ah, slopes)
+    tq, tk, tv = ah.tensor(dq, q.shape, F16), ah.tensor(dk, k.shape, F16), ah.tensor(dv, v.shape, F16)
+    ts = ah.tensor(ds, (h,), ah.F32)
+    L = ah.lib
+
+    def run(fn, *args):
+        out = ah.DeviceBuffer(q.nbytes)
+        out.fill_bytes(0xEE)
+        assert fn(*args, ah.ref(ah.tensor(out, q.shape, F16))) == 0, ah.last_error()
+        ah.synchronize()
+        return out.numpy(np.uint16, q.shape)
+    R = ah.ref
+    plain = {c: run(L.atoma_flash_attn, R(tq), R(tk), R(tv), 0.125, c) for c in (0, 1)}
+    assert np.array_equal(run(L.atoma_flash_attn_windowed, R(tq), R(tk), R(tv), 0.125, -1, 0), plain[1])        # (None, Some(0)) = causal
+    assert np.array_equal(run(L.atoma_flash_attn_windowed, R(tq), R(tk), R(tv), 0.125, -1, -1), plain[0])
+    assert np.array_equal(run(L.atoma_flash_attn_windowed, R(tq), R(tk), R(tv), 0.125, 7, 3), plain[0])         # a real window: compiled out
+    assert np.array_equal(run(L.atoma_flash_attn_windowed, R(tq), R(tk), R(tv), 0.125, -1, s + 5), plain[0])    # beyond seqlen_k -> None
+    for causal in (0, 1):
+        got = run(L.atoma_flash_attn_alibi, R(tq), R(tk), R(tv), R(ts), 0.125, causal)
+        ref = A.flash_attn(q, k, v, 0.125, bool(causal), F16, alibi_slopes=slopes)
+        assert_close(got, ref, F16, atol=ATOL_VS_F32[F16], what=f"flash_attn_alibi causal={causal}")
+        assert np.array_equal(run(L.atoma_flash_attn_alibi_windowed, R(tq), R(tk), R(tv), R(ts), 0.125, -1, 0 if causal else -1), got)
+        assert np.array_equal(run(L.atoma_flash_attn_alibi_windowed_with_softcap, R(tq), R(tk), R(tv), R(ts), 0.125, -1, 0 if causal else -1, 30.0), got)
+    assert L.atoma_flash_attn_alibi(R(tq), R(tk), R(tv), None, 0.125, 0, R(tq)) == -1 and "alibi_slopes" in ah.last_error()
+    # varlen forms on the same data packed as two sequences
+    T = b * s
+    cu = np.array([0, s, 2 * s], np.uint32)
+    dcu = dev(ah, cu)
+    tcu = ah.tensor(dcu, (3,), ah.U32)
+    q3, k3, v3 = (ah.tensor(x, shp, F16) for x, shp in ((dq, (T, h, d)), (dk, (T, hk, d)), (dv, (T, hk, d))))
+
+    def run3(fn, *args):
+        out = ah.DeviceBuffer(q.nbytes)
+        out.fill_bytes(0xEE)
+        assert fn(*args, ah.ref(ah.tensor(out, (T, h, d), F16))) == 0, ah.last_error()
+        ah.synchronize()
+        return out.numpy(np.uint16, q.shape)
+    for causal in (0, 1):
+        base = run3(L.atoma_flash_attn_varlen, R(q3), R(k3), R(v3), R(tcu), R(tcu), s, s, 0.125, causal)
+        assert np.array_equal(base, plain[causal])                                   # the padded and the packed op agree to the bit here
+        assert np.array_equal(run3(L.atoma_flash_attn_varlen_windowed, R(q3), R(k3), R(v3), R(tcu), R(tcu), s, s, 0.125, -1, 0 if causal else -1), base)
+        al = run3(L.atoma_flash_attn_varlen_alibi, R(q3), R(k3), R(v3), R(ts), R(tcu), R(tcu), s, s, 0.125, causal)
+        ref = A.flash_attn_varlen(q.reshape(T, h, d), k.reshape(T, hk, d), v.reshape(T, hk, d), cu.astype(np.int32), cu.astype(np.int32), 0.125, bool(causal), F16,
+                                  alibi_slopes=slopes)
+        assert_close(al.reshape(T, h, d), ref, F16, atol=ATOL_VS_F32[F16], what=f"flash_attn_varlen_alibi causal={causal}")
+        assert np.array_equal(run3(L.atoma_flash_attn_varlen_alibi_windowed, R(q3), R(k3), R(v3), R(ts), R(tcu), R(tcu), s, s, 0.125, -1, 0 if causal else -1), al)
+        assert np.array_equal(run3(L.atoma_flash_attn_varlen_full, R(q3), R(k3), R(v3), R(ts), R(tcu), R(tcu), s, s, 0.125, -1, 0 if causal else -1, None, None, 0.0), al)
+    # seqused_k: only the first `used` keys of every sequence take part (block_info.h:16-23)
+    used = np.array([20, 33], np.uint32)
+    du = dev(ah, used)
+    got = run3(L.atoma_flash_attn_varlen_full, R(q3), R(k3), R(v3), None, R(tcu), R(tcu), s, s, 0.125, -1, -1, None, R(ah.tensor(du, (b,), ah.U32)), 0.0)
+    for i in range(b):
+        ref = A.flash_attn(q[i:i + 1], k[i:i + 1, :used[i]], v[i:i + 1, :used[i]], 0.125, False, F16)
+        assert_close(got[i:i + 1], ref, F16, atol=ATOL_VS_F32[F16], what=f"varlen_full seqused_k seq {i}")
+    # kv-cache forms (one query row per sequence, contiguous caches)
+    q1 = rand_half(rng, (b, 1, h, d), F16)
+    dq1 = dev(ah, q1)
+    tq1 = ah.tensor(dq1, q1.shape, F16)
+    lens = np.array([17, 48], np.uint32)
+    dl = dev(ah, lens)
+    tl = ah.tensor(dl, (b,), ah.U32)
+
+    def run1(fn, *args):
+        out = ah.DeviceBuffer(q1.nbytes)
+        assert fn(*args, ah.ref(ah.tensor(out, q1.shape, F16))) == 0, ah.last_error()
+        ah.synchronize()
+        return out.numpy(np.uint16, q1.shape)
+    full = run1(L.atoma_flash_attn_kv_cache_full, R(tq1), R(tk), R(tv), None, 0.125, None, None, 1)
+    assert np.array_equal(run1(L.atoma_flash_attn_kv_cache, R(tq1), R(tk), R(tv), 0.125, 1), full)
+    with_lens = run1(L.atoma_flash_attn_kv_cache_full, R(tq1), R(tk), R(tv), None, 0.125, None, R(tl), 0)
+    assert np.array_equal(run1(L.atoma_flash_attn_kv_cache_windowed, R(tq1), R(tk), R(tv), R(tl), 0.125, -1, -1), with_lens)
+    al = run1(L.atoma_flash_attn_kv_cache_alibi, R(tq1), R(tk), R(tv), R(ts), R(tl), 0.125, 1)
+    ref = A.flash_attn_kv_cache(q1, k, v, 0.125, F16, None, lens.astype(np.int32), causal=True, alibi_slopes=slopes)
+    assert_close(al, ref, F16, atol=ATOL_VS_F32[F16], what="flash_attn_kv_cache_alibi")
+    al_all = run1(L.atoma_flash_attn_kv_cache_alibi_windowed, R(tq1), R(tk), R(tv), R(ts), 0.125, -1, 0)
+    ref = A.flash_attn_kv_cache(q1, k, v, 0.125, F16, None, None, causal=True, alibi_slopes=slopes)
+    assert_close(al_all, ref, F16, atol=ATOL_VS_F32[F16], what="flash_attn_kv_cache_alibi_windowed")
+
+
 def test_copy_and_swap_through_tensor_api(gpu):
     ah = gpu
     rng = np.random.default_rng(29)

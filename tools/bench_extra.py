@@ -13,6 +13,8 @@ import ctypes as C
 import os
 import sys
 
+import time
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,9 +28,17 @@ import tp_step as TS  # noqa: E402
 HBM_PEAK, MFMA_PEAK_BF16 = 8e12, 2.5e15
 
 
+WARM_MS = float(os.environ.get("ATOMA_BENCH_WARM_MS", "60"))
+
+
 def _timed(stream, fn, iters, warm=2):
-    for _ in range(warm):
+    """Mean time per call at the device's SUSTAINED clocks: the warm-up lasts at least WARM_MS of device time (after the uploads that precede
+    every case the device needs ~30 ms of load to leave its idle power state: tools/probes/warm_probe.py, profiles/r04_clock_ramp_probe.txt)."""
+    t0, n = time.perf_counter(), 0
+    while n < warm or (time.perf_counter() - t0) * 1e3 < WARM_MS:
         fn()
+        stream.synchronize()
+        n += 1
     stream.synchronize()
     a, b = ah.Event(), ah.Event()
     a.record(stream.s)

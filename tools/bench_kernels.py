@@ -24,10 +24,19 @@ from halfs import BF16, from_f32  # noqa: E402  (atoma-infer_amd/bindings/halfs.
 HBM, MFMA_BF16 = 8000.0, 2500.0  # GB/s, TFLOP/s dense (MI355X_MICROARCH.md)
 
 
+WARM_MS = float(os.environ.get("ATOMA_BENCH_WARM_MS", "60"))
+
+
 def timeit(fn, iters=20, warmup=3):
-    for _ in range(warmup):
+    """Mean time of `iters` back-to-back calls AT THE DEVICE'S SUSTAINED CLOCKS: the warm-up runs for at least WARM_MS of device time.
+    After half a second of idling (an upload, a host-side oracle) an MI355X needs ~30 ms of load to return to its sustained clocks; ten
+    calls of a 0.6 ms kernel timed after two warm-up calls read 833 TF/s where the steady state is 1020 (tools/probes/warm_probe.py,
+    profiles/r04_clock_ramp_probe.txt) -- a serving engine never idles that long between steps."""
+    t0, n = time.perf_counter(), 0
+    while n < warmup or (time.perf_counter() - t0) * 1e3 < WARM_MS:
         fn()
-    ah.synchronize()
+        ah.synchronize()
+        n += 1
     a, b = ah.Event(), ah.Event()
     a.record(None)
     for _ in range(iters):
@@ -174,10 +183,11 @@ def bench_decode_fp8():
 
 
 def bench_prefill():
-    cfg = int(os.environ.get("ATOMA_PREFILL_CFG", "0"))
-    ah.lib.atoma_set_option(b"prefill_cfg", cfg)
+    """Every shape on the default kernel (prefill_cfg 4: the hand-scheduled stream for head_dim 128) and on round 2's kernel (cfg 0) beside it;
+    ATOMA_PREFILL_CFG = one configuration only."""
+    cfgs = (int(os.environ["ATOMA_PREFILL_CFG"]),) if os.environ.get("ATOMA_PREFILL_CFG") else (4, 0)
     rng = np.random.default_rng(1)
-    shapes = ((2048, 4, 128), (4096, 2, 128), (512, 16, 128), (2048, 16, 128), (2048, 16, 64))
+    shapes = ((2048, 4, 128), (4096, 2, 128), (4096, 4, 128), (512, 16, 128), (2048, 16, 128), (2048, 16, 64))
     if os.environ.get("ATOMA_BENCH_PREFILL_SHAPE"):    # e.g. "2048x16x128": one shape, for counter passes
         shapes = (tuple(int(t) for t in os.environ["ATOMA_BENCH_PREFILL_SHAPE"].split("x")),)
     for S, nseq, d in shapes:
@@ -191,9 +201,14 @@ def bench_prefill():
             ah.run_mha(q, k, v, o, b=nseq, h=h, h_k=hk, d=d, seqlen_q=S, seqlen_k=S, softmax_scale=d ** -0.5, is_bf16=1,
                        q_strides=(0, h * d, d), o_strides=(0, h * d, d), k_strides=(0, hk * d, d), v_strides=(0, hk * d, d),
                        is_causal=1, cu_seqlens_q=cu, cu_seqlens_k=cu)
-        ms = timeit(run, iters=10)
-        flops = 4 * S * S * h * d / 2 * nseq
-        emit(f"P1 prefill causal varlen S={S} x{nseq} d={d} (32 q / 8 kv heads) cfg={cfg}", ms, flops=flops, tokens_per_s=round(T / (ms * 1e-3)))
+        for cfg in cfgs:
+            if d != 128 and cfg == 4 and 0 in cfgs:
+                continue                                  # (head_dim 64 runs on cfg 0 either way)
+            ah.lib.atoma_set_option(b"prefill_cfg", cfg)
+            ms = timeit(run, iters=10)
+            flops = 4 * S * S * h * d / 2 * nseq
+            emit(f"P1 prefill causal varlen S={S} x{nseq} d={d} (32 q / 8 kv heads) cfg={cfg}", ms, flops=flops, tokens_per_s=round(T / (ms * 1e-3)))
+        ah.lib.atoma_set_option(b"prefill_cfg", 4)
         for b_ in (q, k, v, o, cu):
             b_.free()
 

@@ -20,6 +20,13 @@ for f in glob.glob(os.path.join(root, "gpurun_out", f"pfprof_{tag}", "*kernel_st
     for r in csv.DictReader(open(f)):
         if KERNEL in r["Name"]:
             dur, name = float(r["AverageNs"]), r["Name"]
+# the sustained-clock duration: the last 10 launches of the trace (the timed ones; the 60 ms of warm-up launches before them include the clock ramp)
+for f in glob.glob(os.path.join(root, "gpurun_out", f"pfprof_{tag}", "*kernel_trace.csv")):
+    rows = [r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    d10 = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[-10:]]
+    if d10:
+        dur_all, dur = dur, sum(d10) / len(d10)
 ctr = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, "gpurun_out", f"pfpmc_{tag}_*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
@@ -45,6 +52,7 @@ if c.get("SQ_WAVE_CYCLES"):
               "SQ_ACTIVE_INST_VMEM"):
         if k in c:
             res[k.lower()[3:] + "_frac_of_wave_cycles"] = round(c[k] / c["SQ_WAVE_CYCLES"], 4)
-res["note"] = "counter passes run slower than un-profiled launches (lower clock under the profiler); duration_ns is from the --kernel-trace --stats pass"
+res["note"] = ("duration_ns = mean of the last 10 launches of the --kernel-trace pass (sustained clocks: 60 ms of warm-up launches precede them); the counters are "
+               "means over all launches of their own passes (cycle and instruction counts do not depend on the clock)")
 json.dump(res, open(os.path.join(out, f"{tag}_prefill_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -75,9 +75,13 @@ def step_bytes(c, B, ctx):
     return w + 2 * B * (ctx + 1) * c.hk * c.d * 2 * c.layers
 
 
-def timed(stream, fn, iters):
-    fn()
-    stream.synchronize()
+def timed(stream, fn, iters, warm_ms=60.0):
+    import time
+    t0, n = time.perf_counter(), 0
+    while n < 1 or (time.perf_counter() - t0) * 1e3 < warm_ms:     # at least warm_ms of device time: sustained clocks (tools/probes/warm_probe.py)
+        fn()
+        stream.synchronize()
+        n += 1
     a, b = ah.Event(), ah.Event()
     a.record(stream.s)
     for _ in range(iters):
