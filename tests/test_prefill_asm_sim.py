@@ -67,6 +67,23 @@ def test_two_persistent_workgroups_and_the_kernels_own_choice_of_arithmetic():
     run_case([600], 2, 1, False, auto=True, g=3)
 
 
+def test_split_request_variant_of_the_block_boundary(monkeypatch):
+    """PFA_SPLIT_REQ=1 (an experiment kept in the generator: K(0), K(1) ride in the epilogue, V(0), K(2) under the S(0) products, V(1) with
+    K(3) around the mask / max sections -- measured level, profiles/r04_prefill_split_requests_ab.txt): another order of the same requests,
+    other wait counts; both DMA timings, idle wavefronts, empty entries, a block without any key"""
+    harness = H
+    monkeypatch.setenv("PFA_SPLIT_REQ", "1")
+    saved = dict(harness._progs)
+    harness._progs.clear()
+    try:
+        run_case([700, 33, 300], 2, 1, True, auto=True, g=2)
+        run_case([700], 1, 1, True, late_dma=False, reverse=True)
+        run_case([100, 40, 70], 1, 1, True, lens_k=[400, 10, 0], exact=True)
+    finally:
+        harness._progs.clear()
+        harness._progs.update(saved)
+
+
 def test_f16_and_more_queries_than_keys_and_empty():
     run_case([513], 1, 1, True, dtype=F16)
     run_case([100, 40, 70], 1, 1, True, lens_k=[400, 10, 0], exact=True)

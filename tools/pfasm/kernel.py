@@ -250,6 +250,7 @@ class Builder:
         assert not (timing and paged)
         self.dtype, self.paged, self.timing = dtype, paged, timing
         self.persistent = not paged
+        self.split_req = self.persistent and os.environ.get("PFA_SPLIT_REQ", "0") != "0"   # (experiment, measured level to 2 % worse: profiles/r04_prefill_split_requests_ab.txt) the first five K/V tiles of a block: two with the epilogue, three under the prologue's products
         self.inp = inputs or (dict(param=S(4)) if paged else dict(tab=S(4, 2), first=S(6), n=S(7), g=S(8), wave=S(9), dbg=S(10, 2), g2=S(12)))
         self.exact, self.sfx = False, ""
         self.mfma = "v_mfma_f32_32x32x16_" + dtype
@@ -873,9 +874,19 @@ class Builder:
             e("s_mov_b32", S_VSOFF, 0)
         self.request_tile(False, 0)
         self.request_tile(False, 1)
-        self.request_tile(True, 2)
-        self.request_tile(False, 2)
-        self.request_tile(True, 0)
+        if not self.split_req:
+            self.request_tile(True, 2)
+            self.request_tile(False, 2)
+            self.request_tile(True, 0)
+
+    def req_items(self, tiles):
+        """the requests of K/V tiles [(is_v, ring slot)] as scheduler items (contiguous K/V): 4 pieces + the offset step per tile"""
+        items = []
+        for is_v, slot in tiles:
+            its = self.dma_tile(is_v)
+            its[0].ins = [Ins("s_add_u32", S_KDMA, S_W1024, slot * SLOT)] + its[0].ins
+            items += its
+        return items
 
     def q_offsets(self, regs, rows=None, ns=None, hi=None, tmp=None):
         """per-lane byte offsets of the Q rows of both slots -> regs[0..1]; a slot that sees no key reads (harmlessly) the head of
@@ -938,7 +949,9 @@ class Builder:
         first = True
         if os.environ.get("PFA_EXP", "") == "noreq":          # TIMING EXPERIMENT ONLY (wrong results): what the K/V requests between two blocks cost
             return groups
-        for is_v, slot in ((False, 0), (False, 1), (True, 2), (False, 2), (True, 0)):
+        # (split_req: only K(0) and K(1) ride in the epilogue -- 20 pieces back to back stall the issue for 210 cycles each, the CU's LDS-DMA
+        #  rate; V(0), K(2) go out under the S(0) products of pro_compute, V(1) with K(3) between its mask / max sections)
+        for is_v, slot in (((False, 0), (False, 1)) if self.split_req else ((False, 0), (False, 1), (True, 2), (False, 2), (True, 0))):
             items = self.dma_tile(is_v)
             head = [Ins("s_add_u32", S_KDMA, S_W1024, slot * SLOT)]
             if first:
@@ -1002,14 +1015,16 @@ class Builder:
                             Ins("v_accvgpr_write_b32", QA(s, j)[k], lo)]
             return out
 
+        split = self.split_req
+
         def k0_fragments():
-            e("s_waitcnt", vmcnt=16)
+            e("s_waitcnt", vmcnt=4 if split else 16)
             e("s_barrier")                                         # K(0) landed
             P.extend(self.stamp(4, "block"))
             P.extend(self.k_reads())                               # KAD points at slot 0 here
             e("s_waitcnt", lgkmcnt=0)
             self.nop(2)
-        e("s_waitcnt", vmcnt=20)                                   # Q arrived (first on the queue: 20 K/V pieces were issued after it)
+        e("s_waitcnt", vmcnt=8 if split else 20)                   # Q arrived (first on the queue: the K/V pieces were issued after it)
         for exact, tag in ((False, "F"), (True, "X")):
             if not exact:
                 e("s_bitcmp1_b32", W("flags"), 0)
@@ -1025,24 +1040,36 @@ class Builder:
             k0_fragments()
             a = [Item(i, -1, max(2 * j - 3, -1)) for j in range(2, 8) for i in q_to_acc(0, exact, (j,))]
             b = [Item(i, -1, 13 + 2 * j) for j in range(8) for i in q_to_acc(1, exact, (j,))]
-            P.extend(schedule(self.qk_mfmas(0, [0]) + self.qk_mfmas(0, [1]), [a, b], cap=12))
+            c = self.req_items(((True, 2), (False, 2))) if split else []          # V(0), K(2): spread over the 32 products
+            for i, it in enumerate(c):
+                it.deadline = 2 + (i * 28) // max(len(c), 1)
+            P.extend(schedule(self.qk_mfmas(0, [0]) + self.qk_mfmas(0, [1]), [a, b, c], cap=12))
             e("s_branch", "PRO_K1")
             # ---- slot 1 only ----
             P.label(one)
             P.extend(q_to_acc(1, exact, (0, 1)))
             k0_fragments()
             a = [Item(i, -1, max(2 * j - 3, -1)) for j in range(2, 8) for i in q_to_acc(1, exact, (j,))]
-            P.extend(schedule(self.qk_mfmas(0, [1]), [a], cap=12))
+            c = self.req_items(((True, 2), (False, 2))) if split else []
+            for i, it in enumerate(c):
+                it.deadline = 1 + (i * 14) // max(len(c), 1)
+            P.extend(schedule(self.qk_mfmas(0, [1]), [a, c], cap=12))
             if not exact:
                 e("s_branch", "PRO_K1")
         # ---- K(1) fragments (K(1) sits in slot 1); K(3) may now replace K(0) ----
         P.label("PRO_K1")
-        e("s_waitcnt", vmcnt=12)
+        e("s_waitcnt", vmcnt=8 if split else 12)
         e("s_barrier")
         P.extend(self.k_reads(extra=SLOT))
         for j in range(8):
             e("v_add_u32", KAD[j], 2 * SLOT, KAD[j])               # next K read: K(2) in slot 2
-        self.request_tile(False, 0)
+        # K(3) into K(0)'s slot [+ V(1)]: the pieces in three portions around the two slots' mask / max sections
+        late = self.req_items(((False, 0), (True, 0))) if split else None
+        if not split:
+            self.request_tile(False, 0)
+        portions = [late[0:3], late[3:7], late[7:]] if split else [[], [], []]
+        for it in portions[0]:
+            P.extend(it.ins)
         # ---- [mask] + row max of tile 0, the rows' first reference ----
         e("s_mov_b32", S_T1, 0)                                    # kv1 = 0 for the mask code
         self.nop(MFMA_SAFE)
@@ -1060,23 +1087,30 @@ class Builder:
                 P.extend(it.ins)
             self.first_reference(0, s)
             P.label(skip)
+            for it in portions[1 + s]:
+                P.extend(it.ins)
         self.nop(MFMA_SRCC_SAFE)
         e("s_branch", "PRO_ENTRY")
         # ---- no row of this wavefront sees a key: only the barriers and its share of the DMA ----
         P.label("PRO_IDLE")
+        if split:
+            self.request_tile(True, 2)                            # V(0), K(2): this wavefront's share (nobody else requests its rows)
+            self.request_tile(False, 2)
         if self.persistent:                                       # this wavefront has no draining iteration: its share of the next block's Q goes out here
-            e("s_waitcnt", vmcnt=20, lgkmcnt=0)                    # (behind this block's own -- unused -- Q loads: same registers)
+            e("s_waitcnt", vmcnt=16 if split else 20, lgkmcnt=0)   # (behind this block's own -- unused -- Q loads: same registers)
             v, loads = self.qpre_code()
             P.extend(v + loads)
-        e("s_waitcnt", vmcnt=16 + (16 if self.persistent else 0))
+        e("s_waitcnt", vmcnt=(12 if split else 16) + (16 if self.persistent else 0))
         e("s_barrier")
-        e("s_waitcnt", vmcnt=12 + (16 if self.persistent else 0))
+        e("s_waitcnt", vmcnt=(8 if split else 12) + (16 if self.persistent else 0))
         e("s_barrier")
         for j in range(8):
             e("v_add_u32", KAD[j], 2 * SLOT, KAD[j])
         self.request_tile(False, 0)
+        if split:
+            self.request_tile(True, 0)
         if self.persistent:
-            e("s_waitcnt", vmcnt=8 + 16, lgkmcnt=0)                # (the 16 prefetch loads are younger than V(0), K(2))
+            e("s_waitcnt", vmcnt=8 + 16, lgkmcnt=0)                # (the 16 prefetch loads are younger than V(0), K(2); K(3), V(1) younger still)
             e("s_branch", "PRO_ENTRY_STATE")
         P.label("PRO_ENTRY")
         e("s_waitcnt", vmcnt=8, lgkmcnt=0)
@@ -1181,14 +1215,18 @@ class Builder:
         are dead by now (the K fragments), the NEXT block's entry is fetched and its Q rows and first K/V tiles requested
         (new_block), and only then this block's O is normalised and stored: the requests' round trips ride under the stores."""
         e, P = self.e, self.p
-        P.label("BLOCK_DRAIN")             # no K/V tile at all: the requests in flight must land before the ring is reused
         if self.persistent:
+            P.label("BLOCK_DRAIN")         # no K/V tile at all: every request in flight must land before the ring is reused
+            e("s_waitcnt", vmcnt=0, lgkmcnt=0)
+            e("s_branch", "BLOCK_END_BAR")
             P.label("BLOCK_END_Q")         # the 16 youngest requests are the next block's Q rows (accumulator registers): only the ring's must have landed
             P.extend(self.stamp(3))
             P.extend(self.stamp(None, "block"))
             self.nop(MFMA_SAFE)
             e("s_waitcnt", vmcnt=16, lgkmcnt=0)
             e("s_branch", "BLOCK_END_BAR")
+        if not self.persistent:
+            P.label("BLOCK_DRAIN")
         P.label("BLOCK_END")
         P.extend(self.stamp(3))
         P.extend(self.stamp(None, "block"))
