@@ -9,6 +9,7 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 (timeout 1200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -60) > $OUT/pytest_gpu_$TAG.log
 (timeout 600 python bench.py 2>&1 | tail -2) > $OUT/bench_$TAG.log
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2) > $OUT/smoke_$TAG.log
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o decode -- python $REPO/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra --no-traffic > $OUT/prof_$TAG.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -o decode -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-traffic > $OUT/pmc_fetch_$TAG.log 2>&1
@@ -23,4 +24,4 @@ cd $REPO
 (timeout 400 python tools/engine_trace.py 2>&1 | tail -1) > $OUT/trace_$TAG.json
 (timeout 400 python tools/engine_trace.py --model 70b-tp8-shard --requests 64 --prompt 4096 --decode-steps 256 2>&1 | tail -1) > $OUT/trace_70b_tp8_rank_$TAG.json
 (timeout 400 python tools/tp_step.py --steps 10 2>&1 | tail -1) > $OUT/tp_step_n1_$TAG.json
-find $OUT/prof_$TAG -name "*stats*" | head; tail -3 $OUT/pytest_gpu_$TAG.log; cat $OUT/bench_$TAG.log | cut -c1-600
+find $OUT/prof_$TAG -name "*stats*" | head; tail -3 $OUT/pytest_gpu_$TAG.log; cat $OUT/smoke_$TAG.log; cat $OUT/bench_$TAG.log | cut -c1-600
