@@ -1215,43 +1215,63 @@ class Builder:
         are dead by now (the K fragments), the NEXT block's entry is fetched and its Q rows and first K/V tiles requested
         (new_block), and only then this block's O is normalised and stored: the requests' round trips ride under the stores."""
         e, P = self.e, self.p
-        if self.persistent:
-            P.label("BLOCK_DRAIN")         # no K/V tile at all: every request in flight must land before the ring is reused
-            e("s_waitcnt", vmcnt=0, lgkmcnt=0)
-            e("s_branch", "BLOCK_END_BAR")
-            P.label("BLOCK_END_Q")         # the 16 youngest requests are the next block's Q rows (accumulator registers): only the ring's must have landed
+        stash = ["o0_lo", "o0_hi", "o0_bytes", "o0_flags", "lse0_lo", "lse0_hi", "rows0", "mscale",
+                 "o1_lo", "o1_hi", "o1_bytes", "o1_flags", "lse1_lo", "lse1_hi", "rows1", "o_stride"]
+        if not self.persistent:
+            P.label("BLOCK_DRAIN")
+            P.label("BLOCK_END")
             P.extend(self.stamp(3))
             P.extend(self.stamp(None, "block"))
             self.nop(MFMA_SAFE)
-            e("s_waitcnt", vmcnt=16, lgkmcnt=0)
-            e("s_branch", "BLOCK_END_BAR")
-        if not self.persistent:
-            P.label("BLOCK_DRAIN")
-        P.label("BLOCK_END")
-        P.extend(self.stamp(3))
-        P.extend(self.stamp(None, "block"))
-        self.nop(MFMA_SAFE)
-        e("s_waitcnt", vmcnt=0, lgkmcnt=0)
-        P.label("BLOCK_END_BAR")
-        e("s_barrier")                     # every wavefront is done with the ring and with its requests
-        P.extend(self.stamp(0, "block"))
-        if not self.persistent:
+            e("s_waitcnt", vmcnt=0, lgkmcnt=0)
+            e("s_barrier")                     # every wavefront is done with the ring and with its requests
+            P.extend(self.stamp(0, "block"))
             e("v_mbcnt_lo_u32_b32", TMP[9], -1, 0)
             e("v_mbcnt_hi_u32_b32", TMP[9], -1, TMP[9])
             self.epi_slot(0, "A", S_ODESC[0], [W("lse0_lo"), W("lse0_hi")], S_ROWS[0], S_OST, W("mscale"))
             self.epi_slot(1, "A", S_ODESC[1], [W("lse1_lo"), W("lse1_hi")], S_ROWS[1], S_OST, W("mscale"))
             P.label("KERNEL_END")
             return
-        stash = ["o0_lo", "o0_hi", "o0_bytes", "o0_flags", "lse0_lo", "lse0_hi", "rows0", "mscale",
-                 "o1_lo", "o1_hi", "o1_bytes", "o1_flags", "lse1_lo", "lse1_hi", "rows1", "o_stride"]
+        # Persistent.  Three ways in, differing in what must have landed before the ring is reused (S_T = 1: everything but the 16 youngest
+        # requests -- the next block's Q rows, on their way into accumulator registers).  The epilogue's parameters move to the (dead) K
+        # fragment registers and the NEXT entry's fetch goes out BEFORE the drain wait and the barrier: its round trip to memory (1.2k
+        # cycles after the barrier, `profiles/r04_prefill_block_regions.txt`) rides under them.
+        P.label("BLOCK_DRAIN")             # no K/V tile at all: every request in flight must land
+        e("s_mov_b32", S_T, 0)
+        e("s_branch", "BLOCK_END_COMMON")
+        P.label("BLOCK_END_Q")
+        P.extend(self.stamp(3))
+        P.extend(self.stamp(None, "block"))
+        e("s_mov_b32", S_T, 1)
+        e("s_branch", "BLOCK_END_COMMON")
+        P.label("BLOCK_END")
+        P.extend(self.stamp(3))
+        P.extend(self.stamp(None, "block"))
+        e("s_mov_b32", S_T, 0)
+        P.label("BLOCK_END_COMMON")
+        self.nop(MFMA_SAFE)
         for k, name in enumerate(stash):
             e("v_accvgpr_write_b32", A(192 + k), W(name))
         e("s_mov_b32", S_HASNEXT, 1)
-        e("s_mov_b32", S_T, 0)
         e("s_mov_b32", S_T1, S_SAVE[5])                           # 1: the next entry's Q rows are already in (or on their way to) QA
         P.extend(self.advance())
         e("s_cmp_lt_u32", S_BLK, S_NENT)
-        e("s_cbranch_scc1", "FETCH_ENTRY")
+        e("s_cbranch_scc0", "BLOCK_END_WAIT")
+        e("s_waitcnt", lgkmcnt=0)                                  # (a peeked entry nobody consumed may still be on its way into the window)
+        self.load_entry()
+        P.label("BLOCK_END_WAIT")
+        e("s_cmp_eq_u32", S_T, 1)
+        e("s_cbranch_scc1", "BLOCK_END_WAITQ")
+        e("s_waitcnt", vmcnt=0, lgkmcnt=0)
+        e("s_branch", "BLOCK_END_BAR")
+        P.label("BLOCK_END_WAITQ")
+        e("s_waitcnt", vmcnt=16, lgkmcnt=0)
+        P.label("BLOCK_END_BAR")
+        e("s_barrier")                     # every wavefront is done with the ring and with its requests
+        P.extend(self.stamp(0, "block"))
+        e("s_mov_b32", S_T, 0)
+        e("s_cmp_lt_u32", S_BLK, S_NENT)
+        e("s_cbranch_scc1", "CHECK_ENTRY")
         def epilogue(tag, woven, with_q=True):
             e("s_mov_b32", S_HASNEXT, 0)
             e("v_mbcnt_lo_u32_b32", TMP[9], -1, 0)
@@ -1274,6 +1294,8 @@ class Builder:
                 e("v_readfirstlane_b32", S_TMP[3], TMP[10])             # mscale (slot 0's stash holds it; slot 1's has the stride instead)
                 self.epi_slot(s_, tag, S(S_SAVE[0].idx, 4), [S_SAVE[4], S_SAVE[5]], S_SAVE[6], S_TMP[2], S_TMP[3],
                               weave=groups[:half] if s_ == 0 else groups[half:])
+                if woven:
+                    P.extend(self.stamp(2 + s_, "block"))          # timer build: the epilogue of slot s_ with its share of the woven requests
         P.label("EPI_BOTH")                    # no next block: the plain epilogue
         P.extend(self.stamp(1, "block"))
         epilogue("B", False)
@@ -1283,13 +1305,11 @@ class Builder:
         P.extend(self.stamp(1, "block"))       #  instructions.  (Taken when the Q rows did not go out with the last iteration: an empty entry was
         e("s_waitcnt", vmcnt=0)                #  skipped, or the block had no tile -- whatever that iteration requested into QA lands first.)
         epilogue("C", True)
-        P.extend(self.stamp(None, "block"))
         P.extend(self.stamp(5))
         e("s_branch", "PRO_COMPUTE")
         P.label("EPI_WOVEN_NOQ")
         P.extend(self.stamp(1, "block"))
         epilogue("D", True, with_q=False)
-        P.extend(self.stamp(None, "block"))
         P.extend(self.stamp(5))
         e("s_branch", "PRO_COMPUTE")
         P.label("KERNEL_END")

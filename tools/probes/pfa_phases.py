@@ -43,7 +43,8 @@ for S, nseq, causal, ek in shapes:
     it = nseq * h * sum(nt) / nwg                                        # iterations per wavefront
     bpw = nblk / nwg                                                     # blocks per workgroup
     if BLOCK:
-        names = ["drain+barrier", "next entry fetched", "Q addresses + loads issued", "5 K/V tiles requested", "Q wait + first d-steps + K(0) barrier", "S(0) .. loop entry"]
+        names = ["drain+barrier", "stash + next entry fetched", "epilogue slot 0 (+ woven requests)", "epilogue slot 1 (+ woven requests)",
+                 "peek + state + Q wait + first d-steps + K(0) barrier", "S(0) .. loop entry"]
         print(f"S={S} x{nseq} causal={causal} exact_keys={ek}: cycles per block:", {n: int(t[:, i].mean() / bpw) for i, n in enumerate(names)}, flush=True)
         continue
     names = ["phase1", "phase2", "wait+barrier", "control", "prologue", "epilogue"]
