@@ -7,7 +7,7 @@ import pytest
 
 from oracle import attn_oracle as A
 from oracle.halfs import BF16, to_f32
-from util import rand_half, make_paged_cache, assert_close, ATOL_VS_F32
+from util import rand_half, make_paged_cache, assert_close, ATOL_VS_F32, c_attention, attn_atol
 
 pytestmark = pytest.mark.gpu
 
@@ -244,3 +244,55 @@ def test_scratch_growth_keeps_captured_graphs_valid(gpu):
     assert_close(small_o.numpy(np.uint16, small_shape), small_ref, BF16, atol=ATOL_VS_F32[BF16], what="replay after the scratch grew")
     del g
     assert gpu.lib.atoma_release_workspaces() == 0
+
+
+def test_balanced_line_replays_with_other_lengths(gpu):
+    """The balanced line plans on the device and merges cut sequences inside the launch (arrival counters that return to zero): ONE captured
+    graph must serve batches whose lengths change between replays -- ragged, uniform, with empty sequences, with a straggler -- and a
+    counter reset between two replays (atoma_reset_sync_counters, for hosts that saw a failed launch) must not change a bit."""
+    rng = np.random.default_rng(77)
+    B, h, hk, d, page, cap = 272, 8, 4, 128, 16, 3000
+    pps = (cap + page - 1) // page
+    nb = B * pps
+    kc, vc = rand_half(rng, (nb, page, hk, d), BF16), rand_half(rng, (nb, page, hk, d), BF16)
+    bt = rng.permutation(nb).astype(np.int32).reshape(B, pps)
+    q = rand_half(rng, (B, 1, h, d), BF16)
+    dq, dk, dv, dbt = (gpu.DeviceBuffer.from_numpy(a) for a in (q, kc, vc, bt))
+    dl = gpu.DeviceBuffer.zeros((B,), np.int32)
+    do = gpu.DeviceBuffer(q.nbytes)
+    st = gpu.Stream()
+
+    def call():
+        gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=pps * page, softmax_scale=d ** -0.5, is_bf16=BF16,
+                    q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d),
+                    v_strides=(page * hk * d, hk * d, d), cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt,
+                    block_table_batch_stride=pps, page_block_size=page, force_split_kernel=True, unpadded_lse=False, stream=st.s)
+    first = rng.integers(1, cap, B).astype(np.int32)
+    dl.upload(first)
+    call()                                   # eager once: scratch and counters exist
+    st.synchronize()
+    assert "balanced" in gpu.lib.atoma_last_decode_kernel().decode()
+    with gpu.Graph.capture(st) as g:
+        call()
+    batches = [first, np.full(B, 1777, np.int32), rng.integers(0, 40, B).astype(np.int32)]
+    strag = rng.integers(1, 100, B).astype(np.int32)
+    strag[200] = cap
+    batches.append(strag)
+    batches.append(rng.integers(cap // 2, cap, B).astype(np.int32))
+    for i, lens in enumerate(batches):
+        dl.upload(lens)
+        do.fill_bytes(0xEE)
+        g.launch()
+        st.synchronize()
+        got = do.numpy(np.uint16, q.shape).copy()
+        ref = c_attention(q, kc, vc, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=pps * page, scale=d ** -0.5, is_bf16=BF16, q_strides=(h * d, h * d, d),
+                          k_strides=(page * hk * d, hk * d, d), v_strides=(page * hk * d, hk * d, d), o_shape=q.shape, o_strides=(h * d, h * d, d), cu_k=lens,
+                          k_cumulative=False, block_table=bt, page=page)
+        for j, L in enumerate(lens):
+            assert_close(got[j], ref[j], BF16, atol=attn_atol(BF16, L), what=f"replay {i} seq {j} (L={L})")
+        assert not got[lens == 0].any()
+        if i == 2:
+            assert gpu.lib.atoma_reset_sync_counters(st.s) == 0, gpu.last_error()
+        g.launch()
+        st.synchronize()
+        assert np.array_equal(got, do.numpy(np.uint16, q.shape)), f"replay {i} twice"
