@@ -323,7 +323,7 @@ template <bool STREAM, int NWG = 1, typename F, typename M = DecodeNoMerge> __de
         // position of this wavefront on the line.  The line is kv-head major, so wavefronts w and w + W / 8 walk the same
         // sequences of adjacent heads: with 8 wavefronts per workgroup, give the 8 of a workgroup those ranges (W is a multiple of 8)
         if (stream && wid >= p0.stream_waves) return;      // the line is shared by stream_waves wavefronts; the grid may hold more
-        if (stream && p0.line_merge) {
+        if (stream && p0.line_merge == 1) {
             for (int e = wid; e < p0.b; e += p0.stream_waves)
                 if (__builtin_amdgcn_readfirstlane(cum[e]) == __builtin_amdgcn_readfirstlane(cum[e + 1])) merger.zero(&p0, e);
         }
@@ -371,7 +371,7 @@ template <bool STREAM, int NWG = 1, typename F, typename M = DecodeNoMerge> __de
             }
             item(p, wk);
             if (!stream) break;
-            if (wk.partial && p.line_merge) {
+            if (wk.partial && p.line_merge == 1) {
                 // w0 / w1: the wavefronts of the line that hold the first / last tile of this sequence
                 const int c0 = __builtin_amdgcn_readfirstlane(cum[b]);
                 const int64_t s0 = (int64_t)hkc * pl.T + c0;

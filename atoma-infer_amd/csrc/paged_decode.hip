@@ -628,6 +628,18 @@ __device__ __forceinline__ void paged_decode_mqk_item(const DecodeParams &p, con
             *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + col * 8) = w4;
             if (p.lse && col == 0) p.lse[(int64_t)b * p.h + hq] = lse;
         } else {
+#ifdef ATOMA_DECODE_CUT_PROBE
+            if (p.line_merge == 3) continue;      // TIMING PROBE ONLY: the cut pieces are not even stored
+            if (p.line_merge == 5 && (wk.prow / p.group_tile) % 2 == 1) continue;   // ... only a wavefront's FIRST piece is stored (slot 0)
+            if (p.line_merge == 6 && (wk.prow / p.group_tile) % 2 == 0) continue;   // ... only its LAST piece (slot 1)
+            if (p.line_merge == 4) {              // ... stored with plain (write-back) stores
+                float4 *d4 = reinterpret_cast<float4 *>(p.o_accum + (wk.prow + h) * D + col * 8);
+                d4[0] = make_float4(o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
+                d4[1] = make_float4(o[4][i] * inv, o[5][i] * inv, o[6][i] * inv, o[7][i] * inv);
+                if (col == 0) p.lse_accum[wk.prow + h] = empty ? -INFINITY : lse;
+                continue;
+            }
+#endif
             const int64_t row = wk.prow + h;
             float *dst = p.o_accum + row * D + col * 8;
             partial_store(dst, o[0][i] * inv, o[1][i] * inv, o[2][i] * inv, o[3][i] * inv);
@@ -954,6 +966,9 @@ static void set_stream_waves(DecodeParams &p, int occupancy, hipStream_t stream)
         p.line_merge = p.counters ? 1 : 0;
         if (!p.counters) clear_error();           // (a capture without warm-up: the combine kernel serves)
     }
+#ifdef ATOMA_DECODE_CUT_PROBE   // TIMING PROBE ONLY (make cutprobe; results are wrong): decode_line_merge = 2 -> nobody merges the cut pieces
+    if (decode_options().line_merge >= 2) p.line_merge = decode_options().line_merge;
+#endif
 }
 
 // Which decode kernel the dispatcher took last on this thread (bench.py labels its roofline line with it instead of a literal)
@@ -1041,7 +1056,7 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
 #undef ATOMA_MQK_S
 #undef ATOMA_MQK
     if (!ATOMA_CHECK_LAUNCH("paged_decode_mqk_kernel")) return;
-    if (p.num_splits > 1 || (p.stream_waves > 0 && !p.line_merge)) {
+    if (p.num_splits > 1 || (p.stream_waves > 0 && !p.line_merge)) {   // (cut probe: line_merge = 2 skips this launch too)
         hipLaunchKernelGGL((decode_combine_kernel<T, PAIR64 ? 64 : 128>), dim3((unsigned)std::min<int64_t>((int64_t)p.b * p.h, combine_grid_cap())), dim3(64), 0, stream, p);
         ATOMA_CHECK_LAUNCH("decode_combine_kernel");
     }
