@@ -19,7 +19,27 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `make -C atoma-infer_amd` (or python -c "
         "'import __graft_entry__ as g; g.build()').  There is no CPU fallback.")
-lib = C.CDLL(os.path.abspath(LIB_PATH))
+
+
+class _Lib(C.CDLL):
+    """With ATOMA_HIP_LIB pointing at an OLDER build of the library (tools/ab_binary.py: the previous binary beside the new one), an
+    entry point that build lacks fails when it is CALLED, not when this module declares its argument types.  Without the override a
+    missing symbol is an AttributeError at import, as before."""
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            if not os.environ.get("ATOMA_HIP_LIB") or name.startswith("__"):
+                raise
+
+            def missing(*a, **k):
+                raise RuntimeError(f"{name} is not exported by {LIB_PATH}")
+            setattr(self, name, missing)
+            return missing
+
+
+lib = _Lib(os.path.abspath(LIB_PATH))
 
 _vp, _i32p, _i64p = C.c_void_p, C.c_void_p, C.c_void_p
 _u32, _i64, _f32, _int, _bool = C.c_uint32, C.c_int64, C.c_float, C.c_int, C.c_bool

@@ -9,6 +9,7 @@
 // caller's pointers/strides are not 16-byte aligned.  HBM-bound: bytes = 2x what is moved.
 #include "common.h"
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -202,32 +203,41 @@ namespace {
 constexpr size_t BOUNCE_SLOT = 8u << 20;
 struct Bounce {
     int device = -1;
+    std::mutex mu;                               // one swap at a time per DEVICE (the two slots are the device's): other devices' threads do not wait
     char *host[2] = {nullptr, nullptr};
     char *dev[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};     // the kernel that last touched the slot
     bool busy[2] = {false, false};
 };
-std::mutex g_bounce_mu;
-std::vector<Bounce> g_bounce;
+std::mutex g_bounce_mu;                          // guards the list only
+std::vector<std::unique_ptr<Bounce>> g_bounce;
 
 Bounce *bounce_for_device() {
     int dev = 0;
     if (!check_hip(hipGetDevice(&dev), "hipGetDevice")) return nullptr;
+    std::lock_guard<std::mutex> lock(g_bounce_mu);
     for (auto &b : g_bounce)
-        if (b.device == dev) return &b;
-    Bounce b;
-    b.device = dev;
-    for (int i = 0; i < 2; ++i) {
+        if (b->device == dev) return b.get();
+    auto b = std::make_unique<Bounce>();
+    b->device = dev;
+    bool ok = true;
+    for (int i = 0; i < 2 && ok; ++i) {
         void *h = nullptr, *d = nullptr;
-        if (!check_hip(hipHostMalloc(&h, BOUNCE_SLOT, hipHostMallocMapped | hipHostMallocPortable), "swap_blocks bounce hipHostMalloc") ||
-            !check_hip(hipHostGetDevicePointer(&d, h, 0), "swap_blocks bounce alias") ||
-            !check_hip(hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming), "swap_blocks bounce event"))
-            return nullptr;
-        b.host[i] = static_cast<char *>(h);
-        b.dev[i] = static_cast<char *>(d);
+        ok = check_hip(hipHostMalloc(&h, BOUNCE_SLOT, hipHostMallocMapped | hipHostMallocPortable), "swap_blocks bounce hipHostMalloc");
+        b->host[i] = static_cast<char *>(h);
+        ok = ok && check_hip(hipHostGetDevicePointer(&d, h, 0), "swap_blocks bounce alias");
+        b->dev[i] = static_cast<char *>(d);
+        ok = ok && check_hip(hipEventCreateWithFlags(&b->done[i], hipEventDisableTiming), "swap_blocks bounce event");
     }
-    g_bounce.push_back(b);
-    return &g_bounce.back();
+    if (!ok) {                                   // nothing of a half-built ring is kept (a retry starts from scratch and leaks nothing)
+        for (int i = 0; i < 2; ++i) {
+            if (b->done[i]) (void)hipEventDestroy(b->done[i]);
+            if (b->host[i]) (void)hipHostFree(b->host[i]);
+        }
+        return nullptr;
+    }
+    g_bounce.push_back(std::move(b));
+    return g_bounce.back().get();
 }
 
 // n pages between a packed slot and the caller's pageable pages, split over a few threads (one memcpy stream does ~10 GB/s)
@@ -260,9 +270,17 @@ static int swap_blocks_pageable(const void *const *srcs, void *const *dsts, int6
             }
         return 0;
     }
-    std::lock_guard<std::mutex> lock(g_bounce_mu);
+    // The bounce route BLOCKS the host (like a pageable hipMemcpy) and waits on events: it cannot be recorded into a graph
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        set_error("swap_blocks: pageable host tensors cannot be swapped inside a hipGraph capture (the call waits for the device); pin them "
+                  "(atoma_host_register) or swap outside the capture");
+        return -1;
+    }
+    (void)hipGetLastError();
     Bounce *bn = bounce_for_device();
     if (!bn) return -1;
+    std::lock_guard<std::mutex> lock(bn->mu);
     const bool out = kind == ATOMA_SWAP_GPU_TO_CPU;
     const int64_t per_slot = std::min<int64_t>((int64_t)(BOUNCE_SLOT / (size_t)block_bytes), SWAP_MAX_PAIRS);
     const int64_t spans = cdiv(block_bytes, (int64_t)COPY_SPAN_VECS * 16);

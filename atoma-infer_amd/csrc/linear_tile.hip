@@ -20,6 +20,7 @@
 // with the reference's rounding points -- the same for the paired and the plain kernel on the same matrix.  Epilogues: none / residual
 // add / SiLU.up (MODE 1) / RoPE + KV-cache write (MODE 2, atoma_linear_decode_qkv_rope_cache).
 #include "linear_params.h"
+#include "sync_ticket.h"
 #include <algorithm>
 #include <atomic>
 #include <stdlib.h>
@@ -28,7 +29,7 @@
 
 namespace atoma {
 
-unsigned *sync_counters(hipStream_t stream);   // runtime.hip
+sync_word_t *sync_counters(hipStream_t stream);   // runtime.hip: epoch-tagged arrival words (sync_ticket.h)
 
 // One 1 KiB global->LDS DMA: LDS destination = wave-uniform byte address (M0) + lane * 16, source = wave-uniform 64-bit base + 32-bit
 // lane offset.  Inline asm: hipcc neither counts it nor drains it; the consumer waits with vm_wait<N>() ahead of the barrier.
@@ -59,7 +60,7 @@ struct TileRope {
 struct TileParams {
     LinearParams p;
     float *slabs;                // in-launch merge: [tile][split][wave][group][lane] float4
-    unsigned *counters;          // arrival counter per tile (zero between launches)
+    sync_word_t *counters;       // arrival word per tile (epoch-tagged: any state left by earlier launches is ignored -- sync_ticket.h)
     int chunks_per_split;        // chunks of 128 inputs
     int merge_splits;            // 2..8: K split this many ways and merged here by the last workgroup to arrive; 0: no in-launch merge
     TileRope rope;
@@ -186,11 +187,7 @@ __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned *ticket = reinterpret_cast<unsigned *>(smem);    // the ring is idle now (every DMA was waited for)
-        if (tid == 0) {
-            const unsigned t = __hip_atomic_fetch_add(tp.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t + 1 == (unsigned)S) __hip_atomic_store(tp.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-            *ticket = t;
-        }
+        if (tid == 0) *ticket = sync_arrive(tp.counters + tile, sync_epoch());
         __syncthreads();
         if (*ticket + 1 != (unsigned)S) return;                    // not the last: somebody else finishes the tile
         lf32x4 tot[GPW];

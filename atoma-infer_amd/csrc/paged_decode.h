@@ -2,6 +2,7 @@
 // parameters, the wavefront -> work mapping, the balanced mode, small lane helpers.  See paged_decode.hip for the design.
 #pragma once
 #include "attn_params.h"
+#include "sync_ticket.h"
 #include <type_traits>
 
 #include <atomic>
@@ -40,7 +41,7 @@ struct DecodeParams {
     int group_tile;        // q heads per wavefront (the kernel's G)
     const float *k_scale, *v_scale;   // fp8 (e4m3fn) KV cache: per-kv-head dequantisation scales [h_k]; null for 16-bit caches
     int wg_splits;         // > 0: workgroup-merged split mode (paged_decode_wg_kernel): KV pieces per sequence = wg_splits x wavefronts per workgroup
-    unsigned *counters;    // ... and its arrival counter per (sequence, kv head, q-head chunk), zero between launches
+    sync_word_t *counters; // ... and its arrival word per (sequence, kv head, q-head chunk): epoch-tagged (sync_ticket.h), no state is carried between launches
     int head_major;        // 1: workgroup id -> (kv head, chunk) slowest, (split, sequence) fastest (decode_map_work)
     int stream_force;      // the balanced line also for uniform resident batches (decode_plan_launch says when)
     int fp8_klines;        // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays (not on the balanced line, not with a single kv head: contiguous rows), 2 always
@@ -207,7 +208,7 @@ __device__ __forceinline__ float partial_load(const float *src) {
 // ragged batch paid a second launch per layer).  A sequence cut between the wavefronts w0 .. w0 + nsp - 1 of the line has one arrival
 // counter, index w0 (a wavefront's range ends inside at most one sequence, so w0 names the sequence); every piece is published write-through, the wavefront takes a ticket, and the one that arrives LAST merges the pieces
 // in line order with decode_combine_kernel's arithmetic (flash_fwd_kernel.h:1204-1236) and writes the output.  Nobody waits; the result
-// does not depend on the order of arrival; the counter returns to zero.  Not inlined: the call sits in the segment loop, whose scalar
+// does not depend on the order of arrival; the arrival word is epoch-tagged (sync_ticket.h: nothing to reset, nothing inherited).  Not inlined: the call sits in the segment loop, whose scalar
 // registers are the tight resource of these kernels.
 template <typename T, int D>
 __device__ __attribute__((noinline)) void decode_line_merge(const DecodeParams *pp, int b, int hkc, int w0, int nsp, int first_slot) {
@@ -314,6 +315,8 @@ template <bool STREAM, int NWG = 1, typename F, typename M = DecodeNoMerge> __de
         item(p0, wk);
     } else {
         __shared__ int cum[DECODE_STREAM_MAX_B + 1];
+        __shared__ sync_word_t s_epoch;     // this launch's epoch for the arrival tickets; parked in LDS: scalar registers are the tight resource here
+        if ((threadIdx.x & 63) == 0) s_epoch = sync_epoch();
         const DecodePlan pl = decode_make_plan(p0, cum);
         if (wid == 0) {   // for the combine kernel
             for (int i = threadIdx.x & 63; i <= p0.b; i += 64) p0.plan[2 + i] = cum[i];
@@ -323,9 +326,15 @@ template <bool STREAM, int NWG = 1, typename F, typename M = DecodeNoMerge> __de
         // position of this wavefront on the line.  The line is kv-head major, so wavefronts w and w + W / 8 walk the same
         // sequences of adjacent heads: with 8 wavefronts per workgroup, give the 8 of a workgroup those ranges (W is a multiple of 8)
         if (stream && wid >= p0.stream_waves) return;      // the line is shared by stream_waves wavefronts; the grid may hold more
+        // The out-of-line merge / zero routines take the kernel arguments BY ADDRESS: always the kernarg segment's, never &p0 -- the
+        // address of the by-value parameter makes the compiler copy all 288 bytes of DecodeParams to scratch in the prologue of EVERY
+        // wavefront (18 KiB per wavefront, 36 MiB of HBM writes per headline launch and scratch loads on the start-up chain: the
+        // round-4 regression 0.83 -> 0.80, found in round 5 from WRITE_SIZE and `private_segment_fixed_size: 304` in the metadata).
+        typedef const DecodeParams __attribute__((address_space(4))) *KernArg;
+        KernArg kp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
         if (stream && p0.line_merge == 1) {
             for (int e = wid; e < p0.b; e += p0.stream_waves)
-                if (__builtin_amdgcn_readfirstlane(cum[e]) == __builtin_amdgcn_readfirstlane(cum[e + 1])) merger.zero(&p0, e);
+                if (__builtin_amdgcn_readfirstlane(cum[e]) == __builtin_amdgcn_readfirstlane(cum[e + 1])) merger.zero((const DecodeParams *)kp, e);
         }
         const int lw = NWG == 1 ? wid : (wid % NWG) * (p0.stream_waves / NWG) + wid / NWG;
         int pos = 0, end = 1, hkc = 0, r = 0, b = 0;       // host guarantees total < 2^31
@@ -345,8 +354,6 @@ template <bool STREAM, int NWG = 1, typename F, typename M = DecodeNoMerge> __de
             }
             b = lo;
         }
-        typedef const DecodeParams __attribute__((address_space(4))) *KernArg;
-        KernArg kp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
         for (;;) {
             asm volatile("" : "+s"(kp));
             const DecodeParams &p = *(const DecodeParams *)kp;
@@ -378,10 +385,7 @@ template <bool STREAM, int NWG = 1, typename F, typename M = DecodeNoMerge> __de
                 const int w0 = (int)(s0 / pl.share), w1 = (int)((s0 + wk.n_tiles - 1) / pl.share);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this piece is out
                 unsigned t = 0;
-                if ((threadIdx.x & 63) == 0) {
-                    t = __hip_atomic_fetch_add(p.counters + w0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (t == (unsigned)(w1 - w0)) __hip_atomic_store(p.counters + w0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if ((threadIdx.x & 63) == 0) t = sync_arrive(p.counters + w0, s_epoch);
                 t = __builtin_amdgcn_readfirstlane(t);
                 if (t == (unsigned)(w1 - w0)) merger.merge(&p, b, hkc, w0, w1 - w0 + 1, s0 > (int64_t)w0 * pl.share ? 1 : 0);
             }

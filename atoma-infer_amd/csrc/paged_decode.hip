@@ -738,12 +738,7 @@ __global__ void __launch_bounds__(64 * NWG, 2) paged_decode_wg_kernel(const Deco
     if (last_level) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wavefront drains, then ONE ticket per workgroup
     __syncthreads();
-    unsigned *counter = p.counters + ((int64_t)wk.b * hk_chunks + hkc);
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t + 1 == (unsigned)p.wg_splits) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_ticket = t;
-    }
+    if (tid == 0) s_ticket = sync_arrive(p.counters + ((int64_t)wk.b * hk_chunks + hkc), sync_epoch());
     __syncthreads();
     if (s_ticket + 1 != (unsigned)p.wg_splits) return;
     for (int idx = tid; idx < nq * (D / 2); idx += 64 * NWG) {
@@ -857,7 +852,7 @@ __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p
 // host side
 // ------------------------------------------------------------------------------------------
 void *workspace(hipStream_t stream, size_t bytes);   // runtime.hip: grow-only scratch per (device, stream), never freed under a graph
-unsigned *sync_counters(hipStream_t stream);         // runtime.hip: zero-initialised arrival counters per (device, stream)
+sync_word_t *sync_counters(hipStream_t stream);      // runtime.hip: epoch-tagged arrival words per (device, stream)
 constexpr int64_t DECODE_WG_MAX_COUNTERS = 8192;     // = SYNC_COUNTERS of runtime.hip
 
 // Split count for THIS kernel: enough wavefronts to fill the resident slots of every CU (8, or 4 for the

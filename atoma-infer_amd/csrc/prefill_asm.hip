@@ -24,6 +24,7 @@
 #include "prefill_map.h"
 #include "prefill_asm_gen.h"
 #include <atomic>
+#include <mutex>
 #include <stdlib.h>
 
 namespace atoma {
@@ -224,6 +225,7 @@ std::atomic<int> prefill_simple{0};
 
 bool prefill_asm_supported(const AttnParams &p) {
     if (p.d != 128 || p.alibi_slopes != nullptr || p.seqlen_q <= 1) return false;
+    if (!(p.scale_log2 > 0.f) || !(p.scale_log2 < INFINITY)) return false;   // the deferred-raise threshold is 8 / scale_log2: positive finite scales only
     if (p.block_table) {
         if (p.page_size < 16 || (p.page_size & (p.page_size - 1)) != 0) return false;           // pages of 2^k >= 16 tokens
         if (p.k_batch_stride * 2 >= (int64_t)1 << 32 || p.v_batch_stride * 2 >= (int64_t)1 << 32) return false;
@@ -240,30 +242,56 @@ static int pfa_exact_keys() {
     return env_exact >= 0 ? env_exact : prefill_exact_keys.load();
 }
 
+// The 160 KiB dynamic-LDS opt-in of the four kernels, once per DEVICE (the reference drives every GPU of the node from one process,
+// one thread each: model_executor.rs:428-440), return code checked, never first set inside a capture when atoma_warmup ran
+// (prefill_asm_prepare below).
+static bool pfa_attrs_for_device() {
+    constexpr int MAX_DEV = 64;
+    static std::mutex mu;
+    static bool done[MAX_DEV] = {};
+    int dev = 0;
+    if (!check_hip(hipGetDevice(&dev), "hipGetDevice")) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < MAX_DEV && done[dev]) return true;
+    const void *kernels[4] = {reinterpret_cast<const void *>(&prefill_asm_paged<true>), reinterpret_cast<const void *>(&prefill_asm_paged<false>),
+                              reinterpret_cast<const void *>(&prefill_asm_persistent<true>), reinterpret_cast<const void *>(&prefill_asm_persistent<false>)};
+    for (const void *k : kernels)
+        if (!check_hip(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, PFA_LDS_TOTAL), "prefill_asm: 160 KiB dynamic LDS opt-in")) return false;
+    if (dev >= 0 && dev < MAX_DEV) done[dev] = true;
+    return true;
+}
+bool prefill_asm_prepare() { return pfa_attrs_for_device(); }
+
+// bytes of the persistent kernel's plan table for `tokens` query rows in all, at most `seqs` sequences, `heads` q heads (an upper
+// bound: every sequence may end in a partly filled 256-row block) -- what atoma_warmup adds to the stream's scratch
+size_t prefill_asm_workspace_bound(int64_t tokens, int64_t seqs, int64_t heads) {
+    const int64_t m_blocks = cdiv(tokens, PFA_BM) + seqs, nu_max = cdiv(heads, 8) + 1;
+    return (size_t)(8 * nu_max * m_blocks) * 4 * PFA_PARAM_DWORDS * 4;
+}
+
+// The fast arithmetic rounds q . scale . log2(e) to the storage type once per block (header of this file): safe while that factor neither
+// overflows f16 nor pushes small q into its subnormals -- otherwise every block takes the exact variant (the reference's arithmetic,
+// softmax.h:65-91).  (A scale that is zero, negative or not finite never gets here: prefill_asm_supported.)
+template <bool BF16> static int pfa_exact_keys_for(const AttnParams &p) {
+    const bool fast_ok = BF16 ? (p.scale_log2 >= 0x1p-20f && p.scale_log2 <= 0x1p20f) : (p.scale_log2 >= 0x1p-6f && p.scale_log2 <= 1.0f);
+    return fast_ok ? pfa_exact_keys() : 0x7fffffff;
+}
+
 template <bool BF16>
-static void launch_pfa(const AttnParams &p, hipStream_t stream) {
+static int launch_pfa(const AttnParams &p, hipStream_t stream) {
     const int64_t m_blocks = cdiv(p.seqlen_q, PFA_BM), n_units = (int64_t)p.b * p.h;
     const int64_t nu_max = n_units / 8 + (n_units % 8 ? 1 : 0);
     const int64_t n_entries = 8 * nu_max * m_blocks;   // padded: see prefill_map.h
+    if (!pfa_attrs_for_device()) return -1;
+    const int exact_keys = pfa_exact_keys_for<BF16>(p);
     if (p.block_table) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_asm_paged<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, PFA_LDS_TOTAL);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((prefill_asm_paged<BF16>), dim3((unsigned)n_entries), dim3(256), PFA_LDS_TOTAL, stream, p, pfa_exact_keys(), prefill_simple.load());
-        ATOMA_CHECK_LAUNCH("prefill_asm_paged");
-        return;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_asm_persistent<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, PFA_LDS_TOTAL);
-        attr_set = true;
+        hipLaunchKernelGGL((prefill_asm_paged<BF16>), dim3((unsigned)n_entries), dim3(256), PFA_LDS_TOTAL, stream, p, exact_keys, prefill_simple.load());
+        return ATOMA_CHECK_LAUNCH("prefill_asm_paged") ? 0 : -1;
     }
     uint32_t *tab = static_cast<uint32_t *>(workspace(stream, (size_t)n_entries * 4 * PFA_PARAM_DWORDS * 4));
-    if (!tab) return;   // workspace() has set the error (e.g. first use inside a graph capture: atoma_warmup first)
-    hipLaunchKernelGGL(pfa_plan_kernel, dim3((unsigned)cdiv(n_entries * 4, 256)), dim3(256), 0, stream, p, tab, (int)n_entries, pfa_exact_keys(), prefill_simple.load());
-    ATOMA_CHECK_LAUNCH("pfa_plan_kernel");
+    if (!tab) return -1;   // workspace() has set the error (e.g. first use inside a graph capture: atoma_warmup / atoma_warmup_prefill first)
+    hipLaunchKernelGGL(pfa_plan_kernel, dim3((unsigned)cdiv(n_entries * 4, 256)), dim3(256), 0, stream, p, tab, (int)n_entries, exact_keys, prefill_simple.load());
+    if (!ATOMA_CHECK_LAUNCH("pfa_plan_kernel")) return -1;
     int g = device_num_cus() & ~7;                     // one workgroup per CU (160 KiB of LDS each), a multiple of the 8 XCDs
     if (g < 8) g = 8;
     if ((int64_t)g > n_entries) g = (int)n_entries;    // n_entries is a multiple of 8
@@ -272,13 +300,13 @@ static void launch_pfa(const AttnParams &p, hipStream_t stream) {
     dbg = reinterpret_cast<uint32_t *>(p.lse);
 #endif
     hipLaunchKernelGGL((prefill_asm_persistent<BF16>), dim3((unsigned)g), dim3(256), PFA_LDS_TOTAL, stream, tab, (int)n_entries, dbg);
-    ATOMA_CHECK_LAUNCH("prefill_asm_persistent");
+    return ATOMA_CHECK_LAUNCH("prefill_asm_persistent") ? 0 : -1;
 }
 
-void launch_prefill_asm(const AttnParams &p, bool is_bf16, hipStream_t stream) {
-    if (p.b <= 0 || p.h <= 0 || p.seqlen_q <= 0) return;
-    if (is_bf16) launch_pfa<true>(p, stream);
-    else launch_pfa<false>(p, stream);
+// 0 = launched; -1 = not launched (the error is in atoma_last_error)
+int launch_prefill_asm(const AttnParams &p, bool is_bf16, hipStream_t stream) {
+    if (p.b <= 0 || p.h <= 0 || p.seqlen_q <= 0) return 0;
+    return is_bf16 ? launch_pfa<true>(p, stream) : launch_pfa<false>(p, stream);
 }
 
 }  // namespace atoma

@@ -1184,13 +1184,13 @@ static int prefill_cfg_effective() {
 }
 
 bool prefill_asm_supported(const AttnParams &p);                                   // prefill_asm.hip
-void launch_prefill_asm(const AttnParams &p, bool is_bf16, hipStream_t stream);
+int launch_prefill_asm(const AttnParams &p, bool is_bf16, hipStream_t stream);      // 0 / -1 (error in atoma_last_error)
 
 template <typename T, int D, bool CAUSAL>
 static void launch_pf(const AttnParams &p, hipStream_t stream) {
     switch (prefill_cfg_effective()) {
         case 4:                                                                    // hand-scheduled kernel (prefill_asm.hip); shapes it does not take fall through
-            if (prefill_asm_supported(p)) { launch_prefill_asm(p, std::is_same<T, bf16_t>::value, stream); break; }
+            if (prefill_asm_supported(p)) { (void)launch_prefill_asm(p, std::is_same<T, bf16_t>::value, stream); break; }   // a failure is in the error slot: run_mha is void (ffi.rs), the host layer returns it
             launch_pf_cfg<T, D, CAUSAL, 4, 2>(p, stream);
             break;
         case 2: {

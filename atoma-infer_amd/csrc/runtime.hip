@@ -1,5 +1,6 @@
 // Error slot, device queries and the reference's host-side split heuristic.
 #include "common.h"
+#include "sync_ticket.h"
 
 #include <algorithm>
 #include <math.h>
@@ -87,19 +88,18 @@ void *workspace(hipStream_t stream, size_t bytes) {
     return fresh;
 }
 
-// Arrival counters of the kernels that merge their own split-K / split-KV pieces (the last workgroup to arrive at a tile reduces
-// it): SYNC_COUNTERS zero-initialised words per (device, stream), allocated once and kept zero by the kernels themselves (the last
-// arriver of a tile puts its counter back to zero), so that a captured graph replays without a memset node.  Kernels of one stream
-// run one after the other and may share the words.
-// CONSTRAINTS (the same as for the scratch of `workspace`): the pointer is baked into captured graphs, so a graph must be
-// replayed on the stream it was captured on and never concurrently with eager calls on that stream (two launches counting on the same words
-// mis-merge silently); a launch that aborted half-way may leave a word non-zero -- atoma_reset_sync_counters(stream) re-zeroes them
-// (a memset on the stream; call it after any failed launch, outside capture); atoma_release_workspaces frees them and thereby invalidates
-// every graph captured before it.
+// Arrival words of the kernels that merge their own split-K / split-KV pieces (the last workgroup to arrive at an item reduces it):
+// SYNC_COUNTERS 64-bit words per (device, stream), allocated once.  A word is EPOCH-TAGGED (sync_ticket.h: epoch = the launch's AQL
+// dispatch id): a launch ignores whatever an earlier launch left in it, nobody resets anything, a captured graph replays without a memset
+// node, and an inconsistent episode (a graph replayed beside eager calls on its stream, metadata changed under a running launch) cannot
+// corrupt a LATER launch -- the callee is stateless again (csrc/src/ffi.rs:3-102).  Kernels of one stream run one after the other and
+// share the words.  The pointer is baked into captured graphs (like the scratch of `workspace`): atoma_release_workspaces frees the
+// words and thereby invalidates every graph captured before it.  atoma_reset_sync_counters is kept for callers of round 4's contract;
+// nothing requires it any more.
 constexpr size_t SYNC_COUNTERS = 8192;
-struct SyncWords { int device; hipStream_t stream; unsigned *ptr; };
+struct SyncWords { int device; hipStream_t stream; sync_word_t *ptr; };
 static std::vector<SyncWords> g_sync;
-unsigned *sync_counters(hipStream_t stream) {
+sync_word_t *sync_counters(hipStream_t stream) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(*g_ws_mu);
@@ -110,9 +110,9 @@ unsigned *sync_counters(hipStream_t stream) {
                   "for this stream before capturing, or run the same call once eagerly first");
         return nullptr;
     }
-    unsigned *ptr = nullptr;
-    if (!check_hip(hipMalloc(reinterpret_cast<void **>(&ptr), SYNC_COUNTERS * sizeof(unsigned)), "sync counters hipMalloc")) return nullptr;
-    if (!check_hip(hipMemset(ptr, 0, SYNC_COUNTERS * sizeof(unsigned)), "sync counters hipMemset") || !check_hip(hipDeviceSynchronize(), "sync counters")) {
+    sync_word_t *ptr = nullptr;
+    if (!check_hip(hipMalloc(reinterpret_cast<void **>(&ptr), SYNC_COUNTERS * sizeof(sync_word_t)), "sync counters hipMalloc")) return nullptr;
+    if (!check_hip(hipMemset(ptr, 0, SYNC_COUNTERS * sizeof(sync_word_t)), "sync counters hipMemset") || !check_hip(hipDeviceSynchronize(), "sync counters")) {
         (void)hipFree(ptr);
         return nullptr;
     }
@@ -124,7 +124,7 @@ unsigned *sync_counters(hipStream_t stream) {
 int reset_sync_counters(hipStream_t stream) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    unsigned *ptr = nullptr;
+    sync_word_t *ptr = nullptr;
     {
         std::lock_guard<std::mutex> lock(*g_ws_mu);
         for (auto &w : g_sync)
@@ -132,12 +132,14 @@ int reset_sync_counters(hipStream_t stream) {
     }
     if (!ptr) return 0;
     if (stream_is_capturing(stream)) { set_error("atoma_reset_sync_counters: not inside a hipGraph capture"); return -1; }
-    return check_hip(hipMemsetAsync(ptr, 0, SYNC_COUNTERS * sizeof(unsigned), stream), "atoma_reset_sync_counters") ? 0 : -1;
+    return check_hip(hipMemsetAsync(ptr, 0, SYNC_COUNTERS * sizeof(sync_word_t), stream), "atoma_reset_sync_counters") ? 0 : -1;
 }
 
 size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k);   // paged_decode.hip
 const char *last_decode_kernel();                                                    // paged_decode.hip
 bool linear_tile_prepare();                                                          // linear_tile.hip
+bool prefill_asm_prepare();                                                          // prefill_asm.hip: the kernels' 160 KiB LDS opt-in on this device
+size_t prefill_asm_workspace_bound(int64_t tokens, int64_t seqs, int64_t heads);     // prefill_asm.hip: plan table of the persistent prefill kernel
 int release_gemm_workspaces();                                                       // linear_gemm.hip
 
 // /root/reference/csrc/src/lib.rs:2122-2167, f32 arithmetic as there.
@@ -208,9 +210,28 @@ int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num
     const size_t need = std::max(atoma::decode_workspace_bound((int)std::min<int64_t>(max_batch, 1 << 20), (int)num_heads, (int)num_kv_heads,
                                                                (int)head_dim, (int)std::min<int64_t>(max_seqlen_k, 1 << 30)),
                                  (size_t)extra_bytes);
-    if (!atoma::sync_counters(static_cast<hipStream_t>(stream)) || !atoma::linear_tile_prepare()) return -1;
+    if (!atoma::sync_counters(static_cast<hipStream_t>(stream)) || !atoma::linear_tile_prepare() || !atoma::prefill_asm_prepare()) return -1;
     if (need == 0) return 0;
     return atoma::workspace(static_cast<hipStream_t>(stream), need) ? 0 : -1;
+}
+
+int atoma_warmup_prefill(void *stream, int64_t max_tokens, int64_t max_seqs, int64_t num_heads) {
+    atoma::clear_error();
+    if (max_tokens <= 0 || max_seqs <= 0 || num_heads <= 0) {
+        atoma::set_error("atoma_warmup_prefill: invalid shape");
+        return -1;
+    }
+    if (!atoma::prefill_asm_prepare()) return -1;
+    return atoma::workspace(static_cast<hipStream_t>(stream), atoma::prefill_asm_workspace_bound(max_tokens, max_seqs, num_heads)) ? 0 : -1;
+}
+
+int atoma_debug_sync_words(void *stream, void **words_out, int64_t *count_out) {
+    atoma::clear_error();
+    atoma::sync_word_t *p = atoma::sync_counters(static_cast<hipStream_t>(stream));
+    if (!p) return -1;
+    if (words_out) *words_out = p;
+    if (count_out) *count_out = (int64_t)atoma::SYNC_COUNTERS;
+    return 0;
 }
 
 int atoma_reset_sync_counters(void *stream) {

@@ -1,0 +1,42 @@
+// Arrival tickets of the kernels that merge their own pieces inside the launch (split-KV, the balanced line's cut sequences, the tile
+// kernel's K splits): "the last workgroup to arrive at an item reduces it".
+//
+// The drop-in boundary is a STATELESS callee (csrc/src/ffi.rs:3-102).  Until round 4 the arrival words had to be zero on
+// entry and were put back to zero by the last arriver, so a launch that ended inconsistently (a graph replayed beside eager calls on its
+// stream, metadata changed under a running launch) left words non-zero and every LATER merge on that stream was silently wrong until
+// atoma_reset_sync_counters.  Now a word carries the EPOCH of the launch that last used it and a launch never trusts a word of another
+// epoch:
+//
+//      word (64 bit) = (epoch << 16) | arrivals,      epoch = the launch's AQL dispatch id + 1
+//
+// An arrival is two atomics issued back to back, the second returning:  fetch_max(word, epoch << 16)  -- a word of an older launch
+// (any count, any garbage below this epoch) becomes "epoch, 0 arrivals"; a word of THIS launch is left alone --  then
+// fetch_add(word, 1) -> ticket.  The dispatch id is the packet's index in its hardware queue: every launch of a stream, eager or from a
+// replayed graph, gets a larger one than all launches before it on that stream, with no host involvement and nothing baked into a
+// captured graph; 48 bits of it never wrap.  Both atomics go to the same address from the same lane, so the L2 performs them in issue
+// order; nobody resets anything; nobody waits.  Cost against the old fetch_add: one extra request in flight, no extra round trip.
+// A word's state after a launch is irrelevant to the next one: the boundary is stateless again.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace atoma {
+
+typedef unsigned long long sync_word_t;
+constexpr int SYNC_COUNT_BITS = 16;   // up to 65535 arrivals per item and launch
+
+// The dispatch id is a kernel-entry SGPR pair (ENABLE_SGPR_DISPATCH_ID in the kernel descriptor, set by the compiler when the
+// intrinsic is used).  clang has no __builtin for llvm.amdgcn.dispatch.id; an asm label reaches the intrinsic directly.
+extern "C" __device__ unsigned long long atoma_llvm_amdgcn_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id");
+
+// wave-uniform
+__device__ __forceinline__ sync_word_t sync_epoch() { return ((sync_word_t)atoma_llvm_amdgcn_dispatch_id() + 1ull) << SYNC_COUNT_BITS; }
+
+// ticket of this arrival at `word` in the launch whose epoch is `epoch`: 0 for the first to arrive, n - 1 for the last of n
+__device__ __forceinline__ unsigned sync_arrive(sync_word_t *word, sync_word_t epoch) {
+    __hip_atomic_fetch_max(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const sync_word_t t = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned)(t & ((1ull << SYNC_COUNT_BITS) - 1));
+}
+
+}  // namespace atoma

@@ -246,7 +246,10 @@ def main():
     if world == 1 and not args.no_traffic and not os.environ.get("ATOMA_BENCH_CHILD"):
         measured = measure_traffic(sys.argv[1:])
     if measured is not None:
-        out["roofline"]["traffic"] = int(measured)
+        out["roofline"]["traffic"] = int(measured["bytes"])
+        # the two raw counters: the output of this launch is 2 MiB, so WRITE_SIZE far above 2048 KiB means scratch or partials are being
+        # written (round 4: 38 913 KiB -- a by-value kernel argument whose address escaped was copied to scratch by every wavefront)
+        out["roofline"]["traffic_counters_KiB_per_launch"] = {"FETCH_SIZE": measured["FETCH_SIZE_KiB"], "WRITE_SIZE": measured["WRITE_SIZE_KiB"]}
         out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes over 3 steps of this "
                                              "same command), (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch -- the gfx950 correction of MI355X_MICROARCH.md")
     elif world == 1 and (B, S, h, hk, d, page) == (256, 4096, 32, 8, 128, 16):
@@ -422,7 +425,8 @@ def measure_traffic(argv):
             if not vals:
                 return None
             means[counter] = sum(vals) / len(vals)
-        return (2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024
+        return {"bytes": (2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024, "FETCH_SIZE_KiB": round(means["FETCH_SIZE"], 1),
+                "WRITE_SIZE_KiB": round(means["WRITE_SIZE"], 1)}
     except Exception:
         return None
 

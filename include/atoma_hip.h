@@ -434,17 +434,24 @@ const char *atoma_last_decode_kernel(void);
  *     splits * batch * out_features * 4) -- call it once per stream before capturing, instead of relying on an eager call.
  *   - atoma_release_workspaces frees live and retired blocks of ALL streams: only when no graph that used them will be
  *     replayed and the streams are idle.
- *   - The kernels that merge their own split-K / split-KV pieces count arrivals in 8192 words per (device, stream) that they keep at
- *     zero themselves.  Like the scratch block the words are baked into captured graphs: replay a graph on the stream it was captured
- *     on and never concurrently with eager calls on that stream.  After a launch that FAILED (an error from any entry point, a device
- *     fault) call atoma_reset_sync_counters(stream) before the next call on that stream -- a word left non-zero makes later merges
- *     silently wrong.  Not inside a capture.
+ *   - The kernels that merge their own split-K / split-KV pieces count arrivals in 8192 64-bit words per (device, stream).  A word is
+ *     tagged with the EPOCH of the launch that used it last (the launch's AQL dispatch id; csrc/sync_ticket.h) and a launch ignores
+ *     words of other epochs: nothing has to be zero on entry, nothing is reset, and a launch that ended inconsistently (a graph
+ *     replayed beside eager calls on its stream, lengths changed under a running launch) cannot make a LATER launch wrong -- the
+ *     callee carries no state from call to call (csrc/src/ffi.rs:3-102).  The pointer is baked into captured graphs like the scratch
+ *     block: replay a graph on the stream it was captured on.  atoma_reset_sync_counters (round 4's repair call) is kept and harmless;
+ *     nothing needs it.  atoma_debug_sync_words exposes the words to tests (which fill them with garbage and expect identical bits).
+ *   - atoma_warmup_prefill: the hand-scheduled prefill kernel (head_dim 128) plans a call in a table of 1 KiB per 256 query rows and
+ *     q head in the same scratch block; size it for the largest prefill call (tokens in all, sequences, q heads) before capturing a
+ *     graph that contains one.  A prefill whose table cannot be allocated launches nothing and says so in atoma_last_error().
  * The device is the calling thread's current device (hipSetDevice), as for every entry point. */
 int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, int64_t max_seqlen_k,
                  int64_t extra_bytes);
 int atoma_reserve_workspace(void *stream, int64_t bytes);
 int atoma_release_workspaces(void);
 int atoma_reset_sync_counters(void *stream);
+int atoma_warmup_prefill(void *stream, int64_t max_tokens, int64_t max_seqs, int64_t num_heads);
+int atoma_debug_sync_words(void *stream, void **words_out, int64_t *count_out);
 
 /* Device helpers used by the host layer, tests and bench (plain HIP runtime, no torch). */
 int atoma_device_count(void);

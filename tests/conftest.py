@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# Tests that place up to 8 tensor-parallel ranks on ONE device from one process drive 8 streams whose kernels wait for each other on the
+# device (the direct all-reduce): each stream needs a hardware queue of its own.  The HIP runtime multiplexes streams over 4 queues by
+# default and a queue starts its packets in order, so rank 0's all-reduce would wait for a rank-4 kernel queued behind it
+# (tools/probes/world8_queues_probe.py).  Read once, when the runtime starts -- hence here, before anything loads it.  One rank per
+# device (the product's deployment: one host thread or process per GPU) never needs this.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "atoma-infer_amd", "bindings"))

@@ -51,10 +51,13 @@ def ulps(a, b):
     return np.abs(key(a) - key(b))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("dtype", [BF16, F16, F32])
 def test_virtual_ranks_one_shot_and_two_shot(gpu, world, dtype, monkeypatch):
-    monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "5000")
+    """world 8 = the communicator of configs[3] (TP = 8): 7 peers per rank, two-shot ownership S / 8 (8 streams of this process meet on
+    device 0: tests/conftest.py gives every stream its own hardware queue)."""
+    monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "8000")
+    monkeypatch.setenv("ATOMA_XGMI_ONESHOT_MAX", str(1 << 20))      # (the 1 MiB decode message of the 70B step through BOTH kernels)
     rng = np.random.default_rng(world * 10 + dtype)
     esz = 4 if dtype == F32 else 2
     xs = make_ranks(gpu, world, 4 << 20)
@@ -87,10 +90,10 @@ def test_virtual_ranks_one_shot_and_two_shot(gpu, world, dtype, monkeypatch):
         parts = data(rng, world, count, dtype)
         bufs = [gpu.DeviceBuffer.from_numpy(p) for p in parts]
         cur = parts
-        for it in range(5):
+        for it in range(5 if world < 8 else 3):
             for r in range(world):
                 assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], bufs[r].ptr, bufs[r].ptr, count, dtype, streams[r].s) == 0, gpu.last_error()
-            s = AO.allreduce_sum(cur, dtype, "rank_order")      # values grow by at most x world per round: finite in f16 too
+            s = AO.allreduce_sum(cur, dtype, "rank_order")      # values grow by at most x world per round (3^5, 8^3): finite in f16 too
             cur = [s] * world
         for r in range(world):
             streams[r].synchronize()
@@ -101,10 +104,42 @@ def test_virtual_ranks_one_shot_and_two_shot(gpu, world, dtype, monkeypatch):
             gpu.lib.atoma_xgmi_destroy(x)
 
 
-def test_virtual_ranks_graph_replay(gpu, monkeypatch):
+@pytest.mark.parametrize("world", [2, 8])
+def test_virtual_ranks_prefill_message_64_mib(gpu, world, monkeypatch):
+    """The all-reduce of configs[3]'s prefill chunk: [4096, 8192] bf16 = 64 MiB after the o and the down projection
+    (llama_nccl.rs:139,195), in ONE launch per rank (capacity 64 MiB: rank r owns 8 MiB of it at world 8), by the size rule (two-shot),
+    out of place and then in place on the result."""
+    monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "20000")
+    count = 4096 * 8192
+    rng = np.random.default_rng(64 + world)
+    xs = make_ranks(gpu, world, count * 2)
+    streams = [gpu.Stream() for _ in range(world)]
+    try:
+        assert gpu.lib.atoma_xgmi_capacity(xs[0]) == count * 2
+        parts = data(rng, world, count, BF16)
+        want = AO.allreduce_sum(parts, BF16, "rank_order")
+        din = [gpu.DeviceBuffer.from_numpy(p) for p in parts]
+        dout = [gpu.DeviceBuffer(count * 2) for _ in range(world)]
+        for r in range(world):
+            assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], din[r].ptr, dout[r].ptr, count, BF16, streams[r].s) == 0, gpu.last_error()
+        for r in range(world):
+            assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], dout[r].ptr, dout[r].ptr, count, BF16, streams[r].s) == 0, gpu.last_error()
+        again = AO.allreduce_sum([want] * world, BF16, "rank_order")
+        assert ulps(want, AO.allreduce_sum(parts, BF16, "exact")).max() <= 1
+        for r in range(world):
+            streams[r].synchronize()
+            assert gpu.lib.atoma_xgmi_status(xs[r]) == 0, f"rank {r}: a wait timed out"
+            assert np.array_equal(dout[r].numpy(np.uint16, (count,)), again), f"rank {r}: differs from the rank-order fp32 sum"
+    finally:
+        for x in xs:
+            gpu.lib.atoma_xgmi_destroy(x)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_virtual_ranks_graph_replay(gpu, world, monkeypatch):
     """The call counter lives in device memory, so a captured all-reduce replays correctly any number of times."""
-    monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "5000")
-    world, count = 2, 256 * 4096
+    monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "8000")
+    count = 256 * 4096
     rng = np.random.default_rng(3)
     xs = make_ranks(gpu, world, 4 << 20)
     streams = [gpu.Stream() for _ in range(world)]
@@ -184,7 +219,8 @@ def _ipc_worker(rank, world, conn, device):
         from util import rand_half as rh
         ah.set_device(device)
         h = C.c_void_p()
-        assert ah.lib.atoma_xgmi_create(C.byref(h), rank, world, device, 2 << 20) == 0, ah.last_error()
+        cap = (64 << 20) if world == 8 else (2 << 20)
+        assert ah.lib.atoma_xgmi_create(C.byref(h), rank, world, device, cap) == 0, ah.last_error()
         one = (C.c_uint8 * 128)()
         assert ah.lib.atoma_xgmi_handle(h, one) == 0, ah.last_error()
         conn.send(bytes(one))
@@ -194,7 +230,8 @@ def _ipc_worker(rank, world, conn, device):
         conn.send("connected")
         assert conn.recv() == "go"
         worst = 0
-        for i, count in enumerate((8, 64 * 8192, 700 * 1024)):          # one-shot, one-shot (1 MiB > limit -> two-shot), two-shot
+        # one-shot, the decode message (1 MiB > the one-shot limit -> two-shot), two-shot; the 8 ranks of configs[3] also the prefill chunk's 64 MiB
+        for i, count in enumerate((8, 64 * 8192, 700 * 1024) + ((4096 * 8192,) if world == 8 else ())):
             parts = [rh(np.random.default_rng(100 * i + r), (count,), 1) for r in range(world)]
             want = AO2.allreduce_sum(parts, 1)
             dx = ah.DeviceBuffer.from_numpy(parts[rank])
@@ -213,16 +250,19 @@ def _ipc_worker(rank, world, conn, device):
         conn.send(("error", traceback.format_exc() + repr(e)))
 
 
-def test_two_processes_over_hip_ipc(gpu):
-    world = 2
-    devices = [0, 1] if gpu.lib.atoma_device_count() >= 2 else [0, 0]
+@pytest.mark.parametrize("world", [2, 8])
+def test_processes_over_hip_ipc(gpu, world):
+    """One PROCESS per rank (what torch.distributed.run / bench.py --gpus N starts): staging regions mapped through hipIpcOpenMemHandle.
+    world 8 on one device = the whole TP = 8 communicator of configs[3], minus the links."""
+    ndev = gpu.lib.atoma_device_count()
+    devices = list(range(world)) if ndev >= world else [0] * world
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(world)]
     procs = [ctx.Process(target=_ipc_worker, args=(r, world, pipes[r][1], devices[r])) for r in range(world)]
     for p in procs:
         p.start()
     try:
-        def get(r, timeout=120):
+        def get(r, timeout=300):
             assert pipes[r][0].poll(timeout), f"rank {r} did not answer"
             m = pipes[r][0].recv()
             if isinstance(m, tuple) and m[0] == "error":

@@ -1,4 +1,4 @@
-"""bench.py --gpus 2 end to end on ONE device: two ranks under torch.distributed.run, kv heads sharded over them,
+"""bench.py --gpus 2 / --gpus 8 end to end on ONE device: the ranks under torch.distributed.run, kv heads sharded over them,
 the communicator (direct all-reduce over HIP IPC: RCCL refuses two ranks on one device) counted through itself, and the
 tensor-parallel step of configs[3] in its reduced plumbing form -- what the 8-GPU SCALE run executes, minus the physical links."""
 import json
@@ -12,21 +12,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_on_one_device(gpu):
-    env = dict(os.environ, ATOMA_BENCH_ONE_DEVICE="1", ATOMA_BENCH_TP_SMALL="1", ATOMA_XGMI_TIMEOUT_MS="20000", ATOMA_BENCH_EXTRA_TIMEOUT="240",
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_ranks_on_one_device(gpu, world):
+    """world 8: the command line of the driver's 8-GPU run (`-m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`), all eight
+    ranks on device 0 -- each holds 4 q heads / 1 kv head of the headline workload, the communicator has 8 members."""
+    env = dict(os.environ, ATOMA_BENCH_ONE_DEVICE="1", ATOMA_BENCH_TP_SMALL="1", ATOMA_XGMI_TIMEOUT_MS="30000", ATOMA_BENCH_EXTRA_TIMEOUT="300",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32", "--seq", "1024", "--no-traffic"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(29533 + world),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "32", "--seq", "1024", "--no-traffic"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     out = json.loads(lines[-1])
-    assert out["n_gpus"] == 2 and out["ranks_expected"] == 2
-    assert out["ranks_seen"] == 2, out                         # counted through the communicator itself
-    assert sorted(d["rank"] for d in out["rank_devices"]) == [0, 1] and all(d["pci_bus_id"] for d in out["rank_devices"])
-    assert "tp2" in out["config"]["parallelism"] and out["scaling"] == "strong"
+    assert out["n_gpus"] == world and out["ranks_expected"] == world
+    assert out["ranks_seen"] == world, out                     # counted through the communicator itself
+    assert sorted(d["rank"] for d in out["rank_devices"]) == list(range(world)) and all(d["pci_bus_id"] for d in out["rank_devices"])
+    assert f"tp{world}" in out["config"]["parallelism"] and out["scaling"] == "strong"
     pr = out["per_rank"]                                        # every rank's own shard and kernel time
-    assert [r_["rank"] for r_ in pr] == [0, 1] and all(r_["q_heads"] == 16 and r_["kv_heads"] == 4 and r_["kernel_ms"] > 0 and "paged_decode" in r_["kernel"] for r_ in pr)
+    assert [r_["rank"] for r_ in pr] == list(range(world))
+    assert all(r_["q_heads"] == 32 // world and r_["kv_heads"] == 8 // world and r_["kernel_ms"] > 0 and "paged_decode" in r_["kernel"] for r_ in pr)
     assert "paged_decode" in out["roofline"]["kernel"]
     tps = out["tp_step"]
     assert tps["engines_available"].get("xgmi") is True and tps["xgmi_step_ms"] and tps["xgmi_allreduce_us"], tps

@@ -18,18 +18,20 @@ from util import rand_half
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("graph,own,B", [(False, False, 6), (True, False, 6), (True, True, 6), (True, True, 24)],
                          ids=["eager", "hipgraph", "hipgraph-own-projections", "hipgraph-own-projections-24-rows"])
-def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, own, B, monkeypatch):
+def test_tp_decode_step_matches_unsharded(gpu, world, graph, own, B, monkeypatch):
     """own: the rank's projections on the library's own kernels (gate/up with SiLU.up inside; at 24 rows the LDS-DMA tile kernel with its
-    in-launch K-split merge and the q/k/v projection with RoPE + cache write as its epilogue; tools/tp_step.py and bench.py run it so)."""
+    in-launch K-split merge and the q/k/v projection with RoPE + cache write as its epilogue; tools/tp_step.py and bench.py run it so).
+    world 8: the partition of configs[3] -- every rank one kv head and its q-head group, an eighth of the MLP, 7 peers in every all-reduce."""
     monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "8000")
     import decode_step as DS
     import tp
     from test_allreduce_xgmi_gpu import make_ranks
     rng = np.random.default_rng(21)
-    cfg = DS.Config(layers=3, hidden=512, heads=8, kv_heads=2, head_dim=128, intermediate=1024, vocab=1008, page=16, max_pos=256)
+    cfg = (DS.Config(layers=3, hidden=512, heads=8, kv_heads=2, head_dim=128, intermediate=1024, vocab=1008, page=16, max_pos=256) if world == 2 else
+           DS.Config(layers=3, hidden=512, heads=16, kv_heads=8, head_dim=128, intermediate=2048, vocab=1008, page=16, max_pos=256))
     ctx = np.array([0, 17, 40, 64, 100, 130]) if B == 6 else np.sort(rng.integers(0, 131, B))
     lens = (ctx + 1).astype(np.int32)
     blocks = [(int(L) + cfg.page - 1) // cfg.page for L in lens]
@@ -60,7 +62,7 @@ def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, own, B, monke
     o_full = [t["o"].numpy(np.uint16, (B, H)) for (n, l, t) in full.trace[1:-1]]
     dn_full = [t["dn"].numpy(np.uint16, (B, H)) for (n, l, t) in full.trace[1:-1]]
 
-    # ---- two ranks ----
+    # ---- the ranks ----
     xs = make_ranks(gpu, world, 1 << 20)
     streams = [gpu.Stream() for _ in range(world)]
     scfg = tp.shard_config(cfg, world)
@@ -114,7 +116,8 @@ def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, own, B, monke
             streams[r].synchronize()
             assert gpu.lib.atoma_xgmi_status(xs[r]) == 0, f"rank {r}: an all-reduce wait timed out"
         logits = [s.logits.numpy(np.uint16, (B, cfg.vocab)) for s in steps]
-        assert np.array_equal(logits[0], logits[1]), "ranks disagree: the all-reduce must leave bit-identical activations everywhere"
+        for r in range(1, world):
+            assert np.array_equal(logits[0], logits[r]), f"ranks 0 and {r} disagree: the all-reduce must leave bit-identical activations everywhere"
         l32 = to_f32(logits[0], BF16)
         # sharding moves rounding points (partial projections are rounded before they are summed): a few bf16 ulps on O(1) logits
         assert np.abs(l32 - logits_full).max() < 0.08, np.abs(l32 - logits_full).max()
@@ -131,6 +134,71 @@ def test_two_rank_decode_step_matches_unsharded(gpu, world, graph, own, B, monke
                     # (three to four bf16 ulps at |x| ~ 1 after three layers: 0.0273 observed with the matrix-core decode kernel, 0.02 with dot2)
                     excess = (np.abs(got - r32) - (0.03 + 2.0 ** -5 * np.abs(r32))).max()
                     assert excess <= 0, f"layer {l} {key}: {excess:.4f} beyond 0.03 + 2^-5 |ref| (max |diff| {np.abs(got - r32).max():.4f})"
+    finally:
+        for x in xs:
+            gpu.lib.atoma_xgmi_destroy(x)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_tp_prefill_chunk_matches_unsharded(gpu, world, monkeypatch):
+    """The prefill phase of the tensor-parallel step (llama_nccl.rs:118-200 on prompt tokens): every rank projects all T tokens onto its
+    q / kv heads, runs causal prefill attention over ITS heads, and the [T, hidden] outputs of the o and the down projection are
+    all-reduced -- two prompts of 96 tokens here, against the unsharded PrefillStep on the same weights.  (The full shapes -- T = 4096,
+    hidden 8192, a 64 MiB message among 8 ranks -- run in tests/test_tp_world8_gpu.py.)"""
+    monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "8000")
+    import decode_step as DS
+    import tp
+    from test_allreduce_xgmi_gpu import make_ranks
+    rng = np.random.default_rng(33)
+    cfg = DS.Config(layers=2, hidden=512, heads=16, kv_heads=8, head_dim=128, intermediate=2048, vocab=1008, page=16, max_pos=256)
+    T, n = 192, 2
+    pages = T // cfg.page
+    host = DS.random_host_weights(rng, cfg)
+    ids = rng.integers(0, cfg.vocab, T)
+    slots = (rng.permutation(pages)[np.arange(T) // cfg.page] * cfg.page + np.arange(T) % cfg.page).astype(np.int64)
+
+    st = gpu.Stream()
+    fd = DS.DecodeStep(cfg, 1, pages + 1, pages, DS.upload_weights(cfg, host), st)
+    full = DS.PrefillStep(cfg, T, fd, st, prompts=n)
+    full.set_inputs(ids, slots)
+    full.run()
+    st.synchronize()
+    logits_full = to_f32(full.logits.numpy(np.uint16, (n, cfg.vocab)), BF16)
+
+    xs = make_ranks(gpu, world, 1 << 20)
+    streams = [gpu.Stream() for _ in range(world)]
+    scfg = tp.shard_config(cfg, world)
+    live = [False]
+    steps = []
+    try:
+        for r in range(world):
+            def allreduce(ptr, count, r=r):
+                if live[0]:
+                    assert count == T * cfg.hidden
+                    assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], ptr, ptr, count, BF16, streams[r].s) == 0, gpu.last_error()
+            d = DS.DecodeStep(scfg, 1, pages + 1, pages, DS.upload_weights(scfg, tp.shard_weights(host, cfg, r, world)), streams[r])
+            p = DS.PrefillStep(scfg, T, d, streams[r], prompts=n, allreduce=allreduce)
+            p.set_inputs(ids, slots)
+            steps.append(p)
+        for p in steps:                                        # vendor-GEMM plans with the exchange off (see the decode test)
+            p.run()
+        for r in range(world):
+            streams[r].synchronize()
+        live[0] = True
+        for p in steps:
+            p.run()
+        for r in range(world):
+            streams[r].synchronize()
+            assert gpu.lib.atoma_xgmi_status(xs[r]) == 0, f"rank {r}: an all-reduce wait timed out"
+        logits = [p.logits.numpy(np.uint16, (n, cfg.vocab)) for p in steps]
+        for r in range(1, world):
+            assert np.array_equal(logits[0], logits[r]), f"ranks 0 and {r} disagree"
+        assert np.abs(to_f32(logits[0], BF16) - logits_full).max() < 0.08
+        # the rank's KV cache holds the prompt's K rows of ITS kv heads: equal to the unsharded cache's columns (same projection rows, same RoPE)
+        _, ks = tp.head_shard(cfg.h, cfg.hk, world - 1, world)
+        kfull = fd.kc[0].numpy(np.uint16, (pages + 1, cfg.page, cfg.hk, cfg.d))[:, :, ks]
+        kshard = steps[-1].kc[0].numpy(np.uint16, (pages + 1, cfg.page, scfg.hk, cfg.d))
+        assert np.array_equal(kfull, kshard)
     finally:
         for x in xs:
             gpu.lib.atoma_xgmi_destroy(x)

@@ -214,10 +214,14 @@ class PrefillStep:
     prefill attention over the prompt's own K/V -> o GEMM -> residual -> RMSNorm -> gate/up GEMM -> SiLU.up -> down GEMM ->
     residual] -> RMSNorm of the last token -> lm_head -> argmax.  Shares the KV caches of a DecodeStep."""
 
-    def __init__(self, cfg, T, decode_step, stream, prompts=1):
-        """T tokens in all = `prompts` prompts of T / prompts tokens each, back to back (varlen batch)."""
+    def __init__(self, cfg, T, decode_step, stream, prompts=1, allreduce=None):
+        """T tokens in all = `prompts` prompts of T / prompts tokens each, back to back (varlen batch).
+        allreduce(ptr, count): in-place sum of a [T, hidden] bf16 tensor over the tensor-parallel ranks, enqueued on `stream` -- called
+        after the o and the down projection when `cfg` and the weights are ONE rank's shard (llama_nccl.rs:139,195: the same two
+        TensorParallelRowLinear outputs as in the decode step; at T = 4096 and hidden 8192 that is a 64 MiB message)."""
         c = self.cfg = cfg
         assert T % prompts == 0
+        self.allreduce = allreduce
         self.T, self.n, self.stream, self.w, self.kc, self.vc = T, prompts, stream, decode_step.w, decode_step.kc, decode_step.vc
         self.ids = ah.DeviceBuffer.zeros((T,), np.int32)
         self.pos = ah.DeviceBuffer.from_numpy(np.tile(np.arange(T // prompts, dtype=np.int64), prompts))
@@ -257,10 +261,14 @@ class PrefillStep:
                        is_bf16=BF16, q_strides=(0, qkvw, c.d), k_strides=(0, qkvw, c.d), v_strides=(0, qkvw, c.d), o_strides=(0, hd, c.d),
                        is_causal=1, cu_seqlens_q=self.cu, cu_seqlens_k=self.cu, stream=s)
             self._ok(L.atoma_linear(self.att.ptr, self.w["wo"][l].ptr, self.o.ptr, T, hd, H, hd, hd, H, BF16, s), "o projection")
+            if self.allreduce:
+                self.allreduce(self.o.ptr, T * H)
             self._ok(L.atoma_add_rms_norm(x.ptr, self.o.ptr, self.w["norm2"][l].ptr, x1.ptr, self.xn.ptr, T, H, H, H, H, H, c.eps, BF16, s), "residual add + rms_norm")
             self._ok(L.atoma_linear(self.xn.ptr, self.w["wgu"][l].ptr, self.gu.ptr, T, H, 2 * c.inter, H, H, 2 * c.inter, BF16, s), "gate/up projection")
             self._ok(L.atoma_silu_mul(self.gu.ptr, self.gu.ptr + c.inter * 2, self.act.ptr, T, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
             self._ok(L.atoma_linear(self.act.ptr, self.w["wdown"][l].ptr, self.o.ptr, T, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
+            if self.allreduce:
+                self.allreduce(self.o.ptr, T * H)
             if l + 1 < c.layers:
                 self._ok(L.atoma_add_rms_norm(x1.ptr, self.o.ptr, self.w["norm1"][l + 1].ptr, x2.ptr, self.xn.ptr, T, H, H, H, H, H, c.eps, BF16, s), "residual add + rms_norm")
             else:                                           # the final norm only touches the last token of every prompt
