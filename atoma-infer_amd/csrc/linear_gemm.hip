@@ -85,7 +85,11 @@ struct PlanGuard {
     }
 };
 struct LtDevice {
-    hipblasLtHandle_t handle = nullptr;
+    // One library handle PER STREAM, like the workspace: a handle owns device-side synchronisation state of its own (the split-accumulation
+    // kernels' flags), and two products issued through ONE handle on two streams that run at the same time race on it -- found in round 5 with
+    // eight tensor-parallel ranks on one device (tools/tp_step.py --virtual-ranks 8 --prefill 4096): wrong sums in one run, a GEMM that never
+    // finished in the next.  One stream per device (the reference's one thread per GPU) never met it.
+    std::map<hipStream_t, hipblasLtHandle_t> handles;
     std::map<hipStream_t, void *> workspaces;   // one per stream: two GEMMs on different streams may run concurrently
     std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t>, GemmPlan> plans;
 };
@@ -113,8 +117,9 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
     if (!check_hip(hipGetDevice(&dev), "hipGetDevice")) return -1;
     std::lock_guard<std::mutex> lock(*g_lt_mu);
     LtDevice &d = (*g_lt_devices)[dev];
-    if (!d.handle) {
-        if (!lt_ok(api.create(&d.handle), "hipblasLtCreate")) { d.handle = nullptr; return -1; }
+    hipblasLtHandle_t &handle = d.handles[stream];
+    if (!handle) {
+        if (!lt_ok(api.create(&handle), "hipblasLtCreate")) { handle = nullptr; return -1; }
     }
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &capturing);
@@ -153,9 +158,9 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
         // candidate 0 = the library's own single choice; the longer list it returns is ordered differently and need not contain it
         hipblasLtMatmulHeuristicResult_t res[LT_CANDIDATES + 1];
         int found = 0, more = 0;
-        ok = ok && lt_ok(api.heuristic(d.handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, 1, res, &found), "MatmulAlgoGetHeuristic");
+        ok = ok && lt_ok(api.heuristic(handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, 1, res, &found), "MatmulAlgoGetHeuristic");
         if (ok && found == 1 && linear_autotune &&
-            api.heuristic(d.handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, LT_CANDIDATES, res + 1, &more) == HIPBLAS_STATUS_SUCCESS)
+            api.heuristic(handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, LT_CANDIDATES, res + 1, &more) == HIPBLAS_STATUS_SUCCESS)
             found += more;
         api.pref_destroy(pref);
         if (!ok) return -1;
@@ -171,7 +176,7 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
                 bool good = true;
                 (void)hipEventRecord(e0, stream);
                 for (int rep = 0; rep < reps && good; ++rep)
-                    good = api.matmul(d.handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &res[c].algo, lt_ws,
+                    good = api.matmul(handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &res[c].algo, lt_ws,
                                       LT_WORKSPACE_BYTES, stream) == HIPBLAS_STATUS_SUCCESS;
                 (void)hipEventRecord(e1, stream);
                 if (hipEventSynchronize(e1) != hipSuccess || !good) { (void)hipGetLastError(); return false; }
@@ -209,7 +214,7 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
             // first seen during capture: the candidates could not be timed -- use the heuristic's choice for this launch only,
             // so that a later eager call still tunes the problem
             const float alpha1 = 1.f, beta0 = 0.f;
-            return lt_ok(api.matmul(d.handle, pl.desc, &alpha1, w, pl.a, x, pl.b, &beta0, y, pl.c, y, pl.c, &pl.algo, lt_ws,
+            return lt_ok(api.matmul(handle, pl.desc, &alpha1, w, pl.a, x, pl.b, &beta0, y, pl.c, y, pl.c, &pl.algo, lt_ws,
                                     LT_WORKSPACE_BYTES, stream), "Matmul") ? 0 : -1;
         }
         guard.keep = true;
@@ -217,7 +222,7 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
     }
     const GemmPlan &pl = it->second;
     const float alpha = 1.f, beta = 0.f;
-    if (!lt_ok(api.matmul(d.handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &pl.algo, lt_ws,
+    if (!lt_ok(api.matmul(handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &pl.algo, lt_ws,
                           LT_WORKSPACE_BYTES, stream), "Matmul"))
         return -1;
     return 0;

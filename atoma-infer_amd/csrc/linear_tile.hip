@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(512, 1) linear_tile_kernel(const TileParams tp
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned *ticket = reinterpret_cast<unsigned *>(smem);    // the ring is idle now (every DMA was waited for)
-        if (tid == 0) *ticket = sync_arrive(tp.counters + tile, sync_epoch());
+        if (tid == 0) *ticket = sync_arrive(tp.counters + tile, sync_epoch(), (unsigned)S);
         __syncthreads();
         if (*ticket + 1 != (unsigned)S) return;                    // not the last: somebody else finishes the tile
         lf32x4 tot[GPW];

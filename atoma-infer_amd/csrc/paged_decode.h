@@ -45,6 +45,7 @@ struct DecodeParams {
     int head_major;        // 1: workgroup id -> (kv head, chunk) slowest, (split, sequence) fastest (decode_map_work)
     int stream_force;      // the balanced line also for uniform resident batches (decode_plan_launch says when)
     int fp8_klines;        // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays (not on the balanced line, not with a single kv head: contiguous rows), 2 always
+    int line_pieces;       // > 0: small batch ON THE LINE -- this many wavefronts share it (more than b . h_k . chunks: every sequence is cut), decode_line_small
     int line_merge;        // balanced mode: the cut pieces of a sequence are merged by the LAST wavefront to arrive at it (counters), no combine launch
     int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
     float scale, scale_log2;
@@ -385,7 +386,7 @@ template <bool STREAM, int NWG = 1, typename F, typename M = DecodeNoMerge> __de
                 const int w0 = (int)(s0 / pl.share), w1 = (int)((s0 + wk.n_tiles - 1) / pl.share);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this piece is out
                 unsigned t = 0;
-                if ((threadIdx.x & 63) == 0) t = sync_arrive(p.counters + w0, s_epoch);
+                if ((threadIdx.x & 63) == 0) t = sync_arrive(p.counters + w0, s_epoch, (unsigned)(w1 - w0 + 1));
                 t = __builtin_amdgcn_readfirstlane(t);
                 if (t == (unsigned)(w1 - w0)) merger.merge(&p, b, hkc, w0, w1 - w0 + 1, s0 > (int64_t)w0 * pl.share ? 1 : 0);
             }

@@ -225,6 +225,19 @@ int atoma_warmup_prefill(void *stream, int64_t max_tokens, int64_t max_seqs, int
     return atoma::workspace(static_cast<hipStream_t>(stream), atoma::prefill_asm_workspace_bound(max_tokens, max_seqs, num_heads)) ? 0 : -1;
 }
 
+namespace atoma {
+__global__ void debug_epoch_kernel(unsigned long long *out) {
+    if (threadIdx.x == 0) out[0] = sync_epoch();
+}
+}  // namespace atoma
+
+int atoma_debug_launch_epoch(void *stream, void *epoch_out_device) {
+    atoma::clear_error();
+    if (!epoch_out_device) { atoma::set_error("atoma_debug_launch_epoch: null output"); return -1; }
+    hipLaunchKernelGGL(atoma::debug_epoch_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<unsigned long long *>(epoch_out_device));
+    return ATOMA_CHECK_LAUNCH("debug_epoch_kernel") ? 0 : -1;
+}
+
 int atoma_debug_sync_words(void *stream, void **words_out, int64_t *count_out) {
     atoma::clear_error();
     atoma::sync_word_t *p = atoma::sync_counters(static_cast<hipStream_t>(stream));

@@ -14,8 +14,14 @@
 // fetch_add(word, 1) -> ticket.  The dispatch id is the packet's index in its hardware queue: every launch of a stream, eager or from a
 // replayed graph, gets a larger one than all launches before it on that stream, with no host involvement and nothing baked into a
 // captured graph; 48 bits of it never wrap.  Both atomics go to the same address from the same lane, so the L2 performs them in issue
-// order; nobody resets anything; nobody waits.  Cost against the old fetch_add: one extra request in flight, no extra round trip.
-// A word's state after a launch is irrelevant to the next one: the boundary is stateless again.
+// order; nobody waits.  Cost against the old fetch_add: one extra request in flight, no extra round trip.
+//
+// The last arriver ALSO puts the word back to zero (off the critical path: it is about to merge anyway).  That is not what makes a launch
+// correct -- the epoch does -- but it keeps the words clean across what the epoch cannot see: dispatch ids are per hardware QUEUE, and a
+// stream handle that is destroyed and created again may come back with the same address (the same words here) on another queue whose ids
+// start lower (found in round 5: eight fresh streams of a test inherited the words, and the "future" epochs, of eight dead ones).  So a
+// later launch is wrong only if an inconsistent episode left words non-zero AND the stream then moved to a queue with lower ids -- before,
+// the episode alone sufficed, for ever.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,11 +38,12 @@ extern "C" __device__ unsigned long long atoma_llvm_amdgcn_dispatch_id(void) __a
 // wave-uniform
 __device__ __forceinline__ sync_word_t sync_epoch() { return ((sync_word_t)atoma_llvm_amdgcn_dispatch_id() + 1ull) << SYNC_COUNT_BITS; }
 
-// ticket of this arrival at `word` in the launch whose epoch is `epoch`: 0 for the first to arrive, n - 1 for the last of n
-__device__ __forceinline__ unsigned sync_arrive(sync_word_t *word, sync_word_t epoch) {
+// ticket of this arrival at `word` in the launch whose epoch is `epoch`, n arrivals expected: 0 for the first to arrive, n - 1 for the last
+__device__ __forceinline__ unsigned sync_arrive(sync_word_t *word, sync_word_t epoch, unsigned n) {
     __hip_atomic_fetch_max(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const sync_word_t t = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (unsigned)(t & ((1ull << SYNC_COUNT_BITS) - 1));
+    const unsigned t = (unsigned)(__hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ((1ull << SYNC_COUNT_BITS) - 1));
+    if (t + 1 == n) __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
 }
 
 }  // namespace atoma

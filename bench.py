@@ -263,7 +263,7 @@ def main():
     # ---- end-to-end numbers beside the headline, each timed with HIP events in this same run (tools/bench_extra.py) ----
     # N = 1: the 8B decode step of configs[2], the prefill kernel, the configs[4] swap.  N > 1: the tensor-parallel decode step
     # of configs[3] (70B-shaped shard per rank, 2 all-reduces of [64, 8192] per layer) with RCCL and with the direct xGMI kernels.
-    prefill_smp = None
+    prefill_smp, extra_smp = None, {}
     if not args.no_extra:
         for b_ in (dkc, dvc, dq, do):
             b_.free()
@@ -308,6 +308,9 @@ def main():
             watchdog.cancel()
         if isinstance(extra.get("prefill"), dict):
             prefill_smp = extra["prefill"].pop("sample", None)      # host copies of sampled rows: checked below, not part of the line
+        for name, e in extra.items():                                # the other extras' samples (decode sequences, norm / RoPE rows, prefill rows)
+            if isinstance(e, dict) and "sample" in e:
+                extra_smp[name] = e.pop("sample")
         out["extra"] = extra
         if world > 1:
             out["tp_step"] = tp_summary(extra.get("tp_step") or tp_progress, extra.get("error"))
@@ -327,6 +330,12 @@ def main():
         if prefill_smp is not None:
             out["verified"]["prefill"] = verify_prefill_sample(prefill_smp)
             failed = failed or not out["verified"]["prefill"]["ok"]
+        for name, smp in extra_smp.items():                   # every other driver-timed row: sampled outputs of its TIMED calls against the oracle
+            out["verified"][name] = verify_extra_sample(smp)
+            failed = failed or not out["verified"][name]["ok"]
+        for name in ("k4_reshape_and_cache", "k5_copy_blocks"):   # bit-exact ops checked against their definition where they ran
+            if isinstance(out.get("extra", {}).get(name), dict) and "bit_exact" in out["extra"][name]:
+                failed = failed or not out["extra"][name]["bit_exact"]
     if comm is not None or xgmi is not None:
         if dist is not None:
             dist.barrier()
@@ -363,6 +372,40 @@ def verify_prefill_sample(smp):
             worst = max(worst, float(err.max()))
             n += 1
     return {"ok": ok, "rows": n, "max_err": worst, "against": "oracle/attn_oracle.py attend_rows (f32 definition)"}
+
+
+def verify_extra_sample(smp):
+    """Samples of tools/bench_extra.py rows against the oracle (the checker): decode sequences and prefill rows against the f32 definition
+    (attend_rows; 1e-3 + 1 ulp from 512 visible keys on, the P-rounding bound below), RMSNorm rows within one ulp of the f32 definition,
+    RoPE rows bit-exact in Candle's per-op arithmetic."""
+    from oracle import attn_oracle as A, norm_rope_oracle as NR
+    from halfs import to_f32, BF16
+    if smp and smp[0].get("kind") is None:                       # prefill rows (tools/bench_extra.py prefill)
+        return verify_prefill_sample(smp)
+    ok, worst, n, what = True, 0.0, 0, []
+    for it in smp:
+        if it["kind"] == "decode":
+            ref, _ = A.attend_rows(to_f32(it["q"], BF16)[None], to_f32(it["k"], BF16), to_f32(it["v"], BF16), np.float32(it["scale"]), causal=False)
+            got = to_f32(it["o"], BF16)
+            err = np.abs(got - ref[0])
+            tol = (1e-3 if it["L"] >= 512 else 4e-3) + 2.0 ** -7 * np.abs(ref[0])
+            ok = ok and bool(np.isfinite(got).all() and (err <= tol).all())
+            worst, n = max(worst, float(err.max())), n + got.shape[0]
+            what.append("decode rows vs attend_rows (f32)")
+        elif it["kind"] == "rms_norm":
+            ref = to_f32(NR.rms_norm(it["x"], it["w"], it["eps"], BF16), BF16)
+            got = to_f32(it["y"], BF16)
+            err = np.abs(got - ref)
+            ok = ok and bool((err <= 2.0 ** -7 * np.abs(ref) + 1e-6).all())
+            worst, n = max(worst, float(err.max())), n + got.shape[0]
+            what.append("RMSNorm rows within 1 ulp of norm_rope_oracle.rms_norm")
+        elif it["kind"] == "rope":
+            T = it["x"].shape[0]
+            ref = NR.rope(it["x"], it["cos"], it["sin"], np.arange(T), BF16, mode="per_op")
+            ok = ok and bool(np.array_equal(ref, it["y"]))
+            n += T
+            what.append("RoPE rows bit-exact vs norm_rope_oracle.rope (per-op rounding)")
+    return {"ok": ok, "rows": n, "max_err": worst, "against": "; ".join(sorted(set(what)))}
 
 
 def tp_summary(res, note=None):

@@ -452,6 +452,9 @@ int atoma_release_workspaces(void);
 int atoma_reset_sync_counters(void *stream);
 int atoma_warmup_prefill(void *stream, int64_t max_tokens, int64_t max_seqs, int64_t num_heads);
 int atoma_debug_sync_words(void *stream, void **words_out, int64_t *count_out);
+/* Diagnostics of the arrival tickets: writes the epoch word of ONE tiny launch on `stream` (its AQL dispatch id + 1, shifted by 16) to
+ * *epoch_out_device (8 bytes of device memory).  Tests use it to show that epochs grow from launch to launch, also under graph replay. */
+int atoma_debug_launch_epoch(void *stream, void *epoch_out_device);
 
 /* Device helpers used by the host layer, tests and bench (plain HIP runtime, no torch). */
 int atoma_device_count(void);

@@ -194,11 +194,12 @@ def test_tp_prefill_chunk_matches_unsharded(gpu, world, monkeypatch):
         for r in range(1, world):
             assert np.array_equal(logits[0], logits[r]), f"ranks 0 and {r} disagree"
         assert np.abs(to_f32(logits[0], BF16) - logits_full).max() < 0.08
-        # the rank's KV cache holds the prompt's K rows of ITS kv heads: equal to the unsharded cache's columns (same projection rows, same RoPE)
+        # the rank's KV cache holds the prompt's K rows of ITS kv heads: the unsharded cache's columns (same projection rows of the same
+        # input, same RoPE; the vendor GEMM accumulates a [T, 1280]-wide product in another order than a [T, 160]-wide one: an ulp or two)
         _, ks = tp.head_shard(cfg.h, cfg.hk, world - 1, world)
-        kfull = fd.kc[0].numpy(np.uint16, (pages + 1, cfg.page, cfg.hk, cfg.d))[:, :, ks]
-        kshard = steps[-1].kc[0].numpy(np.uint16, (pages + 1, cfg.page, scfg.hk, cfg.d))
-        assert np.array_equal(kfull, kshard)
+        kfull = to_f32(fd.kc[0].numpy(np.uint16, (pages + 1, cfg.page, cfg.hk, cfg.d))[:, :, ks], BF16)
+        kshard = to_f32(steps[-1].kc[0].numpy(np.uint16, (pages + 1, cfg.page, scfg.hk, cfg.d)), BF16)
+        assert np.abs(kfull).max() > 0.5 and (np.abs(kfull - kshard) <= 1e-2 + 2.0 ** -6 * np.abs(kfull)).all()
     finally:
         for x in xs:
             gpu.lib.atoma_xgmi_destroy(x)

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def tp_step(*args, timeout=900):
+def tp_step(*args, timeout=420):
     env = dict(os.environ, ATOMA_XGMI_TIMEOUT_MS="30000", ATOMA_TP_STEP_WATCHDOG_S=str(timeout - 30))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "tp_step.py"), "--virtual-ranks", "8"] + list(args), env=env, cwd=ROOT,
                        capture_output=True, text=True, timeout=timeout)

@@ -8,6 +8,10 @@
   swap             (+ the pinned hipMemcpyAsync ceiling of the same byte count beside it)
                    CPU<->GPU KV swap of BASELINE configs[4]: 64 tensors (32 layers x K, V), 256 pages of 32 KiB, pinned host
                    memory, both directions -> GB/s over PCIe.
+  c2b_mha, c2c_ragged, k4_reshape_and_cache, k5_copy_blocks, n1_norm_rope, p1_prefill_4096
+                   the remaining rows of BASELINE.md section 2, each with its algorithmic bytes / flops and fraction of the
+                   peak, each checked: bit-exact ops here against their definition, attention / norm / RoPE on sampled outputs by bench.py
+                   against the oracle.
 Bench plumbing over the C ABI; synthetic data; nothing here imports oracle/."""
 import ctypes as C
 import os
@@ -143,6 +147,145 @@ def swap(iters=3, tensors=64, pages=256, nb=512, page_bytes=16 * 8 * 128 * 2, se
     return res
 
 
+def _decode_case(name, B, S, h, hk, ragged, iters, seed, sample_seqs):
+    """A paged-decode workload of BASELINE.md section 2 timed like the headline (one run_mha call per step) + host copies of `sample_seqs`
+    sequences (q, the output the TIMED calls wrote, their K / V gathered through the block table) for bench.py's check against the oracle."""
+    rng = np.random.default_rng(seed)
+    d, page = 128, 16
+    pps = S // page
+    n_pages = int(B * pps * 1.125)
+    bt = rng.permutation(n_pages)[: B * pps].astype(np.int32).reshape(B, pps)
+    lens = (rng.integers(S // 2, S + 1, B) if ragged else np.full(B, S)).astype(np.int32)
+    kc, vc = TS.rand_dev(rng, n_pages * page * hk * d * 2), TS.rand_dev(rng, n_pages * page * hk * d * 2)
+    q = TS.rand_dev(rng, B * h * d * 2)
+    o = ah.DeviceBuffer(B * h * d * 2)
+    dbt, dl = ah.DeviceBuffer.from_numpy(bt), ah.DeviceBuffer.from_numpy(lens)
+    st = ah.Stream()
+
+    def run():
+        ah.run_mha(q, kc, vc, o, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=pps * page, softmax_scale=d ** -0.5, is_bf16=1,
+                   q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d), v_strides=(page * hk * d, hk * d, d),
+                   cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt, block_table_batch_stride=pps, page_block_size=page,
+                   force_split_kernel=True, unpadded_lse=False, stream=st.s)
+    ms = _timed(st, run, iters)
+    kernel = (ah.lib.atoma_last_decode_kernel() or b"").decode()
+    tot = int(lens.astype(np.int64).sum())
+    nbytes = 2 * tot * hk * d * 2 + 2 * B * h * d * 2 + 4 * int(((lens + page - 1) // page).sum()) + 4 * B
+    sample = []
+    if sample_seqs:
+        page_bytes = page * hk * d * 2
+        qh, oh = q.numpy(np.uint16, (B, h, d)), o.numpy(np.uint16, (B, h, d))
+        for b_ in sample_seqs:
+            L = int(lens[b_])
+            ks, vs = np.empty((pps, page, hk, d), np.uint16), np.empty((pps, page, hk, d), np.uint16)
+            for j in range((L + page - 1) // page):
+                for dst, src in ((ks, kc), (vs, vc)):
+                    ah.hip_check(ah.hip.hipMemcpy(dst[j].ctypes.data, src.ptr + int(bt[b_, j]) * page_bytes, page_bytes, ah.D2H), "sample page")
+            sample.append({"kind": "decode", "q": qh[b_].copy(), "o": oh[b_].copy(), "k": ks.reshape(pps * page, hk, d)[:L].copy(),
+                           "v": vs.reshape(pps * page, hk, d)[:L].copy(), "scale": d ** -0.5, "L": L})
+    for b_ in (kc, vc, q, o, dbt, dl):
+        b_.free()
+    return {"sample": sample, "workload": name, "ms": round(ms, 4), "kernel": kernel, "algorithmic_bytes": int(nbytes),
+            "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4), "decode_tokens_per_s": round(B / (ms * 1e-3))}
+
+
+def c2b_mha(iters=20):
+    """the headline workload with 32 kv heads (MHA stress): 17.18 GB per call."""
+    return _decode_case("C2b paged decode, MHA stress: bs=256, 32 q / 32 kv heads, d=128, seq=4096, block 16, bf16, random block table", 256, 4096, 32, 32, False, iters, 2, (3, 200))
+
+
+def c2c_ragged(iters=20):
+    """the headline workload with ragged lengths U[2048, 4096] (bytes from the actual lengths)."""
+    return _decode_case("C2c paged decode, ragged lengths U[2048,4096]: bs=256, 32 q / 8 kv heads, d=128, block 16, bf16, random block table", 256, 4096, 32, 8, True, iters, 3,
+                        (0, 101, 255))
+
+
+def k4_reshape_and_cache(iters=20, T=8192, hk=8, d=128, page=16, seed=5):
+    """reshape_and_cache_flash, T new tokens of 8 kv heads x 128 into random slots; bytes = 4 T h_k d 2 + 8 T.  The check is the
+    op's definition (cache row of slot[t] == key[t]), bit-exact, on every token."""
+    rng = np.random.default_rng(seed)
+    nb = 2 * T // page
+    k, v = TS.rand_dev(rng, T * hk * d * 2), TS.rand_dev(rng, T * hk * d * 2)
+    kc, vc = ah.DeviceBuffer.zeros((nb * page * hk * d,), np.uint16), ah.DeviceBuffer.zeros((nb * page * hk * d,), np.uint16)
+    slots = rng.permutation(nb * page)[:T].astype(np.int64)
+    ds = ah.DeviceBuffer.from_numpy(slots)
+    st = ah.Stream()
+
+    def run():
+        ah.lib.reshape_and_cache_flash(k.ptr, v.ptr, kc.ptr, vc.ptr, ds.ptr, page * hk * d, T, hk, d, page, hk * d, hk * d, 1, st.s)
+    ms = _timed(st, run, iters)
+    kh, vh = k.numpy(np.uint16, (T, hk * d)), v.numpy(np.uint16, (T, hk * d))
+    ok = bool(np.array_equal(kc.numpy(np.uint16, (nb * page, hk * d))[slots], kh) and np.array_equal(vc.numpy(np.uint16, (nb * page, hk * d))[slots], vh))
+    nbytes = 4 * T * hk * d * 2 + 8 * T
+    return {"workload": f"K4 reshape_and_cache_flash: {T} tokens x {hk} kv heads x {d}, block {page}, bf16, random slots", "ms": round(ms, 4), "algorithmic_bytes": nbytes,
+            "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4), "bit_exact": ok, "checked_tokens": T}
+
+
+def k5_copy_blocks(iters=10, layers=32, pairs=1024, page_bytes=32768, nb=4096, seed=6):
+    """copy_blocks over 32 layers x (K, V), 1024 (src, dst) page pairs of 32 KiB: bytes = 4 P L 32 KiB (read + write, K and V).
+    Check: every destination page equals its source page, bit for bit, in the first and the last layer."""
+    rng = np.random.default_rng(seed)
+    kcs, vcs = [TS.rand_dev(rng, nb * page_bytes) for _ in range(layers)], [TS.rand_dev(rng, nb * page_bytes) for _ in range(layers)]
+    perm = rng.permutation(nb)
+    m = np.stack([perm[:pairs], perm[pairs:2 * pairs]], 1).astype(np.int64)      # disjoint sources and destinations
+    dm = ah.DeviceBuffer.from_numpy(m)
+    kp, vp = ah.DeviceBuffer.from_numpy(np.array([b.ptr for b in kcs], np.int64)), ah.DeviceBuffer.from_numpy(np.array([b.ptr for b in vcs], np.int64))
+    st = ah.Stream()
+
+    def run():
+        ah.lib.copy_blocks_bf16(kp.ptr, vp.ptr, dm.ptr, layers, pairs, page_bytes // 2, st.s)
+    ms = _timed(st, run, iters)
+    ok = True
+    for buf in (kcs[0], vcs[-1]):
+        pg = buf.numpy(np.uint16, (nb, page_bytes // 2))
+        ok = ok and bool(np.array_equal(pg[m[:, 1]], pg[m[:, 0]]))
+    nbytes = 4 * pairs * layers * page_bytes
+    return {"workload": f"K5 copy_blocks: {layers} layers x (K, V), {pairs} page pairs of {page_bytes // 1024} KiB, bf16", "ms": round(ms, 4), "algorithmic_bytes": nbytes,
+            "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac_hbm": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4), "bit_exact": ok}
+
+
+def n1_norm_rope(iters=20, T=2048, hidden=4096, h=32, hk=8, d=128, seed=7):
+    """RMSNorm over [T, 4096] (bytes 2 T hidden 2) and RoPE of q and k in place ([T, (32 + 8) x 128]: bytes 2 T (h + h_k) d 2).
+    bench.py checks sampled rows of both against the f32 definitions (oracle/norm_rope_oracle.py)."""
+    rng = np.random.default_rng(seed)
+    c = DS.Config(1, hidden, h, hk, d, 14336, 128256)
+    x, w = TS.rand_dev(rng, T * hidden * 2), TS.norm_dev(rng, hidden)
+    y = ah.DeviceBuffer(T * hidden * 2)
+    st = ah.Stream()
+    ms_norm = _timed(st, lambda: ah.lib.atoma_rms_norm(x.ptr, w.ptr, y.ptr, T, hidden, hidden, hidden, c.eps, 1, st.s), iters)
+    cos, sin = DS.rope_tables(c)
+    dcos, dsin = ah.DeviceBuffer.from_numpy(cos), ah.DeviceBuffer.from_numpy(sin)
+    qk0 = TS.rand_dev(rng, T * (h + hk) * d * 2)
+    qk = ah.DeviceBuffer(T * (h + hk) * d * 2)
+    pos = rng.integers(0, c.max_pos, T).astype(np.int64)
+    dpos = ah.DeviceBuffer.from_numpy(pos)
+    row = (h + hk) * d
+
+    def rope():
+        assert ah.lib.atoma_rope_qk(qk.ptr, qk.ptr + h * d * 2, dcos.ptr, dsin.ptr, dpos.ptr, T, h, hk, d, row, row, 1, 1, st.s) == 0, ah.last_error()
+    ms_rope = _timed(st, rope, iters)
+    # a fresh, single application for the sample (the timed calls rotated the buffer in place many times)
+    ah.hip_check(ah.hip.hipMemcpy(qk.ptr, qk0.ptr, T * row * 2, ah.D2D), "restore")
+    rope()
+    st.synchronize()
+    rows = [0, 1, T // 2, T - 1]
+    xs, ys = x.numpy(np.uint16, (T, hidden)), y.numpy(np.uint16, (T, hidden))
+    q0, q1 = qk0.numpy(np.uint16, (T, h + hk, d)), qk.numpy(np.uint16, (T, h + hk, d))
+    sample = [{"kind": "rms_norm", "x": xs[rows].copy(), "w": w.numpy(np.uint16, (hidden,)), "y": ys[rows].copy(), "eps": c.eps},
+              {"kind": "rope", "x": q0[rows].copy(), "y": q1[rows].copy(), "cos": cos[pos[rows]].copy(), "sin": sin[pos[rows]].copy()}]
+    nb_norm, nb_rope = 2 * T * hidden * 2, 2 * T * (h + hk) * d * 2
+    return {"sample": sample,
+            "rms_norm": {"workload": f"N1 RMSNorm [{T}, {hidden}] bf16", "ms": round(ms_norm, 4), "algorithmic_bytes": nb_norm, "GBps": round(nb_norm / (ms_norm * 1e-3) / 1e9, 1),
+                         "frac_hbm": round(nb_norm / (ms_norm * 1e-3) / HBM_PEAK, 4)},
+            "rope": {"workload": f"N1 RoPE of q and k in place, [{T}, ({h} + {hk}) x {d}] bf16, random positions", "ms": round(ms_rope, 4), "algorithmic_bytes": nb_rope,
+                     "GBps": round(nb_rope / (ms_rope * 1e-3) / 1e9, 1), "frac_hbm": round(nb_rope / (ms_rope * 1e-3) / HBM_PEAK, 4)}}
+
+
+def p1_prefill_4096(iters=10):
+    """BASELINE.md P1 at S = 4096: B such that the tokens in flight stay at 8192 -> 2 prompts of 4096."""
+    return prefill(iters=iters, S=4096, nseq=2, with_sample=True)
+
+
 def c4_rank_step(iters=10):
     """One rank of the Llama-3.1-70B TP = 8 decode step of configs[3] without its all-reduces (tools/rank_step.py): what a rank
     computes between the exchanges, batch 64, context 4096, 80 layers."""
@@ -150,7 +293,13 @@ def c4_rank_step(iters=10):
     return rank_step.run(iters=iters)
 
 
-def collect(which=("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "swap"), prefill_sample=False):
+ALL = ("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "p1_prefill_4096", "c2b_mha", "c2c_ragged", "k4_reshape_and_cache", "k5_copy_blocks",
+       "n1_norm_rope", "swap")
+
+
+def collect(which=ALL, prefill_sample=False):
+    """Every entry that carries a "sample" (host copies of a few inputs / outputs of the TIMED calls) is checked by bench.py against the
+    oracle; bench.py pops the samples before it prints the line."""
     out = {}
     for name in which:
         try:
@@ -163,4 +312,8 @@ def collect(which=("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "p
 if __name__ == "__main__":
     import json
     ah.set_device(0)
-    print(json.dumps(collect(tuple(sys.argv[1:]) or ("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "swap"))))
+    res = collect(tuple(sys.argv[1:]) or ALL)
+    for v in res.values():
+        if isinstance(v, dict):
+            v.pop("sample", None)
+    print(json.dumps(res))
