@@ -101,6 +101,26 @@ __device__ __forceinline__ void copy_span16(const uint4 *__restrict__ src, uint4
     }
 }
 
+// A span of the K page and the same span of the V page together: all eight 16-byte loads of a lane leave before its first store (32 KiB in
+// flight per workgroup), every byte is touched once -> non-temporal on both sides (round 5: 4.85 -> see profiles/r05 K5; the copied pages are
+// read by the NEXT decode step from HBM anyway).
+typedef unsigned int copy_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void copy_span16_kv(const copy_u32x4 *__restrict__ ks, copy_u32x4 *__restrict__ kd, const copy_u32x4 *__restrict__ vs,
+                                               copy_u32x4 *__restrict__ vd, int64_t nvec, int64_t span) {
+    const int64_t base = span * COPY_SPAN_VECS + threadIdx.x;
+    copy_u32x4 rk[COPY_UNROLL], rv[COPY_UNROLL];
+#pragma unroll
+    for (int u = 0; u < COPY_UNROLL; ++u) {
+        const int64_t i = base + (int64_t)u * COPY_THREADS;
+        if (i < nvec) { rk[u] = __builtin_nontemporal_load(ks + i); rv[u] = __builtin_nontemporal_load(vs + i); }
+    }
+#pragma unroll
+    for (int u = 0; u < COPY_UNROLL; ++u) {
+        const int64_t i = base + (int64_t)u * COPY_THREADS;
+        if (i < nvec) { __builtin_nontemporal_store(rk[u], kd + i); __builtin_nontemporal_store(rv[u], vd + i); }
+    }
+}
+
 __global__ void __launch_bounds__(COPY_THREADS)
 copy_blocks_kernel(const int64_t *__restrict__ key_cache_ptrs, const int64_t *__restrict__ value_cache_ptrs,
                    const int64_t *__restrict__ block_mapping, int64_t numel_per_block) {
@@ -114,8 +134,8 @@ copy_blocks_kernel(const int64_t *__restrict__ key_cache_ptrs, const int64_t *__
                      ((reinterpret_cast<uintptr_t>(vc) & 15u) == 0);
     if (vec) {  // workgroup-uniform branch
         const int64_t nvec = numel_per_block >> 3;
-        copy_span16(reinterpret_cast<const uint4 *>(kc + src), reinterpret_cast<uint4 *>(kc + dst), nvec, span);
-        copy_span16(reinterpret_cast<const uint4 *>(vc + src), reinterpret_cast<uint4 *>(vc + dst), nvec, span);
+        copy_span16_kv(reinterpret_cast<const copy_u32x4 *>(kc + src), reinterpret_cast<copy_u32x4 *>(kc + dst),
+                       reinterpret_cast<const copy_u32x4 *>(vc + src), reinterpret_cast<copy_u32x4 *>(vc + dst), nvec, span);
     } else {
         const int64_t lo = span * COPY_SPAN_VECS * 8;
         int64_t hi = lo + (int64_t)COPY_SPAN_VECS * 8;

@@ -45,7 +45,6 @@ struct DecodeParams {
     int head_major;        // 1: workgroup id -> (kv head, chunk) slowest, (split, sequence) fastest (decode_map_work)
     int stream_force;      // the balanced line also for uniform resident batches (decode_plan_launch says when)
     int fp8_klines;        // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays (not on the balanced line, not with a single kv head: contiguous rows), 2 always
-    int line_pieces;       // > 0: small batch ON THE LINE -- this many wavefronts share it (more than b . h_k . chunks: every sequence is cut), decode_line_small
     int line_merge;        // balanced mode: the cut pieces of a sequence are merged by the LAST wavefront to arrive at it (counters), no combine launch
     int *plan;             // balanced mode: [0] = tiles of the whole batch, [1] = balanced mode taken, [2 .. 2+b] = exclusive prefix of tiles per sequence (b + 3 ints)
     float scale, scale_log2;

@@ -898,7 +898,6 @@ struct DecodeOptions {
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
     opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
     opt_int pair64{env_int("ATOMA_DECODE_PAIR64", 1)};   // head_dim 64 with an even number of kv heads and groups of 1 / 2 / 4 q heads: two kv heads per wavefront on the matrix-core kernel (1) or the dot2 kernel (0)
-    opt_int line_small{env_int("ATOMA_DECODE_LINE_SMALL", 0)};   // small batches (KV splits) on the balanced line, merged inside the launch: 0 never, 1 = instead of split + combine where the launch has lengths on the device (A/B knob, round 5)
     opt_int line_merge{env_int("ATOMA_DECODE_LINE_MERGE", 1)};   // balanced line: cut sequences merged by the last wavefront to arrive (1) or by decode_combine_kernel (0)
     opt_int fp8_klines{env_int("ATOMA_DECODE_FP8_KLINES", 1)};   // fp8 matrix-core kernel, K in full 128-byte lines: 0 never, 1 where it pays, 2 always
     opt_int head_major{env_int("ATOMA_DECODE_HEAD_MAJOR", 1)};   // workgroup order of the non-balanced launches: kv head slowest (1) or fastest (0)
@@ -926,7 +925,6 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_mqk") o.mqk = value;
     else if (name == "decode_wg_merge") o.wg_merge = value;
     else if (name == "decode_line_merge") o.line_merge = value;
-    else if (name == "decode_line_small") o.line_small = value;
     else if (name == "decode_pair64") o.pair64 = value;
     else if (name == "decode_fp8_mqk") o.fp8_mqk = value;
     else if (name == "decode_fp8_wg") o.fp8_wg = value;
@@ -956,7 +954,7 @@ template <typename K> static int resident_waves_per_cu(K kernel) {
 static void set_stream_waves(DecodeParams &p, int occupancy, hipStream_t stream) {
     const int opt = decode_options().stream_waves_per_cu;
     const int wpc = opt > 0 ? std::min(opt, DECODE_STREAM_MAX_WAVES_PER_CU) : occupancy;
-    p.stream_waves = (int)std::min<int64_t>(p.line_pieces > 0 ? (int64_t)p.line_pieces : (int64_t)p.b * p.h_k * p.gchunks, (int64_t)device_num_cus() * wpc);
+    p.stream_waves = (int)std::min<int64_t>((int64_t)p.b * p.h_k * p.gchunks, (int64_t)device_num_cus() * wpc);
     p.line_merge = 0;
     if (decode_options().line_merge && p.stream_waves <= DECODE_WG_MAX_COUNTERS) {
         p.counters = sync_counters(stream);
@@ -978,11 +976,10 @@ static void note_decode_kernel(const char *kernel, const char *t, int d, int g, 
 
 template <typename T, int D, int G, int P, int MINW, bool NT>
 static void launch_decode_cfg(DecodeParams &p, hipStream_t stream) {
-    int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
+    const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
     if (p.stream_waves > 0) {
         static const int occ = resident_waves_per_cu(paged_decode_kernel<T, D, G, P, MINW, NT, true>);
         set_stream_waves(p, occ, stream);
-        blocks = std::max<int64_t>(blocks, p.stream_waves);
     }
     note_decode_kernel("paged_decode_kernel", decode_tname<T>(), D, G, P, NT,
                        p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? (std::to_string(p.num_splits) + " KV splits + combine").c_str() : "one wavefront per (sequence, kv head)"));
@@ -1041,9 +1038,8 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
             return;
         }
     }
-    int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
+    const int64_t blocks = (int64_t)p.b * p.num_splits * p.h_k * p.gchunks;
     if (p.stream_waves > 0) set_stream_waves(p, 8, stream);   // __launch_bounds__(64, 2)
-    if (p.stream_waves > 0) blocks = std::max<int64_t>(blocks, p.stream_waves);
     note_decode_kernel(PAIR64 ? "paged_decode_mqk_kernel(kv-head pairs)" : "paged_decode_mqk_kernel", decode_tname<T>(), PAIR64 ? 64 : 128, G, p3 ? 3 : 2, nt,
                        p.stream_waves > 0 ? "balanced" : (p.num_splits > 1 ? (std::to_string(p.num_splits) + " KV splits + combine").c_str() : "one wavefront per (sequence, kv head)"));
 #define ATOMA_MQK(P_, NT_, S_) hipLaunchKernelGGL((paged_decode_mqk_kernel<T, G, P_, NT_, S_, PAIR64>), dim3((unsigned)blocks), dim3(64), 0, stream, p)
@@ -1133,19 +1129,15 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
     p.fp8_klines = decode_options().fp8_klines;
     p.head_major = decode_options().head_major != 0 && p.h_k > 1;
     p.stream_waves = 0;
-    p.line_pieces = 0;
     const int64_t hk_chunks = (int64_t)p.h_k * p.gchunks, max_tiles = cdiv(p.seqlen_k, 16);
-    if (p.num_splits > 1 && decode_options().line_small != 0 && decode_options().line_merge != 0 && st_opt != 0 && !fp8 && (p.cu_seqlens_k || p.seqused_k) &&
-        p.b <= DECODE_STREAM_MAX_B && p.b * hk_chunks * max_tiles < (int64_t)1 << 31 && p.b * hk_chunks * p.num_splits <= DECODE_WG_MAX_COUNTERS) {
-        // the pieces the split heuristic would cut, laid on the line instead: one launch, every sequence merged by its last wavefront
-        p.line_pieces = (int)(p.b * hk_chunks * p.num_splits);
-        p.num_splits = 1;
-        p.stream_force = 1;
-    }
+    // (Round 5 re-measured round 3's question with the in-launch merge in place: small batches -- the pieces the split heuristic cuts -- laid on the
+    // line and merged by their last wavefront instead of split + combine.  Slower on every shape: the 70B TP = 8 shard at B = 64 30.5 -> 42.2 us,
+    // B = 1 12.5 -> 20.2, 16 x 8192 90.2 -> 99.0, the 4-head shard at B = 256 83.9 -> 99.7 (profiles/r05_decode_line_small_ab.txt): the pieces of
+    // one sequence sit on consecutive line positions = 8 different XCDs, and one wavefront merges 16-32 pieces through three dependent trips.)
     if (p.num_splits == 1 && st_opt != 0 && (p.cu_seqlens_k || p.seqused_k) && p.b <= DECODE_STREAM_MAX_B &&
         p.b * hk_chunks * max_tiles < (int64_t)1 << 31) {
         // enough wavefronts without splitting and the lengths are on the device: the kernel balances ragged batches itself
-        p.stream_waves = (int)std::min<int64_t>(p.line_pieces > 0 ? (int64_t)p.line_pieces : p.b * hk_chunks, (int64_t)device_num_cus() * DECODE_STREAM_MAX_WAVES_PER_CU);   // upper bound, set per kernel at launch
+        p.stream_waves = (int)std::min<int64_t>(p.b * hk_chunks, (int64_t)device_num_cus() * DECODE_STREAM_MAX_WAVES_PER_CU);   // upper bound, set per kernel at launch
     }
     // bit 3 of decode_mqk: groups of 2..4 q heads take the matrix-core kernel when the launch runs on the balanced line.  In the
     // per-sequence order the two kernels tied (or dot2 won by 2-3 %); on the line the matrix-core kernel's shorter instruction stream

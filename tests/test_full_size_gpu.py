@@ -27,23 +27,24 @@ def close_linear(got, ref, what):
     assert (np.abs(g - r) <= 2.0 ** -7 * np.abs(r) + 3e-5).all(), what
 
 
-def test_8b_decode_step_batch_256(gpu):
+@pytest.mark.parametrize("contexts", ["short", "configs2"])
+def test_8b_decode_step_batch_256(gpu, contexts):
+    """contexts = "configs2": the contexts of BASELINE configs[2] in mid-trace (prefill 2048 + up to 512 decoded tokens: U[2048, 2560)) over a
+    RANDOM KV history in all 32 layers (86 GB of cache) -- VERDICT r4: the step had only been checked at contexts 128..384 over zeroed caches."""
     import decode_step as DS
     import tp_step as TS
     rng = np.random.default_rng(256)
     c = DS.LLAMA_3_1_8B
     B = 256
-    w = TS.random_shard_weights(rng, c)                      # synthetic N(0,1) bf16 weights on the device (magnitudes blow activations up: fine for parity)
-    # activations stay finite only with sane scales: rescale the projections' random slabs is not possible in place -- instead use
-    # small norm weights so that every layer's input is O(0.02)
-    small = from_small(rng, c.hidden)
-    for l in range(c.layers):
-        w["norm1"][l].upload(small)
-        w["norm2"][l].upload(small)
-    w["norm_f"].upload(small)
-    ctx = rng.integers(128, 384, B)
-    pps = 384 // c.page + 1
+    w = TS.random_shard_weights(rng, c)                      # synthetic bf16 weights on the device, scaled like an initialised model (activations O(1))
+    lo, hi = (128, 384) if contexts == "short" else (2048, 2560)
+    ctx = rng.integers(lo, hi, B)
+    pps = hi // c.page + 1
     bt = rng.permutation(B * pps).astype(np.int32).reshape(B, pps)
+    history = None
+    if contexts == "configs2":                               # one random history, shared by the two steps below
+        n = (B * pps + 2) * c.page * c.hk * c.d * 2
+        history = [(TS.rand_dev(rng, n), TS.rand_dev(rng, n)) for _ in range(c.layers)]
     slots = bt[np.arange(B), ctx // c.page].astype(np.int64) * c.page + ctx % c.page
     ids = rng.integers(0, c.vocab, B)
     lens = (ctx + 1).astype(np.int32)
@@ -52,6 +53,9 @@ def test_8b_decode_step_batch_256(gpu):
 
     def fresh(**kw):
         s = DS.DecodeStep(c, B, B * pps + 2, pps, w, st, **kw)
+        if history is not None:
+            for l in range(c.layers):
+                s.kc[l], s.vc[l] = history[l]
         s.set_inputs(ids, ctx, slots, lens, bt)
         return s
     # ---- the bench's route: eager, then a captured graph over the SAME caches (the step rewrites the same K/V rows with the same values)
@@ -101,7 +105,10 @@ def test_8b_decode_step_batch_256(gpu):
     att = dl(t["att"], (B, hd))
     ref = A.flash_attn_kv_cache(q_rot[:, None], kc, vc, c.d ** -0.5, BF16, bt[ROWS], lens[ROWS])[:, 0].reshape(n, hd)
     a32, r32 = to_f32(att, BF16), to_f32(ref, BF16)
-    assert (np.abs(a32 - r32) <= 4e-3 + 2.0 ** -7 * np.abs(r32)).all(), "attention"
+    tol = 4e-3 if contexts == "short" else 1e-3              # BASELINE's 1e-3 from 512 visible keys on (tests/util.py)
+    assert (np.abs(a32 - r32) <= tol + 2.0 ** -7 * np.abs(r32)).all(), "attention"
+    if contexts == "configs2":
+        assert np.abs(r32).max() > 0.05                      # a live signal: the mean of 2000+ random V rows per head, not zeros
     o = dl(t["o"], (B, H))
     close_linear(o, LO.linear(att, host["wo"], BF16), "o projection")
     x1 = dl(t["x1"], (B, H))
@@ -117,7 +124,3 @@ def test_8b_decode_step_batch_256(gpu):
     x2 = dl(t["x2"], (B, H))
     assert np.array_equal(x2, EO.add(x1, dn, BF16))
 
-
-def from_small(rng, hidden):
-    from oracle.halfs import from_f32
-    return from_f32((0.02 * (1 + 0.1 * rng.standard_normal(hidden))).astype(np.float32), BF16)

@@ -118,6 +118,8 @@ def bench_decode():
     decode_case("C2c decode identity table", 256, 4096, 32, 8, identity=True)
     decode_case("C2c decode ragged U[2048,4096]", 256, 4096, 32, 8, ragged=True)
     decode_case("decode ragged U[2048,4096] MHA hk=32", 256, 4096, 32, 32, ragged=True)
+    decode_case("decode narrow spread U[2048,2560) (the contexts of the C3 step)", 256, 2560, 32, 8, lens=np.random.default_rng(9).integers(2048, 2560, 256))
+    decode_case("decode narrow spread U[3800,4096]", 256, 4096, 32, 8, lens=np.random.default_rng(10).integers(3800, 4097, 256))
     decode_case("C2b decode MHA hk=32", 256, 4096, 32, 32)
     decode_case("C4 decode Llama-70B shape TP=1: B=256 h=64 hk=8 S=4096", 256, 4096, 64, 8)
     decode_case("C4 decode 70B TP=8 shard: B=256 h=8 hk=1 S=4096", 256, 4096, 8, 1)
