@@ -181,10 +181,15 @@ __device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, in
     const int hk_chunks = p.h_k * p.gchunks;
     const int64_t total = (int64_t)pl.T * hk_chunks;
     pl.share = (int)max((total + p.stream_waves - 1) / p.stream_waves, (int64_t)DECODE_MIN_SHARE);
-    // one wavefront per (sequence, kv head) is already balanced when every sequence is (nearly) as long as the
-    // longest and all of them are resident at once: idle share 1 - mean/max below 4 %
-    const bool ragged = (int64_t)mx * p.b * 96 > (int64_t)pl.T * 100;
-    pl.stream = ragged || p.b * hk_chunks > p.stream_waves || p.stream_force;
+    // When do equal shares (= cut sequences) pay?  A cut costs ~4.5 % of the launch whatever the spread (two start-up chains, fp32 partials, a
+    // merge per sequence); one wavefront per (sequence, kv head) in the same kv-head-major order costs the idle tail of the short
+    // sequences.  Measured round 5 (profiles/r05_decode_narrow_spread_ab.txt, B = 256, 8 kv heads): lengths U[3800,4096] (idle share
+    // 1 - mean/max = 4 %) 0.648 ms cut / 0.627 whole; U[2048,2560) (10 %, the contexts of the configs[2] step) 0.397 / 0.385;
+    // U[2048,4096] (25 %) 0.521 / 0.552.  So: cut from 15 % idle share on, or when the batch has more (sequence, kv head) items than
+    // resident wavefronts; an exactly uniform batch is the same launch either way (no share boundary falls inside a sequence).
+    const bool ragged = (int64_t)mx * p.b * 85 > (int64_t)pl.T * 100;
+    const bool uniform = (int64_t)mx * p.b == (int64_t)pl.T;
+    pl.stream = ragged || p.b * hk_chunks > p.stream_waves || p.stream_force == 2 || (p.stream_force && uniform);
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS writes above
     __builtin_amdgcn_wave_barrier();
     return pl;

@@ -1125,7 +1125,7 @@ static DecodeLaunchPlan decode_plan_launch(DecodeParams &p, int D, bool fp8 = fa
     // (0.385 -> 0.42 ms), so d = 64 keeps the old order.  Neither rotating the kv head by the sequence index nor dealing the sequences
     // of a block of 8 to the 8 XCDs (all heads of a sequence behind one L2) reproduces it: it is the CU, not the XCD, that matters.
     const int st_opt = decode_options().stream;
-    p.stream_force = st_opt == 2 || (st_opt == 1 && p.h_k > 1 && D == 128);
+    p.stream_force = st_opt == 2 ? 2 : ((st_opt == 1 && p.h_k > 1 && D == 128) ? 1 : 0);   // 2: the cut line whatever the lengths; 1: the line for exactly uniform batches (the order), cuts from 15 % idle share on
     p.fp8_klines = decode_options().fp8_klines;
     p.head_major = decode_options().head_major != 0 && p.h_k > 1;
     p.stream_waves = 0;

@@ -39,9 +39,19 @@ extern "C" __device__ unsigned long long atoma_llvm_amdgcn_dispatch_id(void) __a
 __device__ __forceinline__ sync_word_t sync_epoch() { return ((sync_word_t)atoma_llvm_amdgcn_dispatch_id() + 1ull) << SYNC_COUNT_BITS; }
 
 // ticket of this arrival at `word` in the launch whose epoch is `epoch`, n arrivals expected: 0 for the first to arrive, n - 1 for the last
+// Memory order.  The pieces an arriver publishes before its ticket are agent-scope write-through stores (past the XCD's L2) drained
+// with s_waitcnt vmcnt(0); the last arriver reads them with agent-scope loads: correct on gfx950 by what those instructions do, but the
+// HIP / LLVM memory model only promises it for a RELEASE ticket and an ACQUIRE before the reads.  `make syncrel` builds that variant
+// (ATOMA_SYNC_RELEASE: release fetch_add = L2 write-back + wait in front of the atomic, acquire fence = L2 / L1 invalidate in the last
+// arriver) for the A/B of tools/probes; the numbers decide which one ships.
 __device__ __forceinline__ unsigned sync_arrive(sync_word_t *word, sync_word_t epoch, unsigned n) {
     __hip_atomic_fetch_max(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef ATOMA_SYNC_RELEASE
+    const unsigned t = (unsigned)(__hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) & ((1ull << SYNC_COUNT_BITS) - 1));
+    if (t + 1 == n) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
     const unsigned t = (unsigned)(__hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ((1ull << SYNC_COUNT_BITS) - 1));
+#endif
     if (t + 1 == n) __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return t;
 }
