@@ -43,7 +43,12 @@ __device__ __forceinline__ sync_word_t sync_epoch() { return ((sync_word_t)atoma
 // with s_waitcnt vmcnt(0); the last arriver reads them with agent-scope loads: correct on gfx950 by what those instructions do, but the
 // HIP / LLVM memory model only promises it for a RELEASE ticket and an ACQUIRE before the reads.  `make syncrel` builds that variant
 // (ATOMA_SYNC_RELEASE: release fetch_add = L2 write-back + wait in front of the atomic, acquire fence = L2 / L1 invalidate in the last
-// arriver) for the A/B of tools/probes; the numbers decide which one ships.
+// arriver).  Measured round 5 (profiles/r05_sync_ticket_release_vs_relaxed_ab.txt, same box, interleaved): the ragged headline shape
+// 0.516-0.525 -> 0.686 ms (every wavefront of the line writes the XCD's whole L2 back once or twice), the 70B rank step 8.73 -> 9.6 ms
+// (every workgroup of every K-split projection), split + combine launches level (no ticket there).  So the relaxed variant ships, with
+// its ordering argument stated in ISA terms: (1) pieces leave as sc1 (write-through) stores, (2) s_waitcnt vmcnt(0) returns when the
+// memory side has acknowledged them, (3) only then the lane issues the ticket atomic (performed at L2 / memory, device-coherent), (4) the
+// last arriver's reads are sc1 loads issued after its own atomic returned: they miss the non-coherent caches by construction.
 __device__ __forceinline__ unsigned sync_arrive(sync_word_t *word, sync_word_t epoch, unsigned n) {
     __hip_atomic_fetch_max(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef ATOMA_SYNC_RELEASE
