@@ -242,6 +242,23 @@ int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, in
                                              static_cast<hipStream_t>(stream)), "ncclAllReduce") ? 0 : -1;
 }
 
+// llama_nccl.rs:139 -> llama.rs:404,408 (and :195 -> :409, next layer's :402): x_out = residual + allreduce(in), norm_out = RMSNorm(x_out) * weight.
+// Direct engine: ONE launch (atoma_xgmi_allreduce_add_rms_norm); RCCL engine: ncclAllReduce into x_out, then atoma_add_rms_norm over it.
+// Both engines end with the bits of "all-reduce, then atoma_add_rms_norm" of that engine.  in / x_out contiguous [rows, hidden].
+int atoma_allreduce_add_rms_norm(void *comm, const void *in, const void *residual, const void *weight, void *x_out, void *norm_out, int64_t rows,
+                                 int64_t hidden, float eps, int dtype, void *stream) {
+    atoma::clear_error();
+    if (!comm) { atoma::set_error("atoma_allreduce_add_rms_norm: null communicator"); return -1; }
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { atoma::set_error("atoma_allreduce_add_rms_norm: dtype must be f16 or bf16"); return -1; }
+    if (rows <= 0) return 0;
+    auto *c = static_cast<atoma::Comm *>(comm);
+    const int64_t bytes = rows * hidden * 2;
+    if (c->mode != atoma::AR_RCCL && c->xgmi && bytes <= atoma_xgmi_capacity(c->xgmi) && (c->mode == atoma::AR_XGMI || bytes <= c->xgmi_auto_max))
+        return atoma_xgmi_allreduce_add_rms_norm(c->xgmi, in, residual, weight, x_out, norm_out, rows, hidden, hidden, hidden, hidden, eps, dtype, 0, stream);
+    if (atoma_allreduce_sum(comm, in, x_out, rows * hidden, dtype, stream) != 0) return -1;
+    return atoma_add_rms_norm(residual, x_out, weight, x_out, norm_out, rows, hidden, hidden, hidden, hidden, hidden, eps, dtype, stream);
+}
+
 int atoma_comm_destroy(void *comm) {
     atoma::clear_error();
     if (!comm) return 0;

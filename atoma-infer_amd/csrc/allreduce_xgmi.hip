@@ -34,6 +34,7 @@
 // torch.distributed gloo or RCCL itself) and every rank connects.  Same-process peers use the raw pointer, other
 // processes hipIpcOpenMemHandle (dmabuf IPC, HSA_ENABLE_IPC_MODE_LEGACY=0).
 #include "common.h"
+#include "norm_shared.h"
 
 #include <algorithm>
 #include <stdlib.h>
@@ -225,6 +226,187 @@ __global__ void __launch_bounds__(XGMI_THREADS) xgmi_twoshot_kernel(const XgmiPa
         const int64_t n = chunk_len(c), base = (int64_t)c * p.chunk_vec;
         const __amdgpu_buffer_rsrc_t src = xgmi_rsrc(gathered + (int64_t)c * p.slot_bytes);
         for (int64_t i = first; i < n; i += stride) out[base + i] = load_sys(src, i * 16);
+    }
+    xgmi_leave(p, seq);
+}
+
+// ------------------------------------------------------------------------------------------
+// all-reduce + residual add + RMSNorm in ONE launch per rank
+// ------------------------------------------------------------------------------------------
+// What follows both all-reduces of a tensor-parallel decoder layer (llama_nccl.rs:139 -> llama.rs:404,408; :195 -> :409 and the next
+// layer's :402): x' = x + allreduce(partial), then RMSNorm(x').  Every rank holds the whole summed row after the exchange, so the rank
+// that sums it can add the residual and normalise it while the row is in registers: two launches per layer fewer in the TP step (the
+// all-reduce kernel's tail replaces `atoma_add_rms_norm`), bit-identical to atoma_xgmi_allreduce_sum followed by atoma_add_rms_norm --
+// the sum is rounded to the storage type first (what the all-reduce writes), the add and the norm are norm_shared.h's arithmetic in
+// rms_norm_kernel's thread layout: 256 threads per row, thread t owns the row's 16-byte vectors t, t + 256, ...
+// Blocks of NORM_THREADS threads; a block owns the rows blockIdx.x, blockIdx.x + gridDim.x, ...
+
+// the signal half of xgmi_signal_and_wait: after this block's stores, one flag per peer (and, `self` set, one in this rank's own region:
+// the rows other blocks of this rank will read)
+__device__ __forceinline__ void xgmi_signal(const XgmiParams &p, int parity, int stage, uint32_t seq, bool self) {
+    __threadfence_system();
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < p.world && (self || t != p.rank))
+        __hip_atomic_store(xgmi_flag(p.peer[t], p, parity, stage, p.rank, blockIdx.x), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// wait for the flags of EVERY block of every rank (this rank's own included when `self`): a row of the result was produced by several
+// blocks of its owner
+__device__ __forceinline__ void xgmi_wait_all_blocks(const XgmiParams &p, int parity, int stage, uint32_t seq, bool self) {
+    const int n = p.world * (int)gridDim.x;
+    const long long limit = __hip_atomic_load(p.seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 0 : p.timeout_ticks;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int src = i / (int)gridDim.x, blk = i - src * (int)gridDim.x;
+        if (src == p.rank && !self) continue;
+        uint32_t *mine = xgmi_flag(p.peer[p.rank], p, parity, stage, src, blk);
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > limit) {
+                __hip_atomic_store(p.status, 1u + (uint32_t)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(p.seq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct XgmiNormParams {
+    const uint16_t *residual, *weight;
+    uint16_t *x_out, *norm_out;
+    int64_t res_stride, x_stride, norm_stride;   // elements
+    int rows, hidden;
+    float eps;
+};
+
+// One row, its summed vectors in sv[ITERS] (already rounded to T): x' = residual + sum -> x_out, RMSNorm(x') -> norm_out
+template <typename T, int ITERS>
+__device__ __forceinline__ void xgmi_add_norm_row(const XgmiNormParams &n, int64_t row, uint4 (&sv)[ITERS], float *red) {
+    const int nvec = n.hidden >> 3;
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = it * NORM_THREADS + threadIdx.x;
+        if (i < nvec) {
+            float fa[8], fb[8];
+            unpack8<T>(reinterpret_cast<const uint4 *>(n.residual + row * n.res_stride)[i], fa);
+            unpack8<T>(sv[it], fb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+            sv[it] = pack8<T>(fa);
+            reinterpret_cast<uint4 *>(n.x_out + row * n.x_stride)[i] = sv[it];
+        } else {
+            sv[it] = make_uint4(0, 0, 0, 0);
+        }
+        ss = norm_sumsq8<T>(sv[it], ss);
+    }
+    ss = norm_wave_sum(ss);
+    __syncthreads();                                   // (red is reused from the previous row)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float redr[NORM_THREADS / 64];
+#pragma unroll
+    for (int i = 0; i < NORM_THREADS / 64; ++i) redr[i] = red[i];
+    const float scale = norm_scale(redr, n.hidden, n.eps);
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = it * NORM_THREADS + threadIdx.x;
+        if (i < nvec) reinterpret_cast<uint4 *>(n.norm_out + row * n.norm_stride)[i] = norm_apply8<T>(sv[it], reinterpret_cast<const uint4 *>(n.weight)[i], scale);
+    }
+}
+
+template <typename T, int ITERS>
+__global__ void __launch_bounds__(NORM_THREADS) xgmi_oneshot_add_norm_kernel(const XgmiParams p, const XgmiNormParams n) {
+    __shared__ float red[NORM_THREADS / 64];
+    const uint32_t seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
+    const int parity = (int)(seq & 1u);
+    const int64_t half = (int64_t)parity * p.half_bytes;
+    const int nvec = n.hidden >> 3;                    // vectors per row; the message is rows x nvec vectors, row-major (p.in contiguous)
+    const xu32x4 *in = reinterpret_cast<const xu32x4 *>(p.in);
+    // push this block's rows into slot[rank] of every peer
+    for (int r = 1; r < p.world; ++r) {
+        const int q = (p.rank + r) % p.world;
+        const __amdgpu_buffer_rsrc_t dst = xgmi_rsrc(p.peer[q] + half + p.off_scatter + (int64_t)p.rank * p.slot_bytes);
+        for (int64_t row = blockIdx.x; row < n.rows; row += gridDim.x)
+            for (int i = threadIdx.x; i < nvec; i += NORM_THREADS) store_sys(dst, (row * nvec + i) * 16, in[row * nvec + i]);
+    }
+    xgmi_signal_and_wait(p, parity, 0, seq);           // block b of every rank owns the same rows: the per-block flags suffice
+    char *mine = p.peer[p.rank] + half + p.off_scatter;
+    for (int64_t row = blockIdx.x; row < n.rows; row += gridDim.x) {
+        uint4 sv[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = it * NORM_THREADS + threadIdx.x;
+            sv[it] = make_uint4(0, 0, 0, 0);
+            if (i < nvec) {
+                XgmiAcc<T> acc;
+                for (int q = 0; q < p.world; ++q) {
+                    const xu32x4 v = q == p.rank ? in[row * nvec + i] : load_sys(xgmi_rsrc(mine + (int64_t)q * p.slot_bytes), (row * nvec + i) * 16);
+                    if (q == 0) acc.set(v); else acc.add(v);
+                }
+                sv[it] = __builtin_bit_cast(uint4, acc.round());
+            }
+        }
+        xgmi_add_norm_row<T, ITERS>(n, row, sv, red);
+    }
+    xgmi_leave(p, seq);
+}
+
+template <typename T, int ITERS>
+__global__ void __launch_bounds__(NORM_THREADS) xgmi_twoshot_add_norm_kernel(const XgmiParams p, const XgmiNormParams n) {
+    __shared__ float red[NORM_THREADS / 64];
+    const uint32_t seq = __hip_atomic_load(p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
+    const int parity = (int)(seq & 1u);
+    const int64_t half = (int64_t)parity * p.half_bytes;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const xu32x4 *in = reinterpret_cast<const xu32x4 *>(p.in);
+    auto chunk_len = [&](int c) -> int64_t {
+        const int64_t left = p.nvec - (int64_t)c * p.chunk_vec;
+        return left <= 0 ? 0 : (left < p.chunk_vec ? left : p.chunk_vec);
+    };
+    // stage 0 (reduce-scatter), as xgmi_twoshot_kernel
+    for (int r = 1; r < p.world; ++r) {
+        const int c = (p.rank + r) % p.world;
+        const int64_t len = chunk_len(c), base = (int64_t)c * p.chunk_vec;
+        const __amdgpu_buffer_rsrc_t dst = xgmi_rsrc(p.peer[c] + half + p.off_scatter + (int64_t)p.rank * p.slot_bytes);
+        for (int64_t i = first; i < len; i += stride) store_sys(dst, i * 16, in[base + i]);
+    }
+    xgmi_signal_and_wait(p, parity, 0, seq);
+    // stage 1: my chunk summed in rank order, rounded, into slot[rank] of EVERYBODY's gather area -- my own too: the rows are put together from there
+    {
+        const int64_t len = chunk_len(p.rank), base = (int64_t)p.rank * p.chunk_vec;
+        char *mine = p.peer[p.rank] + half + p.off_scatter;
+        for (int64_t i = first; i < len; i += stride) {
+            XgmiAcc<T> acc;
+            for (int q = 0; q < p.world; ++q) {
+                const xu32x4 v = q == p.rank ? in[base + i] : load_sys(xgmi_rsrc(mine + (int64_t)q * p.slot_bytes), i * 16);
+                if (q == 0) acc.set(v); else acc.add(v);
+            }
+            const xu32x4 r = acc.round();
+            for (int rr = 0; rr < p.world; ++rr) {
+                const int q = (p.rank + rr) % p.world;
+                store_sys(xgmi_rsrc(p.peer[q] + half + p.off_gather + (int64_t)p.rank * p.slot_bytes), i * 16, r);
+            }
+        }
+    }
+    xgmi_signal(p, parity, 1, seq, true);
+    xgmi_wait_all_blocks(p, parity, 1, seq, true);     // a row's vectors were summed by several blocks of its owner(s)
+    char *gathered = p.peer[p.rank] + half + p.off_gather;
+    const int nvec = n.hidden >> 3;
+    for (int64_t row = blockIdx.x; row < n.rows; row += gridDim.x) {
+        uint4 sv[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = it * NORM_THREADS + threadIdx.x;
+            sv[it] = make_uint4(0, 0, 0, 0);
+            if (i < nvec) {
+                const int64_t gi = row * nvec + i;
+                const int c = (int)(gi / p.chunk_vec);
+                sv[it] = __builtin_bit_cast(uint4, load_sys(xgmi_rsrc(gathered + (int64_t)c * p.slot_bytes), (gi - (int64_t)c * p.chunk_vec) * 16));
+            }
+        }
+        xgmi_add_norm_row<T, ITERS>(n, row, sv, red);
     }
     xgmi_leave(p, seq);
 }
@@ -429,6 +611,57 @@ int atoma_xgmi_allreduce_sum_mode(void *xg, const void *in, void *out, int64_t c
         if (!ATOMA_CHECK_LAUNCH("xgmi all-reduce kernel")) return -1;
     }
     return 0;
+}
+
+// all-reduce(in) + residual -> x_out, RMSNorm(x_out) * weight -> norm_out, one launch (see the kernels above).  in: [rows, hidden] contiguous;
+// mode as atoma_xgmi_allreduce_sum_mode.  The message must fit ONE launch (rows * hidden * 2 <= capacity) -- a decode step's always does.
+int atoma_xgmi_allreduce_add_rms_norm(void *xg, const void *in, const void *residual, const void *weight, void *x_out, void *norm_out, int64_t rows,
+                                      int64_t hidden, int64_t residual_row_stride, int64_t x_row_stride, int64_t norm_row_stride, float eps, int dtype,
+                                      int mode, void *stream) {
+    using namespace atoma;
+    clear_error();
+    auto *x = static_cast<Xgmi *>(xg);
+    if (!x) { set_error("atoma_xgmi_allreduce_add_rms_norm: null communicator"); return -1; }
+    if (!x->connected) { set_error("atoma_xgmi_allreduce_add_rms_norm: atoma_xgmi_connect has not been called"); return -1; }
+    if (dtype != ATOMA_F16 && dtype != ATOMA_BF16) { set_error("atoma_xgmi_allreduce_add_rms_norm: dtype must be f16 or bf16"); return -1; }
+    if (rows < 0 || hidden <= 0 || hidden % 8 || hidden > 8 * 8 * NORM_THREADS) { set_error("atoma_xgmi_allreduce_add_rms_norm: hidden must be a multiple of 8, at most 16384"); return -1; }
+    if (residual_row_stride % 8 || x_row_stride % 8 || norm_row_stride % 8) { set_error("atoma_xgmi_allreduce_add_rms_norm: row strides must be multiples of 8 elements"); return -1; }
+    if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(x_out) |
+         reinterpret_cast<uintptr_t>(norm_out)) & 15u) { set_error("atoma_xgmi_allreduce_add_rms_norm: tensors must be 16-byte aligned"); return -1; }
+    if (rows == 0) return 0;
+    const int64_t bytes = rows * hidden * 2;
+    if ((size_t)bytes > x->capacity) { set_error("atoma_xgmi_allreduce_add_rms_norm: the message exceeds the communicator's capacity (one launch only)"); return -1; }
+    if (*reinterpret_cast<volatile uint32_t *>(x->status) != 0) { set_error("atoma_xgmi_allreduce_add_rms_norm: an earlier call timed out waiting for a peer (atoma_xgmi_status)"); return -1; }
+    const auto s = static_cast<hipStream_t>(stream);
+    if (x->world == 1)       // nothing to exchange: the sum is the input
+        return atoma_add_rms_norm(residual, in, weight, x_out, norm_out, rows, hidden, residual_row_stride, hidden, x_row_stride, norm_row_stride, eps, dtype, stream);
+    XgmiParams p{};
+    for (int q = 0; q < x->world; ++q) p.peer[q] = x->peer[q];
+    p.in = static_cast<const char *>(in);
+    p.out = nullptr;
+    p.seq = x->seq;
+    p.status = x->status_dev;
+    p.nvec = bytes / 16;
+    p.chunk_vec = (p.nvec + x->world - 1) / x->world;
+    p.slot_bytes = (int64_t)x->slot_bytes;
+    p.off_scatter = (int64_t)x->off_scatter; p.off_gather = (int64_t)x->off_gather; p.half_bytes = (int64_t)x->half_bytes;
+    p.off_flags = (int64_t)x->off_flags;
+    p.timeout_ticks = x->timeout_ticks;
+    p.rank = x->rank; p.world = x->world;
+    XgmiNormParams n{static_cast<const uint16_t *>(residual), static_cast<const uint16_t *>(weight), static_cast<uint16_t *>(x_out), static_cast<uint16_t *>(norm_out),
+                     residual_row_stride, x_row_stride, norm_row_stride, (int)rows, (int)hidden, eps};
+    const bool fits_slot = (size_t)bytes <= x->slot_bytes;
+    const bool oneshot = mode == 1 ? true : (mode == 2 ? false : (size_t)bytes <= x->oneshot_max && fits_slot);
+    if (oneshot && !fits_slot) { set_error("atoma_xgmi_allreduce_add_rms_norm: message too large for the one-shot slots"); return -1; }
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(XGMI_MAX_BLOCKS, rows));
+    const int64_t iters = cdiv(hidden / 8, NORM_THREADS);
+#define ATOMA_XGN(K, TT, IT) hipLaunchKernelGGL((K<TT, IT>), dim3(blocks), dim3(NORM_THREADS), 0, s, p, n)
+#define ATOMA_XGN_I(K, TT) do { if (iters <= 1) ATOMA_XGN(K, TT, 1); else if (iters <= 2) ATOMA_XGN(K, TT, 2); else if (iters <= 4) ATOMA_XGN(K, TT, 4); else ATOMA_XGN(K, TT, 8); } while (0)
+    if (oneshot) { if (dtype == ATOMA_BF16) ATOMA_XGN_I(xgmi_oneshot_add_norm_kernel, bf16_t); else ATOMA_XGN_I(xgmi_oneshot_add_norm_kernel, f16_t); }
+    else { if (dtype == ATOMA_BF16) ATOMA_XGN_I(xgmi_twoshot_add_norm_kernel, bf16_t); else ATOMA_XGN_I(xgmi_twoshot_add_norm_kernel, f16_t); }
+#undef ATOMA_XGN_I
+#undef ATOMA_XGN
+    return ATOMA_CHECK_LAUNCH("xgmi all-reduce + add + rms_norm kernel") ? 0 : -1;
 }
 
 int atoma_xgmi_allreduce_sum(void *xg, const void *in, void *out, int64_t count, int dtype, void *stream) {

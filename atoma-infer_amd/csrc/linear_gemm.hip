@@ -94,7 +94,9 @@ struct LtDevice {
     std::map<std::tuple<int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t>, GemmPlan> plans;
 };
 static const size_t LT_WORKSPACE_BYTES = 64u << 20;
-static const int LT_CANDIDATES = 16, LT_TIMED_REPS = 10;
+static const int LT_MAX_CANDIDATES = 128, LT_TIMED_REPS = 10;
+// how many of the library's candidate algorithms are timed on first use of a problem (ATOMA_LINEAR_CANDIDATES, 1..128)
+static const int LT_CANDIDATES = [] { const char *e = getenv("ATOMA_LINEAR_CANDIDATES"); const int n = e ? atoi(e) : 16; return n < 1 ? 1 : (n > LT_MAX_CANDIDATES ? LT_MAX_CANDIDATES : n); }();
 // time the library's candidate algorithms on first use of a problem (ATOMA_LINEAR_AUTOTUNE=0: take the heuristic's first choice)
 static const int linear_autotune = getenv("ATOMA_LINEAR_AUTOTUNE") ? atoi(getenv("ATOMA_LINEAR_AUTOTUNE")) : 1;
 static std::mutex *g_lt_mu = new std::mutex;
@@ -156,11 +158,11 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
         // The heuristic's first choice is often not the fastest kernel for a skinny problem: take its candidates, time
         // each once on this problem (first use only; y is overwritten with the same product every time) and keep the best.
         // candidate 0 = the library's own single choice; the longer list it returns is ordered differently and need not contain it
-        hipblasLtMatmulHeuristicResult_t res[LT_CANDIDATES + 1];
+        std::vector<hipblasLtMatmulHeuristicResult_t> res((size_t)LT_CANDIDATES + 1);
         int found = 0, more = 0;
-        ok = ok && lt_ok(api.heuristic(handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, 1, res, &found), "MatmulAlgoGetHeuristic");
+        ok = ok && lt_ok(api.heuristic(handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, 1, res.data(), &found), "MatmulAlgoGetHeuristic");
         if (ok && found == 1 && linear_autotune &&
-            api.heuristic(handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, LT_CANDIDATES, res + 1, &more) == HIPBLAS_STATUS_SUCCESS)
+            api.heuristic(handle, pl.desc, pl.a, pl.b, pl.c, pl.c, pref, LT_CANDIDATES, res.data() + 1, &more) == HIPBLAS_STATUS_SUCCESS)
             found += more;
         api.pref_destroy(pref);
         if (!ok) return -1;

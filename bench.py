@@ -416,6 +416,7 @@ def tp_summary(res, note=None):
     out = {"workload": (res or {}).get("workload"), "world": (res or {}).get("world"),
            "rccl_step_ms": pick("rccl", "step_ms"), "xgmi_step_ms": pick("xgmi", "step_ms"),
            "rccl_allreduce_us": pick("rccl", "allreduce_us"), "xgmi_allreduce_us": pick("xgmi", "allreduce_us"),
+           "xgmi_fused_add_norm_step_ms": pick("xgmi_fused_add_norm", "step_ms"),   # residual add + RMSNorm inside the all-reduce's launch (2 launches per layer fewer)
            "engines_available": {k: v is not None for k, v in eng.items()}, "xgmi_setup": (res or {}).get("xgmi_setup"),
            "tokens_per_s": (res or {}).get("tokens_per_s"), "step_frac_of_roofline": (res or {}).get("step_frac_of_roofline"),
            "allreduces_per_step": (res or {}).get("allreduces_per_step"), "allreduce_message_bytes": (res or {}).get("allreduce_message_bytes")}

@@ -323,6 +323,9 @@ int atoma_sample_rows(const void *logits, int64_t rows, int64_t vocab, int64_t r
 int atoma_comm_unique_id(void *id128_out);
 int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128, int device);
 int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, int dtype, void *stream);
+/* ... and through a communicator: the direct engine runs the fused launch above, the RCCL engine ncclAllReduce + atoma_add_rms_norm. */
+int atoma_allreduce_add_rms_norm(void *comm, const void *in, const void *residual, const void *weight, void *x_out, void *norm_out,
+                                 int64_t rows, int64_t hidden, float eps, int dtype, void *stream);
 int atoma_comm_destroy(void *comm);
 /* Engine behind atoma_allreduce_sum: 0 = RCCL's ncclAllReduce (default), 1 = the direct xGMI kernels below (error when
  * they could not be brought up), 2 = auto (direct up to ATOMA_XGMI_MAX_BYTES, default 8 MiB, when the message is a
@@ -354,6 +357,14 @@ int atoma_xgmi_create(void **xgmi_out, int rank, int world_size, int device, int
 int atoma_xgmi_handle(void *xgmi, void *handle128_out);
 int atoma_xgmi_connect(void *xgmi, const void *handles);
 int atoma_xgmi_allreduce_sum(void *xgmi, const void *in, void *out, int64_t count, int dtype, void *stream);
+/* The tail of both all-reduces of a tensor-parallel decoder layer in the all-reduce's own launch (llama_nccl.rs:139 -> llama.rs:404,408;
+ * :195 -> :409 and the next layer's :402): x_out = residual + allreduce_sum(in) (one rounding each, as the separate calls), norm_out =
+ * RMSNorm(x_out) * weight.  Bit-identical to atoma_xgmi_allreduce_sum followed by atoma_add_rms_norm; two launches per layer fewer.  in:
+ * [rows, hidden] contiguous, rows * hidden * 2 bytes <= the communicator's capacity (one launch); strides in elements; mode as
+ * atoma_xgmi_allreduce_sum_mode (0 = by size).  All ranks must call it with the same shapes, like every collective. */
+int atoma_xgmi_allreduce_add_rms_norm(void *xgmi, const void *in, const void *residual, const void *weight, void *x_out, void *norm_out,
+                                      int64_t rows, int64_t hidden, int64_t residual_row_stride, int64_t x_row_stride,
+                                      int64_t norm_row_stride, float eps, int dtype, int mode, void *stream);
 /* mode: 0 = by size, 1 = one-shot (message must fit a staging slot), 2 = two-shot -- for A/B measurements and tests */
 int atoma_xgmi_allreduce_sum_mode(void *xgmi, const void *in, void *out, int64_t count, int dtype, int mode, void *stream);
 int atoma_xgmi_status(void *xgmi);

@@ -364,3 +364,63 @@ def test_rccl_vs_direct_one_rank_per_device(gpu):
             p.join(30)
             if p.is_alive():
                 p.kill()
+
+
+# ---- all-reduce + residual add + RMSNorm in the all-reduce's own launch ----
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("dtype", [BF16, F16])
+def test_fused_allreduce_add_rms_norm_equals_the_three_ops(gpu, world, dtype, monkeypatch):
+    """atoma_xgmi_allreduce_add_rms_norm against atoma_xgmi_allreduce_sum + atoma_add_rms_norm on the same tensors: bit for bit on every rank, both
+    kernels (one-shot / two-shot), the decode message of configs[3] ([64, 8192]), more rows than blocks, a hidden size that is not a multiple
+    of a block's 256 vectors, strided outputs; and against the oracle (rank-order sum, add, RMSNorm within one ulp).  Twice in a row and after
+    plain all-reduces on the same communicator (sequence numbers and flags are shared)."""
+    from oracle import elementwise_oracle as EO
+    from oracle import norm_rope_oracle as NR
+    monkeypatch.setenv("ATOMA_XGMI_TIMEOUT_MS", "8000")
+    monkeypatch.setenv("ATOMA_XGMI_ONESHOT_MAX", str(1 << 20))
+    rng = np.random.default_rng(500 + world * 7 + dtype)
+    xs = make_ranks(gpu, world, 4 << 20)
+    streams = [gpu.Stream() for _ in range(world)]
+    eps = 1e-5
+    try:
+        for rows, hidden, pad in ((64, 8192, 0), (5, 512, 0), (70, 1024, 16), (1, 8, 0), (33, 2056, 8)):
+            count = rows * hidden
+            parts = [rand_half(rng, (rows, hidden), dtype) for _ in range(world)]
+            res = rand_half(rng, (rows, hidden + pad), dtype)
+            w = rand_half(rng, (hidden,), dtype)
+            din = [gpu.DeviceBuffer.from_numpy(p) for p in parts]
+            dres, dw = gpu.DeviceBuffer.from_numpy(res), gpu.DeviceBuffer.from_numpy(w)
+            st_x, st_n = hidden + pad, hidden + 2 * pad
+            # the three ops, on rank 0's stream after a plain all-reduce of every rank
+            dsum = [gpu.DeviceBuffer(count * 2) for _ in range(world)]
+            for r in range(world):
+                assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], din[r].ptr, dsum[r].ptr, count, dtype, streams[r].s) == 0, gpu.last_error()
+            x_ref, n_ref = gpu.DeviceBuffer.zeros((rows, st_x), np.uint16), gpu.DeviceBuffer.zeros((rows, st_n), np.uint16)
+            assert gpu.lib.atoma_add_rms_norm(dres.ptr, dsum[0].ptr, dw.ptr, x_ref.ptr, n_ref.ptr, rows, hidden, hidden + pad, hidden, st_x, st_n, eps, dtype, streams[0].s) == 0, gpu.last_error()
+            for r in range(world):
+                streams[r].synchronize()
+            want_x, want_n = x_ref.numpy(np.uint16, (rows, st_x)), n_ref.numpy(np.uint16, (rows, st_n))
+            # ... the oracle agrees with them
+            s_or = AO.allreduce_sum([p.reshape(-1) for p in parts], dtype).reshape(rows, hidden)
+            x_or = EO.add(np.ascontiguousarray(res[:, :hidden]), s_or, dtype)
+            assert np.array_equal(want_x[:, :hidden], x_or)
+            assert ulps(want_n[:, :hidden], NR.rms_norm(x_or, w, eps, dtype)).max() <= 1
+            for mode in (1, 2, 0, 2):
+                xo = [gpu.DeviceBuffer.zeros((rows, st_x), np.uint16) for _ in range(world)]
+                no = [gpu.DeviceBuffer.zeros((rows, st_n), np.uint16) for _ in range(world)]
+                for r in range(world):
+                    rc = gpu.lib.atoma_xgmi_allreduce_add_rms_norm(xs[r], din[r].ptr, dres.ptr, dw.ptr, xo[r].ptr, no[r].ptr, rows, hidden, hidden + pad, st_x, st_n,
+                                                                   eps, dtype, mode, streams[r].s)
+                    assert rc == 0, gpu.last_error()
+                for r in range(world):
+                    streams[r].synchronize()
+                    assert gpu.lib.atoma_xgmi_status(xs[r]) == 0, f"rank {r}: a wait timed out"
+                    assert np.array_equal(xo[r].numpy(np.uint16, (rows, st_x)), want_x), f"{rows}x{hidden} mode {mode} rank {r}: residual + sum differs from the three ops"
+                    assert np.array_equal(no[r].numpy(np.uint16, (rows, st_n)), want_n), f"{rows}x{hidden} mode {mode} rank {r}: norm differs from the three ops"
+        # too large for one launch: refused, not cut
+        big = gpu.DeviceBuffer(16)
+        assert gpu.lib.atoma_xgmi_allreduce_add_rms_norm(xs[0], big.ptr, big.ptr, big.ptr, big.ptr, big.ptr, 1024, 8192, 8192, 8192, 8192, eps, dtype, 0, None) == -1
+        assert "capacity" in gpu.last_error()
+    finally:
+        for x in xs:
+            gpu.lib.atoma_xgmi_destroy(x)

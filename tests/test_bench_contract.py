@@ -64,7 +64,24 @@ def test_bench_py_prints_one_json_line(gpu):
     d = json.loads(lines[0])
     check_line(d, full=False)
     assert d["steps"] == 5 and d["warmup"] == 2 and d["n_gpus"] == 1
-    assert d["roofline"]["frac"] >= 0.70          # north_star: >= 70 % of HBM peak on the paged-attention decode micro-bench
+    assert d["roofline"]["frac"] >= 0.80          # north_star asks >= 0.70; 0.834-0.855 measured over the boxes of the pool in round 5 (round 4's regressed binary: 0.798-0.808)
     assert "G=4" in d["roofline"]["kernel"]
     v = d["verified"]
     assert v["ok"] is True and v["sequences"] == 4 and v["max_err"] < 0.05
+
+
+@pytest.mark.gpu
+def test_bench_extras_hold_their_floors(gpu):
+    """the rows of BASELINE.md that ride in the driver's line (tools/bench_extra.py), where they actually run: bit-exact ops bit-exact, and
+    each number above a floor a regression would break (the swap / rank-step thresholds belong in a GPU test, not nowhere)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_extra.py"), "swap", "c4_rank_step", "k5_copy_blocks", "k4_reshape_and_cache", "c2b_mha", "c2c_ragged"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert all("error" not in v for v in d.values()), d
+    assert d["swap"]["gpu_to_cpu_frac_of_memcpy"] >= 0.85 and d["swap"]["cpu_to_gpu_frac_of_memcpy"] >= 0.85, d["swap"]
+    assert d["c4_rank_step"]["ms_per_step"] <= 9.5 and d["c4_rank_step"]["frac_of_hbm_roofline"] >= 0.37, d["c4_rank_step"]
+    assert d["k5_copy_blocks"]["bit_exact"] and d["k5_copy_blocks"]["frac_hbm"] >= 0.65, d["k5_copy_blocks"]
+    assert d["k4_reshape_and_cache"]["bit_exact"] and d["k4_reshape_and_cache"]["frac_hbm"] >= 0.45, d["k4_reshape_and_cache"]
+    assert d["c2b_mha"]["frac_hbm"] >= 0.75 and "balanced" in d["c2b_mha"]["kernel"], d["c2b_mha"]
+    assert d["c2c_ragged"]["frac_hbm"] >= 0.72, d["c2c_ragged"]

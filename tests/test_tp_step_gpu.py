@@ -19,9 +19,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world", [2, 8])
-@pytest.mark.parametrize("graph,own,B", [(False, False, 6), (True, False, 6), (True, True, 6), (True, True, 24)],
-                         ids=["eager", "hipgraph", "hipgraph-own-projections", "hipgraph-own-projections-24-rows"])
-def test_tp_decode_step_matches_unsharded(gpu, world, graph, own, B, monkeypatch):
+@pytest.mark.parametrize("graph,own,B,fused", [(False, False, 6, False), (True, False, 6, False), (True, True, 6, False), (True, True, 24, False), (True, True, 24, True), (False, False, 6, True)],
+                         ids=["eager", "hipgraph", "hipgraph-own-projections", "hipgraph-own-projections-24-rows", "hipgraph-own-24-rows-allreduce+add+norm-in-one-launch",
+                              "eager-allreduce+add+norm-in-one-launch"])
+def test_tp_decode_step_matches_unsharded(gpu, world, graph, own, B, fused, monkeypatch):
     """own: the rank's projections on the library's own kernels (gate/up with SiLU.up inside; at 24 rows the LDS-DMA tile kernel with its
     in-launch K-split merge and the q/k/v projection with RoPE + cache write as its epilogue; tools/tp_step.py and bench.py run it so).
     world 8: the partition of configs[3] -- every rank one kv head and its q-head group, an eighth of the MLP, 7 peers in every all-reduce."""
@@ -68,13 +69,22 @@ def test_tp_decode_step_matches_unsharded(gpu, world, graph, own, B, monkeypatch
     scfg = tp.shard_config(cfg, world)
     steps = []
     live = [False]
+    fused_calls = [0]
     try:
         for r in range(world):
             def allreduce(ptr, count, r=r):
                 if live[0]:
                     assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], ptr, ptr, count, BF16, streams[r].s) == 0, gpu.last_error()
+            def allreduce_norm(inp, res, wn, xo, no, rows, r=r):   # fused: the residual add and the RMSNorm ride in the all-reduce's launch
+                if not (live[0] and fused):
+                    return False
+                assert gpu.lib.atoma_xgmi_allreduce_add_rms_norm(xs[r], inp, res, wn, xo, no, rows, cfg.hidden, cfg.hidden, cfg.hidden, cfg.hidden, cfg.eps, BF16, 0,
+                                                                 streams[r].s) == 0, gpu.last_error()
+                fused_calls[0] += 1
+                return True
             w = DS.upload_weights(scfg, tp.shard_weights(host, cfg, r, world))
-            s = DS.DecodeStep(scfg, B, num_pages, bt.shape[1], w, streams[r], keep_intermediates=not graph, allreduce=allreduce, fused_epilogues=own)
+            s = DS.DecodeStep(scfg, B, num_pages, bt.shape[1], w, streams[r], keep_intermediates=not graph and not fused, allreduce=allreduce, fused_epilogues=own,
+                              allreduce_norm=allreduce_norm)
             assert s.tp_own == own
             _, ks = tp.head_shard(cfg.h, cfg.hk, r, world)
             for l in range(cfg.layers):                        # the rank's KV cache holds its kv heads (worker.rs:584-591)
@@ -125,7 +135,19 @@ def test_tp_decode_step_matches_unsharded(gpu, world, graph, own, B, monkeypatch
         top2 = np.sort(logits_full, 1)[:, -2:]
         clear = (top2[:, 1] - top2[:, 0]) > 0.1                  # rows whose winner is not a near tie
         assert clear.any() and np.array_equal(ids_tp[clear], ids_full[clear])
-        if not graph:
+        assert (fused_calls[0] > 0) == fused
+        if fused:      # the same step with the two separate calls: the fused launch must not move a bit
+            fused_logits = logits[0].copy()
+            live[0] = False
+            for s_ in steps:
+                s_.allreduce_norm = None
+            live[0] = True
+            for s_ in steps:
+                s_.run()
+            for r in range(world):
+                streams[r].synchronize()
+            assert np.array_equal(steps[0].logits.numpy(np.uint16, (B, cfg.vocab)), fused_logits), "all-reduce + add + norm in one launch differs from the three calls"
+        if not graph and not fused:
             for li, (n, l, t) in enumerate(steps[0].trace[1:-1]):
                 # the summed projection outputs against the unsharded projection (same inputs up to earlier rounding)
                 for key, ref in (("o", o_full[li]), ("dn", dn_full[li])):

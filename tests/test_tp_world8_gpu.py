@@ -38,7 +38,9 @@ def common_checks(out, layers, message_bytes):
 def test_decode_step_as_eight_ranks_full_shapes():
     out = tp_step("--layers", "4", "--steps", "3", "--check-unsharded")
     common_checks(out, 4, 64 * 8192 * 2)
-    assert set(out["engines"]) == {"xgmi_one_shot", "xgmi_two_shot"}       # the 1 MiB message through both kernels
+    # the 1 MiB message through both kernels, plain and with the residual add + RMSNorm inside the all-reduce's launch (the last engine measured
+    # leaves the logits that are compared: a fused one)
+    assert set(out["engines"]) == {"xgmi_one_shot", "xgmi_two_shot", "xgmi_two_shot_fused_add_norm", "xgmi_one_shot_fused_add_norm"}
     v = out["vs_unsharded"]
     assert v["rows"] == 64 and v["max_abs_diff"] < 0.12 and v["argmax_agree_where_clear"], v
 

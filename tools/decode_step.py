@@ -34,13 +34,17 @@ class DecodeStep:
     """Device-resident weights, caches and activations of a model + `run()` = one decode step for `batch` sequences."""
 
     def __init__(self, cfg, batch, num_pages, max_blocks, weights, stream, keep_intermediates=False, fused_epilogues=False, fuse_norm=True,
-                 allreduce=None, kv_fp8=False, kv_scale=0.05, own_projections=False):
+                 allreduce=None, kv_fp8=False, kv_scale=0.05, own_projections=False, allreduce_norm=None):
         """allreduce(ptr, count): in-place sum of a [batch, hidden] bf16 tensor over the tensor-parallel ranks, enqueued on
         `stream` -- called after the o and the down projection when `cfg` / `weights` are ONE rank's shard
         (llama_nccl.rs:139,195 via TensorParallelRowLinear, multi_gpu.rs:48-50); None = not tensor parallel."""
         c = self.cfg = cfg
         self.B, self.stream, self.keep = batch, stream, keep_intermediates
         self.allreduce = allreduce
+        # allreduce_norm(in, residual, weight, x_out, norm_out, rows) -> True when it enqueued "x_out = residual + allreduce(in); norm_out =
+        # RMSNorm(x_out) * weight" as ONE launch (atoma_xgmi_allreduce_add_rms_norm / atoma_allreduce_add_rms_norm); False = not available now:
+        # the step falls back to allreduce + atoma_add_rms_norm (same bits)
+        self.allreduce_norm = allreduce_norm
         # Residual adds, SiLU.up (and at 1 row the RMSNorms) inside the library's own projection kernels.  Up to 128 rows that is the
         # faster step although the vendor GEMM wins most of the single products from 5 rows up (three launches per layer fewer:
         # batch 8 5.17 -> 4.62 ms, 32 7.58 -> 6.96, 64 11.2 -> 10.3, 96 14.9 -> 14.6, 128 16.9 -> 16.8; at 256 rows 19.4 -> 20.1, so
@@ -174,9 +178,13 @@ class DecodeStep:
             else:
                 o = self._buf("o", l, B * H * 2)
                 self._ok(self.linear(att.ptr, self.w["wo"][l].ptr, o.ptr, B, hd, H, hd, hd, H, BF16, s), "o projection")
-                if self.allreduce:
+                # all-reduce + residual add + RMSNorm in the all-reduce's own launch where the engine offers it, else the two calls (same bits)
+                one = bool(self.fuse_norm and self.allreduce_norm and self.allreduce_norm(o.ptr, x.ptr, self.w["norm2"][l].ptr, x1.ptr, xn2.ptr, B))
+                if not one and self.allreduce:
                     self.allreduce(o.ptr, B * H)
-                if self.fuse_norm:
+                if one:
+                    pass
+                elif self.fuse_norm:
                     self._ok(L.atoma_add_rms_norm(x.ptr, o.ptr, self.w["norm2"][l].ptr, x1.ptr, xn2.ptr, B, H, H, H, H, H, c.eps, BF16, s), "residual add + rms_norm")
                 else:
                     self._ok(L.atoma_add(x.ptr, o.ptr, x1.ptr, B * H, BF16, s), "residual add")
@@ -189,11 +197,14 @@ class DecodeStep:
                     self._ok(L.atoma_silu_mul(gu.ptr, gu.ptr + c.inter * 2, act.ptr, B, c.inter, 2 * c.inter, 2 * c.inter, c.inter, BF16, s), "silu * up")
                 dn = self._buf("dn", l, B * H * 2)
                 self._ok(self.linear(act.ptr, self.w["wdown"][l].ptr, dn.ptr, B, c.inter, H, c.inter, c.inter, H, BF16, s), "down projection")
-                if self.allreduce:
+                last = l == c.layers - 1
+                nw, nout = (self.w["norm_f"], xf) if last else (self.w["norm1"][l + 1], self._buf("xn1", l + 1, B * H * 2))
+                one = bool(self.fuse_norm and self.allreduce_norm and self.allreduce_norm(dn.ptr, x1.ptr, nw.ptr, x2.ptr, nout.ptr, B))
+                if not one and self.allreduce:
                     self.allreduce(dn.ptr, B * H)
-                if self.fuse_norm:                       # ... + the next layer's input norm (or the final norm)
-                    last = l == c.layers - 1
-                    nw, nout = (self.w["norm_f"], xf) if last else (self.w["norm1"][l + 1], self._buf("xn1", l + 1, B * H * 2))
+                if one:
+                    pass
+                elif self.fuse_norm:                     # ... + the next layer's input norm (or the final norm)
                     self._ok(L.atoma_add_rms_norm(x1.ptr, dn.ptr, nw.ptr, x2.ptr, nout.ptr, B, H, H, H, H, H, c.eps, BF16, s), "residual add + rms_norm")
                 else:
                     self._ok(L.atoma_add(x1.ptr, dn.ptr, x2.ptr, B * H, BF16, s), "residual add")

@@ -162,9 +162,11 @@ class Rank:
         self.c = tp.shard_config(full_cfg, world)
         self.stream = ah.Stream()
         self.engine = None                                   # callable(ptr, count) or None
+        self.engine_norm = None                              # callable(in, residual, weight, x_out, norm_out, rows) -> all-reduce + add + RMSNorm in one launch, or None
         rng = np.random.default_rng(seed + rank)
         self.w = weights if weights is not None else random_shard_weights(rng, self.c, replicated)
         hook = (lambda ptr, count: self.engine(ptr, count)) if world > 1 else None
+        hook_norm = (lambda *a: (self.engine_norm(*a) or True) if self.engine_norm is not None else False) if world > 1 else None
         meta = np.random.default_rng(seed)                   # identical metadata on every rank
         if prefill:
             T = prefill
@@ -177,7 +179,7 @@ class Rank:
             self.rows, self.logits_rows = T, 1
         else:
             pps = (ctx + 1 + self.c.page - 1) // self.c.page
-            self.step = DS.DecodeStep(self.c, B, B * pps + 2, pps, self.w, self.stream, fused_epilogues=True, allreduce=hook)
+            self.step = DS.DecodeStep(self.c, B, B * pps + 2, pps, self.w, self.stream, fused_epilogues=True, allreduce=hook, allreduce_norm=hook_norm)
             bt = meta.permutation(B * pps).astype(np.int32).reshape(B, pps)
             pos = np.full(B, ctx)
             slots = bt[np.arange(B), pos // self.c.page].astype(np.int64) * self.c.page + pos % self.c.page
@@ -208,14 +210,19 @@ def measure(ranks, engines, steps, barrier, reduce_max, progress=None, use_graph
     # whose kernels this thread has not enqueued yet.
     for rk in ranks:
         rk.engine = lambda ptr, count: None
+        rk.engine_norm = None
         rk.step.run()
         rk.stream.synchronize()
     for name, fns in engines.items():
         if fns is None:
             out[name] = None
             continue
-        for rk, fn in zip(ranks, fns):
+        fused = None
+        if isinstance(fns, dict):                            # an engine that also offers all-reduce + residual add + RMSNorm as one launch
+            fns, fused = fns["allreduce"], fns["fused"]
+        for i, (rk, fn) in enumerate(zip(ranks, fns)):
             rk.engine = (lambda ptr, count, fn=fn, rk=rk: fn(ptr, count, rk.stream.s))
+            rk.engine_norm = (lambda *a, g=fused[i], rk=rk: g(*a, rk.stream.s)) if fused else None
         res = {}
         # ---- the whole step ----
         graphs = []
@@ -364,8 +371,18 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
                     assert ah.lib.atoma_xgmi_allreduce_sum_mode(xs[r], ptr, ptr, count, BF16, mode, s) == 0, ah.last_error()
                 return f
             return [make(r) for r in range(virtual_ranks)]
-        # the 1 MiB decode message through both kernels; the 64 MiB prefill message through the size rule (two-shot)
-        engines = {"xgmi_by_size": mk(0)} if msg > (1 << 20) else {"xgmi_one_shot": mk(1), "xgmi_two_shot": mk(2)}
+        def mk_fused(mode):
+            def make(r):
+                def f(inp, res, w, xo, no, rows, s):
+                    assert ah.lib.atoma_xgmi_allreduce_add_rms_norm(xs[r], inp, res, w, xo, no, rows, full_cfg.hidden, full_cfg.hidden, full_cfg.hidden, full_cfg.hidden,
+                                                                    full_cfg.eps, BF16, mode, s) == 0, ah.last_error()
+                return f
+            return [make(r) for r in range(virtual_ranks)]
+        # the 1 MiB decode message through both kernels, and with the residual add + RMSNorm that follows it inside the all-reduce's launch;
+        # the 64 MiB prefill message through the size rule (two-shot)
+        engines = ({"xgmi_by_size": mk(0)} if msg > (1 << 20) else
+                   {"xgmi_one_shot": mk(1), "xgmi_two_shot": mk(2), "xgmi_two_shot_fused_add_norm": {"allreduce": mk(2), "fused": mk_fused(2)},
+                    "xgmi_one_shot_fused_add_norm": {"allreduce": mk(1), "fused": mk_fused(1)}})
         c = scfg
         info = None
     else:
@@ -374,7 +391,10 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
         if world > 1 and xgmi is not None:                   # direct kernels only (no RCCL communicator)
             def via_xgmi(ptr, count, s):
                 assert ah.lib.atoma_xgmi_allreduce_sum(xgmi, ptr, ptr, count, BF16, s) == 0, ah.last_error()
-            engines = {"rccl": None, "xgmi": [via_xgmi]}
+            def fused_xgmi(inp, res, w, xo, no, rows, s):
+                assert ah.lib.atoma_xgmi_allreduce_add_rms_norm(xgmi, inp, res, w, xo, no, rows, full_cfg.hidden, full_cfg.hidden, full_cfg.hidden, full_cfg.hidden,
+                                                                full_cfg.eps, BF16, 0, s) == 0, ah.last_error()
+            engines = {"rccl": None, "xgmi": [via_xgmi], "xgmi_fused_add_norm": None if prefill else {"allreduce": [via_xgmi], "fused": [fused_xgmi]}}
             info = "xgmi: ready (direct-only communicator, no RCCL)"
         elif world > 1:
             if comm is None:
@@ -388,7 +408,11 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
                     assert ah.lib.atoma_comm_set_mode(comm, mode) == 0, ah.last_error()
                     assert ah.lib.atoma_allreduce_sum(comm, ptr, ptr, count, BF16, s) == 0, ah.last_error()
                 return [f]
-            engines = {"rccl": via_comm(0), "xgmi": via_comm(1) if "ready" in info else None}
+            def fused_comm(inp, res, w, xo, no, rows, s):
+                assert ah.lib.atoma_comm_set_mode(comm, 1) == 0, ah.last_error()
+                assert ah.lib.atoma_allreduce_add_rms_norm(comm, inp, res, w, xo, no, rows, full_cfg.hidden, full_cfg.eps, BF16, s) == 0, ah.last_error()
+            engines = {"rccl": via_comm(0), "xgmi": via_comm(1) if "ready" in info else None,
+                       "xgmi_fused_add_norm": {"allreduce": via_comm(1), "fused": [fused_comm]} if ("ready" in info and not prefill) else None}
             if engines["xgmi"]:
                 # preflight: one direct all-reduce of a known pattern; every rank must agree that it worked before it is timed
                 probe = ah.DeviceBuffer.from_numpy(np.full(4096, from_f32(np.float32([rank + 1]), BF16)[0], np.uint16))
