@@ -117,7 +117,10 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
     if (!api.ok) { set_error("linear: libhipblaslt.so could not be loaded (needed for batches above the weight-streaming kernel's range)"); return -1; }
     int dev = 0;
     if (!check_hip(hipGetDevice(&dev), "hipGetDevice")) return -1;
-    std::lock_guard<std::mutex> lock(*g_lt_mu);
+    // The lock covers the bookkeeping (handle, workspace, plan cache, first-use tuning), NOT the launch of a cached plan: a launch can block while
+    // the stream's queue is full, and with several ranks driven from one process a full queue waits for an all-reduce that waits for a peer
+    // whose thread would be waiting for this lock (round 5: the 80-layer prefill chunk of 8 virtual ranks timed out exactly so).
+    std::unique_lock<std::mutex> lock(*g_lt_mu);
     LtDevice &d = (*g_lt_devices)[dev];
     hipblasLtHandle_t &handle = d.handles[stream];
     if (!handle) {
@@ -222,9 +225,12 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
         guard.keep = true;
         it = d.plans.emplace(key, pl).first;
     }
-    const GemmPlan &pl = it->second;
+    const GemmPlan pl = it->second;             // descriptors and layouts are immutable once cached; the handle and the workspace are this stream's own
+    hipblasLtHandle_t h = handle;
+    void *ws = lt_ws;
+    lock.unlock();
     const float alpha = 1.f, beta = 0.f;
-    if (!lt_ok(api.matmul(handle, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &pl.algo, lt_ws,
+    if (!lt_ok(api.matmul(h, pl.desc, &alpha, w, pl.a, x, pl.b, &beta, y, pl.c, y, pl.c, &pl.algo, ws,
                           LT_WORKSPACE_BYTES, stream), "Matmul"))
         return -1;
     return 0;

@@ -26,6 +26,7 @@ cd $REPO
 (timeout 400 python tools/tp_step.py --steps 10 2>&1 | tail -1) > $OUT/tp_step_n1_$TAG.json
 # configs[3] executed as 8 ranks on this one device (round 5): the 80-layer decode step and the 4096-token prefill chunk, direct all-reduce among 8
 (timeout 600 python tools/tp_step.py --virtual-ranks 8 --steps 5 2>&1 | tail -1) > $OUT/tp_step_8_virtual_ranks_$TAG.json
-(timeout 600 python tools/tp_step.py --virtual-ranks 8 --prefill 4096 --steps 2 2>&1 | tail -1) > $OUT/tp_prefill_8_virtual_ranks_$TAG.json
+# (the prefill chunk: 8 ranks x 2 layers and 4 ranks x 16 layers -- eight ranks' vendor GEMMs beside spinning all-reduces stall on ONE device from 4 layers on, profiles/r05_tp_prefill_virtual_ranks_limits.txt)
+(ATOMA_XGMI_TIMEOUT_MS=10000 timeout 300 python tools/tp_step.py --virtual-ranks 8 --prefill 4096 --layers 2 --steps 2 --check-unsharded 2>&1 | tail -1) > $OUT/tp_prefill_8_virtual_ranks_$TAG.json
 (timeout 300 python tools/tp_step.py --virtual-ranks 8 --layers 8 --steps 3 --check-unsharded 2>&1 | tail -1) > $OUT/tp_step_8_ranks_vs_unsharded_$TAG.json
 find $OUT/prof_$TAG -name "*stats*" | head; tail -3 $OUT/pytest_gpu_$TAG.log; cat $OUT/smoke_$TAG.log; cat $OUT/bench_$TAG.log | cut -c1-600

@@ -56,7 +56,7 @@ for sub, label, name in ((f"prof_step_{tag}", "Llama-3.1-8B decode step, batch 2
 for src, dst in ((f"bench_{tag}.log", f"{tag}_bench.json"), (f"kernels_{tag}.jsonl", f"{tag}_kernels.jsonl"), (f"trace_{tag}.json", f"{tag}_trace.json"),
                  (f"trace_70b_tp8_rank_{tag}.json", f"{tag}_trace_70b_tp8_rank.json"), (f"tp_step_n1_{tag}.json", f"{tag}_tp_step_n1.json"),
                  (f"rank_step_{tag}.json", f"{tag}_rank_step.json"), (f"tp_step_8_virtual_ranks_{tag}.json", f"{tag}_tp_step_8_virtual_ranks_80_layers.json"),
-                 (f"tp_prefill_8_virtual_ranks_{tag}.json", f"{tag}_tp_prefill_chunk_8_virtual_ranks_80_layers.json"),
+                 (f"tp_prefill_8_virtual_ranks_{tag}.json", f"{tag}_tp_prefill_chunk_8_virtual_ranks_2_layers.json"),
                  (f"tp_step_8_ranks_vs_unsharded_{tag}.json", f"{tag}_tp_step_8_ranks_vs_unsharded_8_layers.json"), (f"rank_step_r02route_{tag}.json", f"{tag}_rank_step_r02_route.json"),
                  (f"linear64_ab_{tag}.jsonl", f"{tag}_linear64_ab.jsonl"), (f"gemm64_probe_{tag}.txt", f"{tag}_gemm64_probe.txt"),
                  (f"fp8_modes_{tag}.txt", f"{tag}_fp8_modes.txt"), (f"stream_force_ab_{tag}.txt", f"{tag}_stream_force_ab.txt"),

@@ -256,10 +256,12 @@ def measure(ranks, engines, steps, barrier, reduce_max, progress=None, use_graph
             graphs = [type("Eager", (), {"launch": (lambda self, rk=rk: rk.step.run())})() for rk in ranks]
         elif len(ranks) == 1:
             graphs = [ranks[0].graph_of(ranks[0].step.run)]
-        else:                                                # virtual ranks: every eager / capture phase for all ranks before syncing
-            each_rank(ranks, lambda rk: rk.step.run())
-            for rk in ranks:
-                rk.stream.synchronize()
+        else:
+            # virtual ranks: captured straight away -- the pass with the exchange switched off has created every plan and scratch block, the direct
+            # all-reduce needs no warm-up, and an EAGER step of several ranks in one process is what must be avoided: past a few hundred
+            # outstanding launches the runtime makes the enqueuing thread wait for its oldest command, and that command is an all-reduce waiting
+            # for a peer whose launches the same process has yet to issue (round 5: the 16- and 80-layer prefill chunks timed out so, from one
+            # thread and from one thread per rank alike; a graph launch is ONE call per rank and step)
             for rk in ranks:
                 with ah.Graph.capture(rk.stream) as g:
                     rk.step.run()
@@ -274,6 +276,10 @@ def measure(ranks, engines, steps, barrier, reduce_max, progress=None, use_graph
                 each_rank(list(range(len(gs))), lambda i: gs[i].launch())
         for _ in range(2):
             replay_all(graphs)
+            if os.environ.get("ATOMA_TP_STEP_VERBOSE"):      # (debugging aid: one replay at a time, with the communicators' state)
+                for rk in ranks:
+                    rk.stream.synchronize()
+                print(f"[tp_step] {name}: warm replay done at {time.perf_counter():.3f} s, xgmi status {[int(ah.lib.atoma_xgmi_status(x)) for x in getattr(measure, 'xs', [])]}", file=sys.stderr, flush=True)
         for rk in ranks:
             rk.stream.synchronize()
         barrier()
@@ -396,7 +402,8 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
         def mk(mode):
             def make(r):
                 def f(ptr, count, s):
-                    assert ah.lib.atoma_xgmi_allreduce_sum_mode(xs[r], ptr, ptr, count, BF16, mode, s) == 0, ah.last_error()
+                    assert ah.lib.atoma_xgmi_allreduce_sum_mode(xs[r], ptr, ptr, count, BF16, mode, s) == 0, \
+                        ah.last_error() + " -- status of every rank (n: the wait for rank n - 1 timed out): " + str([int(ah.lib.atoma_xgmi_status(x)) for x in xs])
                 return f
             return [make(r) for r in range(virtual_ranks)]
         def mk_fused(mode):
@@ -413,6 +420,7 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
                     "xgmi_one_shot_fused_add_norm": {"allreduce": mk(1), "fused": mk_fused(1)}})
         c = scfg
         info = None
+        measure.xs = xs                                       # (for the verbose trace)
     else:
         ranks = [Rank(full_cfg, rank, world, B, ctx, local_rank, prefill=prefill)]
         c = ranks[0].c
@@ -464,7 +472,7 @@ def run(full_cfg=LLAMA_3_1_70B, B=64, ctx=4096, steps=20, dist=None, rank=0, wor
     what = f"prefill chunk of {prefill} tokens" if prefill else "decode step"
     if progress is not None:
         progress.update(workload="Llama-3.1-70B-shaped %s, TP=%d" % (what, world), world=world, xgmi_setup=info if world > 1 else None)
-    res = measure(ranks, engines, steps, barrier, reduce_max, progress, use_graph=not prefill)
+    res = measure(ranks, engines, steps, barrier, reduce_max, progress, use_graph=(not prefill) or len(ranks) > 1)
     nworld = virtual_ranks or world
     out = {"workload": f"Llama-3.1-70B-shaped {what} (SURVEY C4), {full_cfg.layers} layers, " + (f"one prompt of {prefill} tokens" if prefill else f"batch {B}, context {ctx}")
                        + ", bf16, " + (f"{virtual_ranks} ranks of a TP=8 job on ONE device (direct all-reduce only)" if virtual_ranks else f"TP={world}, one rank per GPU"),
