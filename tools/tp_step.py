@@ -198,32 +198,6 @@ class Rank:
         return g
 
 
-def each_rank(ranks, fn):
-    """fn(rank) for every rank this process drives.  Several ranks (virtual ranks): one HOST THREAD per rank, as the reference drives its GPUs
-    (model_executor.rs:428) -- an eager step is ~1000 launches, a stream's queue holds fewer, and rank 0's first all-reduce waits on the device for
-    kernels of rank 7: enqueued from ONE thread, the host blocks on rank 0's full queue before it ever reaches rank 7 (the 80-layer prefill
-    chunk of round 5's first run: every rank timed out)."""
-    if len(ranks) == 1:
-        fn(ranks[0])
-        return
-    import threading
-    errs = []
-
-    def work(rk):
-        try:
-            ah.set_device(0)
-            fn(rk)
-        except Exception as e:       # surface in the caller
-            errs.append(e)
-    ts = [threading.Thread(target=work, args=(rk,)) for rk in ranks]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    if errs:
-        raise errs[0]
-
-
 def measure(ranks, engines, steps, barrier, reduce_max, progress=None, use_graph=True):
     """ranks: the Rank objects THIS process drives (1 under torch.distributed.run, W with --virtual-ranks).
     engines: name -> list (one per local rank) of callables(ptr, count, stream) or None when unavailable.
@@ -269,11 +243,8 @@ def measure(ranks, engines, steps, barrier, reduce_max, progress=None, use_graph
         barrier()
 
         def replay_all(gs):
-            if use_graph or len(gs) == 1:
-                for g in gs:
-                    g.launch()
-            else:                                            # eager steps of several ranks: one host thread each
-                each_rank(list(range(len(gs))), lambda i: gs[i].launch())
+            for g in gs:
+                g.launch()
         for _ in range(2):
             replay_all(graphs)
             if os.environ.get("ATOMA_TP_STEP_VERBOSE"):      # (debugging aid: one replay at a time, with the communicators' state)
