@@ -584,3 +584,43 @@ def test_decode_random_shapes_through_the_default_dispatch(gpu, seed):
         assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"seed {seed} {name}: B={B} h={h}/{hk} d={d} page={page} seq {i} (L={L})")
     empty = lens == 0
     assert not out[empty].any() and np.isposinf(lse[empty]).all() and np.isfinite(lse[~empty]).all(), name
+
+
+@pytest.mark.parametrize("d", [8, 32, 96, 160, 192, 224, 256])
+@pytest.mark.parametrize("dtype", [BF16, F16])
+def test_decode_other_head_sizes_streaming_kernel(gpu, d, dtype, monkeypatch):
+    """Decode for the head sizes the reference instantiates besides 64 / 128 (csrc/build.rs:7-74) -- `attn_decode_anyd_kernel`: one wavefront per
+    (sequence, kv head, up to 4 q heads) streaming K / V once, instead of the row-per-lane coverage kernel.  Ragged lengths incl. 0, 1 and a
+    non-multiple of 16, groups of 1 / 3 / 5 q heads (one and two chunks), paged and contiguous caches, ALiBi, the LSE output; against the
+    oracle, and against the coverage kernel on the same call (ATOMA_GENERIC_DECODE_STREAM switches back to it)."""
+    rng = np.random.default_rng(1000 + d + dtype)
+    page = 16
+    for h, hk in ((4, 4), (6, 2), (5, 1)):
+        lens = np.array([0, 1, 15, 16, 17, 100, 333, 77], np.int32)
+        nb = int(sum((x + page - 1) // page for x in lens)) + 3
+        kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+        q = rand_half(rng, (len(lens), 1, h, d), dtype)
+        scale = np.float32(d ** -0.5)
+        for alibi in (None, (0.5 ** np.arange(1, h + 1)).astype(np.float32)):
+            ref = A.flash_attn_kv_cache(q, kc, vc, scale, dtype, bt, lens, alibi_slopes=alibi)
+            out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)
+            for i, L in enumerate(lens):
+                assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} h={h}/{hk} alibi={alibi is not None} seq {i} (L={L})")
+            assert not out[0].any() and np.isinf(lse[0]).all()
+            monkeypatch.setenv("ATOMA_GENERIC_DECODE_STREAM", "0")      # the row-per-lane coverage kernel on the same call
+            old, lse_old = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)
+            monkeypatch.delenv("ATOMA_GENERIC_DECODE_STREAM")
+            for i, L in enumerate(lens):
+                assert_close(out[i], old[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} vs the coverage kernel, seq {i}")
+            live = lens > 0
+            assert np.allclose(lse[live], lse_old[live], rtol=1e-4, atol=1e-4)
+        # contiguous cache [B, S, hk, d] with per-sequence lengths
+        S = 64
+        kd, vd = rand_half(rng, (4, S, hk, d), dtype), rand_half(rng, (4, S, hk, d), dtype)
+        ld = np.array([64, 1, 33, 50], np.int32)
+        qd = rand_half(rng, (4, 1, h, d), dtype)
+        out, _ = gpu_decode(gpu, qd, kd, vd, None, ld, scale, dtype)
+        ref = A.flash_attn_kv_cache(qd, kd, vd, scale, dtype, None, ld)
+        for i, L in enumerate(ld):
+            assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} contiguous seq {i}")
+
