@@ -36,6 +36,7 @@ struct LtApi {
     decltype(&hipblasLtMatmul) matmul = nullptr;
     decltype(&hipblasLtMatmulDescDestroy) desc_destroy = nullptr;        // optional: a library without them only leaks on error paths
     decltype(&hipblasLtMatrixLayoutDestroy) layout_destroy = nullptr;
+    decltype(&hipblasLtDestroy) destroy = nullptr;                       // optional: the per-stream handles go with the workspaces
     bool ok = false;
 };
 
@@ -57,6 +58,7 @@ static LtApi &lt_api() {
         ATOMA_LT_SYM(matmul, hipblasLtMatmul);
         ATOMA_LT_SYM(desc_destroy, hipblasLtMatmulDescDestroy);
         ATOMA_LT_SYM(layout_destroy, hipblasLtMatrixLayoutDestroy);
+        ATOMA_LT_SYM(destroy, hipblasLtDestroy);
 #undef ATOMA_LT_SYM
         a.ok = a.create && a.desc_create && a.desc_set && a.layout_create && a.pref_create && a.pref_set && a.pref_destroy &&
                a.heuristic && a.matmul;
@@ -246,6 +248,14 @@ int release_gemm_workspaces() {
         for (auto &ws : dev.second.workspaces)
             if (ws.second && hipFree(ws.second) != hipSuccess) { (void)hipGetLastError(); rc = -1; }
         dev.second.workspaces.clear();
+        // ... and the per-stream library handles (a process that creates and destroys streams would otherwise keep one per handle value ever seen);
+        // the caller has made the streams idle (atoma_release_workspaces' contract)
+        if (!dev.second.handles.empty()) {      // (only then has the library been loaded)
+            LtApi &api = lt_api();
+            for (auto &h : dev.second.handles)
+                if (h.second && api.destroy) (void)api.destroy(h.second);
+            dev.second.handles.clear();
+        }
     }
     return rc;
 }
