@@ -198,9 +198,13 @@ __device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, in
 // fp32 partials (split-KV pieces, cut pieces of the balanced line) are published WRITE-THROUGH (agent-scope stores: past the XCD's
 // L2), so that a wavefront on another XCD -- the last arriver of decode_line_merge, or the combine kernel -- reads them with
 // agent-scope loads and no fence.
+// One 16-byte write-through store (sc1, what the compiler emits for an agent-scope atomic store, at twice the width the atomics allow): the
+// counters of round 5 showed 34 MiB written per ragged launch for ~10 MiB of pieces -- every 8-byte store its own 32-byte write request
+// (profiles/r05_decode_counters.json).  The readers' accesses are unchanged (8-byte agent-scope loads of the same bytes).
 __device__ __forceinline__ void partial_store(float *dst, float a, float b, float c, float d) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst), ((unsigned long long)__float_as_uint(b) << 32) | __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + 2), ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    typedef float f32x4_st __attribute__((ext_vector_type(4)));
+    const f32x4_st v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void partial_store(float *dst, float a) {
     __hip_atomic_store(reinterpret_cast<unsigned *>(dst), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

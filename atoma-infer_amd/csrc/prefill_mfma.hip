@@ -29,6 +29,8 @@
 #include "attn_params.h"
 #include "prefill_map.h"
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1134,6 +1136,21 @@ bool prefill_mfma_supported(const AttnParams &p) {
     return (p.d == 64 || p.d == 128) && p.alibi_slopes == nullptr && p.seqlen_q > 1;
 }
 
+// The dynamic-LDS opt-in of a kernel, once per DEVICE and per kernel (one host thread per GPU calls in: model_executor.rs:428-440; a process-wide
+// flag served only the device that came first -- ADVICE r4 on prefill_asm.hip, the same pattern here), return code checked.
+static bool pf_lds_opt_in(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;       // (kernel, device)
+    int dev = 0;
+    if (!check_hip(hipGetDevice(&dev), "hipGetDevice")) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &e : done)
+        if (e.first == kernel && e.second == dev) return true;
+    if (!check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "prefill: dynamic LDS opt-in")) return false;
+    done.emplace_back(kernel, dev);
+    return true;
+}
+
 template <typename T, int D, bool CAUSAL, int W, int NB, bool PP = false>
 static void launch_pf_cfg(const AttnParams &p, hipStream_t stream) {
 #ifdef PF_TIMING   // ATOMA_PF_ONE_WG=1: pad the LDS request so that only one workgroup fits a CU (occupancy experiment)
@@ -1142,12 +1159,7 @@ static void launch_pf_cfg(const AttnParams &p, hipStream_t stream) {
 #else
     constexpr int smem = NB * 2 * PF_BN * D * 2;
 #endif
-    static bool attr_set = false;  // up to 96 KiB: above the default dynamic-LDS limit
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL, W, NB, PP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    if (!pf_lds_opt_in(reinterpret_cast<const void *>(&prefill_mfma_kernel<T, D, CAUSAL, W, NB, PP>), smem)) return;   // up to 96 KiB: above the default dynamic-LDS limit
     const int64_t m_blocks = cdiv(p.seqlen_q, 32 * W), n_units = (int64_t)p.b * p.h;
     const int64_t nu_max = n_units / 8 + (n_units % 8 ? 1 : 0);
     dim3 grid((unsigned)(8 * nu_max * m_blocks));   // padded: see the mapping comment in the kernel
@@ -1158,12 +1170,7 @@ static void launch_pf_cfg(const AttnParams &p, hipStream_t stream) {
 template <typename T, int D, bool CAUSAL, int RB>
 static void launch_pf_pipe(const AttnParams &p, hipStream_t stream) {
     constexpr int smem = (RB == 2 ? 6 : 4) * PF_BN * D * 2;   // K and V rings of 3 (RB = 2) or 2 tiles
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&prefill_pipe_kernel<T, D, CAUSAL, RB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    if (!pf_lds_opt_in(reinterpret_cast<const void *>(&prefill_pipe_kernel<T, D, CAUSAL, RB>), smem)) return;
     const int64_t m_blocks = cdiv(p.seqlen_q, 128 * RB), n_units = (int64_t)p.b * p.h;
     const int64_t nu_max = n_units / 8 + (n_units % 8 ? 1 : 0);
     dim3 grid((unsigned)(8 * nu_max * m_blocks));
