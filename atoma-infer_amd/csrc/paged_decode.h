@@ -204,7 +204,9 @@ __device__ __forceinline__ DecodePlan decode_make_plan(const DecodeParams &p, in
 __device__ __forceinline__ void partial_store(float *dst, float a, float b, float c, float d) {
     typedef float f32x4_st __attribute__((ext_vector_type(4)));
     const f32x4_st v = {a, b, c, d};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+    // (s_nop 1: a VMEM store of more than 64 bits reads its data registers late -- a VALU write to them needs a wait state in between, and the
+    //  compiler's hazard recognizer does not look inside an asm string; without it the first GPU run stored overwritten registers)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void partial_store(float *dst, float a) {
     __hip_atomic_store(reinterpret_cast<unsigned *>(dst), __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
