@@ -45,6 +45,7 @@ class DecodeStep:
         # RMSNorm(x_out) * weight" as ONE launch (atoma_xgmi_allreduce_add_rms_norm / atoma_allreduce_add_rms_norm); False = not available now:
         # the step falls back to allreduce + atoma_add_rms_norm (same bits)
         self.allreduce_norm = allreduce_norm
+        self.after_attention = None                        # optional callable(layer), invoked right after a layer's attention call is enqueued (probes: staggering two half-batches)
         # Residual adds, SiLU.up (and at 1 row the RMSNorms) inside the library's own projection kernels.  Up to 128 rows that is the
         # faster step although the vendor GEMM wins most of the single products from 5 rows up (three launches per layer fewer:
         # batch 8 5.17 -> 4.62 ms, 32 7.58 -> 6.96, 64 11.2 -> 10.3, 96 14.9 -> 14.6, 128 16.9 -> 16.8; at 256 rows 19.4 -> 20.1, so
@@ -160,6 +161,8 @@ class DecodeStep:
                            k_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d), v_strides=(c.page * c.hk * c.d, c.hk * c.d, c.d),
                            cu_seqlens_k=self.lens.ptr, is_seqlens_k_cumulative=False, block_table=self.bt.ptr, block_table_batch_stride=self.max_blocks,
                            page_block_size=c.page, force_split_kernel=True, unpadded_lse=False, stream=s)
+            if self.after_attention is not None:
+                self.after_attention(l)
             x1 = self._buf("x1", l, B * H * 2)
             xn2 = self._buf("xn2", l, B * H * 2)
             act = self._buf("act", l, B * c.inter * 2)
