@@ -234,6 +234,164 @@ __global__ void __launch_bounds__(64) attn_decode_anyd_kernel(const AttnParams p
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Prefill (several query rows per sequence) for the other head sizes that are multiples of 16 (32, 96, 160, 192, 224, 256): one wavefront per block
+// of 16 query rows of one (sequence, q head), K / V tiles of 16 keys shared by the 16 rows (the row-per-wavefront kernel above re-reads all of K
+// and V for every row), both products on v_mfma_f32_16x16x16 in the swapped form of the tuned kernels:
+//     S^T[key][q] = K . Q^T   -- A = K  (lane (grp, col): K[key0 + col][16 c + 4 grp ..+3], 8 bytes straight from the row),
+//                                B = Q^T (Q[q0 + col][16 c + 4 grp ..+3], held in registers for the whole block); result: S^T[4 grp + i][col]
+//     O^T[d][q]  += V^T . P^T  -- B = the lane's own four probabilities (keys 4 grp ..+3 of row col), A = V^T from the tile staged in LDS.
+// So a lane owns ONE query row (col) and four keys per tile: online softmax state per lane (max shared over the 4 lanes of a column), P rounded to
+// the storage type before P.V (softmax.h:65-185), O^T[16 c + 4 grp + i][col] in D / 4 accumulator registers.  Untuned (no pipelining, V through
+// a row-major LDS tile read 2 bytes at a time): the point is 16 x less K / V traffic, not the matrix pipe.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float gf32x4;
+template <typename T> __device__ __forceinline__ gf32x4 gmfma16(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, gf32x4 c);
+template <> __device__ __forceinline__ gf32x4 gmfma16<bf16_t>(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, gf32x4 c) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, u2{a0, a1}), __builtin_bit_cast(s16x4, u2{b0, b1}), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ gf32x4 gmfma16<f16_t>(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, gf32x4 c) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, u2{a0, a1}), __builtin_bit_cast(h16x4, u2{b0, b1}), c, 0, 0, 0);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) attn_prefill_tile16_kernel(const AttnParams p) {
+    constexpr int NCMAX = 16;                                    // head_dim / 16 <= 16
+    __shared__ __attribute__((aligned(16))) uint16_t v_sm[16 * 256];
+    const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15;
+    const int mblk = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+    const SeqInfo si(p, b);
+    const int q0 = mblk * 16;
+    if (q0 >= si.len_q) return;
+    const int D = p.d, nc = D >> 4;
+    const int hk = hq / (p.h / p.h_k);
+    const int shift = si.len_k - si.len_q;                        // mask.h:170
+    const int qrow = q0 + col;                                   // this lane's query row
+    const bool qvalid = qrow < si.len_q;
+    const int qr = min(qrow, si.len_q - 1);
+    int hi_q = p.is_causal ? min(si.len_k, qr + shift + 1) : si.len_k;   // keys this row sees
+    if (hi_q < 0) hi_q = 0;
+    const int last = min(q0 + 15, si.len_q - 1);
+    int hi_blk = p.is_causal ? min(si.len_k, last + shift + 1) : si.len_k;
+    if (hi_blk < 0) hi_blk = 0;
+    const uint16_t *qptr = p.q + si.q_offset(p.q_batch_stride, p.q_row_stride, b) + (int64_t)qr * p.q_row_stride + (int64_t)hq * p.q_head_stride + 4 * grp;
+    uint32_t qreg[NCMAX][2];
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) {
+        qreg[c][0] = qreg[c][1] = 0;
+        if (c < nc) {
+            const uint2 t = *reinterpret_cast<const uint2 *>(qptr + 16 * c);
+            qreg[c][0] = t.x; qreg[c][1] = t.y;
+        }
+    }
+    const bool paged = p.block_table != nullptr;
+    const int *bt = paged ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+    const int64_t koff = paged ? 0 : si.k_offset(p.k_batch_stride, p.k_row_stride, b);
+    const int64_t voff = paged ? 0 : si.k_offset(p.v_batch_stride, p.v_row_stride, b);
+    const float slope_l2 = p.alibi_slopes ? p.alibi_slopes[b * p.alibi_batch_stride + hq] * 1.4426950408889634f : 0.f;
+    auto row_off = [&](int t, bool is_v) -> int64_t {             // element offset of token t's row of this kv head
+        if (paged) {
+            const int64_t pg = bt[t / p.page_size];
+            return is_v ? pg * p.v_batch_stride + (int64_t)(t % p.page_size) * p.v_row_stride + (int64_t)hk * p.v_head_stride
+                        : pg * p.k_batch_stride + (int64_t)(t % p.page_size) * p.k_row_stride + (int64_t)hk * p.k_head_stride;
+        }
+        return is_v ? voff + (int64_t)t * p.v_row_stride + (int64_t)hk * p.v_head_stride : koff + (int64_t)t * p.k_row_stride + (int64_t)hk * p.k_head_stride;
+    };
+    gf32x4 o[NCMAX];
+#pragma unroll
+    for (int c = 0; c < NCMAX; ++c) o[c] = gf32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l = 0.f;
+    const int vpr = D >> 3;                                       // 16-byte pieces per V row
+    for (int j0 = 0; j0 < hi_blk; j0 += 16) {
+        // ---- V tile -> LDS (row-major [key][D]); rows behind the sequence re-read its last row and meet p = 0
+        for (int idx = lane; idx < 16 * vpr; idx += 64) {
+            const int kr = idx / vpr, ch = idx - kr * vpr;
+            const int t = min(j0 + kr, si.len_k - 1);
+            *reinterpret_cast<uint4 *>(&v_sm[kr * D + ch * 8]) = *reinterpret_cast<const uint4 *>(p.v + row_off(t, true) + ch * 8);
+        }
+        // ---- S^T = K . Q^T
+        const int tk = min(j0 + col, si.len_k - 1);
+        const uint16_t *kptr = p.k + row_off(tk, false) + 4 * grp;
+        gf32x4 sacc = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCMAX; ++c) {
+            if (c < nc) {
+                const uint2 kk = *reinterpret_cast<const uint2 *>(kptr + 16 * c);
+                sacc = gmfma16<T>(kk.x, kk.y, qreg[c][0], qreg[c][1], sacc);
+            }
+        }
+        float sv[4], mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = j0 + 4 * grp + i;
+            float x = sacc[i] * p.scale_log2;
+            if (p.alibi_slopes) x -= slope_l2 * fabsf((float)(qr + shift - key));   // mask.h:179-186
+            sv[i] = key < hi_q ? x : -INFINITY;
+            mx = fmaxf(mx, sv[i]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float ms = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
+        m_run = m_new;
+        float pr[4], psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float pj = __builtin_amdgcn_exp2f(sv[i] - ms);
+            psum += pj;
+            pr[i] = pj;
+        }
+        l = l * alpha + psum;
+        const uint32_t b0 = pack2<T>(pr[0], pr[1]), b1 = pack2<T>(pr[2], pr[3]);
+        __syncthreads();                                          // the V tile is in LDS
+#pragma unroll
+        for (int c = 0; c < NCMAX; ++c) {
+            if (c < nc) {
+                const uint16_t *vp = &v_sm[(4 * grp) * D + 16 * c + col];
+                const uint32_t a0 = (uint32_t)vp[0] | ((uint32_t)vp[D] << 16), a1 = (uint32_t)vp[2 * D] | ((uint32_t)vp[3 * D] << 16);
+                gf32x4 acc = o[c];
+                acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+                o[c] = gmfma16<T>(a0, a1, b0, b1, acc);
+            }
+        }
+        __syncthreads();                                          // before the next tile overwrites it
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const bool empty = !(l > 0.f);                                // no visible key: O = 0, LSE = +inf (flash_fwd_kernel.h:97-133)
+    const float inv = empty ? 0.f : 1.f / l;
+    if (qvalid) {
+        uint16_t *orow = p.o + si.q_offset(p.o_batch_stride, p.o_row_stride, b) + (int64_t)qrow * p.o_row_stride + (int64_t)hq * p.o_head_stride + 4 * grp;
+#pragma unroll
+        for (int c = 0; c < NCMAX; ++c) {
+            if (c < nc) {
+                uint2 w;
+                w.x = pack2<T>(o[c][0] * inv, o[c][1] * inv);
+                w.y = pack2<T>(o[c][2] * inv, o[c][3] * inv);
+                *reinterpret_cast<uint2 *>(orow + 16 * c) = w;
+            }
+        }
+        if (p.lse && grp == 0) {
+            const float lse = empty ? INFINITY : (m_run + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+            if (p.unpadded_lse && p.cu_seqlens_q) p.lse[(int64_t)hq * p.cu_seqlens_q[p.b] + si.sum_q + qrow] = lse;
+            else p.lse[((int64_t)b * p.h + hq) * p.seqlen_q + qrow] = lse;
+        }
+    }
+}
+
+static bool attn_prefill_tile16_applicable(const AttnParams &p) {
+    const int64_t strides = p.q_head_stride | p.k_head_stride | p.v_head_stride | p.o_head_stride | p.q_row_stride | p.o_row_stride | p.k_row_stride | p.v_row_stride |
+                            p.q_batch_stride | p.o_batch_stride | p.k_batch_stride | p.v_batch_stride;
+    return p.seqlen_q > 1 && p.d >= 16 && p.d <= 256 && p.d % 16 == 0 && p.h % p.h_k == 0 && strides % 8 == 0 &&
+           ((reinterpret_cast<uintptr_t>(p.q) | reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.o)) & 15u) == 0 &&
+           getenv("ATOMA_GENERIC_PREFILL_TILE") == nullptr;      // (set to anything: the row-per-wavefront kernel, for A/B runs)
+}
+
 static bool attn_decode_anyd_applicable(const AttnParams &p) {
     const int64_t strides = p.q_head_stride | p.k_head_stride | p.v_head_stride | p.o_head_stride | p.k_row_stride | p.v_row_stride | p.q_batch_stride |
                             p.o_batch_stride | p.k_batch_stride | p.v_batch_stride;
@@ -252,6 +410,13 @@ void launch_attn_generic(const AttnParams &p, bool is_bf16, hipStream_t stream) 
         if (C <= 4) ATOMA_ANYD(4); else if (C <= 8) ATOMA_ANYD(8); else if (C <= 16) ATOMA_ANYD(16); else ATOMA_ANYD(32);
 #undef ATOMA_ANYD
         ATOMA_CHECK_LAUNCH("attn_decode_anyd_kernel");
+        return;
+    }
+    if (attn_prefill_tile16_applicable(p)) {
+        const dim3 grid((unsigned)((p.seqlen_q + 15) / 16), (unsigned)p.h, (unsigned)p.b);
+        if (is_bf16) hipLaunchKernelGGL(attn_prefill_tile16_kernel<bf16_t>, grid, dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL(attn_prefill_tile16_kernel<f16_t>, grid, dim3(64), 0, stream, p);
+        ATOMA_CHECK_LAUNCH("attn_prefill_tile16_kernel");
         return;
     }
     // gridDim.y/z <= 65535: heads and batch are far below that in every caller of this path

@@ -147,6 +147,39 @@ def test_other_head_sizes_causal_paged_prefix(gpu, d):
         assert_close(out, ref, BF16, atol=ATOL_VS_F32[BF16], what=f"d={d} causal={causal} (f32 oracle)")
 
 
+@pytest.mark.parametrize("d,dtype", [(32, BF16), (96, F16), (192, BF16), (224, F16), (256, BF16)])
+def test_other_head_sizes_tiled_prefill(gpu, d, dtype, monkeypatch):
+    """The 16-query-row MFMA kernel for the other head sizes (attn_generic.hip: attn_prefill_tile16_kernel): several row blocks per sequence,
+    lengths that are not multiples of the 16-key tile, Lq < Lk, Lq > Lk (rows that see no key: O = 0, LSE = +inf), an empty sequence, GQA,
+    ALiBi, paged and contiguous K / V -- against the f32 oracle, and against the row-per-wavefront kernel it replaces (LSE included)."""
+    rng = np.random.default_rng(1000 + d)
+    lens_k = np.array([150, 33, 16, 5, 0, 97], np.int32)
+    lens_q = np.array([150, 20, 16, 9, 3, 1], np.int32)
+    cu_q = np.concatenate([[0], np.cumsum(lens_q)]).astype(np.int32)
+    cu_k = np.concatenate([[0], np.cumsum(lens_k)]).astype(np.int32)
+    h, hk = 6, 2
+    q = rand_half(rng, (int(cu_q[-1]), h, d), dtype)
+    kc, vc, bt = make_paged_cache(rng, 24, 16, hk, d, dtype, lens_k)
+    kd, vd = rand_half(rng, (int(cu_k[-1]), hk, d), dtype), rand_half(rng, (int(cu_k[-1]), hk, d), dtype)
+    slopes = (2.0 ** -np.arange(1, h + 1)).astype(np.float32)
+    for causal in (True, False):
+        for alibi in (None, slopes):
+            for paged in (True, False):
+                k, v, kw = (kc, vc, dict(bt=bt)) if paged else (kd, vd, {})
+                out, lse = gpu_varlen(gpu, q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi=alibi, **kw)
+                okw = dict(block_table=bt) if paged else {}
+                ref = A.flash_attn_varlen(q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi_slopes=alibi, **okw)
+                what = f"d={d} causal={causal} alibi={alibi is not None} paged={paged}"
+                assert_close(out, ref, dtype, atol=ATOL_VS_F32[dtype], what=what + " (f32 oracle)")
+                monkeypatch.setenv("ATOMA_GENERIC_PREFILL_TILE", "0")
+                out_row, lse_row = gpu_varlen(gpu, q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi=alibi, **kw)
+                monkeypatch.delenv("ATOMA_GENERIC_PREFILL_TILE")
+                assert_close(out, out_row, dtype, atol=ATOL_VS_F32[dtype], what=what + " (row kernel)")
+                assert np.array_equal(np.isinf(lse), np.isinf(lse_row)), what
+                fin = np.isfinite(lse_row)
+                assert np.allclose(lse[fin], lse_row[fin], atol=2e-3, rtol=1e-3), what
+
+
 def test_alibi_causal_and_non_causal(gpu):
     rng = np.random.default_rng(21)
     cu = np.array([0, 20, 50], np.int32)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Prefill at the head sizes without a tuned kernel: the 16-row tiled MFMA kernel (attn_prefill_tile16_kernel) against the row-per-wavefront
+kernel it replaces (ATOMA_GENERIC_PREFILL_TILE set), same process, same buffers.  4 causal prompts of 2048 tokens, 32 q / 8 kv heads."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench_extra as BE  # noqa: E402
+
+BE.ah.set_device(0)
+res = {}
+for d in (32, 96, 160, 256):
+    e = {}
+    for name, env in (("tile16", None), ("row_per_wavefront", "0")):
+        if env is None:
+            os.environ.pop("ATOMA_GENERIC_PREFILL_TILE", None)
+        else:
+            os.environ["ATOMA_GENERIC_PREFILL_TILE"] = env
+        r = BE.prefill(iters=3, S=2048, nseq=4, d=d)
+        e[name] = {"ms": r["ms"], "TFLOPs": r["TFLOPs"]}
+    os.environ.pop("ATOMA_GENERIC_PREFILL_TILE", None)
+    e["speedup"] = round(e["row_per_wavefront"]["ms"] / e["tile16"]["ms"], 2)
+    res["d=%d" % d] = e
+print(json.dumps(res, indent=1))
