@@ -9,6 +9,7 @@
 // Same numerics contract as the reference kernel: exp2-domain softmax, fp32 accumulation,
 // P rounded to the storage dtype before P.V (csrc/kernels/softmax.h:65-185).
 #include "attn_params.h"
+#include <cstring>
 #include <stdlib.h>
 
 namespace atoma {
@@ -384,12 +385,223 @@ __global__ void __launch_bounds__(64) attn_prefill_tile16_kernel(const AttnParam
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same products for head sizes that are multiples of 32 (every one the reference instantiates: 32 ... 256) and more than 16 query rows:
+// a workgroup of 4 wavefronts = 64 query rows of one (sequence, q head), K / V tiles of KT keys staged ONCE per workgroup through LDS
+// (register prefetch of tile t + 1 while tile t is computed), v_mfma_f32_16x16x32 for both products:
+//     S^T sub-tile h of key group g: A = K[32 g + 16 h + col][32 c + 8 grp ..+7] (one ds_read_b128; rows padded to 16 * odd bytes: 16 rows on 16
+//                                    different 16-byte slots), B = Q[q col][32 c + 8 grp ..+7] in registers; the lane gets keys 32 g + 16 h + 4 grp + i
+//     O^T chunk dc (16 head-dim columns): B = the lane's 8 probabilities of group g in k order (h, i) = keys {32 g + 4 grp ..+3, 32 g + 16 + 4 grp ..+3},
+//                                    A = V^T for those 8 keys = two ds_read_b64_tr_b16 of the row-major V tile (rows padded to 32 * odd bytes).
+// The 4 wavefronts of a causal block end at different keys: a wavefront skips the tiles behind its last row, the loads and barriers are the
+// workgroup's.  Workgroups are numbered so that the q heads of one kv head, and neighbouring row blocks, run on ONE XCD (its L2 then serves the
+// K / V re-reads), heaviest (last) row blocks first.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short gshort4;
+typedef __attribute__((ext_vector_type(4))) unsigned int gu32x4;
+template <typename T> __device__ __forceinline__ gf32x4 gmfma32(const gu32x4 &a, const gu32x4 &b, gf32x4 c);
+template <> __device__ __forceinline__ gf32x4 gmfma32<bf16_t>(const gu32x4 &a, const gu32x4 &b, gf32x4 c) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ gf32x4 gmfma32<f16_t>(const gu32x4 &a, const gu32x4 &b, gf32x4 c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 v8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
+}
+
+template <typename T, int NC, int KT>
+__global__ void __launch_bounds__(256) attn_prefill_tile64_kernel(const AttnParams p, const int mblocks) {
+    constexpr int D = 32 * NC, KRB = 2 * D + 16, VRB = 2 * D + 32, KG = KT / 32, CPR = D / 8;
+    constexpr int PIECES = KT * CPR, NPC = (PIECES + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char smem[KT * (KRB + VRB)];
+    const uint32_t k_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem, v_lds = k_lds + KT * KRB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, col = lane & 15;
+    // ---- workgroup -> (row block, q head): consecutive ids of one XCD walk the q heads first, then the row blocks from the last one down
+    const int N = gridDim.x, full = (N >> 3) << 3;
+    int w = blockIdx.x;
+    if (w < full) w = (w & 7) * (N >> 3) + (w >> 3);
+    const int hq = w % p.h, mblk = mblocks - 1 - w / p.h, b = blockIdx.z;
+    const SeqInfo si(p, b);
+    const int q0 = mblk * 64;
+    if (q0 >= si.len_q) return;
+    const int hk = hq / (p.h / p.h_k);
+    const int shift = si.len_k - si.len_q;                        // mask.h:170
+    const int wq0 = q0 + 16 * wave;
+    const int qrow = wq0 + col;
+    const bool qvalid = qrow < si.len_q;
+    const int qr = min(qrow, si.len_q - 1);
+    const int hi_q = max(0, p.is_causal ? min(si.len_k, qr + shift + 1) : si.len_k);
+    const int hi_wave = wq0 < si.len_q ? max(0, p.is_causal ? min(si.len_k, min(wq0 + 15, si.len_q - 1) + shift + 1) : si.len_k) : 0;
+    const int hi_wg = max(0, p.is_causal ? min(si.len_k, min(q0 + 63, si.len_q - 1) + shift + 1) : si.len_k);
+    gu32x4 qreg[NC];
+    {
+        const uint16_t *qptr = p.q + si.q_offset(p.q_batch_stride, p.q_row_stride, b) + (int64_t)qr * p.q_row_stride + (int64_t)hq * p.q_head_stride + 8 * grp;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qreg[c] = *reinterpret_cast<const gu32x4 *>(qptr + 32 * c);
+    }
+    const bool paged = p.block_table != nullptr;
+    const int *bt = paged ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+    const int pshift = (paged && (p.page_size & (p.page_size - 1)) == 0) ? __builtin_ctz(p.page_size) : -1;
+    const int64_t kbase = (paged ? 0 : si.k_offset(p.k_batch_stride, p.k_row_stride, b)) + (int64_t)hk * p.k_head_stride;
+    const int64_t vbase = (paged ? 0 : si.k_offset(p.v_batch_stride, p.v_row_stride, b)) + (int64_t)hk * p.v_head_stride;
+    const float slope_l2 = p.alibi_slopes ? p.alibi_slopes[b * p.alibi_batch_stride + hq] * 1.4426950408889634f : 0.f;
+    gu32x4 kreg[NPC], vreg[NPC];
+    auto load_tile = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int idx = tid + 256 * i;
+            if (PIECES % 256 == 0 || idx < PIECES) {
+                const int kr = idx / CPR, ch = idx - kr * CPR;
+                const int t = min(j0 + kr, si.len_k - 1);         // rows behind the sequence re-read its last row and meet p = 0
+                int64_t ko, vo;
+                if (paged) {
+                    const int pi = pshift >= 0 ? t >> pshift : t / p.page_size, r = t - pi * p.page_size;
+                    const int64_t pg = bt[pi];
+                    ko = pg * p.k_batch_stride + (int64_t)r * p.k_row_stride;
+                    vo = pg * p.v_batch_stride + (int64_t)r * p.v_row_stride;
+                } else {
+                    ko = (int64_t)t * p.k_row_stride;
+                    vo = (int64_t)t * p.v_row_stride;
+                }
+                kreg[i] = *reinterpret_cast<const gu32x4 *>(p.k + kbase + ko + ch * 8);
+                vreg[i] = *reinterpret_cast<const gu32x4 *>(p.v + vbase + vo + ch * 8);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int idx = tid + 256 * i;
+            if (PIECES % 256 == 0 || idx < PIECES) {
+                const int kr = idx / CPR, ch = idx - kr * CPR;
+                *reinterpret_cast<gu32x4 *>(smem + kr * KRB + ch * 16) = kreg[i];
+                *reinterpret_cast<gu32x4 *>(smem + KT * KRB + kr * VRB + ch * 16) = vreg[i];
+            }
+        }
+    };
+    gf32x4 o[2 * NC];
+#pragma unroll
+    for (int c = 0; c < 2 * NC; ++c) o[c] = gf32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l = 0.f;
+    const uint32_t k_rd = k_lds + col * KRB + grp * 16;                                  // + (32 g + 16 h) rows + 64 c
+    const uint32_t v_rd = v_lds + (4 * grp + (col >> 2)) * VRB + (col & 3) * 8;          // + (32 g + 16 h) rows + 32 dc
+    if (hi_wg > 0) load_tile(0);
+    for (int j0 = 0; j0 < hi_wg; j0 += KT) {
+        store_tile();
+        __syncthreads();
+        if (j0 + KT < hi_wg) load_tile(j0 + KT);
+        if (j0 < hi_wave) {
+            gf32x4 sacc[KG][2];
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    gf32x4 acc = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const gu32x4 a = *(const __attribute__((address_space(3))) gu32x4 *)(uintptr_t)(k_rd + (32 * g + 16 * hh) * KRB + 64 * c);
+                        acc = gmfma32<T>(a, qreg[c], acc);
+                    }
+                    sacc[g][hh] = acc;
+                }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int key = j0 + 32 * g + 16 * hh + 4 * grp + i;
+                        float x = sacc[g][hh][i] * p.scale_log2;
+                        if (p.alibi_slopes) x -= slope_l2 * fabsf((float)(qr + shift - key));   // mask.h:179-186
+                        x = key < hi_q ? x : -INFINITY;
+                        sacc[g][hh][i] = x;
+                        mx = fmaxf(mx, x);
+                    }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float ms = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
+            m_run = m_new;
+            float psum = 0.f;
+            gu32x4 pb[KG];
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                float pr[2][4];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        pr[hh][i] = __builtin_amdgcn_exp2f(sacc[g][hh][i] - ms);
+                        psum += pr[hh][i];
+                    }
+                pb[g] = gu32x4{pack2<T>(pr[0][0], pr[0][1]), pack2<T>(pr[0][2], pr[0][3]), pack2<T>(pr[1][0], pr[1][1]), pack2<T>(pr[1][2], pr[1][3])};
+            }
+            l = l * alpha + psum;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // (the running max settles after the first tiles of a row block)
+#pragma unroll
+                for (int dc = 0; dc < 2 * NC; ++dc) { o[dc][0] *= alpha; o[dc][1] *= alpha; o[dc][2] *= alpha; o[dc][3] *= alpha; }
+            }
+#pragma unroll
+            for (int dc = 0; dc < 2 * NC; ++dc) {
+                gf32x4 acc = o[dc];
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    const uint32_t a0 = v_rd + (32 * g) * VRB + 32 * dc;
+                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gshort4 *)(uintptr_t)a0));
+                    const uint2 hi2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gshort4 *)(uintptr_t)(a0 + 16 * VRB)));
+                    acc = gmfma32<T>(gu32x4{lo.x, lo.y, hi2.x, hi2.y}, pb[g], acc);
+                }
+                o[dc] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const bool empty = !(l > 0.f);                                // no visible key: O = 0, LSE = +inf (flash_fwd_kernel.h:97-133)
+    const float inv = empty ? 0.f : 1.f / l;
+    if (qvalid) {
+        uint16_t *orow = p.o + si.q_offset(p.o_batch_stride, p.o_row_stride, b) + (int64_t)qrow * p.o_row_stride + (int64_t)hq * p.o_head_stride + 4 * grp;
+#pragma unroll
+        for (int dc = 0; dc < 2 * NC; ++dc) {
+            uint2 wv;
+            wv.x = pack2<T>(o[dc][0] * inv, o[dc][1] * inv);
+            wv.y = pack2<T>(o[dc][2] * inv, o[dc][3] * inv);
+            *reinterpret_cast<uint2 *>(orow + 16 * dc) = wv;
+        }
+        if (p.lse && grp == 0) {
+            const float lse = empty ? INFINITY : (m_run + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+            if (p.unpadded_lse && p.cu_seqlens_q) p.lse[(int64_t)hq * p.cu_seqlens_q[p.b] + si.sum_q + qrow] = lse;
+            else p.lse[((int64_t)b * p.h + hq) * p.seqlen_q + qrow] = lse;
+        }
+    }
+}
+
+template <typename T>
+static void launch_prefill_tile64(const AttnParams &p, hipStream_t stream) {
+    const int mblocks = (p.seqlen_q + 63) / 64;
+    const dim3 grid((unsigned)(mblocks * p.h), 1, (unsigned)p.b);
+    switch (p.d / 32) {
+#define ATOMA_T64(NC_, KT_) case NC_: hipLaunchKernelGGL((attn_prefill_tile64_kernel<T, NC_, KT_>), grid, dim3(256), 0, stream, p, mblocks); break
+        ATOMA_T64(1, 64); ATOMA_T64(2, 64); ATOMA_T64(3, 64); ATOMA_T64(4, 64); ATOMA_T64(5, 32); ATOMA_T64(6, 32); ATOMA_T64(7, 32); ATOMA_T64(8, 32);
+#undef ATOMA_T64
+    }
+}
+
+// ATOMA_GENERIC_PREFILL_TILE (A/B runs): unset = the tiled kernels; "16" = only the 16-row one; anything else = the row-per-wavefront kernel
+static int attn_prefill_tile_choice() {
+    const char *e = getenv("ATOMA_GENERIC_PREFILL_TILE");
+    return e == nullptr ? 64 : (strcmp(e, "16") == 0 ? 16 : 0);
+}
+
 static bool attn_prefill_tile16_applicable(const AttnParams &p) {
     const int64_t strides = p.q_head_stride | p.k_head_stride | p.v_head_stride | p.o_head_stride | p.q_row_stride | p.o_row_stride | p.k_row_stride | p.v_row_stride |
                             p.q_batch_stride | p.o_batch_stride | p.k_batch_stride | p.v_batch_stride;
     return p.seqlen_q > 1 && p.d >= 16 && p.d <= 256 && p.d % 16 == 0 && p.h % p.h_k == 0 && strides % 8 == 0 &&
            ((reinterpret_cast<uintptr_t>(p.q) | reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.o)) & 15u) == 0 &&
-           getenv("ATOMA_GENERIC_PREFILL_TILE") == nullptr;      // (set to anything: the row-per-wavefront kernel, for A/B runs)
+           attn_prefill_tile_choice() != 0;
 }
 
 static bool attn_decode_anyd_applicable(const AttnParams &p) {
@@ -410,6 +622,12 @@ void launch_attn_generic(const AttnParams &p, bool is_bf16, hipStream_t stream) 
         if (C <= 4) ATOMA_ANYD(4); else if (C <= 8) ATOMA_ANYD(8); else if (C <= 16) ATOMA_ANYD(16); else ATOMA_ANYD(32);
 #undef ATOMA_ANYD
         ATOMA_CHECK_LAUNCH("attn_decode_anyd_kernel");
+        return;
+    }
+    if (attn_prefill_tile16_applicable(p) && p.d % 32 == 0 && p.seqlen_q > 16 && attn_prefill_tile_choice() == 64) {
+        if (is_bf16) launch_prefill_tile64<bf16_t>(p, stream);
+        else launch_prefill_tile64<f16_t>(p, stream);
+        ATOMA_CHECK_LAUNCH("attn_prefill_tile64_kernel");
         return;
     }
     if (attn_prefill_tile16_applicable(p)) {

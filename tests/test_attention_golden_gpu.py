@@ -171,13 +171,16 @@ def test_other_head_sizes_tiled_prefill(gpu, d, dtype, monkeypatch):
                 ref = A.flash_attn_varlen(q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi_slopes=alibi, **okw)
                 what = f"d={d} causal={causal} alibi={alibi is not None} paged={paged}"
                 assert_close(out, ref, dtype, atol=ATOL_VS_F32[dtype], what=what + " (f32 oracle)")
-                monkeypatch.setenv("ATOMA_GENERIC_PREFILL_TILE", "0")
-                out_row, lse_row = gpu_varlen(gpu, q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi=alibi, **kw)
-                monkeypatch.delenv("ATOMA_GENERIC_PREFILL_TILE")
-                assert_close(out, out_row, dtype, atol=ATOL_VS_F32[dtype], what=what + " (row kernel)")
-                assert np.array_equal(np.isinf(lse), np.isinf(lse_row)), what
-                fin = np.isfinite(lse_row)
-                assert np.allclose(lse[fin], lse_row[fin], atol=2e-3, rtol=1e-3), what
+                for other in ("16", "0"):      # the 16-row kernel alone; the row-per-wavefront kernel
+                    monkeypatch.setenv("ATOMA_GENERIC_PREFILL_TILE", other)
+                    out_o, lse_o = gpu_varlen(gpu, q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi=alibi, **kw)
+                    monkeypatch.delenv("ATOMA_GENERIC_PREFILL_TILE")
+                    if other == "16":
+                        assert_close(out_o, ref, dtype, atol=ATOL_VS_F32[dtype], what=what + " (16-row kernel, f32 oracle)")
+                    assert_close(out, out_o, dtype, atol=ATOL_VS_F32[dtype], what=what + f" (kernel {other})")
+                    assert np.array_equal(np.isinf(lse), np.isinf(lse_o)), what
+                    fin = np.isfinite(lse_o)
+                    assert np.allclose(lse[fin], lse_o[fin], atol=2e-3, rtol=1e-3), what
 
 
 def test_alibi_causal_and_non_causal(gpu):

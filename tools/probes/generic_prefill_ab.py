@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prefill at the head sizes without a tuned kernel: the 16-row tiled MFMA kernel (attn_prefill_tile16_kernel) against the row-per-wavefront
+"""Prefill at the head sizes without a tuned kernel: the 64-row LDS-staged kernel (attn_prefill_tile64_kernel) and the 16-row kernel (attn_prefill_tile16_kernel) against the row-per-wavefront
 kernel it replaces (ATOMA_GENERIC_PREFILL_TILE set), same process, same buffers.  4 causal prompts of 2048 tokens, 32 q / 8 kv heads."""
 import json
 import os
@@ -10,9 +10,9 @@ import bench_extra as BE  # noqa: E402
 
 BE.ah.set_device(0)
 res = {}
-for d in (32, 96, 160, 256):
+for d in (32, 96, 160, 192, 256):
     e = {}
-    for name, env in (("tile16", None), ("row_per_wavefront", "0")):
+    for name, env in (("tile64", None), ("tile16", "16"), ("row_per_wavefront", "0")):
         if env is None:
             os.environ.pop("ATOMA_GENERIC_PREFILL_TILE", None)
         else:
@@ -20,6 +20,6 @@ for d in (32, 96, 160, 256):
         r = BE.prefill(iters=3, S=2048, nseq=4, d=d)
         e[name] = {"ms": r["ms"], "TFLOPs": r["TFLOPs"]}
     os.environ.pop("ATOMA_GENERIC_PREFILL_TILE", None)
-    e["speedup"] = round(e["row_per_wavefront"]["ms"] / e["tile16"]["ms"], 2)
+    e["speedup_over_row"] = round(e["row_per_wavefront"]["ms"] / e["tile64"]["ms"], 2)
     res["d=%d" % d] = e
 print(json.dumps(res, indent=1))
