@@ -259,16 +259,15 @@ template <> __device__ __forceinline__ gf32x4 gmfma16<f16_t>(uint32_t a0, uint32
     return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h16x4, u2{a0, a1}), __builtin_bit_cast(h16x4, u2{b0, b1}), c, 0, 0, 0);
 }
 
-template <typename T>
+template <typename T, int NCMAX, bool EXACT>                     // head_dim / 16 <= NCMAX (EXACT: == NCMAX, no predicated chunks)
 __global__ void __launch_bounds__(64) attn_prefill_tile16_kernel(const AttnParams p) {
-    constexpr int NCMAX = 16;                                    // head_dim / 16 <= 16
-    __shared__ __attribute__((aligned(16))) uint16_t v_sm[16 * 256];
+    __shared__ __attribute__((aligned(16))) uint16_t v_sm[16 * 16 * NCMAX];
     const int lane = threadIdx.x, grp = lane >> 4, col = lane & 15;
     const int mblk = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
     const SeqInfo si(p, b);
     const int q0 = mblk * 16;
     if (q0 >= si.len_q) return;
-    const int D = p.d, nc = D >> 4;
+    const int D = EXACT ? 16 * NCMAX : p.d, nc = D >> 4;
     const int hk = hq / (p.h / p.h_k);
     const int shift = si.len_k - si.len_q;                        // mask.h:170
     const int qrow = q0 + col;                                   // this lane's query row
@@ -410,7 +409,7 @@ template <> __device__ __forceinline__ gf32x4 gmfma32<f16_t>(const gu32x4 &a, co
 }
 
 template <typename T, int NC, int KT>
-__global__ void __launch_bounds__(256) attn_prefill_tile64_kernel(const AttnParams p, const int mblocks) {
+__global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnParams p, const int mblocks) {
     constexpr int D = 32 * NC, KRB = 2 * D + 16, VRB = 2 * D + 32, KG = KT / 32, CPR = D / 8;
     constexpr int PIECES = KT * CPR, NPC = (PIECES + 255) / 256;
     __shared__ __attribute__((aligned(16))) char smem[KT * (KRB + VRB)];
@@ -632,8 +631,15 @@ void launch_attn_generic(const AttnParams &p, bool is_bf16, hipStream_t stream) 
     }
     if (attn_prefill_tile16_applicable(p)) {
         const dim3 grid((unsigned)((p.seqlen_q + 15) / 16), (unsigned)p.h, (unsigned)p.b);
-        if (is_bf16) hipLaunchKernelGGL(attn_prefill_tile16_kernel<bf16_t>, grid, dim3(64), 0, stream, p);
-        else hipLaunchKernelGGL(attn_prefill_tile16_kernel<f16_t>, grid, dim3(64), 0, stream, p);
+#define ATOMA_T16(N_) do { if (p.d == 16 * N_) { if (is_bf16) hipLaunchKernelGGL((attn_prefill_tile16_kernel<bf16_t, N_, true>), grid, dim3(64), 0, stream, p); \
+                                                 else hipLaunchKernelGGL((attn_prefill_tile16_kernel<f16_t, N_, true>), grid, dim3(64), 0, stream, p); } \
+                           else { if (is_bf16) hipLaunchKernelGGL((attn_prefill_tile16_kernel<bf16_t, N_, false>), grid, dim3(64), 0, stream, p); \
+                                  else hipLaunchKernelGGL((attn_prefill_tile16_kernel<f16_t, N_, false>), grid, dim3(64), 0, stream, p); } } while (0)
+        switch ((p.d + 31) / 32) {
+        case 1: ATOMA_T16(2); break; case 2: ATOMA_T16(4); break; case 3: ATOMA_T16(6); break; case 4: ATOMA_T16(8); break;
+        case 5: ATOMA_T16(10); break; case 6: ATOMA_T16(12); break; case 7: ATOMA_T16(14); break; default: ATOMA_T16(16); break;
+        }
+#undef ATOMA_T16
         ATOMA_CHECK_LAUNCH("attn_prefill_tile16_kernel");
         return;
     }
