@@ -74,7 +74,7 @@ def test_bench_py_prints_one_json_line(gpu):
 def test_bench_extras_hold_their_floors(gpu):
     """the rows of BASELINE.md that ride in the driver's line (tools/bench_extra.py), where they actually run: bit-exact ops bit-exact, and
     each number above a floor a regression would break (the swap / rank-step thresholds belong in a GPU test, not nowhere)"""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_extra.py"), "swap", "c4_rank_step", "k5_copy_blocks", "k4_reshape_and_cache", "c2b_mha", "c2c_ragged"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_extra.py"), "swap", "c4_rank_step", "k5_copy_blocks", "k4_reshape_and_cache", "c2b_mha", "c2c_ragged", "p2_prefill_d96", "p2_prefill_d256"],
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -85,3 +85,5 @@ def test_bench_extras_hold_their_floors(gpu):
     assert d["k4_reshape_and_cache"]["bit_exact"] and d["k4_reshape_and_cache"]["frac_hbm"] >= 0.45, d["k4_reshape_and_cache"]
     assert d["c2b_mha"]["frac_hbm"] >= 0.75 and "balanced" in d["c2b_mha"]["kernel"], d["c2b_mha"]
     assert d["c2c_ragged"]["frac_hbm"] >= 0.72, d["c2c_ragged"]
+    # the other head sizes run on the matrix pipe (the row-per-wavefront kernel reads 7-8 TFLOP/s here)
+    assert d["p2_prefill_d96"]["TFLOPs"] >= 150 and d["p2_prefill_d256"]["TFLOPs"] >= 150, (d["p2_prefill_d96"], d["p2_prefill_d256"])

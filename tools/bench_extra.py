@@ -286,6 +286,16 @@ def p1_prefill_4096(iters=10):
     return prefill(iters=iters, S=4096, nseq=2, with_sample=True)
 
 
+def p2_prefill_d96(iters=10):
+    """Prefill at a head size without a hand-scheduled kernel (Phi-3-mini's 96): attn_generic.hip's 64-row tiled kernel, 4 causal prompts of 2048."""
+    return prefill(iters=iters, S=2048, nseq=4, d=96, with_sample=True)
+
+
+def p2_prefill_d256(iters=10):
+    """The same at head size 256 (Gemma-class heads)."""
+    return prefill(iters=iters, S=2048, nseq=4, d=256, with_sample=True)
+
+
 def c4_rank_step(iters=10):
     """One rank of the Llama-3.1-70B TP = 8 decode step of configs[3] without its all-reduces (tools/rank_step.py): what a rank
     computes between the exchanges, batch 64, context 4096, 80 layers."""
@@ -293,7 +303,7 @@ def c4_rank_step(iters=10):
     return rank_step.run(iters=iters)
 
 
-ALL = ("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "p1_prefill_4096", "c2b_mha", "c2c_ragged", "k4_reshape_and_cache", "k5_copy_blocks",
+ALL = ("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "p1_prefill_4096", "p2_prefill_d96", "p2_prefill_d256", "c2b_mha", "c2c_ragged", "k4_reshape_and_cache", "k5_copy_blocks",
        "n1_norm_rope", "swap")
 
 
