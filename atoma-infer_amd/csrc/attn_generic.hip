@@ -10,6 +10,7 @@
 // P rounded to the storage dtype before P.V (csrc/kernels/softmax.h:65-185).
 #include "attn_params.h"
 #include <cstring>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace atoma {
@@ -246,6 +247,26 @@ __global__ void __launch_bounds__(64) attn_decode_anyd_kernel(const AttnParams p
 // the storage type before P.V (softmax.h:65-185), O^T[16 c + 4 grp + i][col] in D / 4 accumulator registers.  Untuned (no pipelining, V through
 // a row-major LDS tile read 2 bytes at a time): the point is 16 x less K / V traffic, not the matrix pipe.
 // ------------------------------------------------------------------------------------------
+// two f32 -> one packed pair of the storage type, round to nearest even in hardware (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+template <typename T> __device__ __forceinline__ uint32_t gpack(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t gpack<bf16_t>(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_v));
+}
+template <> __device__ __forceinline__ uint32_t gpack<f16_t>(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2_v));
+}
+
+// max over the four lanes (grp = 0 .. 3) that hold the same query row: two VALU lane swaps instead of two LDS round trips
+__device__ __forceinline__ float gcol_max4(float x) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 typedef __attribute__((ext_vector_type(4))) float gf32x4;
 template <typename T> __device__ __forceinline__ gf32x4 gmfma16(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, gf32x4 c);
 template <> __device__ __forceinline__ gf32x4 gmfma16<bf16_t>(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, gf32x4 c) {
@@ -333,8 +354,7 @@ __global__ void __launch_bounds__(64) attn_prefill_tile16_kernel(const AttnParam
             sv[i] = key < hi_q ? x : -INFINITY;
             mx = fmaxf(mx, sv[i]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = gcol_max4(mx);
         const float m_new = fmaxf(m_run, mx);
         const float ms = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
@@ -347,7 +367,7 @@ __global__ void __launch_bounds__(64) attn_prefill_tile16_kernel(const AttnParam
             pr[i] = pj;
         }
         l = l * alpha + psum;
-        const uint32_t b0 = pack2<T>(pr[0], pr[1]), b1 = pack2<T>(pr[2], pr[3]);
+        const uint32_t b0 = gpack<T>(pr[0], pr[1]), b1 = gpack<T>(pr[2], pr[3]);
         __syncthreads();                                          // the V tile is in LDS
 #pragma unroll
         for (int c = 0; c < NCMAX; ++c) {
@@ -371,8 +391,8 @@ __global__ void __launch_bounds__(64) attn_prefill_tile16_kernel(const AttnParam
         for (int c = 0; c < NCMAX; ++c) {
             if (c < nc) {
                 uint2 w;
-                w.x = pack2<T>(o[c][0] * inv, o[c][1] * inv);
-                w.y = pack2<T>(o[c][2] * inv, o[c][3] * inv);
+                w.x = gpack<T>(o[c][0] * inv, o[c][1] * inv);
+                w.y = gpack<T>(o[c][2] * inv, o[c][3] * inv);
                 *reinterpret_cast<uint2 *>(orow + 16 * c) = w;
             }
         }
@@ -408,7 +428,7 @@ template <> __device__ __forceinline__ gf32x4 gmfma32<f16_t>(const gu32x4 &a, co
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
 }
 
-template <typename T, int NC, int KT>
+template <typename T, int NC, int KT, int ST>
 __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnParams p, const int mblocks) {
     constexpr int D = 32 * NC, KRB = 2 * D + 16, VRB = 2 * D + 32, KG = KT / 32, CPR = D / 8;
     constexpr int PIECES = KT * CPR, NPC = (PIECES + 255) / 256;
@@ -432,6 +452,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     const int hi_q = max(0, p.is_causal ? min(si.len_k, qr + shift + 1) : si.len_k);
     const int hi_wave = wq0 < si.len_q ? max(0, p.is_causal ? min(si.len_k, min(wq0 + 15, si.len_q - 1) + shift + 1) : si.len_k) : 0;
     const int hi_wg = max(0, p.is_causal ? min(si.len_k, min(q0 + 63, si.len_q - 1) + shift + 1) : si.len_k);
+    const int hi_first = p.is_causal ? min(si.len_k, wq0 + shift + 1) : si.len_k;      // keys EVERY row of this wavefront sees
     gu32x4 qreg[NC];
     {
         const uint16_t *qptr = p.q + si.q_offset(p.q_batch_stride, p.q_row_stride, b) + (int64_t)qr * p.q_row_stride + (int64_t)hq * p.q_head_stride + 8 * grp;
@@ -443,38 +464,56 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     const int pshift = (paged && (p.page_size & (p.page_size - 1)) == 0) ? __builtin_ctz(p.page_size) : -1;
     const int64_t kbase = (paged ? 0 : si.k_offset(p.k_batch_stride, p.k_row_stride, b)) + (int64_t)hk * p.k_head_stride;
     const int64_t vbase = (paged ? 0 : si.k_offset(p.v_batch_stride, p.v_row_stride, b)) + (int64_t)hk * p.v_head_stride;
-    const float slope_l2 = p.alibi_slopes ? p.alibi_slopes[b * p.alibi_batch_stride + hq] * 1.4426950408889634f : 0.f;
-    gu32x4 kreg[NPC], vreg[NPC];
-    auto load_tile = [&](int j0) {
+    const float slope_raw = p.alibi_slopes ? p.alibi_slopes[b * p.alibi_batch_stride + hq] / p.scale : 0.f;   // slope.log2(e) / scale_log2
+    gu32x4 kreg[ST][NPC], vreg[ST][NPC];                          // ST register stages: tile t + ST is requested while tile t is computed
+    // Addresses: 32-bit arithmetic inside a page / a row, ONE 32 x 32 -> 64-bit multiply-add per tensor and piece (the strides arrive as u32 over
+    // the FFI: ffi.rs:3-102).  Paged: the page numbers of tile t + 1's rows are requested right after tile t's K / V loads, so the block-table
+    // latency never sits in front of a K / V load.
+    const uint32_t krs = (uint32_t)p.k_row_stride, vrs = (uint32_t)p.v_row_stride, kbs = (uint32_t)p.k_batch_stride, vbs = (uint32_t)p.v_batch_stride;
+    const uint16_t *kg = p.k + kbase, *vg = p.v + vbase;
+    const uint32_t pmask = (uint32_t)p.page_size - 1u;
+    int pg[NPC];
+    auto piece_row = [&](int i, int j0) { return min(j0 + (tid + 256 * i) / CPR, si.len_k - 1); };   // rows behind the sequence re-read its last row and meet p = 0
+    auto load_pages = [&](int j0) {
+#pragma unroll
+        for (int i = 0; i < NPC; ++i)
+            if (PIECES % 256 == 0 || tid + 256 * i < PIECES) {
+                const int t = piece_row(i, j0);
+                pg[i] = bt[pshift >= 0 ? t >> pshift : t / p.page_size];
+            }
+    };
+    auto load_tile = [&](auto sel, int j0) {
+        constexpr int SG = decltype(sel)::value;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
             const int idx = tid + 256 * i;
             if (PIECES % 256 == 0 || idx < PIECES) {
-                const int kr = idx / CPR, ch = idx - kr * CPR;
-                const int t = min(j0 + kr, si.len_k - 1);         // rows behind the sequence re-read its last row and meet p = 0
-                int64_t ko, vo;
+                const uint32_t ch8 = (uint32_t)(idx % CPR) * 8u;
+                const int t = piece_row(i, j0);
+                uint64_t ko, vo;
                 if (paged) {
-                    const int pi = pshift >= 0 ? t >> pshift : t / p.page_size, r = t - pi * p.page_size;
-                    const int64_t pg = bt[pi];
-                    ko = pg * p.k_batch_stride + (int64_t)r * p.k_row_stride;
-                    vo = pg * p.v_batch_stride + (int64_t)r * p.v_row_stride;
+                    const uint32_t r = pshift >= 0 ? (uint32_t)t & pmask : (uint32_t)(t % p.page_size);
+                    ko = (uint64_t)(uint32_t)pg[i] * kbs + (__umul24(r, krs) + ch8);
+                    vo = (uint64_t)(uint32_t)pg[i] * vbs + (__umul24(r, vrs) + ch8);
                 } else {
-                    ko = (int64_t)t * p.k_row_stride;
-                    vo = (int64_t)t * p.v_row_stride;
+                    ko = (uint64_t)(uint32_t)t * krs + ch8;
+                    vo = (uint64_t)(uint32_t)t * vrs + ch8;
                 }
-                kreg[i] = *reinterpret_cast<const gu32x4 *>(p.k + kbase + ko + ch * 8);
-                vreg[i] = *reinterpret_cast<const gu32x4 *>(p.v + vbase + vo + ch * 8);
+                kreg[SG][i] = *reinterpret_cast<const gu32x4 *>(kg + ko);
+                vreg[SG][i] = *reinterpret_cast<const gu32x4 *>(vg + vo);
             }
         }
+        if (paged && j0 + KT < hi_wg) load_pages(j0 + KT);
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](auto sel) {
+        constexpr int SG = decltype(sel)::value;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
             const int idx = tid + 256 * i;
             if (PIECES % 256 == 0 || idx < PIECES) {
                 const int kr = idx / CPR, ch = idx - kr * CPR;
-                *reinterpret_cast<gu32x4 *>(smem + kr * KRB + ch * 16) = kreg[i];
-                *reinterpret_cast<gu32x4 *>(smem + KT * KRB + kr * VRB + ch * 16) = vreg[i];
+                *reinterpret_cast<gu32x4 *>(smem + kr * KRB + ch * 16) = kreg[SG][i];
+                *reinterpret_cast<gu32x4 *>(smem + KT * KRB + kr * VRB + ch * 16) = vreg[SG][i];
             }
         }
     };
@@ -484,12 +523,8 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     float m_run = -INFINITY, l = 0.f;
     const uint32_t k_rd = k_lds + col * KRB + grp * 16;                                  // + (32 g + 16 h) rows + 64 c
     const uint32_t v_rd = v_lds + (4 * grp + (col >> 2)) * VRB + (col & 3) * 8;          // + (32 g + 16 h) rows + 32 dc
-    if (hi_wg > 0) load_tile(0);
-    for (int j0 = 0; j0 < hi_wg; j0 += KT) {
-        store_tile();
-        __syncthreads();
-        if (j0 + KT < hi_wg) load_tile(j0 + KT);
-        if (j0 < hi_wave) {
+    auto compute_tile = [&](int j0) {
+        {
             gf32x4 sacc[KG][2];
 #pragma unroll
             for (int g = 0; g < KG; ++g)
@@ -503,22 +538,34 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
                     }
                     sacc[g][hh] = acc;
                 }
+            // scores stay raw: p = exp2(s * scale_log2 - m) is one fma + one exp; the mask / ALiBi pass only runs on tiles that reach past the first
+            // row's last key (the diagonal, the sequence's tail) or when slopes are given (softmax.h:65-185 in the exp2 domain; scale_log2 > 0)
+            const bool plain = !p.alibi_slopes && j0 + KT <= hi_first;
             float mx = -INFINITY;
+            if (plain) {
 #pragma unroll
-            for (int g = 0; g < KG; ++g)
+                for (int g = 0; g < KG; ++g)
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
+                    for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int key = j0 + 32 * g + 16 * hh + 4 * grp + i;
-                        float x = sacc[g][hh][i] * p.scale_log2;
-                        if (p.alibi_slopes) x -= slope_l2 * fabsf((float)(qr + shift - key));   // mask.h:179-186
-                        x = key < hi_q ? x : -INFINITY;
-                        sacc[g][hh][i] = x;
-                        mx = fmaxf(mx, x);
-                    }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                        for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sacc[g][hh][i]);
+                mx *= p.scale_log2;
+            } else {
+#pragma unroll
+                for (int g = 0; g < KG; ++g)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int key = j0 + 32 * g + 16 * hh + 4 * grp + i;
+                            float x = sacc[g][hh][i];
+                            if (p.alibi_slopes) x -= slope_raw * fabsf((float)(qr + shift - key));   // mask.h:179-186, in units of 1 / scale_log2
+                            x = key < hi_q ? x : -INFINITY;
+                            sacc[g][hh][i] = x;
+                            mx = fmaxf(mx, x * p.scale_log2);
+                        }
+            }
+            mx = gcol_max4(mx);
             const float m_new = fmaxf(m_run, mx);
             const float ms = m_new == -INFINITY ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
@@ -532,10 +579,10 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        pr[hh][i] = __builtin_amdgcn_exp2f(sacc[g][hh][i] - ms);
+                        pr[hh][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[g][hh][i], p.scale_log2, -ms));
                         psum += pr[hh][i];
                     }
-                pb[g] = gu32x4{pack2<T>(pr[0][0], pr[0][1]), pack2<T>(pr[0][2], pr[0][3]), pack2<T>(pr[1][0], pr[1][1]), pack2<T>(pr[1][2], pr[1][3])};
+                pb[g] = gu32x4{gpack<T>(pr[0][0], pr[0][1]), gpack<T>(pr[0][2], pr[0][3]), gpack<T>(pr[1][0], pr[1][1]), gpack<T>(pr[1][2], pr[1][3])};
             }
             l = l * alpha + psum;
             if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // (the running max settles after the first tiles of a row block)
@@ -555,7 +602,22 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
                 o[dc] = acc;
             }
         }
+    };
+    typedef std::integral_constant<int, 0> Stage0;
+    typedef std::integral_constant<int, ST - 1> Stage1;
+    auto step = [&](auto sel, int j0) {
+        store_tile(sel);
         __syncthreads();
+        if (j0 + ST * KT < hi_wg) load_tile(sel, j0 + ST * KT);
+        if (j0 < hi_wave) compute_tile(j0);
+        __syncthreads();
+    };
+    if (paged && hi_wg > 0) load_pages(0);
+    if (hi_wg > 0) load_tile(Stage0(), 0);
+    if (ST == 2 && KT < hi_wg) load_tile(Stage1(), KT);
+    for (int j0 = 0; j0 < hi_wg; j0 += ST * KT) {
+        step(Stage0(), j0);
+        if (ST == 2 && j0 + KT < hi_wg) step(Stage1(), j0 + KT);
     }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -566,8 +628,8 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
 #pragma unroll
         for (int dc = 0; dc < 2 * NC; ++dc) {
             uint2 wv;
-            wv.x = pack2<T>(o[dc][0] * inv, o[dc][1] * inv);
-            wv.y = pack2<T>(o[dc][2] * inv, o[dc][3] * inv);
+            wv.x = gpack<T>(o[dc][0] * inv, o[dc][1] * inv);
+            wv.y = gpack<T>(o[dc][2] * inv, o[dc][3] * inv);
             *reinterpret_cast<uint2 *>(orow + 16 * dc) = wv;
         }
         if (p.lse && grp == 0) {
@@ -582,11 +644,16 @@ template <typename T>
 static void launch_prefill_tile64(const AttnParams &p, hipStream_t stream) {
     const int mblocks = (p.seqlen_q + 63) / 64;
     const dim3 grid((unsigned)(mblocks * p.h), 1, (unsigned)p.b);
+    int kt = (p.d == 192 || p.d == 256) ? 32 : 64;               // measured per head size: profiles/r05_generic_prefill_cfg.json
+    if (const char *e = getenv("ATOMA_GENERIC_PREFILL_KT")) kt = atoi(e) == 32 ? 32 : 64;   // A/B runs
+    // (two register stages -- tile t + 2 requested while tile t is computed -- were measured and never won: ST stays 1)
+#define ATOMA_T64B(NC_, KT_) hipLaunchKernelGGL((attn_prefill_tile64_kernel<T, NC_, KT_, 1>), grid, dim3(256), 0, stream, p, mblocks)
+#define ATOMA_T64(NC_) case NC_: if (kt == 64) ATOMA_T64B(NC_, 64); else ATOMA_T64B(NC_, 32); break
     switch (p.d / 32) {
-#define ATOMA_T64(NC_, KT_) case NC_: hipLaunchKernelGGL((attn_prefill_tile64_kernel<T, NC_, KT_>), grid, dim3(256), 0, stream, p, mblocks); break
-        ATOMA_T64(1, 64); ATOMA_T64(2, 64); ATOMA_T64(3, 64); ATOMA_T64(4, 64); ATOMA_T64(5, 32); ATOMA_T64(6, 32); ATOMA_T64(7, 32); ATOMA_T64(8, 32);
-#undef ATOMA_T64
+        ATOMA_T64(1); ATOMA_T64(2); ATOMA_T64(3); ATOMA_T64(4); ATOMA_T64(5); ATOMA_T64(6); ATOMA_T64(7); ATOMA_T64(8);
     }
+#undef ATOMA_T64
+#undef ATOMA_T64B
 }
 
 // ATOMA_GENERIC_PREFILL_TILE (A/B runs): unset = the tiled kernels; "16" = only the 16-row one; anything else = the row-per-wavefront kernel
