@@ -656,6 +656,204 @@ static void launch_prefill_tile64(const AttnParams &p, hipStream_t stream) {
 #undef ATOMA_T64B
 }
 
+// ------------------------------------------------------------------------------------------
+// attn_decode_anyd_kernel, second version (round 5): same decomposition -- one wavefront per (sequence, kv head, chunk of NQ q heads), a row's 16-byte chunks
+// on CP adjacent lanes, 16-token tiles -- with what the counters of the prefill kernel above taught:
+//  * a 16-token tile lies in ONE page (pages are multiples of 16 tokens: lib.rs:778-785), so its page number is wave-uniform: a scalar load, fetched two tiles
+//    ahead of the tile's K / V loads; the tile's base address is scalar, the lane's offset inside a tile is 32-bit (one 24-bit multiply for the tail clamp);
+//  * two register sets: tile t + 1's K / V loads are in flight while tile t is computed (NQ is a template parameter -- MHA, Phi-3's case, keeps one softmax
+//    state, not four -- so the second set still fits three wavefronts per SIMD at d = 96);
+//  * the q.k reduction over a row's lanes and the row maximum by DPP / lane swaps instead of LDS shuffles; P rounded by v_cvt_pk.
+// ------------------------------------------------------------------------------------------
+template <int CP> __device__ __forceinline__ float grow_sum(float x) {                         // all-reduce over the CP adjacent lanes of a row
+    if constexpr (CP >= 2) x += __builtin_amdgcn_update_dpp(0.f, x, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+    if constexpr (CP >= 4) x += __builtin_amdgcn_update_dpp(0.f, x, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+    if constexpr (CP >= 8) x += __builtin_amdgcn_update_dpp(0.f, x, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    if constexpr (CP >= 16) x += __builtin_amdgcn_update_dpp(0.f, x, 0x140, 0xf, 0xf, true);  // row_mirror
+    if constexpr (CP >= 32) {
+        typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+        const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return x;
+}
+template <int CP> __device__ __forceinline__ float gwave_max_over_rows(float x) {              // x is uniform over each row's CP lanes: max over the 64 / CP rows
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2;
+    if constexpr (CP <= 4) x = fmaxf(x, __builtin_amdgcn_update_dpp(-INFINITY, x, 0x141, 0xf, 0xf, false));
+    if constexpr (CP <= 8) x = fmaxf(x, __builtin_amdgcn_update_dpp(-INFINITY, x, 0x140, 0xf, 0xf, false));
+    if constexpr (CP <= 16) {
+        const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+        x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <typename T, int CP, int NQ>
+__global__ void __launch_bounds__(64) attn_decode_anyd2_kernel(const AttnParams p, const int gchunks) {
+    constexpr int R = 64 / CP, NP = 16 / R;    // rows per load instruction, load instructions per 16-token tile
+    constexpr bool DB = CP <= 16;              // two register sets up to head size 128; one above (measured: a second set of 64 registers does not pay there)
+    const int lane = threadIdx.x, r = lane / CP, c = lane % CP;
+    const int g = p.h / p.h_k;
+    // workgroup -> unit: consecutive units (the kv heads of one token row share 128-byte lines when a head's row is not a multiple of 128 bytes) on ONE XCD
+    const int N = gridDim.x, full = (N >> 3) << 3;
+    int w = blockIdx.x;
+    if (w < full) w = (w & 7) * (N >> 3) + (w >> 3);
+    const int gc = w % gchunks, hk = (w / gchunks) % p.h_k, b = w / (gchunks * p.h_k);
+    const int hq0 = hk * g + gc * NQ, nq = min(NQ, g - gc * NQ);
+    const SeqInfo si(p, b);
+    const int L = si.len_k, C = p.d >> 3;
+    const bool act = c < C;
+    uint4 qv[NQ];
+    float m[NQ], l[NQ], o[NQ][8], slope[NQ];
+#pragma unroll
+    for (int gq = 0; gq < NQ; ++gq) {
+        qv[gq] = make_uint4(0, 0, 0, 0);
+        if (act && gq < nq) qv[gq] = *reinterpret_cast<const uint4 *>(p.q + (int64_t)b * p.q_batch_stride + (int64_t)(hq0 + gq) * p.q_head_stride + c * 8);
+        m[gq] = -INFINITY;
+        l[gq] = 0.f;
+        slope[gq] = (p.alibi_slopes && gq < nq) ? p.alibi_slopes[b * p.alibi_batch_stride + hq0 + gq] * 1.4426950408889634f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[gq][e] = 0.f;
+    }
+    const bool paged = p.block_table != nullptr;
+    const int *bt = paged ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
+    const int pshift = (paged && (p.page_size & (p.page_size - 1)) == 0) ? __builtin_ctz(p.page_size) : -1;
+    const uint32_t krs = (uint32_t)p.k_row_stride, vrs = (uint32_t)p.v_row_stride;
+    const uint16_t *kg = p.k + (paged ? 0 : si.k_offset(p.k_batch_stride, p.k_row_stride, b)) + (int64_t)hk * p.k_head_stride;
+    const uint16_t *vg = p.v + (paged ? 0 : si.k_offset(p.v_batch_stride, p.v_row_stride, b)) + (int64_t)hk * p.v_head_stride;
+    auto page_of = [&](int t0) -> int {                          // wave-uniform: the page of tile t0 (tiles behind the sequence: its last page)
+        if (!paged) return 0;
+        const int t = min(t0, L - 1);
+        return __builtin_amdgcn_readfirstlane(bt[pshift >= 0 ? t >> pshift : t / p.page_size]);
+    };
+    uint4 kk[DB ? 2 : 1][NP], vv[DB ? 2 : 1][NP];
+    auto load_tile = [&](auto sel, int t0, int pg) {
+        constexpr int SG = decltype(sel)::value;
+        const uint16_t *kb, *vb;                                  // scalar: the tile's first row
+        if (paged) {
+            const uint32_t r0 = pshift >= 0 ? (uint32_t)t0 & ((uint32_t)p.page_size - 1u) : (uint32_t)(t0 % p.page_size);
+            kb = kg + (int64_t)pg * p.k_batch_stride + (uint64_t)r0 * krs;
+            vb = vg + (int64_t)pg * p.v_batch_stride + (uint64_t)r0 * vrs;
+        } else {
+            kb = kg + (uint64_t)(uint32_t)t0 * krs;
+            vb = vg + (uint64_t)(uint32_t)t0 * vrs;
+        }
+        const uint32_t last = (uint32_t)(L - 1 - t0);            // rows behind the sequence re-read its last row (never-written slots may hold anything) and get p = 0
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {
+            const uint32_t row = min((uint32_t)(pi * R + r), last);
+            kk[SG][pi] = make_uint4(0, 0, 0, 0);
+            vv[SG][pi] = make_uint4(0, 0, 0, 0);
+            if (act) {
+                kk[SG][pi] = *reinterpret_cast<const uint4 *>(kb + (__umul24(row, krs) + (uint32_t)c * 8u));
+                vv[SG][pi] = *reinterpret_cast<const uint4 *>(vb + (__umul24(row, vrs) + (uint32_t)c * 8u));
+            }
+        }
+    };
+    auto compute_tile = [&](auto sel, int t0) {
+        constexpr int SG = decltype(sel)::value;
+        constexpr int NPP = (NP + 1) / 2;
+        uint32_t pk[NQ][NPP];                                     // the tile's probabilities, rounded to the storage type (softmax.h:65-185), two per register
+#pragma unroll
+        for (int gq = 0; gq < NQ; ++gq) {
+#pragma unroll
+            for (int i = 0; i < NPP; ++i) pk[gq][i] = 0;
+            if (gq >= nq) continue;                              // wave-uniform
+            float sc[NP], mx = -INFINITY;
+#pragma unroll
+            for (int pi = 0; pi < NP; ++pi) {
+                float acc = dot2<T>(kk[SG][pi].x, qv[gq].x, 0.f);
+                acc = dot2<T>(kk[SG][pi].y, qv[gq].y, acc);
+                acc = dot2<T>(kk[SG][pi].z, qv[gq].z, acc);
+                acc = dot2<T>(kk[SG][pi].w, qv[gq].w, acc);
+                acc = grow_sum<CP>(acc);
+                const int tok = t0 + pi * R + r;
+                sc[pi] = tok < L ? acc * p.scale_log2 - slope[gq] * (float)(L - 1 - tok) : -INFINITY;   // ALiBi: mask.h:179-186 with one query row at position L - 1
+                mx = fmaxf(mx, sc[pi]);
+            }
+            mx = gwave_max_over_rows<CP>(mx);
+            const float m_new = fmaxf(m[gq], mx);
+            const float ms = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m[gq] - ms);
+            m[gq] = m_new;
+            l[gq] *= alpha;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[gq][e] *= alpha;
+#pragma unroll
+            for (int pi = 0; pi < NP; pi += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(sc[pi] - ms);                       // exp2(-inf) = 0 for the rows behind the sequence
+                const float p1 = pi + 1 < NP ? __builtin_amdgcn_exp2f(sc[pi + 1 < NP ? pi + 1 : pi] - ms) : 0.f;
+                l[gq] += p0 + p1;
+                pk[gq][pi / 2] = gpack<T>(p0, p1);
+            }
+        }
+#pragma unroll
+        for (int pi = 0; pi < NP; ++pi) {                        // V unpacked once per load instruction, used by every q head of the chunk
+            const float v0 = lo_to_f32<T>(vv[SG][pi].x), v1 = hi_to_f32<T>(vv[SG][pi].x), v2 = lo_to_f32<T>(vv[SG][pi].y), v3 = hi_to_f32<T>(vv[SG][pi].y);
+            const float v4 = lo_to_f32<T>(vv[SG][pi].z), v5 = hi_to_f32<T>(vv[SG][pi].z), v6 = lo_to_f32<T>(vv[SG][pi].w), v7 = hi_to_f32<T>(vv[SG][pi].w);
+#pragma unroll
+            for (int gq = 0; gq < NQ; ++gq) {
+                const float pr = (pi & 1) ? hi_to_f32<T>(pk[gq][pi / 2]) : lo_to_f32<T>(pk[gq][pi / 2]);
+                o[gq][0] += pr * v0; o[gq][1] += pr * v1; o[gq][2] += pr * v2; o[gq][3] += pr * v3;
+                o[gq][4] += pr * v4; o[gq][5] += pr * v5; o[gq][6] += pr * v6; o[gq][7] += pr * v7;
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> SetA;
+    typedef std::integral_constant<int, DB ? 1 : 0> SetB;
+    if (L > 0) {
+        int pg_cur = page_of(0), pg_nxt = page_of(16);
+        if (DB) {
+            load_tile(SetA(), 0, pg_cur);
+            pg_cur = pg_nxt; pg_nxt = page_of(32);
+            for (int t0 = 0; t0 < L; t0 += 32) {
+                if (t0 + 16 < L) { load_tile(SetB(), t0 + 16, pg_cur); pg_cur = pg_nxt; pg_nxt = page_of(t0 + 48); }
+                compute_tile(SetA(), t0);
+                if (t0 + 16 < L) {
+                    if (t0 + 32 < L) { load_tile(SetA(), t0 + 32, pg_cur); pg_cur = pg_nxt; pg_nxt = page_of(t0 + 64); }
+                    compute_tile(SetB(), t0 + 16);
+                }
+            }
+        } else {
+            for (int t0 = 0; t0 < L; t0 += 16) {
+                load_tile(SetA(), t0, pg_cur);
+                pg_cur = pg_nxt; pg_nxt = page_of(t0 + 32);
+                compute_tile(SetA(), t0);
+            }
+        }
+    }
+#pragma unroll
+    for (int gq = 0; gq < NQ; ++gq) {
+        if (gq >= nq) continue;
+        float lt = l[gq];
+#pragma unroll
+        for (int off = CP; off < 64; off <<= 1) {
+            lt += __shfl_xor(lt, off, 64);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[gq][e] += __shfl_xor(o[gq][e], off, 64);
+        }
+        const bool empty = !(lt > 0.f);                          // no key: O = 0, LSE = +inf (flash_fwd_kernel.h:97-133)
+        const float inv = empty ? 0.f : 1.f / lt;
+        if (act && r == 0) {
+            uint4 w;
+            w.x = gpack<T>(o[gq][0] * inv, o[gq][1] * inv); w.y = gpack<T>(o[gq][2] * inv, o[gq][3] * inv);
+            w.z = gpack<T>(o[gq][4] * inv, o[gq][5] * inv); w.w = gpack<T>(o[gq][6] * inv, o[gq][7] * inv);
+            *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)(hq0 + gq) * p.o_head_stride + c * 8) = w;
+        }
+        if (p.lse && lane == 0) p.lse[(int64_t)b * p.h + hq0 + gq] = empty ? INFINITY : (m[gq] + __builtin_amdgcn_logf(lt)) * 0.6931471805599453f;
+    }
+}
+
+template <typename T, int CP>
+static void launch_decode_anyd2(const AttnParams &p, hipStream_t stream) {
+    const int g = p.h / p.h_k, nq = g == 1 ? 1 : (g == 2 ? 2 : 4), gchunks = (g + nq - 1) / nq;
+    const dim3 grid((unsigned)((int64_t)p.b * p.h_k * gchunks));
+    if (nq == 1) hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, 1>), grid, dim3(64), 0, stream, p, gchunks);
+    else if (nq == 2) hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, 2>), grid, dim3(64), 0, stream, p, gchunks);
+    else hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, 4>), grid, dim3(64), 0, stream, p, gchunks);
+}
+
 // ATOMA_GENERIC_PREFILL_TILE (A/B runs): unset = the tiled kernels; "16" = only the 16-row one; anything else = the row-per-wavefront kernel
 static int attn_prefill_tile_choice() {
     const char *e = getenv("ATOMA_GENERIC_PREFILL_TILE");
@@ -675,13 +873,22 @@ static bool attn_decode_anyd_applicable(const AttnParams &p) {
                             p.o_batch_stride | p.k_batch_stride | p.v_batch_stride;
     return p.seqlen_q == 1 && p.cu_seqlens_q == nullptr && p.d >= 8 && p.d <= 256 && p.d % 8 == 0 && p.h % p.h_k == 0 && strides % 8 == 0 &&
            ((reinterpret_cast<uintptr_t>(p.q) | reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.o)) & 15u) == 0 &&
-           getenv("ATOMA_GENERIC_DECODE_STREAM") == nullptr;     // (set to anything: the row-per-lane kernel, for A/B runs)
+           (getenv("ATOMA_GENERIC_DECODE_STREAM") == nullptr || strcmp(getenv("ATOMA_GENERIC_DECODE_STREAM"), "1") == 0);   // (any other value: the row-per-lane kernel, for A/B runs)
 }
 
 void launch_attn_generic(const AttnParams &p, bool is_bf16, hipStream_t stream) {
     if (p.b <= 0 || p.h <= 0 || p.seqlen_q <= 0) return;
     if (attn_decode_anyd_applicable(p)) {
-        const int g = p.h / p.h_k, gchunks = (g + 3) / 4, C = p.d / 8;
+        const int C = p.d / 8;
+        const char *which = getenv("ATOMA_GENERIC_DECODE_STREAM");   // unset: the second version; "1": the first (A/B runs); anything else: see attn_decode_anyd_applicable
+        if (which == nullptr) {
+#define ATOMA_ANYD2(CP_) do { if (is_bf16) launch_decode_anyd2<bf16_t, CP_>(p, stream); else launch_decode_anyd2<f16_t, CP_>(p, stream); } while (0)
+            if (C <= 4) ATOMA_ANYD2(4); else if (C <= 8) ATOMA_ANYD2(8); else if (C <= 16) ATOMA_ANYD2(16); else ATOMA_ANYD2(32);
+#undef ATOMA_ANYD2
+            ATOMA_CHECK_LAUNCH("attn_decode_anyd2_kernel");
+            return;
+        }
+        const int g = p.h / p.h_k, gchunks = (g + 3) / 4;
         const dim3 grid((unsigned)((int64_t)p.b * p.h_k * gchunks));
 #define ATOMA_ANYD(CP_) do { if (is_bf16) hipLaunchKernelGGL((attn_decode_anyd_kernel<bf16_t, CP_>), grid, dim3(64), 0, stream, p, gchunks); \
                              else hipLaunchKernelGGL((attn_decode_anyd_kernel<f16_t, CP_>), grid, dim3(64), 0, stream, p, gchunks); } while (0)

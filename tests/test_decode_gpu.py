@@ -594,8 +594,7 @@ def test_decode_other_head_sizes_streaming_kernel(gpu, d, dtype, monkeypatch):
     non-multiple of 16, groups of 1 / 3 / 5 q heads (one and two chunks), paged and contiguous caches, ALiBi, the LSE output; against the
     oracle, and against the coverage kernel on the same call (ATOMA_GENERIC_DECODE_STREAM switches back to it)."""
     rng = np.random.default_rng(1000 + d + dtype)
-    page = 16
-    for h, hk in ((4, 4), (6, 2), (5, 1)):
+    for h, hk, page in ((4, 4, 16), (6, 2, 16), (5, 1, 16), (4, 2, 32), (4, 4, 48)):      # groups of 1 / 3 / 5 / 2 q heads; pages of 16, 32 and 48 tokens
         lens = np.array([0, 1, 15, 16, 17, 100, 333, 77], np.int32)
         nb = int(sum((x + page - 1) // page for x in lens)) + 3
         kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
@@ -607,13 +606,14 @@ def test_decode_other_head_sizes_streaming_kernel(gpu, d, dtype, monkeypatch):
             for i, L in enumerate(lens):
                 assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} h={h}/{hk} alibi={alibi is not None} seq {i} (L={L})")
             assert not out[0].any() and np.isinf(lse[0]).all()
-            monkeypatch.setenv("ATOMA_GENERIC_DECODE_STREAM", "0")      # the row-per-lane coverage kernel on the same call
-            old, lse_old = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)
-            monkeypatch.delenv("ATOMA_GENERIC_DECODE_STREAM")
-            for i, L in enumerate(lens):
-                assert_close(out[i], old[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} vs the coverage kernel, seq {i}")
-            live = lens > 0
-            assert np.allclose(lse[live], lse_old[live], rtol=1e-4, atol=1e-4)
+            for other in ("1", "0"):      # the first streaming kernel; the row-per-lane coverage kernel -- on the same call
+                monkeypatch.setenv("ATOMA_GENERIC_DECODE_STREAM", other)
+                old, lse_old = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)
+                monkeypatch.delenv("ATOMA_GENERIC_DECODE_STREAM")
+                for i, L in enumerate(lens):
+                    assert_close(out[i], old[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} vs kernel {other}, seq {i}")
+                live = lens > 0
+                assert np.allclose(lse[live], lse_old[live], rtol=1e-4, atol=1e-4)
         # contiguous cache [B, S, hk, d] with per-sequence lengths
         S = 64
         kd, vd = rand_half(rng, (4, S, hk, d), dtype), rand_half(rng, (4, S, hk, d), dtype)
