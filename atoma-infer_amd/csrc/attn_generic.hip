@@ -428,7 +428,7 @@ template <> __device__ __forceinline__ gf32x4 gmfma32<f16_t>(const gu32x4 &a, co
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8, a), __builtin_bit_cast(v8, b), c, 0, 0, 0);
 }
 
-template <typename T, int NC, int KT, int ST>
+template <typename T, int NC, int KT, int ST, int RQ>   // RQ 16-row blocks per wavefront: a workgroup covers 64 RQ query rows
 __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnParams p, const int mblocks) {
     constexpr int D = 32 * NC, KRB = 2 * D + 16, VRB = 2 * D + 32, KG = KT / 32, CPR = D / 8;
     constexpr int PIECES = KT * CPR, NPC = (PIECES + 255) / 256;
@@ -441,23 +441,29 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     if (w < full) w = (w & 7) * (N >> 3) + (w >> 3);
     const int hq = w % p.h, mblk = mblocks - 1 - w / p.h, b = blockIdx.z;
     const SeqInfo si(p, b);
-    const int q0 = mblk * 64;
+    const int q0 = mblk * (64 * RQ);
     if (q0 >= si.len_q) return;
     const int hk = hq / (p.h / p.h_k);
     const int shift = si.len_k - si.len_q;                        // mask.h:170
-    const int wq0 = q0 + 16 * wave;
-    const int qrow = wq0 + col;
-    const bool qvalid = qrow < si.len_q;
-    const int qr = min(qrow, si.len_q - 1);
-    const int hi_q = max(0, p.is_causal ? min(si.len_k, qr + shift + 1) : si.len_k);
-    const int hi_wave = wq0 < si.len_q ? max(0, p.is_causal ? min(si.len_k, min(wq0 + 15, si.len_q - 1) + shift + 1) : si.len_k) : 0;
-    const int hi_wg = max(0, p.is_causal ? min(si.len_k, min(q0 + 63, si.len_q - 1) + shift + 1) : si.len_k);
-    const int hi_first = p.is_causal ? min(si.len_k, wq0 + shift + 1) : si.len_k;      // keys EVERY row of this wavefront sees
-    gu32x4 qreg[NC];
-    {
-        const uint16_t *qptr = p.q + si.q_offset(p.q_batch_stride, p.q_row_stride, b) + (int64_t)qr * p.q_row_stride + (int64_t)hq * p.q_head_stride + 8 * grp;
+    const int wq0 = q0 + 16 * RQ * wave;                          // this wavefront's rows: RQ blocks of 16, block s at wq0 + 16 s
+    int qrow[RQ], qr[RQ], hi_q[RQ], hi_first[RQ];
+    bool qvalid[RQ];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) qreg[c] = *reinterpret_cast<const gu32x4 *>(qptr + 32 * c);
+    for (int s = 0; s < RQ; ++s) {
+        qrow[s] = wq0 + 16 * s + col;
+        qvalid[s] = qrow[s] < si.len_q;
+        qr[s] = min(qrow[s], si.len_q - 1);
+        hi_q[s] = max(0, p.is_causal ? min(si.len_k, qr[s] + shift + 1) : si.len_k);
+        hi_first[s] = p.is_causal ? min(si.len_k, wq0 + 16 * s + shift + 1) : si.len_k;   // keys EVERY row of block s sees
+    }
+    const int hi_wave = wq0 < si.len_q ? max(0, p.is_causal ? min(si.len_k, min(wq0 + 16 * RQ - 1, si.len_q - 1) + shift + 1) : si.len_k) : 0;
+    const int hi_wg = max(0, p.is_causal ? min(si.len_k, min(q0 + 64 * RQ - 1, si.len_q - 1) + shift + 1) : si.len_k);
+    gu32x4 qreg[RQ][NC];
+#pragma unroll
+    for (int s = 0; s < RQ; ++s) {
+        const uint16_t *qptr = p.q + si.q_offset(p.q_batch_stride, p.q_row_stride, b) + (int64_t)qr[s] * p.q_row_stride + (int64_t)hq * p.q_head_stride + 8 * grp;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qreg[s][c] = *reinterpret_cast<const gu32x4 *>(qptr + 32 * c);
     }
     const bool paged = p.block_table != nullptr;
     const int *bt = paged ? p.block_table + (int64_t)b * p.block_table_batch_stride : nullptr;
@@ -517,30 +523,39 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
             }
         }
     };
-    gf32x4 o[2 * NC];
+    gf32x4 o[RQ][2 * NC];
+    float m_run[RQ], l[RQ];
 #pragma unroll
-    for (int c = 0; c < 2 * NC; ++c) o[c] = gf32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l = 0.f;
+    for (int s = 0; s < RQ; ++s) {
+        m_run[s] = -INFINITY;
+        l[s] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2 * NC; ++c) o[s][c] = gf32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const uint32_t k_rd = k_lds + col * KRB + grp * 16;                                  // + (32 g + 16 h) rows + 64 c
     const uint32_t v_rd = v_lds + (4 * grp + (col >> 2)) * VRB + (col & 3) * 8;          // + (32 g + 16 h) rows + 32 dc
     auto compute_tile = [&](int j0) {
-        {
-            gf32x4 sacc[KG][2];
+        // ---- S^T = K . Q^T: one K operand read feeds the RQ row blocks
+        gf32x4 sacc[RQ][KG][2];
 #pragma unroll
-            for (int g = 0; g < KG; ++g)
+        for (int g = 0; g < KG; ++g)
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    gf32x4 acc = gf32x4{0.f, 0.f, 0.f, 0.f};
+            for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const gu32x4 a = *(const __attribute__((address_space(3))) gu32x4 *)(uintptr_t)(k_rd + (32 * g + 16 * hh) * KRB + 64 * c);
-                        acc = gmfma32<T>(a, qreg[c], acc);
-                    }
-                    sacc[g][hh] = acc;
+                for (int s = 0; s < RQ; ++s) sacc[s][g][hh] = gf32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const gu32x4 a = *(const __attribute__((address_space(3))) gu32x4 *)(uintptr_t)(k_rd + (32 * g + 16 * hh) * KRB + 64 * c);
+#pragma unroll
+                    for (int s = 0; s < RQ; ++s) sacc[s][g][hh] = gmfma32<T>(a, qreg[s][c], sacc[s][g][hh]);
                 }
-            // scores stay raw: p = exp2(s * scale_log2 - m) is one fma + one exp; the mask / ALiBi pass only runs on tiles that reach past the first
-            // row's last key (the diagonal, the sequence's tail) or when slopes are given (softmax.h:65-185 in the exp2 domain; scale_log2 > 0)
-            const bool plain = !p.alibi_slopes && j0 + KT <= hi_first;
+            }
+        // ---- softmax per row block.  Scores stay raw: p = exp2(s * scale_log2 - m) is one fma + one exp; the mask / ALiBi pass only runs on tiles that reach
+        // past the block's first row's last key (the diagonal, the sequence's tail) or when slopes are given (softmax.h:65-185 in the exp2 domain; scale_log2 > 0)
+        gu32x4 pb[RQ][KG];
+#pragma unroll
+        for (int s = 0; s < RQ; ++s) {
+            const bool plain = !p.alibi_slopes && j0 + KT <= hi_first[s];
             float mx = -INFINITY;
             if (plain) {
 #pragma unroll
@@ -548,7 +563,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sacc[g][hh][i]);
+                        for (int i = 0; i < 4; ++i) mx = fmaxf(mx, sacc[s][g][hh][i]);
                 mx *= p.scale_log2;
             } else {
 #pragma unroll
@@ -558,20 +573,19 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int key = j0 + 32 * g + 16 * hh + 4 * grp + i;
-                            float x = sacc[g][hh][i];
-                            if (p.alibi_slopes) x -= slope_raw * fabsf((float)(qr + shift - key));   // mask.h:179-186, in units of 1 / scale_log2
-                            x = key < hi_q ? x : -INFINITY;
-                            sacc[g][hh][i] = x;
+                            float x = sacc[s][g][hh][i];
+                            if (p.alibi_slopes) x -= slope_raw * fabsf((float)(qr[s] + shift - key));   // mask.h:179-186, in units of 1 / scale_log2
+                            x = key < hi_q[s] ? x : -INFINITY;
+                            sacc[s][g][hh][i] = x;
                             mx = fmaxf(mx, x * p.scale_log2);
                         }
             }
             mx = gcol_max4(mx);
-            const float m_new = fmaxf(m_run, mx);
+            const float m_new = fmaxf(m_run[s], mx);
             const float ms = m_new == -INFINITY ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - ms);
-            m_run = m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[s] - ms);
+            m_run[s] = m_new;
             float psum = 0.f;
-            gu32x4 pb[KG];
 #pragma unroll
             for (int g = 0; g < KG; ++g) {
                 float pr[2][4];
@@ -579,29 +593,29 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
                 for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        pr[hh][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[g][hh][i], p.scale_log2, -ms));
+                        pr[hh][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[s][g][hh][i], p.scale_log2, -ms));
                         psum += pr[hh][i];
                     }
-                pb[g] = gu32x4{gpack<T>(pr[0][0], pr[0][1]), gpack<T>(pr[0][2], pr[0][3]), gpack<T>(pr[1][0], pr[1][1]), gpack<T>(pr[1][2], pr[1][3])};
+                pb[s][g] = gu32x4{gpack<T>(pr[0][0], pr[0][1]), gpack<T>(pr[0][2], pr[0][3]), gpack<T>(pr[1][0], pr[1][1]), gpack<T>(pr[1][2], pr[1][3])};
             }
-            l = l * alpha + psum;
+            l[s] = l[s] * alpha + psum;
             if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {  // (the running max settles after the first tiles of a row block)
 #pragma unroll
-                for (int dc = 0; dc < 2 * NC; ++dc) { o[dc][0] *= alpha; o[dc][1] *= alpha; o[dc][2] *= alpha; o[dc][3] *= alpha; }
-            }
-#pragma unroll
-            for (int dc = 0; dc < 2 * NC; ++dc) {
-                gf32x4 acc = o[dc];
-#pragma unroll
-                for (int g = 0; g < KG; ++g) {
-                    const uint32_t a0 = v_rd + (32 * g) * VRB + 32 * dc;
-                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gshort4 *)(uintptr_t)a0));
-                    const uint2 hi2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gshort4 *)(uintptr_t)(a0 + 16 * VRB)));
-                    acc = gmfma32<T>(gu32x4{lo.x, lo.y, hi2.x, hi2.y}, pb[g], acc);
-                }
-                o[dc] = acc;
+                for (int dc = 0; dc < 2 * NC; ++dc) { o[s][dc][0] *= alpha; o[s][dc][1] *= alpha; o[s][dc][2] *= alpha; o[s][dc][3] *= alpha; }
             }
         }
+        // ---- O^T += V^T . P^T: one V^T operand (two transposing reads) feeds the RQ row blocks
+#pragma unroll
+        for (int dc = 0; dc < 2 * NC; ++dc)
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const uint32_t a0 = v_rd + (32 * g) * VRB + 32 * dc;
+                const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gshort4 *)(uintptr_t)a0));
+                const uint2 hi2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gshort4 *)(uintptr_t)(a0 + 16 * VRB)));
+                const gu32x4 a = gu32x4{lo.x, lo.y, hi2.x, hi2.y};
+#pragma unroll
+                for (int s = 0; s < RQ; ++s) o[s][dc] = gmfma32<T>(a, pb[s][g], o[s][dc]);
+            }
     };
     typedef std::integral_constant<int, 0> Stage0;
     typedef std::integral_constant<int, ST - 1> Stage1;
@@ -619,40 +633,50 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
         step(Stage0(), j0);
         if (ST == 2 && j0 + KT < hi_wg) step(Stage1(), j0 + KT);
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const bool empty = !(l > 0.f);                                // no visible key: O = 0, LSE = +inf (flash_fwd_kernel.h:97-133)
-    const float inv = empty ? 0.f : 1.f / l;
-    if (qvalid) {
-        uint16_t *orow = p.o + si.q_offset(p.o_batch_stride, p.o_row_stride, b) + (int64_t)qrow * p.o_row_stride + (int64_t)hq * p.o_head_stride + 4 * grp;
 #pragma unroll
-        for (int dc = 0; dc < 2 * NC; ++dc) {
-            uint2 wv;
-            wv.x = gpack<T>(o[dc][0] * inv, o[dc][1] * inv);
-            wv.y = gpack<T>(o[dc][2] * inv, o[dc][3] * inv);
-            *reinterpret_cast<uint2 *>(orow + 16 * dc) = wv;
-        }
-        if (p.lse && grp == 0) {
-            const float lse = empty ? INFINITY : (m_run + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
-            if (p.unpadded_lse && p.cu_seqlens_q) p.lse[(int64_t)hq * p.cu_seqlens_q[p.b] + si.sum_q + qrow] = lse;
-            else p.lse[((int64_t)b * p.h + hq) * p.seqlen_q + qrow] = lse;
+    for (int s = 0; s < RQ; ++s) {
+        float lt = l[s];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const bool empty = !(lt > 0.f);                           // no visible key: O = 0, LSE = +inf (flash_fwd_kernel.h:97-133)
+        const float inv = empty ? 0.f : 1.f / lt;
+        if (qvalid[s]) {
+            uint16_t *orow = p.o + si.q_offset(p.o_batch_stride, p.o_row_stride, b) + (int64_t)qrow[s] * p.o_row_stride + (int64_t)hq * p.o_head_stride + 4 * grp;
+#pragma unroll
+            for (int dc = 0; dc < 2 * NC; ++dc) {
+                uint2 wv;
+                wv.x = gpack<T>(o[s][dc][0] * inv, o[s][dc][1] * inv);
+                wv.y = gpack<T>(o[s][dc][2] * inv, o[s][dc][3] * inv);
+                *reinterpret_cast<uint2 *>(orow + 16 * dc) = wv;
+            }
+            if (p.lse && grp == 0) {
+                const float lse = empty ? INFINITY : (m_run[s] + __builtin_amdgcn_logf(lt)) * 0.6931471805599453f;
+                if (p.unpadded_lse && p.cu_seqlens_q) p.lse[(int64_t)hq * p.cu_seqlens_q[p.b] + si.sum_q + qrow[s]] = lse;
+                else p.lse[((int64_t)b * p.h + hq) * p.seqlen_q + qrow[s]] = lse;
+            }
         }
     }
 }
 
 template <typename T>
 static void launch_prefill_tile64(const AttnParams &p, hipStream_t stream) {
-    const int mblocks = (p.seqlen_q + 63) / 64;
-    const dim3 grid((unsigned)(mblocks * p.h), 1, (unsigned)p.b);
     int kt = (p.d == 192 || p.d == 256) ? 32 : 64;               // measured per head size: profiles/r05_generic_prefill_cfg.json
     if (const char *e = getenv("ATOMA_GENERIC_PREFILL_KT")) kt = atoi(e) == 32 ? 32 : 64;   // A/B runs
+    // two 16-row blocks per wavefront (128-row workgroups: every K / V operand read from LDS feeds two MFMAs) up to head size 128, where the registers allow it
+    int rq = (p.d <= 128 && p.seqlen_q > 64) ? 2 : 1;
+    if (const char *e = getenv("ATOMA_GENERIC_PREFILL_RQ")) rq = (atoi(e) == 2 && p.d <= 128) ? 2 : 1;   // A/B runs
+    const int mblocks = (p.seqlen_q + 64 * rq - 1) / (64 * rq);
+    const dim3 grid((unsigned)(mblocks * p.h), 1, (unsigned)p.b);
     // (two register stages -- tile t + 2 requested while tile t is computed -- were measured and never won: ST stays 1)
-#define ATOMA_T64B(NC_, KT_) hipLaunchKernelGGL((attn_prefill_tile64_kernel<T, NC_, KT_, 1>), grid, dim3(256), 0, stream, p, mblocks)
-#define ATOMA_T64(NC_) case NC_: if (kt == 64) ATOMA_T64B(NC_, 64); else ATOMA_T64B(NC_, 32); break
+#define ATOMA_T64B(NC_, KT_, RQ_) hipLaunchKernelGGL((attn_prefill_tile64_kernel<T, NC_, KT_, 1, RQ_>), grid, dim3(256), 0, stream, p, mblocks)
+#define ATOMA_T64S(NC_) case NC_: if (rq == 2) { if (kt == 64) ATOMA_T64B(NC_, 64, 2); else ATOMA_T64B(NC_, 32, 2); } \
+                                  else { if (kt == 64) ATOMA_T64B(NC_, 64, 1); else ATOMA_T64B(NC_, 32, 1); } break
+#define ATOMA_T64(NC_) case NC_: if (kt == 64) ATOMA_T64B(NC_, 64, 1); else ATOMA_T64B(NC_, 32, 1); break
     switch (p.d / 32) {
-        ATOMA_T64(1); ATOMA_T64(2); ATOMA_T64(3); ATOMA_T64(4); ATOMA_T64(5); ATOMA_T64(6); ATOMA_T64(7); ATOMA_T64(8);
+        ATOMA_T64S(1); ATOMA_T64S(2); ATOMA_T64S(3); ATOMA_T64S(4); ATOMA_T64(5); ATOMA_T64(6); ATOMA_T64(7); ATOMA_T64(8);
     }
 #undef ATOMA_T64
+#undef ATOMA_T64S
 #undef ATOMA_T64B
 }
 

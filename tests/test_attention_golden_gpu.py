@@ -171,12 +171,13 @@ def test_other_head_sizes_tiled_prefill(gpu, d, dtype, monkeypatch):
                 ref = A.flash_attn_varlen(q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi_slopes=alibi, **okw)
                 what = f"d={d} causal={causal} alibi={alibi is not None} paged={paged}"
                 assert_close(out, ref, dtype, atol=ATOL_VS_F32[dtype], what=what + " (f32 oracle)")
-                for other in ("16", "0"):      # the 16-row kernel alone; the row-per-wavefront kernel
-                    monkeypatch.setenv("ATOMA_GENERIC_PREFILL_TILE", other)
+                for other in ("rq1", "16", "0"):      # 64-row workgroups (one row block per wavefront); the 16-row kernel alone; the row-per-wavefront kernel
+                    var, val = ("ATOMA_GENERIC_PREFILL_RQ", "1") if other == "rq1" else ("ATOMA_GENERIC_PREFILL_TILE", other)
+                    monkeypatch.setenv(var, val)
                     out_o, lse_o = gpu_varlen(gpu, q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi=alibi, **kw)
-                    monkeypatch.delenv("ATOMA_GENERIC_PREFILL_TILE")
-                    if other == "16":
-                        assert_close(out_o, ref, dtype, atol=ATOL_VS_F32[dtype], what=what + " (16-row kernel, f32 oracle)")
+                    monkeypatch.delenv(var)
+                    if other != "0":
+                        assert_close(out_o, ref, dtype, atol=ATOL_VS_F32[dtype], what=what + f" (kernel {other}, f32 oracle)")
                     assert_close(out, out_o, dtype, atol=ATOL_VS_F32[dtype], what=what + f" (kernel {other})")
                     assert np.array_equal(np.isinf(lse), np.isinf(lse_o)), what
                     fin = np.isfinite(lse_o)

@@ -12,14 +12,18 @@ BE.ah.set_device(0)
 res = {}
 for d in (32, 96, 160, 192, 256):
     e = {}
-    for name, env in (("tile64", None), ("tile16", "16"), ("row_per_wavefront", "0")):
-        if env is None:
-            os.environ.pop("ATOMA_GENERIC_PREFILL_TILE", None)
-        else:
-            os.environ["ATOMA_GENERIC_PREFILL_TILE"] = env
-        r = BE.prefill(iters=3, S=2048, nseq=4, d=d)
+    for name, env, rq in (("tile64", None, None), ("tile64_one_row_block_per_wavefront", None, "1"), ("tile16", "16", None), ("row_per_wavefront", "0", None)):
+        if name.startswith("tile64_one") and d > 128:
+            continue                    # (above head size 128 the default already is one block per wavefront)
+        for var, val in (("ATOMA_GENERIC_PREFILL_TILE", env), ("ATOMA_GENERIC_PREFILL_RQ", rq)):
+            if val is None:
+                os.environ.pop(var, None)
+            else:
+                os.environ[var] = val
+        r = BE.prefill(iters=3 if env else 10, S=2048, nseq=4, d=d)
         e[name] = {"ms": r["ms"], "TFLOPs": r["TFLOPs"]}
     os.environ.pop("ATOMA_GENERIC_PREFILL_TILE", None)
+    os.environ.pop("ATOMA_GENERIC_PREFILL_RQ", None)
     e["speedup_over_row"] = round(e["row_per_wavefront"]["ms"] / e["tile64"]["ms"], 2)
     res["d=%d" % d] = e
 print(json.dumps(res, indent=1))
