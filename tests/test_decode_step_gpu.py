@@ -28,11 +28,15 @@ def close_linear(got, ref, what):
     assert (np.abs(g - r) <= 2.0 ** -7 * np.abs(r) + 3e-5).all(), what
 
 
+@pytest.mark.parametrize("family", ["llama", "llama-1b-heads", "phi3-heads"])
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
-def test_llama_decode_step_op_by_op(gpu, graph):
+def test_llama_decode_step_op_by_op(gpu, graph, family):
+    """One decode step, every intermediate against the oracle.  The layer is the one the reference's three model files share (llama.rs, mistral.rs:
+    head size 128; phi3.rs: the same block with fused qkv / gate_up weights -- the layout this step uses anyway -- and 32 MHA heads of size 96)."""
     import decode_step as DS
     rng = np.random.default_rng(11)
-    cfg = DS.Config(layers=2, hidden=512, heads=4, kv_heads=2, head_dim=128, intermediate=1024, vocab=1008, page=16, max_pos=256)
+    heads, kv_heads, head_dim = {"llama": (4, 2, 128), "llama-1b-heads": (8, 2, 64), "phi3-heads": (4, 4, 96)}[family]
+    cfg = DS.Config(layers=2, hidden=512, heads=heads, kv_heads=kv_heads, head_dim=head_dim, intermediate=1024, vocab=1008, page=16, max_pos=256)
     B = 5
     ctx = np.array([0, 17, 40, 64, 100])                    # tokens already in the cache; the step adds one per sequence
     lens = (ctx + 1).astype(np.int32)
