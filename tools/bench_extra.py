@@ -53,9 +53,12 @@ def _timed(stream, fn, iters, warm=2):
     return a.elapsed_ms(b) / iters
 
 
-def c3_decode_step(iters=10, batch=256, seed=9, kv_fp8=False, weights=None):
+PHI_3_MINI = DS.Config(32, 3072, 32, 32, 96, 8192, 32064)      # models/src/phi3.rs: 32 MHA heads of size 96, fused qkv / gate_up weights
+
+
+def c3_decode_step(iters=10, batch=256, seed=9, kv_fp8=False, weights=None, cfg=None, name="Llama-3.1-8B decode step (BASELINE configs[2] mid-trace)"):
     rng = np.random.default_rng(seed)
-    c = DS.LLAMA_3_1_8B
+    c = cfg or DS.LLAMA_3_1_8B
     w = weights or TS.random_shard_weights(rng, c)
     st = ah.Stream()
     S = 2560
@@ -72,7 +75,7 @@ def c3_decode_step(iters=10, batch=256, seed=9, kv_fp8=False, weights=None):
     ms = _timed(st, g.launch, iters)
     weight_bytes = 2 * (c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden)) + 2 * batch * c.hidden
     nbytes = weight_bytes + 2 * int((ctx + 1).sum()) * c.hk * c.d * (1 if kv_fp8 else 2) * c.layers
-    out = {"workload": f"Llama-3.1-8B decode step (BASELINE configs[2] mid-trace), batch {batch}, contexts U[2048,2560), block {c.page}, bf16 weights and activations, "
+    out = {"workload": f"{name}, batch {batch}, contexts U[2048,2560), block {c.page}, bf16 weights and activations, "
                        + ("fp8 e4m3fn KV cache" if kv_fp8 else "bf16 KV cache") + ", hipGraph replay",
            "ms_per_step": round(ms, 3), "decode_tokens_per_s_per_gpu": round(batch / (ms * 1e-3), 1), "algorithmic_bytes": int(nbytes),
            "roofline_tokens_per_s": round(batch / (nbytes / HBM_PEAK), 1), "frac_of_hbm_roofline": round(nbytes / HBM_PEAK / (ms * 1e-3), 4)}
@@ -80,6 +83,12 @@ def c3_decode_step(iters=10, batch=256, seed=9, kv_fp8=False, weights=None):
     if weights is None:
         del w
     return out
+
+
+def c5_phi3_mini_decode_step(iters=10):
+    """The same step with the reference's third model family (models/src/phi3.rs): Phi-3-mini shapes -- head size 96 runs on attn_generic.hip's streaming
+    decode kernel, not on the tuned head-size-128 kernel; batch 64 (MHA: 384 KiB of KV per token)."""
+    return c3_decode_step(iters=iters, batch=64, cfg=PHI_3_MINI, name="Phi-3-mini-shaped decode step (32 layers, hidden 3072, 32 MHA heads of 96)")
 
 
 def c3_decode_step_fp8_kv(iters=10):
