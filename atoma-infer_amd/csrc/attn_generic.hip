@@ -713,11 +713,11 @@ template <int CP> __device__ __forceinline__ float gwave_max_over_rows(float x) 
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <typename T, int CP, int NQ>
-__global__ void __launch_bounds__(64) attn_decode_anyd2_kernel(const AttnParams p, const int gchunks) {
+template <typename T, int CP, int NQ, int NW>                    // NW wavefronts share one unit's tiles (batches that do not fill the chip) and merge in LDS
+__global__ void __launch_bounds__(64 * NW) attn_decode_anyd2_kernel(const AttnParams p, const int gchunks) {
     constexpr int R = 64 / CP, NP = 16 / R;    // rows per load instruction, load instructions per 16-token tile
     constexpr bool DB = CP <= 16;              // two register sets up to head size 128; one above (measured: a second set of 64 registers does not pay there)
-    const int lane = threadIdx.x, r = lane / CP, c = lane % CP;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane / CP, c = lane % CP;
     const int g = p.h / p.h_k;
     // workgroup -> unit: consecutive units (the kv heads of one token row share 128-byte lines when a head's row is not a multiple of 128 bytes) on ONE XCD
     const int N = gridDim.x, full = (N >> 3) << 3;
@@ -826,27 +826,33 @@ __global__ void __launch_bounds__(64) attn_decode_anyd2_kernel(const AttnParams 
     };
     typedef std::integral_constant<int, 0> SetA;
     typedef std::integral_constant<int, DB ? 1 : 0> SetB;
-    if (L > 0) {
-        int pg_cur = page_of(0), pg_nxt = page_of(16);
+    // this wavefront's tiles, in load order: DB -- pairs of neighbouring tiles, a pair every 32 NW tokens; else every NW-th tile.  The page of load k + 2 is
+    // requested when load k is issued (pg_cur: the page of the next load, pg_nxt: of the one after)
+    auto tile_at = [&](int kq) { return DB ? 32 * wv + 32 * NW * (kq >> 1) + 16 * (kq & 1) : 16 * (wv + NW * kq); };
+    if (tile_at(0) < L) {
+        int pg_cur = page_of(tile_at(0)), pg_nxt = page_of(tile_at(1));
         if (DB) {
-            load_tile(SetA(), 0, pg_cur);
-            pg_cur = pg_nxt; pg_nxt = page_of(32);
-            for (int t0 = 0; t0 < L; t0 += 32) {
-                if (t0 + 16 < L) { load_tile(SetB(), t0 + 16, pg_cur); pg_cur = pg_nxt; pg_nxt = page_of(t0 + 48); }
+            load_tile(SetA(), tile_at(0), pg_cur);
+            pg_cur = pg_nxt; pg_nxt = page_of(tile_at(2));
+            for (int kq = 0; tile_at(kq) < L; kq += 2) {
+                const int t0 = tile_at(kq);
+                if (t0 + 16 < L) { load_tile(SetB(), t0 + 16, pg_cur); pg_cur = pg_nxt; pg_nxt = page_of(tile_at(kq + 3)); }
                 compute_tile(SetA(), t0);
                 if (t0 + 16 < L) {
-                    if (t0 + 32 < L) { load_tile(SetA(), t0 + 32, pg_cur); pg_cur = pg_nxt; pg_nxt = page_of(t0 + 64); }
+                    const int tn = tile_at(kq + 2);
+                    if (tn < L) { load_tile(SetA(), tn, pg_cur); pg_cur = pg_nxt; pg_nxt = page_of(tile_at(kq + 4)); }
                     compute_tile(SetB(), t0 + 16);
                 }
             }
         } else {
-            for (int t0 = 0; t0 < L; t0 += 16) {
-                load_tile(SetA(), t0, pg_cur);
-                pg_cur = pg_nxt; pg_nxt = page_of(t0 + 32);
-                compute_tile(SetA(), t0);
+            for (int kq = 0; tile_at(kq) < L; ++kq) {
+                load_tile(SetA(), tile_at(kq), pg_cur);
+                pg_cur = pg_nxt; pg_nxt = page_of(tile_at(kq + 2));
+                compute_tile(SetA(), tile_at(kq));
             }
         }
     }
+    __shared__ float s_part[NW > 1 ? NW - 1 : 1][NQ][CP][10];     // the other wavefronts' pieces: running max, row sum, 8 output elements per chunk lane
 #pragma unroll
     for (int gq = 0; gq < NQ; ++gq) {
         if (gq >= nq) continue;
@@ -857,25 +863,64 @@ __global__ void __launch_bounds__(64) attn_decode_anyd2_kernel(const AttnParams 
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[gq][e] += __shfl_xor(o[gq][e], off, 64);
         }
+        float mt = m[gq];
+        if (NW > 1) {                                            // pieces merged in wavefront order by wavefront 0 (LSE-weighted: flash_fwd_kernel.h:1204-1236 in the exp2 domain)
+            if (wv > 0 && r == 0) {
+                float *dst = s_part[wv - 1][gq][c];
+                dst[0] = mt; dst[1] = lt;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[2 + e] = o[gq][e];
+            }
+            __syncthreads();
+            if (wv == 0) {
+                float mm = mt;
+#pragma unroll
+                for (int w2 = 0; w2 < NW - 1; ++w2) mm = fmaxf(mm, s_part[w2][gq][c][0]);
+                const float ms = mm == -INFINITY ? 0.f : mm;
+                const float f0 = __builtin_amdgcn_exp2f(mt - ms);
+                lt *= f0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[gq][e] *= f0;
+#pragma unroll
+                for (int w2 = 0; w2 < NW - 1; ++w2) {
+                    const float *src = s_part[w2][gq][c];
+                    const float fw = __builtin_amdgcn_exp2f(src[0] - ms);
+                    lt += fw * src[1];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[gq][e] += fw * src[2 + e];
+                }
+                mt = mm;
+            }
+            __syncthreads();                                     // (s_part is reused by the next q head)
+        }
         const bool empty = !(lt > 0.f);                          // no key: O = 0, LSE = +inf (flash_fwd_kernel.h:97-133)
         const float inv = empty ? 0.f : 1.f / lt;
-        if (act && r == 0) {
+        if (act && r == 0 && wv == 0) {
             uint4 w;
             w.x = gpack<T>(o[gq][0] * inv, o[gq][1] * inv); w.y = gpack<T>(o[gq][2] * inv, o[gq][3] * inv);
             w.z = gpack<T>(o[gq][4] * inv, o[gq][5] * inv); w.w = gpack<T>(o[gq][6] * inv, o[gq][7] * inv);
             *reinterpret_cast<uint4 *>(p.o + (int64_t)b * p.o_batch_stride + (int64_t)(hq0 + gq) * p.o_head_stride + c * 8) = w;
         }
-        if (p.lse && lane == 0) p.lse[(int64_t)b * p.h + hq0 + gq] = empty ? INFINITY : (m[gq] + __builtin_amdgcn_logf(lt)) * 0.6931471805599453f;
+        if (p.lse && threadIdx.x == 0) p.lse[(int64_t)b * p.h + hq0 + gq] = empty ? INFINITY : (mt + __builtin_amdgcn_logf(lt)) * 0.6931471805599453f;
     }
 }
 
 template <typename T, int CP>
 static void launch_decode_anyd2(const AttnParams &p, hipStream_t stream) {
     const int g = p.h / p.h_k, nq = g == 1 ? 1 : (g == 2 ? 2 : 4), gchunks = (g + nq - 1) / nq;
-    const dim3 grid((unsigned)((int64_t)p.b * p.h_k * gchunks));
-    if (nq == 1) hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, 1>), grid, dim3(64), 0, stream, p, gchunks);
-    else if (nq == 2) hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, 2>), grid, dim3(64), 0, stream, p, gchunks);
-    else hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, 4>), grid, dim3(64), 0, stream, p, gchunks);
+    const int64_t units = (int64_t)p.b * p.h_k * gchunks;
+    // Several wavefronts per unit pay even when one per unit would fill the chip (B = 256 x 32 heads at d = 96: 0.69 -> 0.75 of HBM with 4): the workgroup's
+    // wavefronts walk neighbouring tiles of ONE sequence, and small batches get their parallelism back (B = 8: 0.17 -> 0.41) -- profiles/r05_generic_decode_waves_ab.txt
+    int nw = p.seqlen_k >= 1024 ? 4 : (p.seqlen_k >= 256 ? 2 : 1);
+    if (p.seqlen_k >= 2048 && units < 768) nw = 8;               // (B = 8 x 32 heads x 4096: 0.40 -> 0.68)
+    if (const char *e = getenv("ATOMA_GENERIC_DECODE_WAVES")) nw = atoi(e) == 8 ? 8 : (atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1));   // A/B runs
+    const dim3 grid((unsigned)units);
+#define ATOMA_AD2(NQ_) do { if (nw == 1) hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, NQ_, 1>), grid, dim3(64), 0, stream, p, gchunks); \
+                            else if (nw == 2) hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, NQ_, 2>), grid, dim3(128), 0, stream, p, gchunks); \
+                            else if (nw == 4) hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, NQ_, 4>), grid, dim3(256), 0, stream, p, gchunks); \
+                            else hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, NQ_, 8>), grid, dim3(512), 0, stream, p, gchunks); } while (0)
+    if (nq == 1) ATOMA_AD2(1); else if (nq == 2) ATOMA_AD2(2); else ATOMA_AD2(4);
+#undef ATOMA_AD2
 }
 
 // ATOMA_GENERIC_PREFILL_TILE (A/B runs): unset = the tiled kernels; "16" = only the 16-row one; anything else = the row-per-wavefront kernel

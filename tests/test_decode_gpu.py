@@ -606,6 +606,14 @@ def test_decode_other_head_sizes_streaming_kernel(gpu, d, dtype, monkeypatch):
             for i, L in enumerate(lens):
                 assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} h={h}/{hk} alibi={alibi is not None} seq {i} (L={L})")
             assert not out[0].any() and np.isinf(lse[0]).all()
+            for waves in ("1", "4", "8"):      # 1 / 4 / 8 wavefronts (the default here: 2) share a unit's tiles and merge in LDS (what small batches take)
+                monkeypatch.setenv("ATOMA_GENERIC_DECODE_WAVES", waves)
+                out_w, lse_w = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)
+                monkeypatch.delenv("ATOMA_GENERIC_DECODE_WAVES")
+                for i, L in enumerate(lens):
+                    assert_close(out_w[i], ref[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} h={h}/{hk} {waves} wavefronts per unit, seq {i} (L={L})")
+                assert not out_w[0].any() and np.isinf(lse_w[0]).all()
+                assert np.allclose(lse_w[lens > 0], lse[lens > 0], rtol=1e-4, atol=1e-4)
             for other in ("1", "0"):      # the first streaming kernel; the row-per-lane coverage kernel -- on the same call
                 monkeypatch.setenv("ATOMA_GENERIC_DECODE_STREAM", other)
                 old, lse_old = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)

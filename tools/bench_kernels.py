@@ -137,6 +137,8 @@ def bench_decode():
     # the other head sizes the reference instantiates (attn_decode_anyd_kernel; ATOMA_GENERIC_DECODE_STREAM=0: the row-per-lane coverage kernel)
     decode_case("decode d=96 (Phi-3-mini heads) B=256 S=2048 h=32 hk=32", 256, 2048, 32, 32, d=96)
     decode_case("decode d=256 B=256 S=2048 h=16 hk=4", 256, 2048, 16, 4, d=256)
+    decode_case("decode d=96 B=64 S=2048 h=32 hk=32 (the Phi-3-mini-shaped step's attention)", 64, 2048, 32, 32, d=96)
+    decode_case("decode d=96 B=8 S=4096 h=32 hk=32 (8 wavefronts per unit)", 8, 4096, 32, 32, d=96)
 
 
 def bench_decode_fp8():
