@@ -42,3 +42,29 @@ def test_decode_kernels_use_no_scratch_for_their_arguments(tmp_path):
     for n, v in ks.items():
         if "paged_decode_kernel" in n and v["vspill"] == 0:
             assert v["scratch"] == 0, f"{n}: {v} -- scratch without a register spill"
+
+
+GEN = os.path.join(ROOT, "atoma-infer_amd", "build", "attn_generic.o")
+
+
+@pytest.mark.skipif(not (os.path.exists(GEN) and os.path.exists(os.path.join(LLVM, "llvm-readelf"))), reason="needs the built object and the ROCm llvm tools")
+def test_generic_attention_kernels_keep_their_state_in_registers(tmp_path):
+    """attn_generic.hip's round-5 kernels: the 64-row prefill kernel is built for two wavefronts per SIMD (<= 256 registers, nothing in scratch --
+    its first version with a second register stage put the staging arrays there), the streaming decode kernel spills nothing, the 16-row
+    prefill kernel spills only in its predicated d = 240 form."""
+    ks = kernel_notes(GEN, str(tmp_path))
+    t64 = {n: v for n, v in ks.items() if "attn_prefill_tile64_kernel" in n}
+    assert len(t64) >= 2 * (8 * 2 + 4 * 2)
+    for n, v in t64.items():
+        assert v["vgpr"] <= 256, (n, v)
+        if "ELi7ELi64E" in n:        # d = 224 with 64-key tiles: 19 registers spilled (40 bytes of scratch) and still 1.6 x the 32-key form (profiles/r05_generic_prefill_cfg.json)
+            assert v["scratch"] <= 64, (n, v)
+        else:
+            assert v["scratch"] == 0 and v["vspill"] == 0, (n, v)
+    ad2 = {n: v for n, v in ks.items() if "attn_decode_anyd2_kernel" in n}
+    assert len(ad2) >= 2 * 4 * 3 * 4
+    for n, v in ad2.items():         # (the 4-wavefront, 4-q-head form at head size 128 parks 24 registers in the accumulator file: no memory traffic)
+        assert v["scratch"] == 0, (n, v)
+    for n, v in ks.items():
+        if "attn_prefill_tile16_kernel" in n and "ELb1E" in n:      # the exact head-size instantiations
+            assert v["scratch"] == 0 and v["vspill"] == 0, (n, v)
