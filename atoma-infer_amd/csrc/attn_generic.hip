@@ -535,21 +535,23 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     const uint32_t k_rd = k_lds + col * KRB + grp * 16;                                  // + (32 g + 16 h) rows + 64 c
     const uint32_t v_rd = v_lds + (4 * grp + (col >> 2)) * VRB + (col & 3) * 8;          // + (32 g + 16 h) rows + 32 dc
     auto compute_tile = [&](int j0) {
-        // ---- S^T = K . Q^T: one K operand read feeds the RQ row blocks
+        // ---- S^T = K . Q^T: one K operand read feeds the RQ row blocks.  Head-dim step outermost: consecutive MFMAs then belong to different
+        // accumulators (a chain of dependent MFMAs issues at half rate)
         gf32x4 sacc[RQ][KG][2];
 #pragma unroll
-        for (int g = 0; g < KG; ++g)
+        for (int s = 0; s < RQ; ++s)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int g = 0; g < KG; ++g) { sacc[s][g][0] = gf32x4{0.f, 0.f, 0.f, 0.f}; sacc[s][g][1] = gf32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                for (int s = 0; s < RQ; ++s) sacc[s][g][hh] = gf32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
                     const gu32x4 a = *(const __attribute__((address_space(3))) gu32x4 *)(uintptr_t)(k_rd + (32 * g + 16 * hh) * KRB + 64 * c);
 #pragma unroll
                     for (int s = 0; s < RQ; ++s) sacc[s][g][hh] = gmfma32<T>(a, qreg[s][c], sacc[s][g][hh]);
                 }
-            }
         // ---- softmax per row block.  Scores stay raw: p = exp2(s * scale_log2 - m) is one fma + one exp; the mask / ALiBi pass only runs on tiles that reach
         // past the block's first row's last key (the diagonal, the sequence's tail) or when slopes are given (softmax.h:65-185 in the exp2 domain; scale_log2 > 0)
         gu32x4 pb[RQ][KG];
@@ -606,9 +608,9 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
         }
         // ---- O^T += V^T . P^T: one V^T operand (two transposing reads) feeds the RQ row blocks
 #pragma unroll
-        for (int dc = 0; dc < 2 * NC; ++dc)
+        for (int g = 0; g < KG; ++g)
 #pragma unroll
-            for (int g = 0; g < KG; ++g) {
+            for (int dc = 0; dc < 2 * NC; ++dc) {
                 const uint32_t a0 = v_rd + (32 * g) * VRB + 32 * dc;
                 const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gshort4 *)(uintptr_t)a0));
                 const uint2 hi2 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) gshort4 *)(uintptr_t)(a0 + 16 * VRB)));
