@@ -9,7 +9,9 @@
 // Same numerics contract as the reference kernel: exp2-domain softmax, fp32 accumulation,
 // P rounded to the storage dtype before P.V (csrc/kernels/softmax.h:65-185).
 #include "attn_params.h"
+#include <atomic>
 #include <cstring>
+#include <string>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -660,13 +662,30 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     }
 }
 
+// Knobs of this file: environment at load time, atoma_set_option("generic_*") at run time (A/B runs and tests inside one process) -- no getenv per call.
+static int generic_env_or(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+static std::atomic<int> generic_prefill_tile{generic_env_or("ATOMA_GENERIC_PREFILL_TILE", 64)};   // 64: the tiled kernels; 16: only the 16-row one; 0: the row-per-wavefront kernel
+static std::atomic<int> generic_prefill_kt{generic_env_or("ATOMA_GENERIC_PREFILL_KT", 0)};        // keys per LDS tile of the 64-row kernel: 0 = by head size, 32, 64
+static std::atomic<int> generic_prefill_rq{generic_env_or("ATOMA_GENERIC_PREFILL_RQ", 0)};        // 16-row blocks per wavefront: 0 = by head size, 1, 2
+static std::atomic<int> generic_decode_stream{generic_env_or("ATOMA_GENERIC_DECODE_STREAM", 2)};  // 2: the streaming decode kernel (second version); 1: its first version; 0: the row-per-lane kernel
+static std::atomic<int> generic_decode_waves{generic_env_or("ATOMA_GENERIC_DECODE_WAVES", 0)};    // wavefronts per unit: 0 = by shape, 1 / 2 / 4 / 8
+bool set_generic_attn_option(const std::string &name, int value) {
+    if (name == "generic_prefill_tile") generic_prefill_tile = value;
+    else if (name == "generic_prefill_kt") generic_prefill_kt = value;
+    else if (name == "generic_prefill_rq") generic_prefill_rq = value;
+    else if (name == "generic_decode_stream") generic_decode_stream = value;
+    else if (name == "generic_decode_waves") generic_decode_waves = value;
+    else return false;
+    return true;
+}
+
 template <typename T>
 static void launch_prefill_tile64(const AttnParams &p, hipStream_t stream) {
     int kt = (p.d == 192 || p.d == 256) ? 32 : 64;               // measured per head size: profiles/r05_generic_prefill_cfg.json
-    if (const char *e = getenv("ATOMA_GENERIC_PREFILL_KT")) kt = atoi(e) == 32 ? 32 : 64;   // A/B runs
+    if (const int v = generic_prefill_kt.load()) kt = v == 32 ? 32 : 64;   // A/B runs
     // two 16-row blocks per wavefront (128-row workgroups: every K / V operand read from LDS feeds two MFMAs) up to head size 128, where the registers allow it
     int rq = (p.d <= 128 && p.seqlen_q > 64) ? 2 : 1;
-    if (const char *e = getenv("ATOMA_GENERIC_PREFILL_RQ")) rq = (atoi(e) == 2 && p.d <= 128) ? 2 : 1;   // A/B runs
+    if (const int v = generic_prefill_rq.load()) rq = (v == 2 && p.d <= 128) ? 2 : 1;   // A/B runs
     const int mblocks = (p.seqlen_q + 64 * rq - 1) / (64 * rq);
     const dim3 grid((unsigned)(mblocks * p.h), 1, (unsigned)p.b);
     // (two register stages -- tile t + 2 requested while tile t is computed -- were measured and never won: ST stays 1)
@@ -915,7 +934,7 @@ static void launch_decode_anyd2(const AttnParams &p, hipStream_t stream) {
     // wavefronts walk neighbouring tiles of ONE sequence, and small batches get their parallelism back (B = 8: 0.17 -> 0.41) -- profiles/r05_generic_decode_waves_ab.txt
     int nw = p.seqlen_k >= 1024 ? 4 : (p.seqlen_k >= 256 ? 2 : 1);
     if (p.seqlen_k >= 2048 && units < 768) nw = 8;               // (B = 8 x 32 heads x 4096: 0.40 -> 0.68)
-    if (const char *e = getenv("ATOMA_GENERIC_DECODE_WAVES")) nw = atoi(e) == 8 ? 8 : (atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1));   // A/B runs
+    if (const int v = generic_decode_waves.load()) nw = v == 8 ? 8 : (v == 4 ? 4 : (v == 2 ? 2 : 1));   // A/B runs
     const dim3 grid((unsigned)units);
 #define ATOMA_AD2(NQ_) do { if (nw == 1) hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, NQ_, 1>), grid, dim3(64), 0, stream, p, gchunks); \
                             else if (nw == 2) hipLaunchKernelGGL((attn_decode_anyd2_kernel<T, CP, NQ_, 2>), grid, dim3(128), 0, stream, p, gchunks); \
@@ -925,10 +944,9 @@ static void launch_decode_anyd2(const AttnParams &p, hipStream_t stream) {
 #undef ATOMA_AD2
 }
 
-// ATOMA_GENERIC_PREFILL_TILE (A/B runs): unset = the tiled kernels; "16" = only the 16-row one; anything else = the row-per-wavefront kernel
-static int attn_prefill_tile_choice() {
-    const char *e = getenv("ATOMA_GENERIC_PREFILL_TILE");
-    return e == nullptr ? 64 : (strcmp(e, "16") == 0 ? 16 : 0);
+static int attn_prefill_tile_choice() {                          // generic_prefill_tile: 64 = the tiled kernels; 16 = only the 16-row one; anything else = the row-per-wavefront kernel
+    const int v = generic_prefill_tile.load();
+    return v == 64 ? 64 : (v == 16 ? 16 : 0);
 }
 
 static bool attn_prefill_tile16_applicable(const AttnParams &p) {
@@ -944,15 +962,14 @@ static bool attn_decode_anyd_applicable(const AttnParams &p) {
                             p.o_batch_stride | p.k_batch_stride | p.v_batch_stride;
     return p.seqlen_q == 1 && p.cu_seqlens_q == nullptr && p.d >= 8 && p.d <= 256 && p.d % 8 == 0 && p.h % p.h_k == 0 && strides % 8 == 0 &&
            ((reinterpret_cast<uintptr_t>(p.q) | reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.o)) & 15u) == 0 &&
-           (getenv("ATOMA_GENERIC_DECODE_STREAM") == nullptr || strcmp(getenv("ATOMA_GENERIC_DECODE_STREAM"), "1") == 0);   // (any other value: the row-per-lane kernel, for A/B runs)
+           generic_decode_stream.load() != 0;                    // (0: the row-per-lane kernel, for A/B runs)
 }
 
 void launch_attn_generic(const AttnParams &p, bool is_bf16, hipStream_t stream) {
     if (p.b <= 0 || p.h <= 0 || p.seqlen_q <= 0) return;
     if (attn_decode_anyd_applicable(p)) {
         const int C = p.d / 8;
-        const char *which = getenv("ATOMA_GENERIC_DECODE_STREAM");   // unset: the second version; "1": the first (A/B runs); anything else: see attn_decode_anyd_applicable
-        if (which == nullptr) {
+        if (generic_decode_stream.load() != 1) {                 // 1: the first version of the streaming kernel (A/B runs)
 #define ATOMA_ANYD2(CP_) do { if (is_bf16) launch_decode_anyd2<bf16_t, CP_>(p, stream); else launch_decode_anyd2<f16_t, CP_>(p, stream); } while (0)
             if (C <= 4) ATOMA_ANYD2(4); else if (C <= 8) ATOMA_ANYD2(8); else if (C <= 16) ATOMA_ANYD2(16); else ATOMA_ANYD2(32);
 #undef ATOMA_ANYD2

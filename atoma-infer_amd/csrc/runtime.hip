@@ -15,6 +15,7 @@ void clear_error() { g_error.clear(); }
 bool has_error() { return !g_error.empty(); }
 
 bool set_decode_option(const std::string &name, int value);  // paged_decode.hip
+bool set_generic_attn_option(const std::string &name, int value);  // attn_generic.hip
 bool set_linear_tile_option(const std::string &name, int value);  // linear_tile.hip
 
 int device_num_cus() {
@@ -188,6 +189,7 @@ int atoma_set_option(const char *name, int value) {
     atoma::clear_error();
     if (name && atoma::set_decode_option(name, value)) return 0;
     if (name && atoma::set_linear_tile_option(name, value)) return 0;
+    if (name && atoma::set_generic_attn_option(name, value)) return 0;
     atoma::set_error(std::string("atoma_set_option: unknown option ") + (name ? name : "(null)"));
     return -1;
 }

@@ -428,6 +428,8 @@ int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int6
  * persistent kernel keeps its plan table (256 bytes per 256-row query block and wavefront = 1 KiB per block) in the stream's workspace:
  * count it in atoma_warmup's extra_bytes before capturing a graph.  RoPE: "rope_table_rows" (rows of the caller's cos / sin tables; positions beyond
  * them then read the last row instead of memory behind the table -- the FFI carries no table length; 0 = unchecked [default]).
+ * "generic_prefill_tile" (64 [default] / 16 / 0), "generic_prefill_kt", "generic_prefill_rq", "generic_decode_stream" (2 [default] / 1 / 0),
+ * "generic_decode_waves": kernel choice for head sizes other than 64 / 128 (csrc/attn_generic.hip), for A/B runs; defaults from ATOMA_GENERIC_*.
  * Defaults also come from ATOMA_DECODE_{P,NT,STREAM,WAVES_PER_CU,
  * MIN_TILES,MQK}; ATOMA_PREFILL_CFG overrides "prefill_cfg". */
 int atoma_set_option(const char *name, int value);

@@ -148,7 +148,7 @@ def test_other_head_sizes_causal_paged_prefix(gpu, d):
 
 
 @pytest.mark.parametrize("d,dtype", [(32, BF16), (96, F16), (192, BF16), (224, F16), (256, BF16)])
-def test_other_head_sizes_tiled_prefill(gpu, d, dtype, monkeypatch):
+def test_other_head_sizes_tiled_prefill(gpu, d, dtype):
     """The 16-query-row MFMA kernel for the other head sizes (attn_generic.hip: attn_prefill_tile16_kernel): several row blocks per sequence,
     lengths that are not multiples of the 16-key tile, Lq < Lk, Lq > Lk (rows that see no key: O = 0, LSE = +inf), an empty sequence, GQA,
     ALiBi, paged and contiguous K / V -- against the f32 oracle, and against the row-per-wavefront kernel it replaces (LSE included)."""
@@ -172,10 +172,12 @@ def test_other_head_sizes_tiled_prefill(gpu, d, dtype, monkeypatch):
                 what = f"d={d} causal={causal} alibi={alibi is not None} paged={paged}"
                 assert_close(out, ref, dtype, atol=ATOL_VS_F32[dtype], what=what + " (f32 oracle)")
                 for other in ("rq1", "16", "0"):      # 64-row workgroups (one row block per wavefront); the 16-row kernel alone; the row-per-wavefront kernel
-                    var, val = ("ATOMA_GENERIC_PREFILL_RQ", "1") if other == "rq1" else ("ATOMA_GENERIC_PREFILL_TILE", other)
-                    monkeypatch.setenv(var, val)
-                    out_o, lse_o = gpu_varlen(gpu, q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi=alibi, **kw)
-                    monkeypatch.delenv(var)
+                    name, val, dflt = (b"generic_prefill_rq", 1, 0) if other == "rq1" else (b"generic_prefill_tile", int(other), 64)
+                    assert gpu.lib.atoma_set_option(name, val) == 0
+                    try:
+                        out_o, lse_o = gpu_varlen(gpu, q, k, v, cu_q, cu_k, d ** -0.5, causal, dtype, alibi=alibi, **kw)
+                    finally:
+                        gpu.lib.atoma_set_option(name, dflt)
                     if other != "0":
                         assert_close(out_o, ref, dtype, atol=ATOL_VS_F32[dtype], what=what + f" (kernel {other}, f32 oracle)")
                     assert_close(out, out_o, dtype, atol=ATOL_VS_F32[dtype], what=what + f" (kernel {other})")

@@ -588,11 +588,11 @@ def test_decode_random_shapes_through_the_default_dispatch(gpu, seed):
 
 @pytest.mark.parametrize("d", [8, 32, 96, 160, 192, 224, 256])
 @pytest.mark.parametrize("dtype", [BF16, F16])
-def test_decode_other_head_sizes_streaming_kernel(gpu, d, dtype, monkeypatch):
+def test_decode_other_head_sizes_streaming_kernel(gpu, d, dtype):
     """Decode for the head sizes the reference instantiates besides 64 / 128 (csrc/build.rs:7-74) -- `attn_decode_anyd_kernel`: one wavefront per
     (sequence, kv head, up to 4 q heads) streaming K / V once, instead of the row-per-lane coverage kernel.  Ragged lengths incl. 0, 1 and a
     non-multiple of 16, groups of 1 / 3 / 5 q heads (one and two chunks), paged and contiguous caches, ALiBi, the LSE output; against the
-    oracle, and against the coverage kernel on the same call (ATOMA_GENERIC_DECODE_STREAM switches back to it)."""
+    oracle, and against the coverage kernel on the same call (atoma_set_option generic_decode_stream switches back to it)."""
     rng = np.random.default_rng(1000 + d + dtype)
     for h, hk, page in ((4, 4, 16), (6, 2, 16), (5, 1, 16), (4, 2, 32), (4, 4, 48)):      # groups of 1 / 3 / 5 / 2 q heads; pages of 16, 32 and 48 tokens
         lens = np.array([0, 1, 15, 16, 17, 100, 333, 77], np.int32)
@@ -606,18 +606,22 @@ def test_decode_other_head_sizes_streaming_kernel(gpu, d, dtype, monkeypatch):
             for i, L in enumerate(lens):
                 assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} h={h}/{hk} alibi={alibi is not None} seq {i} (L={L})")
             assert not out[0].any() and np.isinf(lse[0]).all()
-            for waves in ("1", "4", "8"):      # 1 / 4 / 8 wavefronts (the default here: 2) share a unit's tiles and merge in LDS (what small batches take)
-                monkeypatch.setenv("ATOMA_GENERIC_DECODE_WAVES", waves)
-                out_w, lse_w = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)
-                monkeypatch.delenv("ATOMA_GENERIC_DECODE_WAVES")
+            for waves in (1, 4, 8):      # 1 / 4 / 8 wavefronts (the default here: 2) share a unit's tiles and merge in LDS (what small batches take)
+                assert gpu.lib.atoma_set_option(b"generic_decode_waves", waves) == 0
+                try:
+                    out_w, lse_w = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)
+                finally:
+                    gpu.lib.atoma_set_option(b"generic_decode_waves", 0)
                 for i, L in enumerate(lens):
                     assert_close(out_w[i], ref[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} h={h}/{hk} {waves} wavefronts per unit, seq {i} (L={L})")
                 assert not out_w[0].any() and np.isinf(lse_w[0]).all()
                 assert np.allclose(lse_w[lens > 0], lse[lens > 0], rtol=1e-4, atol=1e-4)
-            for other in ("1", "0"):      # the first streaming kernel; the row-per-lane coverage kernel -- on the same call
-                monkeypatch.setenv("ATOMA_GENERIC_DECODE_STREAM", other)
-                old, lse_old = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)
-                monkeypatch.delenv("ATOMA_GENERIC_DECODE_STREAM")
+            for other in (1, 0):      # the first streaming kernel; the row-per-lane coverage kernel -- on the same call
+                assert gpu.lib.atoma_set_option(b"generic_decode_stream", other) == 0
+                try:
+                    old, lse_old = gpu_decode(gpu, q, kc, vc, bt, lens, scale, dtype, alibi=alibi)
+                finally:
+                    gpu.lib.atoma_set_option(b"generic_decode_stream", 2)
                 for i, L in enumerate(lens):
                     assert_close(out[i], old[i], dtype, atol=attn_atol(dtype, int(L)), what=f"d={d} vs kernel {other}, seq {i}")
                 live = lens > 0

@@ -134,7 +134,7 @@ def bench_decode():
     decode_case("decode d=64 ragged U[2048,4096] B=256 h=32 hk=8", 256, 4096, 32, 8, d=64, ragged=True)
     decode_case("decode d=64 B=16 S=8192 h=32 hk=8 (split-KV)", 16, 8192, 32, 8, d=64)
     decode_case("decode d=64 MHA B=256 S=2048 h=16 hk=16", 256, 2048, 16, 16, d=64)
-    # the other head sizes the reference instantiates (attn_decode_anyd_kernel; ATOMA_GENERIC_DECODE_STREAM=0: the row-per-lane coverage kernel)
+    # the other head sizes the reference instantiates (attn_decode_anyd2_kernel; ATOMA_GENERIC_DECODE_STREAM=0 at load time or atoma_set_option generic_decode_stream 0: the row-per-lane coverage kernel)
     decode_case("decode d=96 (Phi-3-mini heads) B=256 S=2048 h=32 hk=32", 256, 2048, 32, 32, d=96)
     decode_case("decode d=256 B=256 S=2048 h=16 hk=4", 256, 2048, 16, 4, d=256)
     decode_case("decode d=96 B=64 S=2048 h=32 hk=32 (the Phi-3-mini-shaped step's attention)", 64, 2048, 32, 32, d=96)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""attn_prefill_tile64_kernel: key-tile size (32 / 64, ATOMA_GENERIC_PREFILL_KT) per head size, 4 causal prompts of 2048 tokens, 32 q / 8 kv heads; and a longer prompt (2 x 8192) for the chosen default."""
+"""attn_prefill_tile64_kernel: key-tile size (32 / 64, atoma_set_option generic_prefill_kt) per head size, 4 causal prompts of 2048 tokens, 32 q / 8 kv heads; and a longer prompt (2 x 8192) for the chosen default."""
 import json
 import os
 import sys
@@ -12,10 +12,10 @@ res = {}
 for d in (32, 96, 160, 192, 224, 256):          # (64 / 128 without ALiBi run on the hand-scheduled kernels)
     e = {}
     for cfg in ("64", "32"):
-        os.environ["ATOMA_GENERIC_PREFILL_KT"] = cfg
+        BE.ah.lib.atoma_set_option(b"generic_prefill_kt", int(cfg))
         r = BE.prefill(iters=5, S=2048, nseq=4, d=d)
         e[cfg] = r["ms"]
-    os.environ.pop("ATOMA_GENERIC_PREFILL_KT", None)
+    BE.ah.lib.atoma_set_option(b"generic_prefill_kt", 0)
     e["best"] = min(e, key=e.get)
     res["d=%d" % d] = e
 print(json.dumps(res, indent=1))
