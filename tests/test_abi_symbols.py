@@ -48,6 +48,18 @@ def test_error_channel_and_host_heuristics_without_gpu():
     assert lib.atoma_last_error().startswith(b"swap_blocks: Either src and dst are on the same cuda device")
 
 
+def test_options_are_known_by_name_without_gpu():
+    """atoma_set_option: every documented knob is accepted (host-side state only), an unknown name is an error, not a silent no-op"""
+    lib = C.CDLL(LIB)
+    lib.atoma_last_error.restype = C.c_char_p
+    lib.atoma_set_option.argtypes = [C.c_char_p, C.c_int]
+    for name, default in ((b"generic_prefill_tile", 64), (b"generic_prefill_kt", 0), (b"generic_prefill_rq", 0), (b"generic_decode_stream", 2), (b"generic_decode_waves", 0),
+                          (b"linear_tile", 1), (b"decode_line_merge", 1)):
+        assert lib.atoma_set_option(name, default) == 0, name
+    assert lib.atoma_set_option(b"no_such_option", 1) == -1
+    assert b"unknown option no_such_option" in lib.atoma_last_error()
+
+
 def test_static_archive_defines_the_same_symbols():
     """lib/libatoma_hip.a (the reference links `static=flashattention`, csrc/build.rs:105-113): every declared symbol is defined in it"""
     import subprocess
