@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     const int64_t kbase = (paged ? 0 : si.k_offset(p.k_batch_stride, p.k_row_stride, b)) + (int64_t)hk * p.k_head_stride;
     const int64_t vbase = (paged ? 0 : si.k_offset(p.v_batch_stride, p.v_row_stride, b)) + (int64_t)hk * p.v_head_stride;
     const float slope_raw = p.alibi_slopes ? p.alibi_slopes[b * p.alibi_batch_stride + hq] / p.scale : 0.f;   // slope.log2(e) / scale_log2
-    gu32x4 kreg[ST][NPC], vreg[ST][NPC];                          // ST register stages: tile t + ST is requested while tile t is computed
+    gu32x4 kreg0[NPC], vreg0[NPC], kreg1[NPC], vreg1[NPC];       // ST register stages (separate arrays: a [ST][NPC] array of this size is left in scratch): tile t + ST is requested while tile t is computed
     // Addresses: 32-bit arithmetic inside a page / a row, ONE 32 x 32 -> 64-bit multiply-add per tensor and piece (the strides arrive as u32 over
     // the FFI: ffi.rs:3-102).  Paged: the page numbers of tile t + 1's rows are requested right after tile t's K / V loads, so the block-table
     // latency never sits in front of a K / V load.
@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     const uint32_t pmask = (uint32_t)p.page_size - 1u;
     int pg[NPC];
     auto piece_row = [&](int i, int j0) { return min(j0 + (tid + 256 * i) / CPR, si.len_k - 1); };   // rows behind the sequence re-read its last row and meet p = 0
-    auto load_pages = [&](int j0) {
+    auto load_pages = [&](int j0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NPC; ++i)
             if (PIECES % 256 == 0 || tid + 256 * i < PIECES) {
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
                 pg[i] = bt[pshift >= 0 ? t >> pshift : t / p.page_size];
             }
     };
-    auto load_tile = [&](auto sel, int j0) {
+    auto load_tile = [&](auto sel, int j0) __attribute__((always_inline)) {
         constexpr int SG = decltype(sel)::value;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
@@ -507,21 +507,21 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
                     ko = (uint64_t)(uint32_t)t * krs + ch8;
                     vo = (uint64_t)(uint32_t)t * vrs + ch8;
                 }
-                kreg[SG][i] = *reinterpret_cast<const gu32x4 *>(kg + ko);
-                vreg[SG][i] = *reinterpret_cast<const gu32x4 *>(vg + vo);
+                const gu32x4 kx = *reinterpret_cast<const gu32x4 *>(kg + ko), vx = *reinterpret_cast<const gu32x4 *>(vg + vo);
+                if constexpr (SG == 0) { kreg0[i] = kx; vreg0[i] = vx; } else { kreg1[i] = kx; vreg1[i] = vx; }
             }
         }
         if (paged && j0 + KT < hi_wg) load_pages(j0 + KT);
     };
-    auto store_tile = [&](auto sel) {
+    auto store_tile = [&](auto sel) __attribute__((always_inline)) {
         constexpr int SG = decltype(sel)::value;
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
             const int idx = tid + 256 * i;
             if (PIECES % 256 == 0 || idx < PIECES) {
                 const int kr = idx / CPR, ch = idx - kr * CPR;
-                *reinterpret_cast<gu32x4 *>(smem + kr * KRB + ch * 16) = kreg[SG][i];
-                *reinterpret_cast<gu32x4 *>(smem + KT * KRB + kr * VRB + ch * 16) = vreg[SG][i];
+                *reinterpret_cast<gu32x4 *>(smem + kr * KRB + ch * 16) = SG == 0 ? kreg0[i] : kreg1[i];
+                *reinterpret_cast<gu32x4 *>(smem + KT * KRB + kr * VRB + ch * 16) = SG == 0 ? vreg0[i] : vreg1[i];
             }
         }
     };
@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     }
     const uint32_t k_rd = k_lds + col * KRB + grp * 16;                                  // + (32 g + 16 h) rows + 64 c
     const uint32_t v_rd = v_lds + (4 * grp + (col >> 2)) * VRB + (col & 3) * 8;          // + (32 g + 16 h) rows + 32 dc
-    auto compute_tile = [&](int j0) {
+    auto compute_tile = [&](int j0) __attribute__((always_inline)) {
         // ---- S^T = K . Q^T: one K operand read feeds the RQ row blocks.  Head-dim step outermost: consecutive MFMAs then belong to different
         // accumulators (a chain of dependent MFMAs issues at half rate)
         gf32x4 sacc[RQ][KG][2];
@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(256, 2) attn_prefill_tile64_kernel(const AttnP
     };
     typedef std::integral_constant<int, 0> Stage0;
     typedef std::integral_constant<int, ST - 1> Stage1;
-    auto step = [&](auto sel, int j0) {
+    auto step = [&](auto sel, int j0) __attribute__((always_inline)) {
         store_tile(sel);
         __syncthreads();
         if (j0 + ST * KT < hi_wg) load_tile(sel, j0 + ST * KT);
@@ -681,14 +681,15 @@ bool set_generic_attn_option(const std::string &name, int value) {
 
 template <typename T>
 static void launch_prefill_tile64(const AttnParams &p, hipStream_t stream) {
-    int kt = (p.d == 192 || p.d == 256) ? 32 : 64;               // measured per head size: profiles/r05_generic_prefill_cfg.json
+    int kt = p.d == 192 ? 32 : 64;                               // measured per head size: profiles/r05_generic_prefill_cfg.json
     if (const int v = generic_prefill_kt.load()) kt = v == 32 ? 32 : 64;   // A/B runs
     // two 16-row blocks per wavefront (128-row workgroups: every K / V operand read from LDS feeds two MFMAs) up to head size 128, where the registers allow it
     int rq = (p.d <= 128 && p.seqlen_q > 64) ? 2 : 1;
     if (const int v = generic_prefill_rq.load()) rq = (v == 2 && p.d <= 128) ? 2 : 1;   // A/B runs
     const int mblocks = (p.seqlen_q + 64 * rq - 1) / (64 * rq);
     const dim3 grid((unsigned)(mblocks * p.h), 1, (unsigned)p.b);
-    // (two register stages -- tile t + 2 requested while tile t is computed -- were measured and never won: ST stays 1)
+    // (two register prefetch stages -- tile t + 2 requested while tile t is computed -- were measured again with everything in registers and never won:
+    // profiles/r05_generic_prefill_cfg.json; ST stays 1)
 #define ATOMA_T64B(NC_, KT_, RQ_) hipLaunchKernelGGL((attn_prefill_tile64_kernel<T, NC_, KT_, 1, RQ_>), grid, dim3(256), 0, stream, p, mblocks)
 #define ATOMA_T64S(NC_) case NC_: if (rq == 2) { if (kt == 64) ATOMA_T64B(NC_, 64, 2); else ATOMA_T64B(NC_, 32, 2); } \
                                   else { if (kt == 64) ATOMA_T64B(NC_, 64, 1); else ATOMA_T64B(NC_, 32, 1); } break
