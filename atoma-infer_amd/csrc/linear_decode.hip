@@ -919,7 +919,9 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
         if (rc <= 0) return rc;
     }
     if (p.batch > 64) {
-        const int rc = launch_linear_big<T>(p, stream);
+        int rc = launch_linear_wide(p, std::is_same<T, bf16_t>::value ? ATOMA_BF16 : ATOMA_F16, stream);   // round 6: LDS-DMA tile, 8 wavefronts
+        if (rc <= 0) return rc;
+        rc = launch_linear_big<T>(p, stream);
         if (rc <= 0) return rc;
         set_error("linear_decode: more than 64 rows need out_features and in_features to be multiples of 128");
         return -1;

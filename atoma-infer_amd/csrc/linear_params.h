@@ -45,4 +45,11 @@ int launch_linear_tile_rope(LinearParams &p, int dtype, hipStream_t stream, cons
                             const int64_t *slot_mapping, uint16_t *k_cache, uint16_t *v_cache, int64_t block_stride, int64_t table_rows, int heads_q,
                             int heads_kv, int head_dim, int page_size, int per_op);
 
+// linear_wide.hip: the LDS-DMA tile kernel for 65..256 rows (K splits merged inside the launch).  0 = launched, 1 = shape not served, -1 = error.
+int launch_linear_wide(LinearParams &p, int dtype, hipStream_t stream);
+bool linear_wide_can_rope(const LinearParams &p, int head_dim);
+int launch_linear_wide_rope(LinearParams &p, int dtype, hipStream_t stream, const uint16_t *cos_t, const uint16_t *sin_t, const int64_t *positions,
+                            const int64_t *slot_mapping, uint16_t *k_cache, uint16_t *v_cache, int64_t block_stride, int64_t table_rows, int heads_q,
+                            int heads_kv, int head_dim, int page_size, int per_op);
+
 }  // namespace atoma

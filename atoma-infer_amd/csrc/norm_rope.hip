@@ -449,7 +449,7 @@ int atoma_linear_decode_qkv_rope_cache(const void *x, const void *w_qkv, void *q
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_qkv) | reinterpret_cast<uintptr_t>(qkv_out) |
                            reinterpret_cast<uintptr_t>(k_cache) | reinterpret_cast<uintptr_t>(v_cache) | reinterpret_cast<uintptr_t>(cos_table) |
                            reinterpret_cast<uintptr_t>(sin_table);
-    const bool plain = (dtype == ATOMA_F16 || dtype == ATOMA_BF16) && batch > 16 && batch <= 64 && num_q_heads > 0 && num_kv_heads > 0 &&
+    const bool plain = (dtype == ATOMA_F16 || dtype == ATOMA_BF16) && batch > 16 && batch <= 256 && num_q_heads > 0 && num_kv_heads > 0 &&
                        head_dim > 0 && head_dim % 16 == 0 && in_features > 0 && in_features % 128 == 0 && page_size > 0 && !(ptrs & 15u) &&
                        x_row_stride >= in_features && w_row_stride >= in_features && out_row_stride >= width &&
                        !(x_row_stride % 8 || w_row_stride % 8 || out_row_stride % 8 || block_stride % 8) && slot_mapping && positions &&
@@ -464,6 +464,13 @@ int atoma_linear_decode_qkv_rope_cache(const void *x, const void *w_qkv, void *q
     p.x_row_stride = x_row_stride; p.w_row_stride = w_row_stride; p.y_row_stride = out_row_stride;
     p.batch = (int)batch; p.n = (int)width; p.k = (int)in_features;
     const auto s = static_cast<hipStream_t>(stream);
+    if (batch > 64) {                                          // 65..256 rows: linear_wide_kernel, same epilogue
+        if (!linear_wide_can_rope(p, (int)head_dim)) return two_ops();
+        const int rc = launch_linear_wide_rope(p, dtype, s, static_cast<const uint16_t *>(cos_table), static_cast<const uint16_t *>(sin_table), positions,
+                                               slot_mapping, static_cast<uint16_t *>(k_cache), static_cast<uint16_t *>(v_cache), block_stride,
+                                               rope_table_rows.load(), (int)num_q_heads, (int)num_kv_heads, (int)head_dim, (int)page_size, per_op_rounding);
+        return rc <= 0 ? rc : two_ops();
+    }
     if (linear_tile_can_rope(p, (int)head_dim)) {              // ONE launch: RoPE and the cache write are the projection's epilogue
         const int rc = launch_linear_tile_rope(p, dtype, s, static_cast<const uint16_t *>(cos_table), static_cast<const uint16_t *>(sin_table), positions,
                                                slot_mapping, static_cast<uint16_t *>(k_cache), static_cast<uint16_t *>(v_cache), block_stride,

@@ -17,6 +17,7 @@ bool has_error() { return !g_error.empty(); }
 bool set_decode_option(const std::string &name, int value);  // paged_decode.hip
 bool set_generic_attn_option(const std::string &name, int value);  // attn_generic.hip
 bool set_linear_tile_option(const std::string &name, int value);  // linear_tile.hip
+bool set_linear_wide_option(const std::string &name, int value);  // linear_wide.hip
 
 int device_num_cus() {
     // The reference queries cudaDeviceGetAttribute on EVERY attention call
@@ -139,6 +140,7 @@ int reset_sync_counters(hipStream_t stream) {
 size_t decode_workspace_bound(int max_b, int h, int h_k, int d, int max_seqlen_k);   // paged_decode.hip
 const char *last_decode_kernel();                                                    // paged_decode.hip
 bool linear_tile_prepare();                                                          // linear_tile.hip
+bool linear_wide_prepare();                                                          // linear_wide.hip
 bool prefill_asm_prepare();                                                          // prefill_asm.hip: the kernels' 160 KiB LDS opt-in on this device
 size_t prefill_asm_workspace_bound(int64_t tokens, int64_t seqs, int64_t heads);     // prefill_asm.hip: plan table of the persistent prefill kernel
 int release_gemm_workspaces();                                                       // linear_gemm.hip
@@ -189,6 +191,7 @@ int atoma_set_option(const char *name, int value) {
     atoma::clear_error();
     if (name && atoma::set_decode_option(name, value)) return 0;
     if (name && atoma::set_linear_tile_option(name, value)) return 0;
+    if (name && atoma::set_linear_wide_option(name, value)) return 0;
     if (name && atoma::set_generic_attn_option(name, value)) return 0;
     atoma::set_error(std::string("atoma_set_option: unknown option ") + (name ? name : "(null)"));
     return -1;
@@ -212,7 +215,7 @@ int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num
     const size_t need = std::max(atoma::decode_workspace_bound((int)std::min<int64_t>(max_batch, 1 << 20), (int)num_heads, (int)num_kv_heads,
                                                                (int)head_dim, (int)std::min<int64_t>(max_seqlen_k, 1 << 30)),
                                  (size_t)extra_bytes);
-    if (!atoma::sync_counters(static_cast<hipStream_t>(stream)) || !atoma::linear_tile_prepare() || !atoma::prefill_asm_prepare()) return -1;
+    if (!atoma::sync_counters(static_cast<hipStream_t>(stream)) || !atoma::linear_tile_prepare() || !atoma::linear_wide_prepare() || !atoma::prefill_asm_prepare()) return -1;
     if (need == 0) return 0;
     return atoma::workspace(static_cast<hipStream_t>(stream), need) ? 0 : -1;
 }

@@ -190,6 +190,36 @@ def test_linear_decode_65_to_256_rows(gpu, dtype, B, K, N):
     check(gpu_linear(gpu, x, w, dtype), LO.linear(x, w, dtype), dtype)
 
 
+@pytest.mark.parametrize("opts", [dict(linear_wide_nw=64, linear_wide_splits=1), dict(linear_wide_nw=128, linear_wide_splits=1), dict(linear_wide_nw=64, linear_wide_splits=2),
+                                  dict(linear_wide_nw=128, linear_wide_splits=3), dict(linear_wide_nw=64, linear_wide_splits=4), dict(linear_wide_nw=128, linear_wide_splits=8),
+                                  dict(linear_wide_nw=64, linear_wide_splits=4, linear_wide_xcd=0), dict(linear_wide_nw=128, linear_wide_splits=5), dict(linear_wide=0)])
+@pytest.mark.parametrize("B", [65, 128, 129, 200, 256])
+def test_linear_wide_every_tile_shape_and_split(gpu, opts, B):
+    """linear_wide_kernel (round 6: 65..256 rows): every template variant (64 / 128 weight rows x 128 / 256 batch rows), K unsplit and
+    split 2..8 ways with the in-launch merge, the XCD map of the splits on and off, uneven splits -- against the oracle bound on random
+    inputs, BIT-exact on integer-valued inputs (every partial sum exact in fp32: any tiling and any merge order must agree), and
+    linear_big_kernel (the kernel it replaces) through the same checks."""
+    from oracle.halfs import from_f32
+    rng = np.random.default_rng(B + sum(opts.values()))
+    K, N = 2048, 1152                                   # 1152 = 9 x 128 = 18 x 64: a tile count no XCD group divides
+    L = gpu.lib
+    names = ("linear_wide", "linear_wide_nw", "linear_wide_splits", "linear_wide_xcd")
+    defaults = dict(linear_wide=1, linear_wide_nw=0, linear_wide_splits=0, linear_wide_xcd=1)
+    try:
+        for n in names:
+            assert L.atoma_set_option(n.encode(), opts.get(n, defaults[n])) == 0
+        for dtype in (BF16, F16):
+            x = rand_half(rng, (B, K), dtype)
+            w = rand_half(rng, (N, K), dtype, K ** -0.5)
+            check(gpu_linear(gpu, x, w, dtype), LO.linear(x, w, dtype), dtype)
+        xi = from_f32(rng.integers(-4, 5, (B, K)).astype(np.float32), BF16)
+        wi = from_f32(rng.integers(-2, 3, (N, K)).astype(np.float32), BF16)
+        assert np.array_equal(gpu_linear(gpu, xi, wi, BF16), LO.linear(xi, wi, BF16))
+    finally:
+        for n in names:
+            L.atoma_set_option(n.encode(), defaults[n])
+
+
 def test_linear_decode_big_exact_cases(gpu):
     """Integer-valued inputs (every partial sum exact in fp32): bit-exact whatever the tiling / split; W = I reproduces x; a
     strided x and a padded y."""
@@ -296,7 +326,9 @@ def test_linear_any_batch_strides_exactness_and_errors(gpu):
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("B,K,h,hk,d", [(64, 8192, 8, 1, 128), (33, 2048, 4, 2, 64), (64, 4096, 32, 8, 128), (17, 1024, 2, 1, 128), (8, 1024, 2, 1, 128),
-                                        (40, 8192, 2, 1, 128), (48, 2048, 16, 16, 128), (64, 1024, 8, 8, 64)])
+                                        (40, 8192, 2, 1, 128), (48, 2048, 16, 16, 128), (64, 1024, 8, 8, 64),
+                                        # 65..256 rows (round 6: linear_wide_kernel with the same epilogue): the 8B layer, a rank's shard, d = 64, ragged batches
+                                        (256, 4096, 32, 8, 128), (65, 8192, 8, 1, 128), (200, 2048, 4, 2, 64), (129, 1024, 2, 1, 128), (256, 1024, 8, 8, 64)])
 def test_qkv_projection_rope_cache_entry_is_the_two_ops_bit_for_bit(gpu, dtype, B, K, h, hk, d):
     """atoma_linear_decode_qkv_rope_cache = atoma_linear_decode followed by atoma_rope_qk_cache on the same buffers, bit for bit: the
     shard of a tensor-parallel rank (1280 rows: 32-row tiles, K split 4 ways and merged inside the launch, RoPE + cache write as the
@@ -304,7 +336,7 @@ def test_qkv_projection_rope_cache_entry_is_the_two_ops_bit_for_bit(gpu, dtype, 
     a matrix with so few rows that K is split 8 ways (the RoPE / cache kernel merges the fp32 partials), MHA, and a batch outside
     17..64 (the entry runs the two ops)."""
     rng = np.random.default_rng(B + K + h)
-    width, page, nb = (h + 2 * hk) * d, 16, 12
+    width, page, nb = (h + 2 * hk) * d, 16, max(12, B // 16 + 3)
     x = rand_half(rng, (B, K), dtype)
     w = rand_half(rng, (width, K), dtype, K ** -0.5)
     cos = rand_half(rng, (4096, d // 2), dtype)

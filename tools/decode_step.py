@@ -57,8 +57,8 @@ class DecodeStep:
         self.tp_own = own_ok and allreduce is not None
         # own_projections: the op-by-op path on atoma_linear_decode at every batch (tests: the fused step must equal it bit for bit)
         self.linear = ah.lib.atoma_linear_decode if (own_projections or self.tp_own) else ah.lib.atoma_linear
-        # 17..64 rows on the fused path: the q/k/v projection, RoPE and the cache write behind one entry (atoma_linear_decode_qkv_rope_cache)
-        self.qkv_fused = (self.fused or self.tp_own) and 16 < batch <= 64 and os.environ.get("ATOMA_STEP_QKV_FUSED", "1") != "0"
+        # 17..256 rows on the fused path: the q/k/v projection, RoPE and the cache write behind one entry (atoma_linear_decode_qkv_rope_cache)
+        self.qkv_fused = (self.fused or self.tp_own) and 16 < batch <= 256 and os.environ.get("ATOMA_STEP_QKV_FUSED", "1") != "0"
         self.norm_in_proj = os.environ.get("ATOMA_STEP_NORM_IN_PROJ", "1") != "0"   # fused path: RMSNorm inside the q/k/v and gate/up projections (A/B switch)
         self.fuse_norm = fuse_norm and not keep_intermediates and not self.fused   # residual add + the RMSNorm that follows it in one kernel
         self.w = weights                                   # dict of DeviceBuffers, see random_weights / upload_weights

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Within-process interleaved A/B of the 65..256-row projection kernels on the Llama-3.1-8B layer shapes at 256 rows (BASELINE configs[2]):
+linear_wide_kernel (options linear_wide_nw / _splits / _xcd), linear_big_kernel (linear_wide = 0), the vendor GEMM (+ the separate epilogue
+launch it needs).  ROUNDS interleaved rounds of ITERS back-to-back launches (HIP events); median and min per variant.  Weights rotate
+through NBUF copies so that a launch never finds its matrix in the 256 MB cache.
+
+    python tools/probes/linear256_ab.py [shape ...]      shapes: qkv o gate_up down (default: all);  L256_BATCH=256  L256_VARIANTS=name,name
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench_kernels as bk  # noqa: E402
+
+ah = bk.ah
+SHAPES = {"qkv": (6144, 4096, 0), "o": (4096, 4096, 1), "gate_up": (28672, 4096, 2), "down": (4096, 14336, 1)}
+VARIANTS = [("wide", {}), ("wide nw64", {"linear_wide_nw": 64}), ("wide nw128", {"linear_wide_nw": 128}),
+            ("wide s1", {"linear_wide_splits": 1}), ("wide s2", {"linear_wide_splits": 2}), ("wide s4", {"linear_wide_splits": 4}), ("wide s8", {"linear_wide_splits": 8}),
+            ("wide nw128 s4", {"linear_wide_nw": 128, "linear_wide_splits": 4}), ("wide nw128 s8", {"linear_wide_nw": 128, "linear_wide_splits": 8}),
+            ("wide nw64 s2", {"linear_wide_nw": 64, "linear_wide_splits": 2}), ("wide nw64 s4", {"linear_wide_nw": 64, "linear_wide_splits": 4}),
+            ("wide no xcd map", {"linear_wide_xcd": 0}),
+            ("big kernel", {"linear_wide": 0}), ("vendor", {"vendor": 1}), ("vendor + epilogue", {"vendor": 2})]
+DEFAULTS = {"linear_wide": 1, "linear_wide_nw": 0, "linear_wide_splits": 0, "linear_wide_xcd": 1}
+ROUNDS, ITERS = 7, 12
+
+
+def main():
+    ah.set_device(0)
+    rng = np.random.default_rng(11)
+    B = int(os.environ.get("L256_BATCH", "256"))
+    only = [v for v in os.environ.get("L256_VARIANTS", "").split(",") if v]
+    variants = [v for v in VARIANTS if not only or v[0] in only]
+    for name in (sys.argv[1:] or list(SHAPES)):
+        N, K, ep = SHAPES[name]
+        nbuf = max(2, int(600e6 // (N * K * 2)))
+        ws = [bk.rand_dev(rng, N * K * 2) for _ in range(nbuf)]
+        x, r = bk.rand_dev(rng, B * K * 2), bk.rand_dev(rng, B * N * 2)
+        y, y2 = ah.DeviceBuffer(B * N * 2), ah.DeviceBuffer(B * N * 2)
+        L = ah.lib
+        calls = {0: lambda w: L.atoma_linear_decode(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None),
+                 1: lambda w: L.atoma_linear_decode_residual(x.ptr, w.ptr, r.ptr, y.ptr, B, K, N, K, K, N, N, 1, None),
+                 2: lambda w: L.atoma_linear_decode_silu_mul(x.ptr, w.ptr, y.ptr, B, K, N // 2, K, K, N // 2, 1, None)}
+
+        def vendor(w, with_epilogue):
+            rc = L.atoma_linear(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None)
+            if with_epilogue and ep == 1:
+                rc |= L.atoma_add(y.ptr, r.ptr, y2.ptr, B * N, 1, None)
+            if with_epilogue and ep == 2:
+                rc |= L.atoma_silu_mul(y.ptr, y.ptr + N, y2.ptr, B, N // 2, N, N, N // 2, 1, None)
+            return rc
+        times = {v[0]: [] for v in variants}
+        for rnd in range(ROUNDS + 1):
+            for vname, opts in variants:
+                for k, v in DEFAULTS.items():
+                    assert L.atoma_set_option(k.encode(), opts.get(k, v)) == 0
+                a, b = ah.Event(), ah.Event()
+                fn = (lambda w, m=opts["vendor"]: vendor(w, m == 2)) if opts.get("vendor") else calls[ep]
+                assert fn(ws[0]) == 0, ah.last_error()
+                ah.synchronize()
+                a.record(None)
+                for i in range(ITERS):
+                    fn(ws[i % nbuf])
+                b.record(None)
+                b.synchronize()
+                if rnd > 0:
+                    times[vname].append(a.elapsed_ms(b) / ITERS * 1e3)
+        for k, v in DEFAULTS.items():
+            L.atoma_set_option(k.encode(), v)
+        for vname, _ in variants:
+            t = times[vname]
+            if t:
+                print(json.dumps({"shape": f"{name} [{N} x {K}] batch {B}", "variant": vname, "median_us": round(float(np.median(t)), 2), "min_us": round(min(t), 2),
+                                  "GBps_W": round(N * K * 2 / np.median(t) / 1e3), "TFLOPs": round(2 * B * N * K / np.median(t) / 1e6)}), flush=True)
+        for w in ws:
+            w.free()
+
+
+if __name__ == "__main__":
+    main()
