@@ -48,11 +48,12 @@ template <> __device__ __forceinline__ float hi_to_f32<f16_t>(uint32_t p) {
 
 // round-to-nearest-even f32 -> 16-bit storage
 template <typename T> __device__ __forceinline__ uint32_t f32_to_bits(float f);
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round to nearest even; a NaN stays a quiet NaN): one instruction for two values where the
+// integer sequence (NaN test, bias, carry, shift) took six per value -- round 6: the RoPE epilogue of the 256-row q/k/v projection spent
+// ~4 us of a 38 us launch in those sequences (10 roundings per rotated pair)
+typedef __attribute__((ext_vector_type(2))) float f32x2_v;
 template <> __device__ __forceinline__ uint32_t f32_to_bits<bf16_t>(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_v{f, 0.f}, bf16x2_v)) & 0xffffu;
 }
 template <> __device__ __forceinline__ uint32_t f32_to_bits<f16_t>(float f) {
     _Float16 h = (_Float16)f;  // v_cvt_f16_f32, RNE
@@ -61,8 +62,14 @@ template <> __device__ __forceinline__ uint32_t f32_to_bits<f16_t>(float f) {
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     return f32_to_bits<T>(lo) | (f32_to_bits<T>(hi) << 16);
 }
+template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_v{lo, hi}, bf16x2_v));
+}
 template <typename T> __device__ __forceinline__ float round_through(float f) {
     return lo_to_f32<T>(f32_to_bits<T>(f));
+}
+template <> __device__ __forceinline__ float round_through<bf16_t>(float f) {
+    return __uint_as_float(__builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_v{f, 0.f}, bf16x2_v)) << 16);
 }
 
 // acc += a.lo*b.lo + a.hi*b.hi on packed 16-bit pairs: v_dot2c_f32_bf16 / v_dot2c_f32_f16

@@ -137,6 +137,18 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
 #pragma unroll
         for (int b = 0; b < BTW; ++b) acc[a][b] = lf32x4{0.f, 0.f, 0.f, 0.f};
     const int bt0 = bq * BTW;                                      // first batch tile of the wavefront
+    // RoPE epilogue: the token's cache slot and (clamped) position are fetched NOW, ahead of the K loop -- the epilogue runs in the last
+    // arriver only, behind the merge, where a chain slot -> position -> table row -> store would be pure latency (measured: 7.5 us of a 38 us launch)
+    int64_t rope_slot[BTW], rope_pos[BTW];
+    if constexpr (MODE == WIDE_ROPE) {
+#pragma unroll
+        for (int b = 0; b < BTW; ++b) {
+            const int brow = min(16 * (bt0 + b) + col, p.batch - 1);
+            rope_slot[b] = tp.rope.slot_mapping[brow];
+            const int64_t pos = tp.rope.positions[brow];
+            rope_pos[b] = tp.rope.table_rows > 0 ? (pos < 0 ? 0 : (pos >= tp.rope.table_rows ? tp.rope.table_rows - 1 : pos)) : pos;      // rope_pos() of norm_rope.hip
+        }
+    }
     int live = 0;                                                  // batch tiles of this wavefront that hold rows of the batch
 #pragma unroll
     for (int b = 0; b < BTW; ++b) live += 16 * (bt0 + b) < p.batch ? 1 : 0;
@@ -169,9 +181,22 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
         slot = slot + 1 == NSLOT ? 0 : slot + 1;
     }
     // lane holds y^T[tile row grow[a] + 4.grp + i][batch row 16.(bt0 + b) + col]
+    // RoPE epilogue: ALL table reads of the lane up front (the epilogue's stores may alias the tables as far as the compiler knows, so reads
+    // left inside the store loop wait one round trip per (pair, batch tile): 8 x ~0.9 us, measured); their latency rides under the merge
+    uint2 rope_cw[GPW / 2][BTW], rope_sw[GPW / 2][BTW];
+    if constexpr (MODE == WIDE_ROPE) {
+        const int tph = half / (NW / 2);
+#pragma unroll
+        for (int b = 0; b < BTW; ++b)
+#pragma unroll
+            for (int a = 0; a < GPW / 2; ++a) {
+                const int j0 = grow[a] + (tile % tph) * (NW / 2) + 4 * grp;
+                rope_cw[a][b] = *reinterpret_cast<const uint2 *>(tp.rope.cos_t + rope_pos[b] * half + j0);
+                rope_sw[a][b] = *reinterpret_cast<const uint2 *>(tp.rope.sin_t + rope_pos[b] * half + j0);
+            }
+    }
     if (tp.splits > 1) {
-        // publish this workgroup's fp32 tile write-through, drain, take a ticket; the LAST arriver adds the tiles in split order (its own from
-        // registers at its own place) and finishes -- linear_tile.hip's merge
+        // publish this workgroup's fp32 tile write-through, drain, take a ticket; the LAST arriver adds the tiles in split order and finishes -- linear_tile.hip's merge
         const int S = tp.splits;
         constexpr int F = GPW * BTW;
         float *mine = tp.slabs + ((int64_t)(tile * S + split) * WAVES + wave) * F * 256;
@@ -187,23 +212,25 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
         if (tid == 0) *ticket = sync_arrive(tp.counters + tile, sync_epoch(), (unsigned)S);
         __syncthreads();
         if (*ticket + 1 != (unsigned)S) return;
-        lf32x4 tot[GPW][BTW];
-        for (int sp = 0; sp < S; ++sp) {
-            float *theirs = tp.slabs + ((int64_t)(tile * S + sp) * WAVES + wave) * F * 256;
-            const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc(theirs, 0, F * 1024, 0x00020000);
+        // (its own tile comes back from memory like the others: the fp32 registers are free for the sum, and the order is split order anyway)
+        // two splits' loads in flight together (the second descriptor is empty past the last split: its loads return zeros, no branch)
+        for (int sp = 0; sp < S; sp += 2) {
+            float *t0 = tp.slabs + ((int64_t)(tile * S + sp) * WAVES + wave) * F * 256;
+            const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(t0, 0, F * 1024, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(t0 + WAVES * F * 256, 0, sp + 1 < S ? F * 1024 : 0, 0x00020000);
+            lf32x4 o0[GPW][BTW], o1[GPW][BTW];
 #pragma unroll
             for (int a = 0; a < GPW; ++a)
 #pragma unroll
                 for (int b = 0; b < BTW; ++b) {
-                    lf32x4 o = acc[a][b];
-                    if (sp != split) o = __builtin_bit_cast(lf32x4, __builtin_amdgcn_raw_buffer_load_b128(tr, ((a * BTW + b) * 64 + lane) * 16, 0, 16 /* sc1 */));
-                    tot[a][b] = sp == 0 ? o : tot[a][b] + o;
+                    o0[a][b] = __builtin_bit_cast(lf32x4, __builtin_amdgcn_raw_buffer_load_b128(r0, ((a * BTW + b) * 64 + lane) * 16, 0, 16 /* sc1 */));
+                    o1[a][b] = __builtin_bit_cast(lf32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, ((a * BTW + b) * 64 + lane) * 16, 0, 16 /* sc1 */));
                 }
+#pragma unroll
+            for (int a = 0; a < GPW; ++a)
+#pragma unroll
+                for (int b = 0; b < BTW; ++b) acc[a][b] = (sp == 0 ? o0[a][b] : acc[a][b] + o0[a][b]) + o1[a][b];
         }
-#pragma unroll
-        for (int a = 0; a < GPW; ++a)
-#pragma unroll
-            for (int b = 0; b < BTW; ++b) acc[a][b] = tot[a][b];
     }
 #pragma unroll
     for (int b = 0; b < BTW; ++b) {
@@ -215,9 +242,7 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
             const int tph = half / (NW / 2);
             const int head = tile / tph;
             const bool is_v = head >= rp.heads_q + rp.heads_kv, is_k = !is_v && head >= rp.heads_q;
-            const int64_t slot_ix = rp.slot_mapping[brow];
-            int64_t pos = rp.positions[brow];
-            pos = rp.table_rows > 0 ? (pos < 0 ? 0 : (pos >= rp.table_rows ? rp.table_rows - 1 : pos)) : pos;      // rope_pos() of norm_rope.hip
+            const int64_t slot_ix = rope_slot[b];
             const int64_t crow = slot_ix >= 0 ? (slot_ix / rp.page_size) * rp.block_stride + (slot_ix % rp.page_size) * (int64_t)rp.heads_kv * rp.head_dim : 0;
 #pragma unroll
             for (int a = 0; a < GPW / 2; ++a) {
@@ -231,7 +256,7 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
                     for (int i = 0; i < 4; ++i) { y1[i] = x1[i]; y2[i] = x2[i]; }
                 } else {
 #pragma clang fp contract(off)
-                    const uint2 cw = *reinterpret_cast<const uint2 *>(rp.cos_t + pos * half + j0), sw = *reinterpret_cast<const uint2 *>(rp.sin_t + pos * half + j0);
+                    const uint2 cw = rope_cw[a][b], sw = rope_sw[a][b];
                     const float cs[4] = {lo_to_f32<T>(cw.x), hi_to_f32<T>(cw.x), lo_to_f32<T>(cw.y), hi_to_f32<T>(cw.y)};
                     const float sn[4] = {lo_to_f32<T>(sw.x), hi_to_f32<T>(sw.x), lo_to_f32<T>(sw.y), hi_to_f32<T>(sw.y)};
 #pragma unroll
@@ -310,7 +335,7 @@ bool set_linear_wide_option(const std::string &name, int value) {
 // Rows per workgroup and K split from the SHAPE OF W (and the batch tile) alone, priced with the queue model in the header: a workgroup's
 // time = (weight KB x 2.0 us + x KB x 0.6 us) / 45 KB, plus ~1.5 us + the slabs the last arriver reads back at ~50 KB/us for an in-launch
 // merge, times the rounds of workgroups over the CUs.  8B at 256 rows: gate/up (128 rows, 1 split, 224 workgroups), down (64, 4, 256),
-// q/k/v (64, 2, 192), o (64, 4, 256).
+// q/k/v (64, 2, 192), o (64, 4, 256).  The plan must NOT depend on the epilogue: the fused entries are bit-identical to projection + separate op only because both split K alike.
 constexpr int WIDE_MAX_MERGE = 8;
 static void wide_plan(int64_t n, int64_t k, int br, int cus, int *nw_out, int *splits_out) {
     const int64_t chunks = k / 64;
@@ -322,7 +347,8 @@ static void wide_plan(int64_t n, int64_t k, int br, int cus, int *nw_out, int *s
             const int64_t wgs = n / nw * s;
             const double kb = (double)cdiv(chunks, s) * 128.0 / 1024.0;
             const double merge = s == 1 ? 0.0 : 1.5 + (double)(s - 1) * (nw * br * 4 / 1024.0) / 50.0;
-            const double t = (double)cdiv(wgs, cus) * ((nw * kb * 2.0 + br * kb * 0.6) / 45.0 + merge);
+            const double tail = nw * br / 8192.0;      // the epilogue of a tile runs in ONE workgroup (measured: the RoPE epilogue of a 128 x 256 tile ~8 us, of a 64 x 256 tile ~3)
+            const double t = (double)cdiv(wgs, cus) * ((nw * kb * 2.0 + br * kb * 0.6) / 45.0 + merge + tail);
             if (t < best_t) { best_t = t; best_nw = nw; best_s = s; }
         }
     *nw_out = best_nw;

@@ -48,15 +48,17 @@ class DecodeStep:
         self.after_attention = None                        # optional callable(layer), invoked right after a layer's attention call is enqueued (probes: staggering two half-batches)
         # Residual adds, SiLU.up (and at 1 row the RMSNorms) inside the library's own projection kernels.  Up to 128 rows that is the
         # faster step although the vendor GEMM wins most of the single products from 5 rows up (three launches per layer fewer:
-        # batch 8 5.17 -> 4.62 ms, 32 7.58 -> 6.96, 64 11.2 -> 10.3, 96 14.9 -> 14.6, 128 16.9 -> 16.8; at 256 rows 19.4 -> 20.1, so
-        # the C3 batch stays on the vendor GEMM); a TP rank must all-reduce before the residual.
-        own_ok = fused_epilogues and not keep_intermediates and batch <= int(os.environ.get("ATOMA_STEP_FUSED_MAX_BATCH", "128"))
+        # batch 8 5.17 -> 4.62 ms, 32 7.58 -> 6.96, 64 11.2 -> 10.3, 96 14.9 -> 14.6, 128 16.9 -> 16.8; at 256 rows round 2's
+        # linear_big_kernel lost (19.4 -> 20.1), round 6's linear_wide_kernel is level with the vendor GEMM product for product and ahead on the
+        # step: 18.88 -> 18.73 ms with NO vendor kernel left in it (tools/probes/c3_own_vs_vendor.py); a TP rank must
+        # all-reduce before the residual.
+        own_ok = fused_epilogues and not keep_intermediates and batch <= int(os.environ.get("ATOMA_STEP_FUSED_MAX_BATCH", "256"))
         self.fused = own_ok and allreduce is None
         # A tensor-parallel rank: the library's own projection kernels as well -- q/k/v with RoPE and the cache write behind one entry,
         # gate/up with SiLU.up inside; o and down stay plain (their outputs are partial sums: the all-reduce comes before the residual)
         self.tp_own = own_ok and allreduce is not None
         # own_projections: the op-by-op path on atoma_linear_decode at every batch (tests: the fused step must equal it bit for bit)
-        self.linear = ah.lib.atoma_linear_decode if (own_projections or self.tp_own) else ah.lib.atoma_linear
+        self.linear = ah.lib.atoma_linear_decode if (own_projections or self.tp_own or (self.fused and batch > 128)) else ah.lib.atoma_linear
         # 17..256 rows on the fused path: the q/k/v projection, RoPE and the cache write behind one entry (atoma_linear_decode_qkv_rope_cache)
         self.qkv_fused = (self.fused or self.tp_own) and 16 < batch <= 256 and os.environ.get("ATOMA_STEP_QKV_FUSED", "1") != "0"
         self.norm_in_proj = os.environ.get("ATOMA_STEP_NORM_IN_PROJ", "1") != "0"   # fused path: RMSNorm inside the q/k/v and gate/up projections (A/B switch)

@@ -17,7 +17,7 @@ rng = np.random.default_rng(9)
 w = BE.TS.random_shard_weights(rng, BE.DS.LLAMA_3_1_8B)
 res = {"own": [], "vendor": []}
 for r in range(rounds):
-    for mode, mb in (("vendor", "128"), ("own", "256")):
+    for mode, mb in (("vendor", "128"), ("own", "256")):      # 128: the vendor GEMM above 128 rows (the default up to round 5)
         os.environ["ATOMA_STEP_FUSED_MAX_BATCH"] = mb
         out = BE.c3_decode_step(iters=10, weights=w)
         res[mode].append(out["ms_per_step"])

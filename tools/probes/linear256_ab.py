@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench_kernels as bk  # noqa: E402
 
 ah = bk.ah
-SHAPES = {"qkv": (6144, 4096, 0), "o": (4096, 4096, 1), "gate_up": (28672, 4096, 2), "down": (4096, 14336, 1)}
+SHAPES = {"qkv": (6144, 4096, 0), "o": (4096, 4096, 1), "gate_up": (28672, 4096, 2), "down": (4096, 14336, 1), "qkv_rope": (6144, 4096, 3), "lm_head": (128256, 4096, 0)}
 VARIANTS = [("wide", {}), ("wide nw64", {"linear_wide_nw": 64}), ("wide nw128", {"linear_wide_nw": 128}),
             ("wide s1", {"linear_wide_splits": 1}), ("wide s2", {"linear_wide_splits": 2}), ("wide s4", {"linear_wide_splits": 4}), ("wide s8", {"linear_wide_splits": 8}),
             ("wide nw128 s4", {"linear_wide_nw": 128, "linear_wide_splits": 4}), ("wide nw128 s8", {"linear_wide_nw": 128, "linear_wide_splits": 8}),
@@ -52,6 +52,21 @@ def main():
             if with_epilogue and ep == 2:
                 rc |= L.atoma_silu_mul(y.ptr, y.ptr + N, y2.ptr, B, N // 2, N, N, N // 2, 1, None)
             return rc
+        if ep == 3:       # q/k/v projection + RoPE + KV-cache write (32 / 8 heads of 128): one entry against vendor GEMM + atoma_rope_qk_cache
+            h, hk, d, page, nb = 32, 8, 128, 16, 64
+            cos, sin = bk.rand_dev(rng, 8192 * d), bk.rand_dev(rng, 8192 * d)
+            pos = ah.DeviceBuffer.from_numpy((rng.integers(0, 8192, B) * (0 if os.environ.get("L256_POS0") else 1)).astype(np.int64))
+            slots = ah.DeviceBuffer.from_numpy(np.full(B, -1, np.int64) if os.environ.get("L256_NOSLOTS") else rng.permutation(nb * page)[:B].astype(np.int64))
+            kc, vc = ah.DeviceBuffer(nb * page * hk * d * 2), ah.DeviceBuffer(nb * page * hk * d * 2)
+            calls[3] = lambda w: L.atoma_linear_decode_qkv_rope_cache(x.ptr, w.ptr, y.ptr, kc.ptr, vc.ptr, slots.ptr, cos.ptr, sin.ptr, pos.ptr, B, K, h, hk, d, K, K, N,
+                                                                      page * hk * d, page, 1, 1, None)
+
+            def vendor(w, with_epilogue):   # noqa: F811
+                rc = L.atoma_linear(x.ptr, w.ptr, y.ptr, B, K, N, K, K, N, 1, None)
+                if with_epilogue:
+                    rc |= L.atoma_rope_qk_cache(y.ptr, y.ptr + h * d * 2, y.ptr + (h + hk) * d * 2, kc.ptr, vc.ptr, slots.ptr, cos.ptr, sin.ptr, pos.ptr, B, h, hk, d,
+                                                N, N, N, page * hk * d, page, 1, 1, None)
+                return rc
         times = {v[0]: [] for v in variants}
         for rnd in range(ROUNDS + 1):
             for vname, opts in variants:
