@@ -113,6 +113,7 @@ _opt("atoma_xgmi_allreduce_add_rms_norm", [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _
 _opt("atoma_allreduce_add_rms_norm", [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _int, _vp])
 _opt("atoma_warmup_prefill", [_vp, _i64, _i64, _i64])
 _opt("atoma_debug_sync_words", [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)])
+_opt("atoma_debug_workspace", [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)])
 _opt("atoma_debug_launch_epoch", [_vp, _vp])
 _opt("atoma_rms_norm", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _int, _vp])
 _opt("atoma_add_rms_norm", [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _int, _vp])
@@ -179,6 +180,7 @@ hip.hipFree.argtypes = [_vp]
 hip.hipMemcpy.argtypes = [_vp, _vp, C.c_size_t, _int]
 hip.hipMemset.argtypes = [_vp, _int, C.c_size_t]
 hip.hipMemcpyAsync.argtypes = [_vp, _vp, C.c_size_t, _int, _vp]
+hip.hipMemsetAsync.argtypes = [_vp, _int, C.c_size_t, _vp]
 hip.hipEventCreate.argtypes = [C.POINTER(_vp)]
 hip.hipEventRecord.argtypes = [_vp, _vp]
 hip.hipEventSynchronize.argtypes = [_vp]

@@ -243,7 +243,7 @@ int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, in
 }
 
 // llama_nccl.rs:139 -> llama.rs:404,408 (and :195 -> :409, next layer's :402): x_out = residual + allreduce(in), norm_out = RMSNorm(x_out) * weight.
-// Direct engine: ONE launch (atoma_xgmi_allreduce_add_rms_norm); RCCL engine: ncclAllReduce into x_out, then atoma_add_rms_norm over it.
+// Direct engine: ONE launch (atoma_xgmi_allreduce_add_rms_norm); RCCL engine: ncclAllReduce into norm_out (scratch), then atoma_add_rms_norm.
 // Both engines end with the bits of "all-reduce, then atoma_add_rms_norm" of that engine.  in / x_out contiguous [rows, hidden].
 int atoma_allreduce_add_rms_norm(void *comm, const void *in, const void *residual, const void *weight, void *x_out, void *norm_out, int64_t rows,
                                  int64_t hidden, float eps, int dtype, void *stream) {
@@ -253,10 +253,28 @@ int atoma_allreduce_add_rms_norm(void *comm, const void *in, const void *residua
     if (rows <= 0) return 0;
     auto *c = static_cast<atoma::Comm *>(comm);
     const int64_t bytes = rows * hidden * 2;
-    if (c->mode != atoma::AR_RCCL && c->xgmi && bytes <= atoma_xgmi_capacity(c->xgmi) && (c->mode == atoma::AR_XGMI || bytes <= c->xgmi_auto_max))
+    // aliasing contract (atoma_hip.h): x_out may be `residual` (the natural in-place x += allreduce(partial)) and may be `in`; norm_out is
+    // written last and must not overlap `in`, `residual` or x_out
+    auto overlaps = [&](const void *a, const void *b) {
+        const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+        return a && b && x < y + (uintptr_t)bytes && y < x + (uintptr_t)bytes;
+    };
+    if (overlaps(norm_out, in) || overlaps(norm_out, residual) || overlaps(norm_out, x_out)) {
+        atoma::set_error("atoma_allreduce_add_rms_norm: norm_out must not overlap in, residual or x_out");
+        return -1;
+    }
+    // the direct engine moves 16-byte pieces: anything it cannot take in AUTO mode goes to RCCL, as in atoma_allreduce_sum
+    const bool fits = c->xgmi && bytes % 16 == 0 && bytes <= atoma_xgmi_capacity(c->xgmi) &&
+                      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(weight) |
+                        reinterpret_cast<uintptr_t>(x_out) | reinterpret_cast<uintptr_t>(norm_out)) & 15u) == 0;
+    if (c->mode == atoma::AR_XGMI || (c->mode != atoma::AR_RCCL && fits && bytes <= c->xgmi_auto_max)) {
+        if (!c->xgmi) { atoma::set_error("atoma_allreduce_add_rms_norm: the direct xGMI path is unavailable: " + c->xgmi_note); return -1; }
         return atoma_xgmi_allreduce_add_rms_norm(c->xgmi, in, residual, weight, x_out, norm_out, rows, hidden, hidden, hidden, hidden, eps, dtype, 0, stream);
-    if (atoma_allreduce_sum(comm, in, x_out, rows * hidden, dtype, stream) != 0) return -1;
-    return atoma_add_rms_norm(residual, x_out, weight, x_out, norm_out, rows, hidden, hidden, hidden, hidden, hidden, eps, dtype, stream);
+    }
+    // RCCL engine: the sum lands in norm_out (scratch until the norm overwrites it row by row, each row read before it is written), so that
+    // `residual` is still intact when x_out == residual (reducing into x_out first silently turned x += sum into x = 2 * sum)
+    if (atoma_allreduce_sum(comm, in, norm_out, rows * hidden, dtype, stream) != 0) return -1;
+    return atoma_add_rms_norm(residual, norm_out, weight, x_out, norm_out, rows, hidden, hidden, hidden, hidden, hidden, eps, dtype, stream);
 }
 
 int atoma_comm_destroy(void *comm) {

@@ -955,7 +955,10 @@ static bool attn_prefill_tile16_applicable(const AttnParams &p) {
                             p.q_batch_stride | p.o_batch_stride | p.k_batch_stride | p.v_batch_stride;
     return p.seqlen_q > 1 && p.d >= 16 && p.d <= 256 && p.d % 16 == 0 && p.h % p.h_k == 0 && strides % 8 == 0 &&
            ((reinterpret_cast<uintptr_t>(p.q) | reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(p.v) | reinterpret_cast<uintptr_t>(p.o)) & 15u) == 0 &&
-           attn_prefill_tile_choice() != 0;
+           attn_prefill_tile_choice() != 0 &&
+           // the tiled kernels keep scores raw and fold the scale into the exp2 argument (max(raw) * scale): positive finite scales only; a
+           // zero, negative or non-finite softmax_scale takes the row-per-wavefront kernel, which handles any finite scale as the reference does
+           p.scale_log2 > 0.f && p.scale_log2 < INFINITY;
 }
 
 static bool attn_decode_anyd_applicable(const AttnParams &p) {

@@ -173,7 +173,16 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
         if (!ok) return -1;
         if (found < 1) { set_error("linear: hipBLASLt has no algorithm for this problem"); return -1; }
         int best = 0;
+        // The timing runs synchronise with the stream (hipEventSynchronize) -- WITHOUT the lock (with several ranks driven from one
+        // process a rank's stream may be waiting for an all-reduce whose peer's thread wants this lock: the deadlock the cached-plan path was
+        // cured of in round 5).  The handle and the workspace are this stream's own and the plan is not in the cache yet; two threads that tune
+        // the same problem at once both finish and the second insert below is dropped.
+        hipblasLtHandle_t tune_handle = handle;
+        void *tune_ws = lt_ws;
+        lock.unlock();
         if (found > 1 && capturing == hipStreamCaptureStatusNone) {
+            hipblasLtHandle_t handle = tune_handle;   // (shadows the map references: nothing below touches the maps)
+            void *lt_ws = tune_ws;
             const float alpha = 1.f, beta = 0.f;
             hipEvent_t e0, e1;
             (void)hipEventCreate(&e0);
@@ -215,6 +224,7 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
         }
+        lock.lock();
         pl.algo = res[best].algo;
         pl.workspace = res[best].workspaceSize;
         if (found > 1 && capturing != hipStreamCaptureStatusNone) {
@@ -224,8 +234,9 @@ static int gemm_tn(const void *x, const void *w, void *y, int64_t batch, int64_t
             return lt_ok(api.matmul(handle, pl.desc, &alpha1, w, pl.a, x, pl.b, &beta0, y, pl.c, y, pl.c, &pl.algo, lt_ws,
                                     LT_WORKSPACE_BYTES, stream), "Matmul") ? 0 : -1;
         }
-        guard.keep = true;
-        it = d.plans.emplace(key, pl).first;
+        auto ins = d.plans.emplace(key, pl);
+        guard.keep = ins.second;                 // lost the race against another thread tuning the same problem: its plan stays, ours is released
+        it = ins.first;
     }
     const GemmPlan pl = it->second;             // descriptors and layouts are immutable once cached; the handle and the workspace are this stream's own
     hipblasLtHandle_t h = handle;

@@ -262,11 +262,15 @@ static bool pfa_attrs_for_device() {
 }
 bool prefill_asm_prepare() { return pfa_attrs_for_device(); }
 
-// bytes of the persistent kernel's plan table for `tokens` query rows in all, at most `seqs` sequences, `heads` q heads (an upper
-// bound: every sequence may end in a partly filled 256-row block) -- what atoma_warmup adds to the stream's scratch
-size_t prefill_asm_workspace_bound(int64_t tokens, int64_t seqs, int64_t heads) {
-    const int64_t m_blocks = cdiv(tokens, PFA_BM) + seqs, nu_max = cdiv(heads, 8) + 1;
-    return (size_t)(8 * nu_max * m_blocks) * 4 * PFA_PARAM_DWORDS * 4;
+// entries of the persistent kernel's plan table for a call with `seqs` sequences, `heads` q heads and a longest sequence of `max_seqlen_q` rows:
+// the table is padded to (units rounded up to 8) x (256-row blocks of the LONGEST sequence) -- prefill_map.h.  ONE formula for launch_pfa and
+// atoma_warmup_prefill (the warm-up's own estimate, tokens / 256 + seqs blocks, was far too small for ragged batches).
+static int64_t pfa_table_entries(int64_t seqs, int64_t heads, int64_t max_seqlen_q) {
+    const int64_t n_units = seqs * heads;
+    return 8 * cdiv(n_units, 8) * cdiv(max_seqlen_q, PFA_BM);
+}
+size_t prefill_asm_workspace_bound(int64_t max_seqlen_q, int64_t seqs, int64_t heads) {
+    return (size_t)pfa_table_entries(seqs, heads, max_seqlen_q) * 4 * PFA_PARAM_DWORDS * 4;
 }
 
 // The fast arithmetic rounds q . scale . log2(e) to the storage type once per block (header of this file): safe while that factor neither
@@ -279,9 +283,7 @@ template <bool BF16> static int pfa_exact_keys_for(const AttnParams &p) {
 
 template <bool BF16>
 static int launch_pfa(const AttnParams &p, hipStream_t stream) {
-    const int64_t m_blocks = cdiv(p.seqlen_q, PFA_BM), n_units = (int64_t)p.b * p.h;
-    const int64_t nu_max = n_units / 8 + (n_units % 8 ? 1 : 0);
-    const int64_t n_entries = 8 * nu_max * m_blocks;   // padded: see prefill_map.h
+    const int64_t n_entries = pfa_table_entries(p.b, p.h, p.seqlen_q);   // padded: see prefill_map.h
     if (!pfa_attrs_for_device()) return -1;
     const int exact_keys = pfa_exact_keys_for<BF16>(p);
     if (p.block_table) {

@@ -142,7 +142,7 @@ const char *last_decode_kernel();                                               
 bool linear_tile_prepare();                                                          // linear_tile.hip
 bool linear_wide_prepare();                                                          // linear_wide.hip
 bool prefill_asm_prepare();                                                          // prefill_asm.hip: the kernels' 160 KiB LDS opt-in on this device
-size_t prefill_asm_workspace_bound(int64_t tokens, int64_t seqs, int64_t heads);     // prefill_asm.hip: plan table of the persistent prefill kernel
+size_t prefill_asm_workspace_bound(int64_t max_seqlen_q, int64_t seqs, int64_t heads);     // prefill_asm.hip: plan table of the persistent prefill kernel
 int release_gemm_workspaces();                                                       // linear_gemm.hip
 
 // /root/reference/csrc/src/lib.rs:2122-2167, f32 arithmetic as there.
@@ -220,14 +220,14 @@ int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num
     return atoma::workspace(static_cast<hipStream_t>(stream), need) ? 0 : -1;
 }
 
-int atoma_warmup_prefill(void *stream, int64_t max_tokens, int64_t max_seqs, int64_t num_heads) {
+int atoma_warmup_prefill(void *stream, int64_t max_seqlen_q, int64_t max_seqs, int64_t num_heads) {
     atoma::clear_error();
-    if (max_tokens <= 0 || max_seqs <= 0 || num_heads <= 0) {
+    if (max_seqlen_q <= 0 || max_seqs <= 0 || num_heads <= 0) {
         atoma::set_error("atoma_warmup_prefill: invalid shape");
         return -1;
     }
     if (!atoma::prefill_asm_prepare()) return -1;
-    return atoma::workspace(static_cast<hipStream_t>(stream), atoma::prefill_asm_workspace_bound(max_tokens, max_seqs, num_heads)) ? 0 : -1;
+    return atoma::workspace(static_cast<hipStream_t>(stream), atoma::prefill_asm_workspace_bound(max_seqlen_q, max_seqs, num_heads)) ? 0 : -1;
 }
 
 namespace atoma {
@@ -249,6 +249,23 @@ int atoma_debug_sync_words(void *stream, void **words_out, int64_t *count_out) {
     if (!p) return -1;
     if (words_out) *words_out = p;
     if (count_out) *count_out = (int64_t)atoma::SYNC_COUNTERS;
+    return 0;
+}
+
+// tests: the stream's current scratch block (split / merge partials, slabs, plan tables) -- to fill it with poison between launches
+int atoma_debug_workspace(void *stream, void **ptr_out, int64_t *bytes_out) {
+    atoma::clear_error();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(*atoma::g_ws_mu);
+    for (auto &w : atoma::g_ws)
+        if (w.device == dev && w.stream == static_cast<hipStream_t>(stream)) {
+            if (ptr_out) *ptr_out = w.ptr;
+            if (bytes_out) *bytes_out = (int64_t)w.bytes;
+            return 0;
+        }
+    if (ptr_out) *ptr_out = nullptr;
+    if (bytes_out) *bytes_out = 0;
     return 0;
 }
 

@@ -323,7 +323,10 @@ int atoma_sample_rows(const void *logits, int64_t rows, int64_t vocab, int64_t r
 int atoma_comm_unique_id(void *id128_out);
 int atoma_comm_init(void **comm_out, int rank, int world_size, const void *id128, int device);
 int atoma_allreduce_sum(void *comm, const void *in, void *out, int64_t count, int dtype, void *stream);
-/* ... and through a communicator: the direct engine runs the fused launch above, the RCCL engine ncclAllReduce + atoma_add_rms_norm. */
+/* ... and through a communicator: the direct engine runs the fused launch above, the RCCL engine ncclAllReduce + atoma_add_rms_norm.
+ * Aliasing: x_out may be `residual` (in-place x += allreduce(partial)) or `in`; norm_out must not overlap in / residual / x_out (checked:
+ * the RCCL engine reduces into norm_out as scratch before the norm overwrites it).  In auto mode operands the direct engine cannot take
+ * (not 16-byte aligned, larger than its staging region) go to RCCL, as in atoma_allreduce_sum. */
 int atoma_allreduce_add_rms_norm(void *comm, const void *in, const void *residual, const void *weight, void *x_out, void *norm_out,
                                  int64_t rows, int64_t hidden, float eps, int dtype, void *stream);
 int atoma_comm_destroy(void *comm);
@@ -455,16 +458,18 @@ const char *atoma_last_decode_kernel(void);
  *     block: replay a graph on the stream it was captured on.  atoma_reset_sync_counters (round 4's repair call) is kept and harmless;
  *     nothing needs it.  atoma_debug_sync_words exposes the words to tests (which fill them with garbage and expect identical bits).
  *   - atoma_warmup_prefill: the hand-scheduled prefill kernel (head_dim 128) plans a call in a table of 1 KiB per 256 query rows and
- *     q head in the same scratch block; size it for the largest prefill call (tokens in all, sequences, q heads) before capturing a
- *     graph that contains one.  A prefill whose table cannot be allocated launches nothing and says so in atoma_last_error().
+ *     q head in the same scratch block, padded to sequences x the LONGEST sequence's blocks; size it for the largest prefill call
+ *     (longest sequence's query rows, sequences, q heads) before capturing a graph that contains one.  A prefill whose table cannot be allocated launches nothing and says so in atoma_last_error().
  * The device is the calling thread's current device (hipSetDevice), as for every entry point. */
 int atoma_warmup(void *stream, int64_t max_batch, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, int64_t max_seqlen_k,
                  int64_t extra_bytes);
 int atoma_reserve_workspace(void *stream, int64_t bytes);
 int atoma_release_workspaces(void);
 int atoma_reset_sync_counters(void *stream);
-int atoma_warmup_prefill(void *stream, int64_t max_tokens, int64_t max_seqs, int64_t num_heads);
+int atoma_warmup_prefill(void *stream, int64_t max_seqlen_q, int64_t max_seqs, int64_t num_heads);
 int atoma_debug_sync_words(void *stream, void **words_out, int64_t *count_out);
+/* tests: the stream's current scratch block (null / 0 when it has none yet): filled with poison between launches by the merge stress tests */
+int atoma_debug_workspace(void *stream, void **ptr_out, int64_t *bytes_out);
 /* Diagnostics of the arrival tickets: writes the epoch word of ONE tiny launch on `stream` (its AQL dispatch id + 1, shifted by 16) to
  * *epoch_out_device (8 bytes of device memory).  Tests use it to show that epochs grow from launch to launch, also under graph replay. */
 int atoma_debug_launch_epoch(void *stream, void *epoch_out_device);

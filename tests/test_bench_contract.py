@@ -51,6 +51,16 @@ def test_committed_bench_line_has_the_contract_fields():
     assert set(d["cpu_baseline"]["placement"]) >= {"OMP_PROC_BIND", "numa_nodes", "cgroup_cpu_max", "cpus_allowed"}
 
 
+# Performance floors: by default only WIDE margins that a functional regression breaks (a fallback kernel, a serialised launch:
+# factors, not per cent) -- a correctness suite must not flake on a noisy or shared box.  ATOMA_TEST_PERF_FLOORS=1 turns on the tight floors
+# (within ~5 % of what the pool's boxes measure), for the builder's own regression runs.
+STRICT = os.environ.get("ATOMA_TEST_PERF_FLOORS", "0") == "1"
+
+
+def floor(strict, loose):
+    return strict if STRICT else loose
+
+
 @pytest.mark.gpu
 def test_bench_py_prints_one_json_line(gpu):
     """the headline on a short schedule, with the CPU leg: the line's fields, the north_star fraction, and the check of what the timed
@@ -64,7 +74,7 @@ def test_bench_py_prints_one_json_line(gpu):
     d = json.loads(lines[0])
     check_line(d, full=False)
     assert d["steps"] == 5 and d["warmup"] == 2 and d["n_gpus"] == 1
-    assert d["roofline"]["frac"] >= 0.80          # north_star asks >= 0.70; 0.834-0.855 measured over the boxes of the pool in round 5 (round 4's regressed binary: 0.798-0.808)
+    assert d["roofline"]["frac"] >= floor(0.80, 0.70)   # north_star asks >= 0.70; 0.83-0.855 measured over the boxes of the pool in rounds 5-6 (round 4's regressed binary: 0.798-0.808)
     assert "G=4" in d["roofline"]["kernel"]
     v = d["verified"]
     assert v["ok"] is True and v["sequences"] == 4 and v["max_err"] < 0.05
@@ -79,11 +89,11 @@ def test_bench_extras_hold_their_floors(gpu):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert all("error" not in v for v in d.values()), d
-    assert d["swap"]["gpu_to_cpu_frac_of_memcpy"] >= 0.85 and d["swap"]["cpu_to_gpu_frac_of_memcpy"] >= 0.85, d["swap"]
-    assert d["c4_rank_step"]["ms_per_step"] <= 9.5 and d["c4_rank_step"]["frac_of_hbm_roofline"] >= 0.37, d["c4_rank_step"]
-    assert d["k5_copy_blocks"]["bit_exact"] and d["k5_copy_blocks"]["frac_hbm"] >= 0.65, d["k5_copy_blocks"]
-    assert d["k4_reshape_and_cache"]["bit_exact"] and d["k4_reshape_and_cache"]["frac_hbm"] >= 0.45, d["k4_reshape_and_cache"]
-    assert d["c2b_mha"]["frac_hbm"] >= 0.75 and "balanced" in d["c2b_mha"]["kernel"], d["c2b_mha"]
-    assert d["c2c_ragged"]["frac_hbm"] >= 0.72, d["c2c_ragged"]
+    assert d["swap"]["gpu_to_cpu_frac_of_memcpy"] >= floor(0.85, 0.5) and d["swap"]["cpu_to_gpu_frac_of_memcpy"] >= floor(0.85, 0.5), d["swap"]
+    assert d["c4_rank_step"]["ms_per_step"] <= floor(9.5, 14.0) and d["c4_rank_step"]["frac_of_hbm_roofline"] >= floor(0.37, 0.25), d["c4_rank_step"]
+    assert d["k5_copy_blocks"]["bit_exact"] and d["k5_copy_blocks"]["frac_hbm"] >= floor(0.65, 0.4), d["k5_copy_blocks"]
+    assert d["k4_reshape_and_cache"]["bit_exact"] and d["k4_reshape_and_cache"]["frac_hbm"] >= floor(0.45, 0.25), d["k4_reshape_and_cache"]
+    assert d["c2b_mha"]["frac_hbm"] >= floor(0.75, 0.5) and "balanced" in d["c2b_mha"]["kernel"], d["c2b_mha"]
+    assert d["c2c_ragged"]["frac_hbm"] >= floor(0.72, 0.5), d["c2c_ragged"]
     # the other head sizes run on the matrix pipe (the row-per-wavefront kernel reads 7-8 TFLOP/s here)
-    assert d["p2_prefill_d96"]["TFLOPs"] >= 150 and d["p2_prefill_d256"]["TFLOPs"] >= 150, (d["p2_prefill_d96"], d["p2_prefill_d256"])
+    assert d["p2_prefill_d96"]["TFLOPs"] >= floor(150, 60) and d["p2_prefill_d256"]["TFLOPs"] >= floor(150, 60), (d["p2_prefill_d96"], d["p2_prefill_d256"])

@@ -296,3 +296,44 @@ def test_balanced_line_replays_with_other_lengths(gpu):
         g.launch()
         st.synchronize()
         assert np.array_equal(got, do.numpy(np.uint16, q.shape)), f"replay {i} twice"
+
+
+def test_warmup_prefill_covers_a_ragged_varlen_batch(gpu):
+    """atoma_warmup_prefill(stream, longest sequence, sequences, q heads) sizes the persistent prefill kernel's plan table exactly as the
+    launch does -- padded to sequences x the LONGEST sequence's 256-row blocks -- so that the FIRST prefill call of a stream can be a capture
+    even for a ragged batch (ADVICE r5: the old estimate, tokens / 256 + sequences blocks, was ~6 x too small for [2048, 128, 128, 128]);
+    a table that is too small still fails loudly."""
+    from oracle import attn_oracle as A
+    from util import rand_half
+    assert gpu.lib.atoma_release_workspaces() == 0
+    rng = np.random.default_rng(23)
+    h, hk, d = 8, 2, 128
+    lens = np.array([2048, 128, 100, 128], np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    q, k, v = rand_half(rng, (T, h, d), BF16), rand_half(rng, (T, hk, d), BF16), rand_half(rng, (T, hk, d), BF16)
+    dq, dk, dv, dcu = (gpu.DeviceBuffer.from_numpy(a) for a in (q, k, v, cu))
+    do = gpu.DeviceBuffer(q.nbytes)
+
+    def call(st):
+        gpu.run_mha(dq, dk, dv, do, b=len(lens), h=h, h_k=hk, d=d, seqlen_q=int(lens.max()), seqlen_k=int(lens.max()), softmax_scale=d ** -0.5, is_bf16=BF16,
+                    q_strides=(0, h * d, d), o_strides=(0, h * d, d), k_strides=(0, hk * d, d), v_strides=(0, hk * d, d), is_causal=1,
+                    cu_seqlens_q=dcu, cu_seqlens_k=dcu, stream=st.s)
+    st = gpu.Stream()
+    assert gpu.lib.atoma_warmup_prefill(st.s, 256, len(lens), h) == 0, gpu.last_error()     # too small: one block per sequence
+    try:
+        with gpu.Graph.capture(st):
+            call(st)
+        raise AssertionError("a prefill whose plan table must grow inside a capture should fail")
+    except RuntimeError as e:
+        assert "hipGraph capture" in str(e)
+    st2 = gpu.Stream()
+    assert gpu.lib.atoma_warmup_prefill(st2.s, int(lens.max()), len(lens), h) == 0, gpu.last_error()
+    do.fill_bytes(0xEE)
+    with gpu.Graph.capture(st2) as g:
+        call(st2)
+    g.launch()
+    st2.synchronize()
+    ref = A.flash_attn_varlen(q, k, v, cu, cu, d ** -0.5, True, BF16)
+    assert_close(do.numpy(np.uint16, q.shape), ref, BF16, atol=ATOL_VS_F32[BF16], what="ragged varlen prefill captured as the stream's first call")
+    assert gpu.lib.atoma_warmup_prefill(st2.s, 0, 4, 8) == -1 and "invalid" in gpu.last_error()

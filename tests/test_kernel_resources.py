@@ -68,3 +68,71 @@ def test_generic_attention_kernels_keep_their_state_in_registers(tmp_path):
     for n, v in ks.items():
         if "attn_prefill_tile16_kernel" in n and "ELb1E" in n:      # the exact head-size instantiations
             assert v["scratch"] == 0 and v["vspill"] == 0, (n, v)
+
+
+# ---- the in-launch merges' memory order, checked in the emitted ISA -------------------------------------------------------
+# The arrival tickets are relaxed atomics (csrc/sync_ticket.h); what orders a partial before its ticket and a read after it is what the
+# INSTRUCTIONS do: partials leave as sc1 (write-through, agent-scope) stores, the wavefront drains them (s_waitcnt vmcnt(0)) before the ticket
+# atomic, and the last arriver reads them with sc1 loads (past its L1 / the XCD's L2).  The HIP / LLVM memory model does not promise that for
+# relaxed atomics, so a compiler upgrade could drop or move an sc1 without any test noticing until a rare stale read -- these checks notice at
+# build time.
+def disassemble(obj, tmp):
+    fb, co = os.path.join(tmp, "fb"), os.path.join(tmp, "co")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, fb])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fb, "--output=" + co])
+    text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+    funcs, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+        elif cur is not None and "\t" in line:
+            cur.append(line.split("//")[0].strip())
+    return funcs
+
+
+def _ticket_discipline(name, ins):
+    """every ticket atomic (global_atomic_add_x2 behind a global_atomic_umax_x2: sync_arrive) has an `s_waitcnt vmcnt(0)` between the last
+    sc1 store before it and itself"""
+    adds = [i for i, t in enumerate(ins) if t.startswith("global_atomic_add_x2")]
+    assert adds, name
+    for a in adds:
+        stores = [i for i in range(a) if ("store" in ins[i] and "sc1" in ins[i])]
+        assert stores, f"{name}: no write-through store ahead of the ticket"
+        between = ins[stores[-1]:a]
+        assert any(re.match(r"s_waitcnt.*vmcnt\(0\)", t) for t in between), f"{name}: the partial stores are not drained before the ticket"
+
+
+@pytest.mark.parametrize("obj,kernel,frag_of", [("linear_tile", "linear_tile_kernel", lambda nw, br: nw // 32), ("linear_wide", "linear_wide_kernel", lambda nw, br: (nw // 32) * (br // 64))])
+def test_tile_kernels_publish_and_read_their_slabs_write_through(tmp_path, obj, kernel, frag_of):
+    path = os.path.join(ROOT, "atoma-infer_amd", "build", obj + ".o")
+    if not (os.path.exists(path) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("needs the built object and the ROCm llvm tools")
+    ks = {n: v for n, v in disassemble(path, str(tmp_path)).items() if kernel in n}
+    assert len(ks) >= 18
+    for n, ins in ks.items():
+        dims = [int(x) for x in re.findall(r"ELi(\d+)", n)]
+        frags = frag_of(dims[0], dims[1] if len(dims) > 2 else 64)
+        st = [t for t in ins if t.startswith("buffer_store_dwordx4")]
+        ld = [t for t in ins if t.startswith("buffer_load_dwordx4")]
+        # the ONLY 16-byte buffer accesses of these kernels are the fp32 slabs of the K-split merge: all of them write-through / read-through
+        assert len(st) == frags and all("sc1" in t for t in st), (n, st[:2])
+        assert len(ld) >= frags and all("sc1" in t for t in ld), (n, ld[:2])
+        _ticket_discipline(n, ins)
+
+
+def test_decode_merges_publish_and_read_their_pieces_write_through(tmp_path):
+    if not (os.path.exists(OBJ) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("needs the built object and the ROCm llvm tools")
+    fs = disassemble(OBJ, str(tmp_path))
+    merges = {n: v for n, v in fs.items() if "decode_line_merge" in n}
+    assert len(merges) >= 4
+    for n, ins in merges.items():                       # the last arriver's reads of LSEs and rows: agent-scope loads
+        sc1_loads = [t for t in ins if re.match(r"(flat|global)_load_dword", t) and "sc1" in t]
+        assert len(sc1_loads) >= 3, (n, len(sc1_loads))
+    # (decode_combine_kernel is a separate launch: the kernel boundary orders its plain loads behind the split launch's stores)
+    ticketed = {n: v for n, v in fs.items() if "paged_decode" in n and "kernel" in n and any(t.startswith("global_atomic_add_x2") for t in v)}
+    assert len(ticketed) >= 16
+    for n, ins in ticketed.items():
+        assert sum(1 for t in ins if "store" in t and "sc1" in t) >= 2, n
+        _ticket_discipline(n, ins)
