@@ -95,3 +95,91 @@ def shard_weights(host, cfg, rank, world):
         out["wgu"].append(np.ascontiguousarray(np.concatenate([wgu[rank * it:(rank + 1) * it], wgu[c.inter + rank * it:c.inter + (rank + 1) * it]])))
         out["wdown"].append(np.ascontiguousarray(host["wdown"][l].reshape(c.hidden, c.inter)[:, rank * it:(rank + 1) * it]))
     return out
+
+
+def preflight(ah, dist, rank, world, comm=None, xgmi=None, sizes=(16, 1 << 20, 64 << 20), log=None, timeout_s=60.0):
+    """First contact: before ANYTHING is timed, every all-reduce engine this job can use sums a known pattern at
+    16 B / 1 MiB / 64 MiB over all ranks; each (engine, size) gets pass / fail and its time in us, agreed over the rendezvous (min over
+    ranks of ok, max of time) -- a wrong sum, an error or a timeout on ANY rank fails the pair for everybody.  Engines: "rccl"
+    (ncclAllReduce through the communicator) and "direct" (the xGMI kernels: through the communicator's direct mode, or a direct-only
+    handle), tested separately.  A pair that would not fit the direct engine's staging region is reported as skipped.  A watchdog turns a
+    hang (RCCL has no timeout of its own) into a failed pair and abandons the remaining ones: the caller's headline must not depend on them.
+    rank value pattern: element i of rank r = (r + 1) * (i % 5 + 1) in bf16 -- small integers, every partial sum exact in any order."""
+    import threading
+    import time
+
+    import numpy as np
+    import torch
+    BF16_ONE = 0x3F80
+
+    def bf16_of(v):          # small non-negative integers as bf16 bit patterns
+        return (np.asarray(v, np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    engines = []
+    if comm is not None:
+        engines.append(("rccl", lambda i, o, n: (ah.lib.atoma_comm_set_mode(comm, 0), ah.lib.atoma_allreduce_sum(comm, i, o, n, 1, None))[1], None))
+        # collective: every rank asks for the direct path alike (it is built on first use, over RCCL's own bootstrap)
+        ok_direct = ah.lib.atoma_comm_set_mode(comm, 1) == 0
+        note = None if ok_direct else ah.last_error()
+        ah.lib.atoma_comm_set_mode(comm, 0)
+        engines.append(("direct", (lambda i, o, n: (ah.lib.atoma_comm_set_mode(comm, 1), ah.lib.atoma_allreduce_sum(comm, i, o, n, 1, None), ah.lib.atoma_comm_set_mode(comm, 0))[1]) if ok_direct else None, note))
+    if xgmi is not None:
+        cap = int(ah.lib.atoma_xgmi_capacity(xgmi))
+        engines.append(("direct", lambda i, o, n: ah.lib.atoma_xgmi_allreduce_sum(xgmi, i, o, n, 1, None) if n * 2 <= cap else -2, None))
+    res = {}
+    state = {"hung": None}
+    for name, fn, note in engines:
+        res[name] = {}
+        for nbytes in sizes:
+            key = "%dB" % nbytes if nbytes < 1024 else ("%dMiB" % (nbytes >> 20))
+            if state["hung"]:
+                res[name][key] = {"ok": False, "us": None, "note": "not run: an earlier pair hung (%s)" % state["hung"]}
+                continue
+            if fn is None:
+                res[name][key] = {"ok": False, "us": None, "note": "engine unavailable: %s" % note}
+                continue
+            n = nbytes // 2
+            mine = bf16_of((rank + 1) * (np.arange(n) % 5 + 1))
+            want = bf16_of(world * (world + 1) // 2 * (np.arange(n) % 5 + 1))
+            src, dst = ah.DeviceBuffer.from_numpy(mine), ah.DeviceBuffer.zeros((n,), np.uint16)
+            out = {"ok": 0.0, "us": 0.0, "note": None}
+
+            def attempt():
+                try:
+                    rc = fn(src.ptr, dst.ptr, n)                        # first touch (connection set-up, code load), then three timed ones
+                    ah.synchronize()
+                    if rc == -2:
+                        out["note"] = "skipped: larger than the direct engine's staging region"
+                        out["ok"] = 1.0
+                        return
+                    if rc != 0:
+                        out["note"] = "error: " + ah.last_error()
+                        return
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        rc |= fn(src.ptr, dst.ptr, n)
+                    ah.synchronize()
+                    out["us"] = (time.perf_counter() - t0) / 3 * 1e6
+                    good = rc == 0 and bool(np.array_equal(dst.numpy(np.uint16, (n,)), want))
+                    out["ok"] = 1.0 if good else 0.0
+                    if not good:
+                        out["note"] = "wrong sum" if rc == 0 else "error: " + ah.last_error()
+                except Exception as e:                                  # a timed-out wait of the direct kernels surfaces as an error of the next call
+                    out["note"] = "exception: %r" % (e,)
+            th = threading.Thread(target=attempt, daemon=True)
+            th.start()
+            th.join(timeout_s)
+            if th.is_alive():
+                out["note"] = "hung: no return within %.0f s" % timeout_s
+                state["hung"] = "%s %s" % (name, key)
+            t = torch.tensor([out["ok"], -out["us"]], dtype=torch.float64)
+            if not state["hung"]:
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)                # ok on every rank; the slowest rank's time
+            res[name][key] = {"ok": bool(t[0].item() >= 1.0), "us": round(-t[1].item(), 1) if out["us"] else None}
+            if out["note"]:
+                res[name][key]["note"] = out["note"]
+            if log is not None and rank == 0:
+                log("[preflight] %-6s all-reduce of %-6s over %d ranks: %s%s" % (name, key, world, "PASS" if res[name][key]["ok"] else "FAIL",
+                                                                                ("  %.1f us" % res[name][key]["us"]) if res[name][key]["us"] else "") + (("  (" + out["note"] + ")") if out["note"] else ""))
+            if not state["hung"]:
+                src.free(); dst.free()
+    return res

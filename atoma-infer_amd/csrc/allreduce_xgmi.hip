@@ -37,7 +37,9 @@
 #include "norm_shared.h"
 
 #include <algorithm>
+#include <atomic>
 #include <stdlib.h>
+#include <string>
 #include <string.h>
 #include <unistd.h>
 
@@ -118,6 +120,17 @@ template <> struct XgmiAcc<float> {
     }
 };
 
+// Poll back-off: a waiting lane polls a system-scope flag; polled at a fixed ~60 ns period, the waiters of eight ranks that
+// share ONE device (the virtual-rank rig) kept the fabric busy enough to starve the vendor GEMMs beside them.  The period grows from ~60 ns
+// over ~0.25 us to ~1 us (s_sleep counts 64-clock units; its operand is an immediate): a flag that is about to flip is still seen at once,
+// a long wait costs 1/16 of the polls.
+__device__ __forceinline__ void xgmi_backoff(int &polls) {
+    if (polls < 8) __builtin_amdgcn_s_sleep(2);
+    else if (polls < 32) __builtin_amdgcn_s_sleep(8);
+    else __builtin_amdgcn_s_sleep(32);
+    ++polls;
+}
+
 // Release this block's remote stores, then tell block `blockIdx.x` of every peer; then wait for theirs.
 __device__ __forceinline__ void xgmi_signal_and_wait(const XgmiParams &p, int parity, int stage, uint32_t seq) {
     __threadfence_system();                    // every thread: its stores are ordered before the flag (system-scope release)
@@ -130,8 +143,9 @@ __device__ __forceinline__ void xgmi_signal_and_wait(const XgmiParams &p, int pa
         // once a wait has timed out (device-side copy of the status in seq[2]) the communicator is broken: later waits give
         // up at once, so a captured graph of 160 calls costs one timeout, not 160
         const long long limit = __hip_atomic_load(p.seq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) ? 0 : p.timeout_ticks;
+        int polls = 0;
         while ((int)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-            __builtin_amdgcn_s_sleep(2);
+            xgmi_backoff(polls);
             if (wall_clock64() - t0 > limit) {
                 __hip_atomic_store(p.status, 1u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // which peer never arrived
                 __hip_atomic_store(p.seq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -260,8 +274,9 @@ __device__ __forceinline__ void xgmi_wait_all_blocks(const XgmiParams &p, int pa
         if (src == p.rank && !self) continue;
         uint32_t *mine = xgmi_flag(p.peer[p.rank], p, parity, stage, src, blk);
         const long long t0 = wall_clock64();
+        int polls = 0;
         while ((int)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-            __builtin_amdgcn_s_sleep(2);
+            xgmi_backoff(polls);
             if (wall_clock64() - t0 > limit) {
                 __hip_atomic_store(p.status, 1u + (uint32_t)src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(p.seq + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -499,6 +514,25 @@ int atoma_xgmi_create(void **out, int rank, int world_size, int device, int64_t 
     return 0;
 }
 
+}  // extern "C" (reopened below)
+namespace atoma {
+// Fault injection for the set-up calls that have only ever run on one device: atoma_set_option("xgmi_fault", n) makes the
+// next set-ups behave as if 1 = hipIpcOpenMemHandle, 2 = hipDeviceEnablePeerAccess, 3 = hipIpcGetMemHandle had failed (0 = off) -- the error
+// path of a first multi-GPU contact (clean message, nothing leaked, the handle reusable or destroyable, RCCL still there) is then testable here.
+static std::atomic<int> xgmi_fault{0};
+bool set_xgmi_option(const std::string &name, int value) {
+    if (name != "xgmi_fault") return false;
+    xgmi_fault = value;
+    return true;
+}
+static bool xgmi_injected(int which, const char *what) {
+    if (xgmi_fault.load() != which) return false;
+    set_error(std::string(what) + ": hipErrorInvalidValue (injected by the xgmi_fault option)");
+    return true;
+}
+}  // namespace atoma
+extern "C" {
+
 int atoma_xgmi_handle(void *xg, void *handle128_out) {
     using namespace atoma;
     clear_error();
@@ -510,6 +544,7 @@ int atoma_xgmi_handle(void *xg, void *handle128_out) {
     b.pid = (int64_t)getpid();
     b.ptr = (uint64_t)reinterpret_cast<uintptr_t>(x->region);
     b.bytes = x->region_bytes; b.capacity = x->capacity;
+    if (xgmi_injected(3, "hipIpcGetMemHandle (xgmi staging region)")) return -1;
     if (!check_hip(hipIpcGetMemHandle(&b.ipc, x->region), "hipIpcGetMemHandle (xgmi staging region)")) return -1;
     memcpy(handle128_out, &b, sizeof b);
     return 0;
@@ -529,8 +564,9 @@ int atoma_xgmi_connect(void *xg, const void *handles /* world_size x 128 bytes, 
                       " of this communicator (all ranks must be created with the same world_size and max_bytes)");
             return -1;
         }
-        if (q == x->rank) continue;
+        if (q == x->rank || x->peer[q]) continue;   // (a peer mapped by an earlier, failed attempt stays mapped: connect can be retried)
         if (b.pid == (int64_t)getpid()) {          // same process (one thread per GPU, as the reference runs): plain peer access
+            if (xgmi_injected(2, "hipDeviceEnablePeerAccess")) return -1;
             if (b.device != x->device) {
                 const hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { check_hip(e, "hipDeviceEnablePeerAccess"); return -1; }
@@ -539,6 +575,7 @@ int atoma_xgmi_connect(void *xg, const void *handles /* world_size x 128 bytes, 
             x->peer[q] = reinterpret_cast<char *>((uintptr_t)b.ptr);
         } else {
             void *mapped = nullptr;
+            if (xgmi_injected(1, "hipIpcOpenMemHandle (peer staging region)")) return -1;
             if (!check_hip(hipIpcOpenMemHandle(&mapped, b.ipc, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle (peer staging region)")) return -1;
             x->peer[q] = static_cast<char *>(mapped);
             x->ipc_opened[q] = true;

@@ -18,6 +18,7 @@ bool set_decode_option(const std::string &name, int value);  // paged_decode.hip
 bool set_generic_attn_option(const std::string &name, int value);  // attn_generic.hip
 bool set_linear_tile_option(const std::string &name, int value);  // linear_tile.hip
 bool set_linear_wide_option(const std::string &name, int value);  // linear_wide.hip
+bool set_xgmi_option(const std::string &name, int value);         // allreduce_xgmi.hip
 
 int device_num_cus() {
     // The reference queries cudaDeviceGetAttribute on EVERY attention call
@@ -192,6 +193,7 @@ int atoma_set_option(const char *name, int value) {
     if (name && atoma::set_decode_option(name, value)) return 0;
     if (name && atoma::set_linear_tile_option(name, value)) return 0;
     if (name && atoma::set_linear_wide_option(name, value)) return 0;
+    if (name && atoma::set_xgmi_option(name, value)) return 0;
     if (name && atoma::set_generic_attn_option(name, value)) return 0;
     atoma::set_error(std::string("atoma_set_option: unknown option ") + (name ? name : "(null)"));
     return -1;

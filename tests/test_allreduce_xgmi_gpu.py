@@ -424,3 +424,55 @@ def test_fused_allreduce_add_rms_norm_equals_the_three_ops(gpu, world, dtype, mo
     finally:
         for x in xs:
             gpu.lib.atoma_xgmi_destroy(x)
+
+
+# ---- first-contact failures, injected: the set-up calls of the direct engine have only ever succeeded here ----
+@pytest.mark.parametrize("fault,what", [(1, "hipIpcOpenMemHandle"), (2, "hipDeviceEnablePeerAccess"), (3, "hipIpcGetMemHandle")])
+def test_injected_setup_failures_are_clean_and_recoverable(gpu, fault, what):
+    """atoma_set_option("xgmi_fault", n) makes hipIpcOpenMemHandle / hipDeviceEnablePeerAccess / hipIpcGetMemHandle fail as they might on the
+    first multi-GPU box: the call returns -1 with the failing call's name, the handle is NOT connected (an all-reduce on it says so instead
+    of touching unmapped memory), nothing has to be torn down by hand -- the same handles connect and sum correctly once the fault is gone,
+    and destroy cleanly either way.  (A communicator's `auto` mode answers a failed direct set-up by staying on RCCL: atoma_comm_info says
+    "xgmi: unavailable (<the message checked here>)"; that route needs two devices.)"""
+    world, count = 2, 4096
+    xs = []
+    for r in range(world):
+        h = C.c_void_p()
+        assert gpu.lib.atoma_xgmi_create(C.byref(h), r, world, 0, 1 << 20) == 0, gpu.last_error()
+        xs.append(h)
+    one = (C.c_uint8 * 128)()
+    try:
+        assert gpu.lib.atoma_set_option(b"xgmi_fault", fault) == 0
+        blobs = (C.c_uint8 * (128 * world))()
+        if fault == 3:
+            assert gpu.lib.atoma_xgmi_handle(xs[0], one) == -1 and what in gpu.last_error() and "injected" in gpu.last_error()
+            gpu.lib.atoma_set_option(b"xgmi_fault", 0)
+        for r in range(world):
+            assert gpu.lib.atoma_xgmi_handle(xs[r], one) == 0, gpu.last_error()
+            C.memmove(C.addressof(blobs) + 128 * r, one, 128)
+        if fault == 1:                        # the IPC branch is taken for a peer of ANOTHER process: forge the peer's pid in rank 0's copy
+            forged = (C.c_uint8 * (128 * world)).from_buffer_copy(bytes(blobs))
+            C.memmove(C.addressof(forged) + 128 * 1 + 16, (C.c_int64 * 1)(os.getpid() + 1), 8)
+            assert gpu.lib.atoma_xgmi_connect(xs[0], forged) == -1 and what in gpu.last_error() and "injected" in gpu.last_error()
+        if fault == 2:
+            assert gpu.lib.atoma_xgmi_connect(xs[0], blobs) == -1 and what in gpu.last_error() and "injected" in gpu.last_error()
+        if fault in (1, 2):                   # not connected: loud, no launch
+            x = gpu.DeviceBuffer.zeros((count,), np.uint16)
+            assert gpu.lib.atoma_xgmi_allreduce_sum(xs[0], x.ptr, x.ptr, count, BF16, None) == -1 and "atoma_xgmi_connect" in gpu.last_error()
+    finally:
+        gpu.lib.atoma_set_option(b"xgmi_fault", 0)
+    for r in range(world):                    # the fault is gone: the SAME handles come up and work
+        assert gpu.lib.atoma_xgmi_connect(xs[r], blobs) == 0, gpu.last_error()
+    rng = np.random.default_rng(fault)
+    parts = [rand_half(rng, (count,), BF16) for _ in range(world)]
+    want = AO.allreduce_sum(parts, BF16)
+    streams = [gpu.Stream() for _ in range(world)]
+    ins = [gpu.DeviceBuffer.from_numpy(p_) for p_ in parts]
+    outs = [gpu.DeviceBuffer(count * 2) for _ in range(world)]
+    for r in range(world):
+        assert gpu.lib.atoma_xgmi_allreduce_sum(xs[r], ins[r].ptr, outs[r].ptr, count, BF16, streams[r].s) == 0, gpu.last_error()
+    for s_ in streams:
+        s_.synchronize()
+    for r in range(world):
+        assert np.array_equal(outs[r].numpy(np.uint16, (count,)), want) and gpu.lib.atoma_xgmi_status(xs[r]) == 0
+        gpu.lib.atoma_xgmi_destroy(xs[r])

@@ -36,3 +36,6 @@ def test_bench_ranks_on_one_device(gpu, world):
     assert tps["engines_available"].get("xgmi") is True and tps["xgmi_step_ms"] and tps["xgmi_allreduce_us"], tps
     assert tps["rccl_step_ms"] is None and "reduced" in tps
     assert "cpu_baseline" not in out                           # an N = 1 leg
+    pf = out["preflight"]["direct"]                            # first contact before the timed region: known pattern, every size the staging region takes
+    assert pf["16B"]["ok"] and pf["16B"]["us"] > 0 and pf["1MiB"]["ok"] and pf["1MiB"]["us"] > 0, pf
+    assert pf["64MiB"]["ok"] and "skipped" in pf["64MiB"].get("note", ""), pf      # bench.py's direct-only handle stages 2 MiB: reported, not silently dropped

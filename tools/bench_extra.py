@@ -86,7 +86,7 @@ def c3_decode_step(iters=10, batch=256, seed=9, kv_fp8=False, weights=None, cfg=
 
 
 def c5_phi3_mini_decode_step(iters=10):
-    """The same step with the reference's third model family (models/src/phi3.rs): Phi-3-mini shapes -- head size 96 runs on attn_generic.hip's streaming
+    """PROBE, not a row of the driver's line (models/src/phi3.rs is outside SURVEY 8's scope).  The same step with the reference's third model family (models/src/phi3.rs): Phi-3-mini shapes -- head size 96 runs on attn_generic.hip's streaming
     decode kernel, not on the tuned head-size-128 kernel; batch 64 (MHA: 384 KiB of KV per token)."""
     return c3_decode_step(iters=iters, batch=64, cfg=PHI_3_MINI, name="Phi-3-mini-shaped decode step (32 layers, hidden 3072, 32 MHA heads of 96)")
 
@@ -156,14 +156,14 @@ def swap(iters=3, tensors=64, pages=256, nb=512, page_bytes=16 * 8 * 128 * 2, se
     return res
 
 
-def _decode_case(name, B, S, h, hk, ragged, iters, seed, sample_seqs):
+def _decode_case(name, B, S, h, hk, ragged, iters, seed, sample_seqs, identity=False):
     """A paged-decode workload of BASELINE.md section 2 timed like the headline (one run_mha call per step) + host copies of `sample_seqs`
     sequences (q, the output the TIMED calls wrote, their K / V gathered through the block table) for bench.py's check against the oracle."""
     rng = np.random.default_rng(seed)
     d, page = 128, 16
     pps = S // page
     n_pages = int(B * pps * 1.125)
-    bt = rng.permutation(n_pages)[: B * pps].astype(np.int32).reshape(B, pps)
+    bt = (np.arange(B * pps) if identity else rng.permutation(n_pages)[: B * pps]).astype(np.int32).reshape(B, pps)
     lens = (rng.integers(S // 2, S + 1, B) if ragged else np.full(B, S)).astype(np.int32)
     kc, vc = TS.rand_dev(rng, n_pages * page * hk * d * 2), TS.rand_dev(rng, n_pages * page * hk * d * 2)
     q = TS.rand_dev(rng, B * h * d * 2)
@@ -305,6 +305,48 @@ def p2_prefill_d256(iters=10):
     return prefill(iters=iters, S=2048, nseq=4, d=256, with_sample=True)
 
 
+def c3_trace():
+    """BASELINE configs[2] AS WRITTEN, end to end (tools/engine_trace.py): 256 requests, prompts of 2048 tokens prefilled
+    two per graph replay, then 512 decode steps at batch 256 with continuous-batching metadata rebuilt every step (atoma_prepare_inputs) and
+    the sampled tokens read back -- wall-clock tokens/s/GPU over the decode phase (host loop included) against SURVEY 8(d)'s byte bound, the
+    prefill phase beside it, and a sample of the LAST step's last-layer attention for the oracle."""
+    import engine_trace
+    r = engine_trace.run()
+    keep = ("workload", "prefill_s", "prefill_tokens_per_s", "decode_s", "decode_ms_per_step", "decode_tokens_per_s_per_gpu", "decode_roofline_tokens_per_s",
+            "decode_frac_of_roofline", "host_metadata_ms_per_step", "trace_s", "generated_tokens_per_s_over_trace", "data", "sample")
+    return {k: r[k] for k in keep}
+
+
+def c5_swap_sizes(iters=3):
+    """BASELINE.md C5's other map sizes: swap-out / swap-in of n = 16 and n = 4096 random distinct pages (n = 256 is extra.swap)."""
+    return {"n16": swap(iters=iters, pages=16, nb=512), "n4096": swap(iters=iters, pages=4096, nb=8192, tensors=16)}
+
+
+def k4_sizes(iters=20):
+    """BASELINE.md K4's other sizes: reshape_and_cache_flash at T = 256 (a decode batch) and T = 2048 (one prompt)."""
+    return {"T256": k4_reshape_and_cache(iters=iters, T=256), "T2048": k4_reshape_and_cache(iters=iters, T=2048)}
+
+
+def k5_sizes(iters=10):
+    """BASELINE.md K5's other sizes: copy_blocks of P = 1 and P = 64 pairs over 32 layers."""
+    return {"P1": k5_copy_blocks(iters=iters, pairs=1, nb=64), "P64": k5_copy_blocks(iters=iters, pairs=64, nb=512)}
+
+
+def n1_norm_rope_t256(iters=20):
+    """BASELINE.md N1 at T = 256 (a decode batch)."""
+    return n1_norm_rope(iters=iters, T=256)
+
+
+def c2c_identity(iters=20):
+    """the headline shape with the identity block table (physical page i = logical page i)."""
+    return _decode_case("C2c decode identity table: B=256, 32/8 heads, d=128, seq 4096, identity block table", 256, 4096, 32, 8, False, iters, 8, (3,), identity=True)
+
+
+def c2a_seeds(iters=20):
+    """The headline workload on seeds 1 and 2 (seeds 0, 1, 2; seed 0 is the headline itself)."""
+    return {"seed%d" % s_: {k: v for k, v in _decode_case("C2a decode, seed %d" % s_, 256, 4096, 32, 8, False, iters, s_, ()).items() if k != "sample"} for s_ in (1, 2)}
+
+
 def c4_rank_step(iters=10):
     """One rank of the Llama-3.1-70B TP = 8 decode step of configs[3] without its all-reduces (tools/rank_step.py): what a rank
     computes between the exchanges, batch 64, context 4096, 80 layers."""
@@ -312,8 +354,8 @@ def c4_rank_step(iters=10):
     return rank_step.run(iters=iters)
 
 
-ALL = ("c3_decode_step", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "p1_prefill_4096", "p2_prefill_d96", "p2_prefill_d256", "c2b_mha", "c2c_ragged", "k4_reshape_and_cache", "k5_copy_blocks",
-       "n1_norm_rope", "swap")
+ALL = ("c3_decode_step", "c3_trace", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "p1_prefill_4096", "p2_prefill_d96", "p2_prefill_d256", "c2b_mha", "c2c_ragged", "c2c_identity",
+       "c2a_seeds", "k4_reshape_and_cache", "k4_sizes", "k5_copy_blocks", "k5_sizes", "n1_norm_rope", "n1_norm_rope_t256", "swap", "c5_swap_sizes")
 
 
 def collect(which=ALL, prefill_sample=False):

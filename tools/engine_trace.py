@@ -51,17 +51,26 @@ def main():
     ap.add_argument("--prompts-per-launch", type=int, default=2, help="prompts prefilled together (one varlen batch per graph replay)")
     a = ap.parse_args()
     ah.set_device(0)
+    out = run(a.requests, a.prompt, a.decode_steps, a.layers, a.model, a.prompts_per_launch)
+    out.pop("sample", None)
+    print(json.dumps(out), flush=True)
+
+
+def run(requests=256, prompt=2048, decode_steps=512, layers=0, model="8b", prompts_per_launch=2, sample_seqs=(0, 131)):
+    """The trace; returns the result dict.  "sample" = host copies of what the LAST decode step's LAST layer attended over for `sample_seqs`
+    (its rotated q, the attention output the timed graph wrote, the sequence's K / V gathered from that layer's cache through the trace's
+    block table): bench.py checks them against the oracle -- every cache write, slot mapping and block table of the whole trace is behind them."""
     rng = np.random.default_rng(3)
-    c = DS.LLAMA_3_1_8B if a.model == "8b" else DS.Config(80, 8192, 8, 1, 128, 28672 // 8, 128256 // 8)
-    if a.layers:
-        c = DS.Config(a.layers, c.hidden, c.h, c.hk, c.d, c.inter, c.vocab)
-    B, P, N = a.requests, a.prompt, a.decode_steps
+    c = DS.LLAMA_3_1_8B if model == "8b" else DS.Config(80, 8192, 8, 1, 128, 28672 // 8, 128256 // 8)
+    if layers:
+        c = DS.Config(layers, c.hidden, c.h, c.hk, c.d, c.inter, c.vocab)
+    B, P, N = requests, prompt, decode_steps
     pps = (P + N + c.page - 1) // c.page                                  # pages a request owns (reserved up front)
     num_pages = B * pps + 1
     w = random_weights(rng, c)
     st = ah.Stream()
     step = DS.DecodeStep(c, B, num_pages, pps, w, st, fused_epilogues=True)
-    G = a.prompts_per_launch
+    G = prompts_per_launch
     assert B % G == 0
     pre = DS.PrefillStep(c, P * G, step, st, prompts=G)
     tables = (1 + rng.permutation(B * pps)).astype(np.uint32).reshape(B, pps)   # page 0 is never used
@@ -127,15 +136,37 @@ def main():
     t_decode = time.perf_counter() - t0
     weight_bytes = 2 * (c.vocab * c.hidden + c.layers * (c.qkv * c.hidden + c.hidden * c.h * c.d + 3 * c.inter * c.hidden))   # lm_head + layers
     kv_bytes_per_token = 2 * c.layers * c.hk * c.d * 2
-    name = "C3-lite trace: Llama-3.1-8B shapes" if a.model == "8b" else "C4-lite trace: one rank of Llama-3.1-70B TP=8 (no all-reduce)"
+    # ---- sample: the last step's last-layer attention of a few sequences (buffers are shared across layers: they hold the last layer's values)
+    sample = []
+    hd, qkvw = c.h * c.d, c.qkv
+    qkv_h = step._buf("qkv", 0, B * qkvw * 2).numpy(np.uint16, (B, qkvw))
+    att_h = step._buf("att", 0, B * hd * 2).numpy(np.uint16, (B, c.h, c.d))
+    page_bytes = c.page * c.hk * c.d * 2
+    for b_ in [x for x in sample_seqs if x < B]:
+        L = int(lengths[b_]) - 1                           # keys the last step attended over, its own token included (`lengths` already counts the token it sampled)
+        npg = (L + c.page - 1) // c.page
+        ks, vs = np.empty((npg, c.page, c.hk, c.d), np.uint16), np.empty((npg, c.page, c.hk, c.d), np.uint16)
+        for j in range(npg):
+            for dst, src in ((ks, step.kc[c.layers - 1]), (vs, step.vc[c.layers - 1])):
+                ah.hip_check(ah.hip.hipMemcpy(dst[j].ctypes.data, src.ptr + int(tables[b_, j]) * page_bytes, page_bytes, ah.D2H), "sample page")
+        sample.append({"kind": "decode", "q": qkv_h[b_, :hd].reshape(c.h, c.d).copy(), "o": att_h[b_].copy(), "k": ks.reshape(npg * c.page, c.hk, c.d)[:L].copy(),
+                       "v": vs.reshape(npg * c.page, c.hk, c.d)[:L].copy(), "scale": c.d ** -0.5, "L": L})
+    name = "C3-lite trace: Llama-3.1-8B shapes" if model == "8b" else "C4-lite trace: one rank of Llama-3.1-70B TP=8 (no all-reduce)"
     out = {"workload": f"{name} ({c.layers} layers), {B} requests, prompt {P}, {N} decode steps, block {c.page}",
            "prefill_s": round(t_prefill, 3), "prefill_tokens_per_s": round(B * P / t_prefill), "prefill_ms_per_prompt": round(t_prefill / B * 1e3, 2),
            "decode_s": round(t_decode, 3), "decode_ms_per_step": round(t_decode / N * 1e3, 3), "decode_tokens_per_s": round(B * N / t_decode),
            "host_metadata_ms_per_step": round(host_s / N * 1e3, 4), "trace_s": round(t_prefill + t_decode, 3),
            "generated_tokens_per_s_over_trace": round(B * (N + 1) / (t_prefill + t_decode)),
            "decode_roofline_tokens_per_s": round(B / ((weight_bytes + B * (P + N / 2) * kv_bytes_per_token) / 8e12)),
-           "data": "synthetic weights and prompts; greedy sampling on the device"}
-    print(json.dumps(out), flush=True)
+           "data": "synthetic weights and prompts; greedy sampling on the device", "sample": sample}
+    out["decode_tokens_per_s_per_gpu"] = out["decode_tokens_per_s"]
+    out["decode_frac_of_roofline"] = round(out["decode_tokens_per_s"] / out["decode_roofline_tokens_per_s"], 4)
+    for b_ in step.kc + step.vc:
+        b_.free()
+    for v in w.values():
+        for b_ in (v if isinstance(v, list) else [v]):
+            b_.free()
+    return out
 
 
 if __name__ == "__main__":
