@@ -14,6 +14,10 @@
 #include <thread>
 #include <vector>
 #include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <emmintrin.h>
+#include <sched.h>
 
 namespace atoma {
 
@@ -214,20 +218,24 @@ static void *device_alias(const void *host_ptr) {
 
 // Pageable host memory (the reference's CPU cache is ordinary Candle tensors: backends/vllm/src/worker.rs:570-598; its swap is one
 // cudaMemcpyAsync per page, csrc/src/ops.rs:158-166,205-216 -- which the runtime stages page by page: 3 GB/s here).  Pages travel
-// through a pinned, device-addressable bounce ring instead: two 8 MiB slots per device; the gather / scatter kernel moves up to a
-// slot's worth of pages between the cache and a slot in one launch, a small team of host threads copies between the slot and the
-// caller's pages, and the two slots alternate so that the PCIe transfer of one chunk runs beside the host copy of the other.  Like
-// a pageable hipMemcpy, the call returns when the host side is done (GPU -> CPU: the data is in the caller's pages; CPU -> GPU: the
-// caller's pages have been read); the device side stays ordered on `stream`.
+// through a pinned, device-addressable bounce ring instead: BOUNCE_SLOTS slots of 16 MiB per device; the gather / scatter kernel moves a
+// slot's worth of pages -- of several tensors at once: a chunk is (tensors x pages) -- between the cache and a slot in one launch, a
+// persistent team of host threads copies between the slot and the caller's pages (non-temporal stores on the way out: a 32 KiB page is
+// below the size from which memcpy stops reading the destination lines first), and the device runs up to BOUNCE_SLOTS - 1 chunks ahead of
+// the host copies.  Round 6 (the unchanged reference hands over pageable tensors): 26-36 -> see DESIGN.md 4.3 (round 5:
+// two 8 MiB slots, one tensor per chunk, threads spawned per chunk).  Like a pageable hipMemcpy, the call returns when the host side is
+// done (GPU -> CPU: the data is in the caller's pages; CPU -> GPU: the caller's pages have been read); the device side stays ordered on
+// `stream`.
 namespace {
-constexpr size_t BOUNCE_SLOT = 8u << 20;
+constexpr size_t BOUNCE_SLOT = 16u << 20;
+constexpr int BOUNCE_SLOTS = 4;
 struct Bounce {
     int device = -1;
-    std::mutex mu;                               // one swap at a time per DEVICE (the two slots are the device's): other devices' threads do not wait
-    char *host[2] = {nullptr, nullptr};
-    char *dev[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};     // the kernel that last touched the slot
-    bool busy[2] = {false, false};
+    std::mutex mu;                               // one swap at a time per DEVICE (the slots are the device's): other devices' threads do not wait
+    char *host[BOUNCE_SLOTS] = {};
+    char *dev[BOUNCE_SLOTS] = {};
+    hipEvent_t done[BOUNCE_SLOTS] = {};          // the kernel that last touched the slot
+    bool busy[BOUNCE_SLOTS] = {};
 };
 std::mutex g_bounce_mu;                          // guards the list only
 std::vector<std::unique_ptr<Bounce>> g_bounce;
@@ -241,7 +249,7 @@ Bounce *bounce_for_device() {
     auto b = std::make_unique<Bounce>();
     b->device = dev;
     bool ok = true;
-    for (int i = 0; i < 2 && ok; ++i) {
+    for (int i = 0; i < BOUNCE_SLOTS && ok; ++i) {
         void *h = nullptr, *d = nullptr;
         ok = check_hip(hipHostMalloc(&h, BOUNCE_SLOT, hipHostMallocMapped | hipHostMallocPortable), "swap_blocks bounce hipHostMalloc");
         b->host[i] = static_cast<char *>(h);
@@ -250,7 +258,7 @@ Bounce *bounce_for_device() {
         ok = ok && check_hip(hipEventCreateWithFlags(&b->done[i], hipEventDisableTiming), "swap_blocks bounce event");
     }
     if (!ok) {                                   // nothing of a half-built ring is kept (a retry starts from scratch and leaks nothing)
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < BOUNCE_SLOTS; ++i) {
             if (b->done[i]) (void)hipEventDestroy(b->done[i]);
             if (b->host[i]) (void)hipHostFree(b->host[i]);
         }
@@ -260,22 +268,87 @@ Bounce *bounce_for_device() {
     return g_bounce.back().get();
 }
 
-// n pages between a packed slot and the caller's pageable pages, split over a few threads (one memcpy stream does ~10 GB/s)
-void host_copy_pages(char *slot, char *tensor, const int64_t *pages, int64_t n, int64_t block_bytes, bool to_slot) {
-    const int64_t bytes = n * block_bytes;
-    const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(4, bytes >> 20));
-    auto work = [&](int64_t lo, int64_t hi) {
-        for (int64_t k = lo; k < hi; ++k) {
-            char *pg = tensor + pages[k] * block_bytes, *sl = slot + k * block_bytes;
-            if (to_slot) memcpy(sl, pg, (size_t)block_bytes); else memcpy(pg, sl, (size_t)block_bytes);
-        }
-    };
-    if (nthreads == 1) { work(0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, n * t / nthreads, n * (t + 1) / nthreads);
-    work(0, n / nthreads);
-    for (auto &t : th) t.join();
+// 16-byte-aligned page copy with non-temporal stores (SSE2: the x86-64 baseline)
+inline void copy_page_stream(char *dst, const char *src, size_t bytes) {
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | bytes) & 15u) != 0) { memcpy(dst, src, bytes); return; }
+    const __m128i *s = reinterpret_cast<const __m128i *>(src);
+    __m128i *d = reinterpret_cast<__m128i *>(dst);
+    size_t n = bytes >> 4, i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const __m128i a = _mm_load_si128(s + i), b = _mm_load_si128(s + i + 1), c = _mm_load_si128(s + i + 2), e = _mm_load_si128(s + i + 3);
+        _mm_stream_si128(d + i, a); _mm_stream_si128(d + i + 1, b); _mm_stream_si128(d + i + 2, c); _mm_stream_si128(d + i + 3, e);
+    }
+    for (; i < n; ++i) _mm_stream_si128(d + i, _mm_load_si128(s + i));
 }
+
+// A persistent team of copy threads (created on first use, ATOMA_SWAP_THREADS, default min(12, the CPUs this process may run on)): a job is
+// a list of page copies handed out in batches through an atomic cursor; the calling thread works too.
+class CopyTeam {
+  public:
+    struct Job { char *slot; char *const *tensors; const int64_t *pages; int64_t nt, np, block_bytes; bool to_slot; };
+    static CopyTeam &get() { static CopyTeam *t = new CopyTeam; return *t; }      // (never destroyed: the threads idle on a condition variable)
+    void run(const Job &j) {
+        std::unique_lock<std::mutex> lk(mu_);              // one job at a time (callers already hold their device's bounce lock)
+        job_ = j;
+        next_.store(0);
+        total_ = j.nt * j.np;
+        pending_ = (int)workers_.size();
+        ++gen_;
+        lk.unlock();
+        cv_.notify_all();
+        work();
+        _mm_sfence();
+        lk.lock();
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+    }
+
+  private:
+    CopyTeam() {
+        const char *e = getenv("ATOMA_SWAP_THREADS");
+        cpu_set_t set;
+        int cpus = 8;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+        int n = e ? atoi(e) : std::min(12, std::max(1, cpus));
+        n = std::max(1, std::min(n, 32));
+        for (int i = 1; i < n; ++i) workers_.emplace_back([this] { loop(); });
+        for (auto &w : workers_) w.detach();
+    }
+    void work() {
+        const int64_t batch = 4;
+        for (;;) {
+            const int64_t lo = next_.fetch_add(batch);
+            if (lo >= total_) return;
+            const int64_t hi = std::min(lo + batch, total_);
+            for (int64_t i = lo; i < hi; ++i) {
+                const int64_t t = i / job_.np, k = i - t * job_.np;
+                char *pg = job_.tensors[t] + job_.pages[k] * job_.block_bytes, *sl = job_.slot + i * job_.block_bytes;
+                if (job_.to_slot) memcpy(sl, pg, (size_t)job_.block_bytes);
+                else copy_page_stream(pg, sl, (size_t)job_.block_bytes);
+            }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            lk.unlock();
+            work();
+            _mm_sfence();
+            lk.lock();
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    Job job_{};
+    std::atomic<int64_t> next_{0};
+    int64_t total_ = 0;
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+};
 }  // namespace
 
 static int swap_blocks_pageable(const void *const *srcs, void *const *dsts, int64_t num_tensors, const int64_t *mapping, int64_t num_pairs,
@@ -301,52 +374,54 @@ static int swap_blocks_pageable(const void *const *srcs, void *const *dsts, int6
     Bounce *bn = bounce_for_device();
     if (!bn) return -1;
     std::lock_guard<std::mutex> lock(bn->mu);
+    CopyTeam &team = CopyTeam::get();
     const bool out = kind == ATOMA_SWAP_GPU_TO_CPU;
-    const int64_t per_slot = std::min<int64_t>((int64_t)(BOUNCE_SLOT / (size_t)block_bytes), SWAP_MAX_PAIRS);
+    // a chunk = nt tensors x np pages (the same page list for every tensor), laid out [tensor][page] in its slot
+    const int64_t slot_pages = (int64_t)(BOUNCE_SLOT / (size_t)block_bytes);
+    const int64_t np_max = std::min<int64_t>(std::min<int64_t>(slot_pages, SWAP_MAX_PAIRS), num_pairs);
+    const int64_t nt_max = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(slot_pages / np_max, SWAP_MAX_TENSORS), num_tensors));
     const int64_t spans = cdiv(block_bytes, (int64_t)COPY_SPAN_VECS * 16);
-    std::vector<int64_t> host_pages((size_t)per_slot);
-    struct Pending { int slot; int64_t t, p0, n; };
-    Pending pend{-1, 0, 0, 0};                   // GPU -> CPU: the chunk whose gather is in flight
-    auto drain = [&](const Pending &c) -> bool {  // wait for its gather, copy the slot out to the caller's pages
-        if (!check_hip(hipEventSynchronize(bn->done[c.slot]), "swap_blocks bounce wait")) return false;
-        bn->busy[c.slot] = false;
-        for (int64_t k = 0; k < c.n; ++k) host_pages[(size_t)k] = mapping[2 * (c.p0 + k) + 1];
-        host_copy_pages(bn->host[c.slot], static_cast<char *>(dsts[c.t]), host_pages.data(), c.n, block_bytes, false);
+    struct Chunk { int64_t t0, nt, p0, np; };
+    Chunk in_slot[BOUNCE_SLOTS] = {};
+    std::vector<int64_t> host_pages((size_t)np_max);
+    std::vector<char *> host_tensors((size_t)nt_max);
+    auto host_side = [&](int slot, const Chunk &c) {       // copy a chunk between its slot and the caller's pages (the whole team)
+        for (int64_t k = 0; k < c.np; ++k) host_pages[(size_t)k] = mapping[2 * (c.p0 + k) + (out ? 1 : 0)];
+        for (int64_t t = 0; t < c.nt; ++t) host_tensors[(size_t)t] = out ? static_cast<char *>(dsts[c.t0 + t]) : const_cast<char *>(static_cast<const char *>(srcs[c.t0 + t]));
+        team.run(CopyTeam::Job{bn->host[slot], host_tensors.data(), host_pages.data(), c.nt, c.np, block_bytes, !out});
+    };
+    auto retire = [&](int slot) -> bool {                  // the slot's last kernel is done; GPU -> CPU: its pages go out to the caller
+        if (!bn->busy[slot]) return true;
+        if (!check_hip(hipEventSynchronize(bn->done[slot]), "swap_blocks bounce wait")) return false;
+        bn->busy[slot] = false;
+        if (out && in_slot[slot].np) { host_side(slot, in_slot[slot]); in_slot[slot].np = 0; }
         return true;
     };
     int slot = 0;
-    for (int64_t t = 0; t < num_tensors; ++t)
-        for (int64_t p0 = 0; p0 < num_pairs; p0 += per_slot, slot ^= 1) {
-            const int64_t n = std::min(per_slot, num_pairs - p0);
-            if (bn->busy[slot]) {                 // the kernel that last read / wrote this slot (this call or an earlier one)
-                if (out && pend.slot == slot) { if (!drain(pend)) return -1; pend.slot = -1; }
-                else if (!check_hip(hipEventSynchronize(bn->done[slot]), "swap_blocks bounce wait")) return -1;
-                bn->busy[slot] = false;
-            }
+    for (int64_t t0 = 0; t0 < num_tensors; t0 += nt_max)
+        for (int64_t p0 = 0; p0 < num_pairs; p0 += np_max, slot = (slot + 1) % BOUNCE_SLOTS) {
+            const Chunk c{t0, std::min(nt_max, num_tensors - t0), p0, std::min(np_max, num_pairs - p0)};
+            if (!retire(slot)) return -1;         // (a slot left busy by an earlier call holds no pending host copy: in_slot starts empty)
+            if (!out) host_side(slot, c);         // CPU -> GPU: fill the slot while the device scatters the chunks before this one
             SwapArgs a;
-            for (int64_t k = 0; k < n; ++k) {
+            for (int64_t k = 0; k < c.np; ++k) {
                 a.pairs[k][0] = out ? (int32_t)mapping[2 * (p0 + k)] : (int32_t)k;
                 a.pairs[k][1] = out ? (int32_t)k : (int32_t)mapping[2 * (p0 + k) + 1];
             }
-            if (out) {
-                a.src[0] = static_cast<const char *>(srcs[t]);
-                a.dst[0] = bn->dev[slot];
-            } else {
-                for (int64_t k = 0; k < n; ++k) host_pages[(size_t)k] = mapping[2 * (p0 + k)];
-                host_copy_pages(bn->host[slot], const_cast<char *>(static_cast<const char *>(srcs[t])), host_pages.data(), n, block_bytes, true);
-                a.src[0] = bn->dev[slot];
-                a.dst[0] = static_cast<char *>(dsts[t]);
+            for (int64_t t = 0; t < c.nt; ++t) {
+                char *in_slot_t = bn->dev[slot] + t * c.np * block_bytes;
+                a.src[t] = out ? static_cast<const char *>(srcs[t0 + t]) : in_slot_t;
+                a.dst[t] = out ? in_slot_t : static_cast<char *>(dsts[t0 + t]);
             }
-            hipLaunchKernelGGL(swap_blocks_kernel, dim3((unsigned)n, 1, (unsigned)spans), dim3(COPY_THREADS), 0, stream, a, block_bytes);
+            hipLaunchKernelGGL(swap_blocks_kernel, dim3((unsigned)c.np, (unsigned)c.nt, (unsigned)spans), dim3(COPY_THREADS), 0, stream, a, block_bytes);
             if (!ATOMA_CHECK_LAUNCH("swap_blocks (bounce)")) return -1;
             if (!check_hip(hipEventRecord(bn->done[slot], stream), "swap_blocks bounce record")) return -1;
             bn->busy[slot] = true;
-            if (out) {                            // the previous chunk's host copy runs beside this chunk's gather
-                if (pend.slot >= 0 && !drain(pend)) return -1;
-                pend = Pending{slot, t, p0, n};
-            }
+            if (out) in_slot[slot] = c;           // GPU -> CPU: copied out when the slot comes round again (the device is BOUNCE_SLOTS - 1 chunks ahead) or at the end
         }
-    if (out && pend.slot >= 0 && !drain(pend)) return -1;
+    if (out)
+        for (int i = 0; i < BOUNCE_SLOTS; ++i, slot = (slot + 1) % BOUNCE_SLOTS)      // oldest first
+            if (!retire(slot)) return -1;
     return 0;
 }
 
