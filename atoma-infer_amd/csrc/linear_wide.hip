@@ -61,6 +61,7 @@ struct WideParams {
     int chunks_per_split;        // chunks of 64 inputs
     int splits;                  // 1..8
     int xcd_map;                 // 1: workgroup b -> split (b % 8) % splits (a K range per XCD); 0: split = b / tiles
+    int var;                     // probe bits (atoma_set_option("linear_wide_var")): 1 = W pieces ahead of the x pieces, 2 = W without the non-temporal hint, 4 = x non-temporal
     WideRope rope;
 };
 constexpr int WIDE_PLAIN = 0, WIDE_GATE_UP = 1, WIDE_ROPE = 2;
@@ -115,13 +116,20 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
     }
     const uint64_t wb = wide_uniform64((uint64_t)(p.w + (int64_t)n0 * p.w_row_stride)) + (uint64_t)c0 * 128;
     const uint64_t xb = wide_uniform64((uint64_t)p.x) + (uint64_t)c0 * 128;
+    const int var = tp.var;
     auto issue = [&](int chunk, int slot) {
         const uint32_t sl = lds0 + slot * SLOT;
+        auto wpieces = [&]() {
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            if (i < PWW) wide_dma_nt(wb + (uint64_t)chunk * 128, voff[i], sl + dst[i]);
-            else wide_dma(xb + (uint64_t)chunk * 128, voff[i], sl + dst[i]);
-        }
+            for (int i = 0; i < PWW; ++i) { if (var & 2) wide_dma(wb + (uint64_t)chunk * 128, voff[i], sl + dst[i]); else wide_dma_nt(wb + (uint64_t)chunk * 128, voff[i], sl + dst[i]); }
+        };
+        auto xpieces = [&]() {
+#pragma unroll
+            for (int i = PWW; i < PPW; ++i) { if (var & 4) wide_dma_nt(xb + (uint64_t)chunk * 128, voff[i], sl + dst[i]); else wide_dma(xb + (uint64_t)chunk * 128, voff[i], sl + dst[i]); }
+        };
+        // x (L2, ~0.6 us) ahead of W (HBM, ~2 us): a wavefront's loads retire in order, so its x pieces would otherwise wait behind its W pieces
+        // (measured: 1-3 % on all four 8B projections; x non-temporal: -12..-17 %; W without the hint: level)
+        if (var & 1) { wpieces(); xpieces(); } else { xpieces(); wpieces(); }
     };
     // wavefront (h, bq): plain: groups h.GPW ..; PAIR: first-half groups h.GPW/2 .. and the matching partner groups; batch tiles bq.BTW ..
     const int h = wave & 1, bq = wave >> 1;
@@ -322,12 +330,14 @@ static int wide_env_or(const char *name, int dflt) { const char *v = getenv(name
 static std::atomic<int> linear_wide_on{wide_env_or("ATOMA_LINEAR_WIDE", 1)};           // 0: linear_big_kernel serves 65..256 rows
 static std::atomic<int> linear_wide_nw{wide_env_or("ATOMA_LINEAR_WIDE_NW", 0)};        // weight rows per workgroup: 0 = by shape
 static std::atomic<int> linear_wide_splits{wide_env_or("ATOMA_LINEAR_WIDE_SPLITS", 0)};   // K splits: 0 = by shape
+static std::atomic<int> linear_wide_var{wide_env_or("ATOMA_LINEAR_WIDE_VAR", 0)};      // probe bits, see WideParams::var
 static std::atomic<int> linear_wide_xcd{wide_env_or("ATOMA_LINEAR_WIDE_XCD", 0)};      // 1: a K range per XCD (splits 2 / 4 / 8) -- measured slower (o 25.2 vs 23.7 us, down 53.4 vs 52.0): off
 bool set_linear_wide_option(const std::string &name, int value) {
     if (name == "linear_wide") linear_wide_on = value;
     else if (name == "linear_wide_nw") linear_wide_nw = value;
     else if (name == "linear_wide_splits") linear_wide_splits = value;
     else if (name == "linear_wide_xcd") linear_wide_xcd = value;
+    else if (name == "linear_wide_var") linear_wide_var = value;
     else return false;
     return true;
 }
@@ -405,6 +415,7 @@ template <typename T> static int launch_linear_wide_t(LinearParams &p, hipStream
     }
     tp.xcd_map = linear_wide_xcd && (splits == 2 || splits == 4 || splits == 8) ? 1 : 0;
     tp.p = p;
+    tp.var = linear_wide_var;
     if (rope) tp.rope = *rope;
     const int mode = rope ? WIDE_ROPE : (p.epilogue == 2 ? WIDE_GATE_UP : WIDE_PLAIN);
     // xcd_map: groups of 8 workgroups cover 8 / S tiles: round the tile count up to a whole group (surplus workgroups leave at once)
