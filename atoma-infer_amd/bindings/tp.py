@@ -115,13 +115,24 @@ def preflight(ah, dist, rank, world, comm=None, xgmi=None, sizes=(16, 1 << 20, 6
     def bf16_of(v):          # small non-negative integers as bf16 bit patterns
         return (np.asarray(v, np.float32).view(np.uint32) >> 16).astype(np.uint16)
     engines = []
+    direct_state = {"built": None, "note": None}
+
+    def direct_via_comm(i, o, n):
+        # collective: every rank asks for the direct path alike (it is built on first use, over RCCL's own bootstrap) -- inside the watched
+        # attempt, so that a set-up that hangs on its first real peer mapping is a failed pair, not a lost run
+        if direct_state["built"] is None:
+            direct_state["built"] = ah.lib.atoma_comm_set_mode(comm, 1) == 0
+            direct_state["note"] = None if direct_state["built"] else ah.last_error()
+            ah.lib.atoma_comm_set_mode(comm, 0)
+        if not direct_state["built"]:
+            raise RuntimeError("direct engine unavailable: %s" % direct_state["note"])
+        ah.lib.atoma_comm_set_mode(comm, 1)
+        rc = ah.lib.atoma_allreduce_sum(comm, i, o, n, 1, None)
+        ah.lib.atoma_comm_set_mode(comm, 0)
+        return rc
     if comm is not None:
         engines.append(("rccl", lambda i, o, n: (ah.lib.atoma_comm_set_mode(comm, 0), ah.lib.atoma_allreduce_sum(comm, i, o, n, 1, None))[1], None))
-        # collective: every rank asks for the direct path alike (it is built on first use, over RCCL's own bootstrap)
-        ok_direct = ah.lib.atoma_comm_set_mode(comm, 1) == 0
-        note = None if ok_direct else ah.last_error()
-        ah.lib.atoma_comm_set_mode(comm, 0)
-        engines.append(("direct", (lambda i, o, n: (ah.lib.atoma_comm_set_mode(comm, 1), ah.lib.atoma_allreduce_sum(comm, i, o, n, 1, None), ah.lib.atoma_comm_set_mode(comm, 0))[1]) if ok_direct else None, note))
+        engines.append(("direct", direct_via_comm, None))
     if xgmi is not None:
         cap = int(ah.lib.atoma_xgmi_capacity(xgmi))
         engines.append(("direct", lambda i, o, n: ah.lib.atoma_xgmi_allreduce_sum(xgmi, i, o, n, 1, None) if n * 2 <= cap else -2, None))

@@ -39,3 +39,23 @@ def test_bench_ranks_on_one_device(gpu, world):
     pf = out["preflight"]["direct"]                            # first contact before the timed region: known pattern, every size the staging region takes
     assert pf["16B"]["ok"] and pf["16B"]["us"] > 0 and pf["1MiB"]["ok"] and pf["1MiB"]["us"] > 0, pf
     assert pf["64MiB"]["ok"] and "skipped" in pf["64MiB"].get("note", ""), pf      # bench.py's direct-only handle stages 2 MiB: reported, not silently dropped
+
+
+def test_bench_one_rank_through_the_rccl_communicator(gpu):
+    """ATOMA_BENCH_FORCE_COMM=1: one rank takes the multi-rank code path of bench.py -- gloo rendezvous, an RCCL communicator (ncclCommInitRank
+    with one member), the first-contact preflight through BOTH engines of that communicator (ncclAllReduce, and the direct kernels the
+    communicator builds on request), ranks counted through it -- the part of the 8-GPU run's plumbing that RCCL lets a 1-GPU box execute."""
+    env = dict(os.environ, ATOMA_BENCH_FORCE_COMM="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "32", "--seq", "1024", "--no-traffic", "--no-extra",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[-1])
+    assert out["ranks_seen"] == 1 and "rccl" in out["communicator"]["kind"]
+    pf = out["preflight"]
+    for size in ("16B", "1MiB", "64MiB"):
+        assert pf["rccl"][size]["ok"] and pf["rccl"][size]["us"] > 0, pf
+        assert pf["direct"][size]["ok"], pf
+    assert "[preflight] rccl" in r.stderr and "PASS" in r.stderr
