@@ -923,8 +923,19 @@ template <typename T> static int launch_linear(LinearParams &p, hipStream_t stre
         if (rc <= 0) return rc;
         rc = launch_linear_big<T>(p, stream);
         if (rc <= 0) return rc;
-        set_error("linear_decode: more than 64 rows need out_features and in_features to be multiples of 128");
-        return -1;
+        // a shape neither tile kernel takes (out_features not a multiple of 64, ...): the batch in slices of 64 rows through the kernels for
+        // 17..64 rows -- every epilogue is row-wise, so slices are independent (correct for any shape the small-batch path accepts; not fast)
+        for (int b0 = 0; b0 < p.batch; b0 += 64) {
+            LinearParams q = p;
+            q.batch = std::min(64, p.batch - b0);
+            q.x = p.x + (int64_t)b0 * p.x_row_stride;
+            q.y = p.y + (int64_t)b0 * p.y_row_stride;
+            if (p.aux) q.aux = p.aux + (int64_t)b0 * p.aux_row_stride;
+            q.partial = nullptr;
+            rc = launch_linear<T>(q, stream);
+            if (rc != 0) return rc;
+        }
+        return 0;
     }
     if (p.batch > 16) {
         int rc = launch_linear_tile(p, std::is_same<T, bf16_t>::value ? ATOMA_BF16 : ATOMA_F16, stream);

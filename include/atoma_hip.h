@@ -455,8 +455,11 @@ const char *atoma_last_decode_kernel(void);
  *     words of other epochs: nothing has to be zero on entry, nothing is reset, and a launch that ended inconsistently (a graph
  *     replayed beside eager calls on its stream, lengths changed under a running launch) cannot make a LATER launch wrong -- the
  *     callee carries no state from call to call (csrc/src/ffi.rs:3-102).  The pointer is baked into captured graphs like the scratch
- *     block: replay a graph on the stream it was captured on.  atoma_reset_sync_counters (round 4's repair call) is kept and harmless;
- *     nothing needs it.  atoma_debug_sync_words exposes the words to tests (which fill them with garbage and expect identical bits).
+ *     block: replay a graph on the stream it was captured on.  ONE residual case (csrc/sync_ticket.h): dispatch ids are per hardware
+ *     QUEUE, so a stream handle that is destroyed and created again may come back on a queue whose ids start lower; words that an
+ *     inconsistent episode left non-zero then look like "future" epochs to it.  The last arriver zeroes its word, so this needs BOTH an
+ *     inconsistent launch AND such a re-mapped stream; atoma_reset_sync_counters(stream) is the recovery after a failed or inconsistent
+ *     launch (round 4's repair call, kept for exactly this), harmless otherwise.  atoma_debug_sync_words exposes the words to tests (which fill them with garbage and expect identical bits).
  *   - atoma_warmup_prefill: the hand-scheduled prefill kernel (head_dim 128) plans a call in a table of 1 KiB per 256 query rows and
  *     q head in the same scratch block, padded to sequences x the LONGEST sequence's blocks; size it for the largest prefill call
  *     (longest sequence's query rows, sequences, q heads) before capturing a graph that contains one.  A prefill whose table cannot be allocated launches nothing and says so in atoma_last_error().

@@ -135,11 +135,12 @@ def test_llama_decode_step_op_by_op(gpu, graph, family):
     assert np.array_equal(step.next_ids.numpy(np.int32, (B,)), to_f32(logits, BF16).argmax(1))
 
 
-@pytest.mark.parametrize("B", [3, 2, 24, 64])
+@pytest.mark.parametrize("B", [3, 2, 24, 64, 100, 256])
 def test_llama_decode_step_fused_epilogues_are_bit_identical(gpu, B):
     """Residual adds and SiLU.up folded into the projections' split merge (and, at 1-2 rows, the RMSNorms folded into the q/k/v and
     gate/up projections) keep the reference's rounding points, so the fused step must reproduce the op-by-op step bit for bit
-    (logits, next tokens, caches) -- at 2-3 rows on the weight-streaming kernel, at 24 / 64 rows on the 17..64-row kernel; the
+    (logits, next tokens, caches) -- at 2-3 rows on the weight-streaming kernel, at 24 / 64 rows on the 17..64-row kernel, at 100 / 256 rows
+    on round 6's linear_wide_kernel (q/k/v + RoPE + cache write behind one entry; the lm_head of 1008 rows in slices of 64 batch rows); the
     op-by-op step runs on the library's own projection kernels too (own_projections), the vendor GEMM rounds differently."""
     import decode_step as DS
     rng = np.random.default_rng(12)

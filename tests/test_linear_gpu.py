@@ -181,7 +181,8 @@ def test_linear_decode_rmsnorm_is_the_two_ops_bit_for_bit(gpu, dtype, B, K, N, I
 
 @pytest.mark.parametrize("dtype", [BF16, F16])
 @pytest.mark.parametrize("B,K,N", [(65, 1024, 256), (100, 4096, 1024), (128, 4096, 4096), (129, 2048, 6144), (200, 14336, 512), (256, 4096, 4096), (256, 1024, 28672),
-                                   (256, 8192, 1280)])
+                                   (256, 8192, 1280),
+                                   (130, 1024, 1008), (256, 512, 48)])      # out_features no tile kernel takes: slices of 64 rows through the small-batch kernels
 def test_linear_decode_65_to_256_rows(gpu, dtype, B, K, N):
     """linear_big_kernel (32x32x16 MFMA tile of 128 weight rows x 128 / 256 batch rows, with and without K splitting)."""
     rng = np.random.default_rng(B + K + N)
