@@ -447,7 +447,9 @@ const char *atoma_last_decode_kernel(void);
  *     (a captured hipGraph may have its address in kernel arguments).
  *   - Growth is impossible during stream capture; atoma_warmup sizes the block for every decode call with
  *     batch <= max_batch, these head counts, contexts <= max_seqlen_k, and at least extra_bytes (projection partials:
- *     splits * batch * out_features * 4) -- call it once per stream before capturing, instead of relying on an eager call.
+ *     splits * batch_rows * out_features * 4 with splits <= 8 and batch_rows = the batch rounded up to 64 (17..64 rows) / 128 / 256
+ *     (65..256 rows: the K-split slabs of the tile kernels); 8 * 256 * the widest layer * 4 bytes covers every decode projection) --
+ *     call it once per stream before capturing, instead of relying on an eager call.
  *   - atoma_release_workspaces frees live and retired blocks of ALL streams: only when no graph that used them will be
  *     replayed and the streams are idle.
  *   - The kernels that merge their own split-K / split-KV pieces count arrivals in 8192 64-bit words per (device, stream).  A word is
