@@ -288,7 +288,8 @@ class CopyTeam {
     struct Job { char *slot; char *const *tensors; const int64_t *pages; int64_t nt, np, block_bytes; bool to_slot; };
     static CopyTeam &get() { static CopyTeam *t = new CopyTeam; return *t; }      // (never destroyed: the threads idle on a condition variable)
     void run(const Job &j) {
-        std::unique_lock<std::mutex> lk(mu_);              // one job at a time (callers already hold their device's bounce lock)
+        std::lock_guard<std::mutex> whole(run_mu_);        // one job at a time: swaps of DIFFERENT devices (one host thread per GPU) share the team
+        std::unique_lock<std::mutex> lk(mu_);
         job_ = j;
         next_.store(0);
         total_ = j.nt * j.np;
@@ -340,7 +341,7 @@ class CopyTeam {
             if (--pending_ == 0) done_cv_.notify_one();
         }
     }
-    std::mutex mu_;
+    std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_cv_;
     std::vector<std::thread> workers_;
     Job job_{};

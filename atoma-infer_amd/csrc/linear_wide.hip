@@ -8,7 +8,7 @@
 // workgroup) that is ~70 us on every decomposition that fills the chip once -- where the vendor GEMM sits too (61-65 us) -- against 30 us of
 // MFMA time.  So the kernel is built around the memory path, not the matrix pipe:
 //   * a workgroup of 8 wavefronts (two per SIMD: one wavefront's DMA issue stalls hide under the other's MFMAs) owns NW = 64 / 128
-//     weight rows (PAIR: NW/2 gate + the NW/2 matching up rows; RoPE: both halves of a head) x BR = 128 / 256 batch rows over a K range;
+//     weight rows (PAIR: NW/2 gate + the NW/2 matching up rows; RoPE: both halves of a head) x BR = 128 / 192 / 256 batch rows over a K range;
 //   * both operands arrive by the global->LDS DMA in full 128-byte lines (a piece = 8 rows x 128 B; image [row][16-byte slot ^ (row & 7)],
 //     the swizzle on the per-lane SOURCE address, fragment reads conflict-free), chunks of 64 inputs, ring of 3-4 chunks, ONE barrier
 //     per chunk, counted vmcnt so that two chunks stay in flight across every barrier; W non-temporal, x default policy (L2-resident);
@@ -365,13 +365,17 @@ static void wide_plan(int64_t n, int64_t k, int br, int cus, int *nw_out, int *s
     *splits_out = best_s;
 }
 
+// batch rows of the tile: 128 / 192 / 256 (a 192-row batch on 256-row tiles streams and multiplies a quarter of dead x rows: the 8B step at
+// batch 192 measured 1 % behind the vendor GEMM that way)
+static int wide_batch_rows(int batch) { return batch <= 128 ? 128 : (batch <= 192 ? 192 : 256); }
+
 // nw = 0: not served
 static void wide_route(const LinearParams &p, int *nw_out, int *splits_out) {
     *nw_out = 0;
     *splits_out = 1;
     if (!linear_wide_on || p.k % 64 || p.n % 64 || p.batch > 256 || p.batch <= 64) return;
     int nw = 0, splits = 1;
-    wide_plan(p.n, p.k, p.batch > 128 ? 256 : 128, device_num_cus(), &nw, &splits);
+    wide_plan(p.n, p.k, wide_batch_rows(p.batch), device_num_cus(), &nw, &splits);
     if (linear_wide_nw > 0 && p.n % linear_wide_nw == 0) nw = linear_wide_nw;
     if (linear_wide_splits > 0) splits = linear_wide_splits;
     if ((nw != 64 && nw != 128) || p.n % nw) return;
@@ -406,7 +410,7 @@ template <typename T> static int launch_linear_wide_t(LinearParams &p, hipStream
     tp.splits = splits;
     p.splits = splits;
     p.partial = nullptr;
-    const int br = p.batch > 128 ? 256 : 128;
+    const int br = wide_batch_rows(p.batch);
     const int64_t tiles = p.n / nw;
     if (splits > 1) {
         tp.slabs = static_cast<float *>(workspace(stream, (size_t)tiles * splits * nw * br * sizeof(float)));
@@ -430,7 +434,7 @@ template <typename T> static int launch_linear_wide_t(LinearParams &p, hipStream
         if (!once[dev].load()) { if (!check_hip(hipFuncSetAttribute((const void *)linear_wide_kernel<T, NW_, BR_, MODE_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "linear_wide LDS")) return -1; once[dev] = true; } \
         hipLaunchKernelGGL((linear_wide_kernel<T, NW_, BR_, MODE_>), grid, block, lds, stream, tp); } while (0)
 #define ATOMA_WIDE_B(NW_, BR_) do { if (mode == WIDE_ROPE) ATOMA_WIDE_M(NW_, BR_, WIDE_ROPE); else if (mode == WIDE_GATE_UP) ATOMA_WIDE_M(NW_, BR_, WIDE_GATE_UP); else ATOMA_WIDE_M(NW_, BR_, WIDE_PLAIN); } while (0)
-#define ATOMA_WIDE(NW_) do { if (br == 256) ATOMA_WIDE_B(NW_, 256); else ATOMA_WIDE_B(NW_, 128); } while (0)
+#define ATOMA_WIDE(NW_) do { if (br == 256) ATOMA_WIDE_B(NW_, 256); else if (br == 192) ATOMA_WIDE_B(NW_, 192); else ATOMA_WIDE_B(NW_, 128); } while (0)
     if (nw == 128) ATOMA_WIDE(128); else ATOMA_WIDE(64);
 #undef ATOMA_WIDE
 #undef ATOMA_WIDE_B
@@ -441,11 +445,11 @@ template <typename T> static int launch_linear_wide_t(LinearParams &p, hipStream
 template <typename T, int NW, int BR, int MODE> static bool wide_prepare_one() {
     return check_hip(hipFuncSetAttribute((const void *)linear_wide_kernel<T, NW, BR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds<T, NW, BR, MODE>()), "linear_wide LDS");
 }
-template <typename T> static bool wide_prepare_t() {
-    return wide_prepare_one<T, 64, 128, WIDE_PLAIN>() && wide_prepare_one<T, 128, 128, WIDE_PLAIN>() && wide_prepare_one<T, 64, 256, WIDE_PLAIN>() && wide_prepare_one<T, 128, 256, WIDE_PLAIN>() &&
-           wide_prepare_one<T, 64, 128, WIDE_GATE_UP>() && wide_prepare_one<T, 128, 128, WIDE_GATE_UP>() && wide_prepare_one<T, 64, 256, WIDE_GATE_UP>() && wide_prepare_one<T, 128, 256, WIDE_GATE_UP>() &&
-           wide_prepare_one<T, 64, 128, WIDE_ROPE>() && wide_prepare_one<T, 128, 128, WIDE_ROPE>() && wide_prepare_one<T, 64, 256, WIDE_ROPE>() && wide_prepare_one<T, 128, 256, WIDE_ROPE>();
+template <typename T, int MODE> static bool wide_prepare_m() {
+    return wide_prepare_one<T, 64, 128, MODE>() && wide_prepare_one<T, 128, 128, MODE>() && wide_prepare_one<T, 64, 192, MODE>() && wide_prepare_one<T, 128, 192, MODE>() &&
+           wide_prepare_one<T, 64, 256, MODE>() && wide_prepare_one<T, 128, 256, MODE>();
 }
+template <typename T> static bool wide_prepare_t() { return wide_prepare_m<T, WIDE_PLAIN>() && wide_prepare_m<T, WIDE_GATE_UP>() && wide_prepare_m<T, WIDE_ROPE>(); }
 // atoma_warmup: raise the LDS limit of every variant on the current device (a hipGraph capture can then be the first call)
 bool linear_wide_prepare() { return wide_prepare_t<bf16_t>() && wide_prepare_t<f16_t>(); }
 

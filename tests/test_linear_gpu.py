@@ -194,7 +194,7 @@ def test_linear_decode_65_to_256_rows(gpu, dtype, B, K, N):
 @pytest.mark.parametrize("opts", [dict(linear_wide_nw=64, linear_wide_splits=1), dict(linear_wide_nw=128, linear_wide_splits=1), dict(linear_wide_nw=64, linear_wide_splits=2),
                                   dict(linear_wide_nw=128, linear_wide_splits=3), dict(linear_wide_nw=64, linear_wide_splits=4), dict(linear_wide_nw=128, linear_wide_splits=8),
                                   dict(linear_wide_nw=64, linear_wide_splits=4, linear_wide_xcd=0), dict(linear_wide_nw=128, linear_wide_splits=5), dict(linear_wide=0)])
-@pytest.mark.parametrize("B", [65, 128, 129, 200, 256])
+@pytest.mark.parametrize("B", [65, 128, 129, 160, 192, 200, 256])
 def test_linear_wide_every_tile_shape_and_split(gpu, opts, B):
     """linear_wide_kernel (round 6: 65..256 rows): every template variant (64 / 128 weight rows x 128 / 256 batch rows), K unsplit and
     split 2..8 ways with the in-launch merge, the XCD map of the splits on and off, uneven splits -- against the oracle bound on random
