@@ -92,6 +92,9 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
         split = blockIdx.x / tiles;
     }
     if (tile >= tiles) return;
+    // batch block: the launch's y dimension cuts the batch into blocks of BR rows (two blocks of 128 for a 256-row batch halve a small product's
+    // slabs and x traffic per workgroup at the price of a second, L2-served pass over W: the plan decides); item = (tile, batch block)
+    const int b0 = (int)blockIdx.y * BR, item = tile + tiles * (int)blockIdx.y;
     const int half = MODE == WIDE_ROPE ? tp.rope.head_dim / 2 : 0;
     const int pair_dist = MODE == WIDE_GATE_UP ? out_n : half;
     int n0 = tile * NW;
@@ -110,7 +113,7 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
         const bool isw = i < PWW;
         const int q = isw ? wave * PWW + i : wave * PXW + (i - PWW);
         const int row = 8 * q + (lane >> 3);
-        const int64_t src_row = isw ? (PAIR && row >= NW / 2 ? (int64_t)pair_dist + row - NW / 2 : (int64_t)row) : (int64_t)min(row, p.batch - 1);
+        const int64_t src_row = isw ? (PAIR && row >= NW / 2 ? (int64_t)pair_dist + row - NW / 2 : (int64_t)row) : (int64_t)min(b0 + row, p.batch - 1);
         voff[i] = (uint32_t)(src_row * (isw ? p.w_row_stride : p.x_row_stride) * 2 + ((lane & 7) ^ (row & 7)) * 16);
         dst[i] = (isw ? 0 : WT) + 8 * q * 128;
     }
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
     if constexpr (MODE == WIDE_ROPE) {
 #pragma unroll
         for (int b = 0; b < BTW; ++b) {
-            const int brow = min(16 * (bt0 + b) + col, p.batch - 1);
+            const int brow = min(b0 + 16 * (bt0 + b) + col, p.batch - 1);
             rope_slot[b] = tp.rope.slot_mapping[brow];
             const int64_t pos = tp.rope.positions[brow];
             rope_pos[b] = tp.rope.table_rows > 0 ? (pos < 0 ? 0 : (pos >= tp.rope.table_rows ? tp.rope.table_rows - 1 : pos)) : pos;      // rope_pos() of norm_rope.hip
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
     }
     int live = 0;                                                  // batch tiles of this wavefront that hold rows of the batch
 #pragma unroll
-    for (int b = 0; b < BTW; ++b) live += 16 * (bt0 + b) < p.batch ? 1 : 0;
+    for (int b = 0; b < BTW; ++b) live += b0 + 16 * (bt0 + b) < p.batch ? 1 : 0;
     auto compute = [&](int slot) {
         const char *base = smem + slot * SLOT;
 #pragma unroll
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
         // publish this workgroup's fp32 tile write-through, drain, take a ticket; the LAST arriver adds the tiles in split order and finishes -- linear_tile.hip's merge
         const int S = tp.splits;
         constexpr int F = GPW * BTW;
-        float *mine = tp.slabs + ((int64_t)(tile * S + split) * WAVES + wave) * F * 256;
+        float *mine = tp.slabs + ((int64_t)(item * S + split) * WAVES + wave) * F * 256;
         const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(mine, 0, F * 1024, 0x00020000);
 #pragma unroll
         for (int a = 0; a < GPW; ++a)
@@ -217,13 +220,13 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned *ticket = reinterpret_cast<unsigned *>(smem);    // the ring is idle now (every DMA was waited for)
-        if (tid == 0) *ticket = sync_arrive(tp.counters + tile, sync_epoch(), (unsigned)S);
+        if (tid == 0) *ticket = sync_arrive(tp.counters + item, sync_epoch(), (unsigned)S);
         __syncthreads();
         if (*ticket + 1 != (unsigned)S) return;
         // (its own tile comes back from memory like the others: the fp32 registers are free for the sum, and the order is split order anyway)
         // two splits' loads in flight together (the second descriptor is empty past the last split: its loads return zeros, no branch)
         for (int sp = 0; sp < S; sp += 2) {
-            float *t0 = tp.slabs + ((int64_t)(tile * S + sp) * WAVES + wave) * F * 256;
+            float *t0 = tp.slabs + ((int64_t)(item * S + sp) * WAVES + wave) * F * 256;
             const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(t0, 0, F * 1024, 0x00020000);
             const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(t0 + WAVES * F * 256, 0, sp + 1 < S ? F * 1024 : 0, 0x00020000);
             lf32x4 o0[GPW][BTW], o1[GPW][BTW];
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
     }
 #pragma unroll
     for (int b = 0; b < BTW; ++b) {
-        const int brow = 16 * (bt0 + b) + col;
+        const int brow = b0 + 16 * (bt0 + b) + col;
         if (brow >= p.batch) continue;
         if constexpr (MODE == WIDE_ROPE) {
             // RoPE (q and k heads) + KV-cache write (k and v heads): rope_cache_kernel's arithmetic on the projection's ROUNDED output
@@ -331,6 +334,7 @@ static std::atomic<int> linear_wide_on{wide_env_or("ATOMA_LINEAR_WIDE", 1)};    
 static std::atomic<int> linear_wide_nw{wide_env_or("ATOMA_LINEAR_WIDE_NW", 0)};        // weight rows per workgroup: 0 = by shape
 static std::atomic<int> linear_wide_splits{wide_env_or("ATOMA_LINEAR_WIDE_SPLITS", 0)};   // K splits: 0 = by shape
 static std::atomic<int> linear_wide_var{wide_env_or("ATOMA_LINEAR_WIDE_VAR", 0)};      // probe bits, see WideParams::var
+static std::atomic<int> linear_wide_bb{wide_env_or("ATOMA_LINEAR_WIDE_BB", 0)};        // batch blocks: 0 = by shape, 1 = one tile over the batch, 2 = blocks of 128 rows
 static std::atomic<int> linear_wide_xcd{wide_env_or("ATOMA_LINEAR_WIDE_XCD", 0)};      // 1: a K range per XCD (splits 2 / 4 / 8) -- measured slower (o 25.2 vs 23.7 us, down 53.4 vs 52.0): off
 bool set_linear_wide_option(const std::string &name, int value) {
     if (name == "linear_wide") linear_wide_on = value;
@@ -338,59 +342,66 @@ bool set_linear_wide_option(const std::string &name, int value) {
     else if (name == "linear_wide_splits") linear_wide_splits = value;
     else if (name == "linear_wide_xcd") linear_wide_xcd = value;
     else if (name == "linear_wide_var") linear_wide_var = value;
+    else if (name == "linear_wide_bb") linear_wide_bb = value;
     else return false;
     return true;
 }
 
-// Rows per workgroup and K split from the SHAPE OF W (and the batch tile) alone, priced with the queue model in the header: a workgroup's
-// time = (weight KB x 2.0 us + x KB x 0.6 us) / 45 KB, plus ~1.5 us + the slabs the last arriver reads back at ~50 KB/us for an in-launch
-// merge, times the rounds of workgroups over the CUs.  8B at 256 rows: gate/up (128 rows, 1 split, 224 workgroups), down (64, 4, 256),
-// q/k/v (64, 2, 192), o (64, 4, 256).  The plan must NOT depend on the epilogue: the fused entries are bit-identical to projection + separate op only because both split K alike.
+// Rows per workgroup, K split and batch blocks from the SHAPE of the product alone (n, k, batch rows), priced with the queue model in the header: a
+// workgroup's time = (weight KB x 2.0 us [x 0.6 for the passes a sibling batch block already pulled into L2] + x KB x 0.6 us) / 45 KB, plus ~1.5 us + the
+// slabs the last arriver reads back at ~50 KB/us for an in-launch merge, plus the one-workgroup epilogue tail, times the rounds of workgroups over the
+// CUs.  8B at 256 rows (measured, profiles/r06_linear256_ab.jsonl): gate/up (128 rows, 1 split, one 256-row tile: 224 workgroups) 72-75 us; down (128 rows,
+// 4 splits, two 128-row batch blocks: 256 workgroups) 49 (one 256-row tile, 64 rows, 4 splits: 52-54); o (64, 2, two blocks: 256) 21.9 (23.6-24.5); q/k/v
+// (64, 1, two blocks: 192 workgroups, no merge) 32.7 with the RoPE epilogue (34.4).  The plan must NOT depend on the epilogue: the fused entries are
+// bit-identical to projection + separate op only because both split K alike.
 constexpr int WIDE_MAX_MERGE = 8;
-static void wide_plan(int64_t n, int64_t k, int br, int cus, int *nw_out, int *splits_out) {
+struct WidePlan { int nw = 0, splits = 1, br = 256, bblocks = 1; };
+// candidates: 128 / 64 rows x 1..8 K splits x (the whole batch in one tile | blocks of 128 batch rows).  Batch blocks: W is streamed once from HBM
+// and (bblocks - 1) more times from L2 by the sibling blocks; x and the slabs per workgroup shrink with the tile.
+static WidePlan wide_plan(int64_t n, int64_t k, int batch, int cus) {
     const int64_t chunks = k / 64;
-    int best_nw = 0, best_s = 1;
+    const int br_one = batch <= 128 ? 128 : (batch <= 192 ? 192 : 256);
+    WidePlan best;
     double best_t = 1e30;
-    for (int s : {1, 2, 3, 4, 5, 6, 8})
-        for (int nw : {128, 64}) {
-            if (n % nw || chunks / s < 4) continue;
-            const int64_t wgs = n / nw * s;
-            const double kb = (double)cdiv(chunks, s) * 128.0 / 1024.0;
-            const double merge = s == 1 ? 0.0 : 1.5 + (double)(s - 1) * (nw * br * 4 / 1024.0) / 50.0;
-            const double tail = nw * br / 8192.0;      // the epilogue of a tile runs in ONE workgroup (measured: the RoPE epilogue of a 128 x 256 tile ~8 us, of a 64 x 256 tile ~3)
-            const double t = (double)cdiv(wgs, cus) * ((nw * kb * 2.0 + br * kb * 0.6) / 45.0 + merge + tail);
-            if (t < best_t) { best_t = t; best_nw = nw; best_s = s; }
-        }
-    *nw_out = best_nw;
-    *splits_out = best_s;
+    for (int bb : {1, 2}) {
+        if (bb == 2 && batch <= 128) continue;
+        const int br = bb == 1 ? br_one : 128;
+        for (int s : {1, 2, 3, 4, 5, 6, 8})
+            for (int nw : {128, 64}) {
+                if (n % nw || chunks / s < 4) continue;
+                const int64_t wgs = n / nw * s * bb;
+                if (s > 1 && n / nw * bb > 8192) continue;                  // one arrival counter per (tile, batch block)
+                const double kb = (double)cdiv(chunks, s) * 128.0 / 1024.0;
+                const double merge = s == 1 ? 0.0 : 1.5 + (double)(s - 1) * (nw * br * 4 / 1024.0) / 50.0;
+                const double tail = nw * br / 8192.0;      // the epilogue of a tile runs in ONE workgroup (measured: the RoPE epilogue of a 128 x 256 tile ~8 us, of a 64 x 256 tile ~3)
+                const double w_cost = nw * kb * (2.0 / bb + 0.6 * (bb - 1) / bb);
+                const double t = (double)cdiv(wgs, cus) * ((w_cost + br * kb * 0.6) / 45.0 + merge + tail);
+                if (t < best_t) { best_t = t; best = WidePlan{nw, s, br, bb}; }
+            }
+    }
+    return best;
 }
 
-// batch rows of the tile: 128 / 192 / 256 (a 192-row batch on 256-row tiles streams and multiplies a quarter of dead x rows: the 8B step at
-// batch 192 measured 1 % behind the vendor GEMM that way)
-static int wide_batch_rows(int batch) { return batch <= 128 ? 128 : (batch <= 192 ? 192 : 256); }
-
 // nw = 0: not served
-static void wide_route(const LinearParams &p, int *nw_out, int *splits_out) {
-    *nw_out = 0;
-    *splits_out = 1;
-    if (!linear_wide_on || p.k % 64 || p.n % 64 || p.batch > 256 || p.batch <= 64) return;
-    int nw = 0, splits = 1;
-    wide_plan(p.n, p.k, wide_batch_rows(p.batch), device_num_cus(), &nw, &splits);
-    if (linear_wide_nw > 0 && p.n % linear_wide_nw == 0) nw = linear_wide_nw;
-    if (linear_wide_splits > 0) splits = linear_wide_splits;
-    if ((nw != 64 && nw != 128) || p.n % nw) return;
+static WidePlan wide_route(const LinearParams &p) {
+    WidePlan none;
+    if (!linear_wide_on || p.k % 64 || p.n % 64 || p.batch > 256 || p.batch <= 64) return none;
+    WidePlan pl = wide_plan(p.n, p.k, p.batch, device_num_cus());
+    if (linear_wide_nw > 0 && p.n % linear_wide_nw == 0) pl.nw = linear_wide_nw;
+    if (linear_wide_splits > 0) pl.splits = linear_wide_splits;
+    if (linear_wide_bb == 1) { pl.bblocks = 1; pl.br = p.batch <= 128 ? 128 : (p.batch <= 192 ? 192 : 256); }
+    if (linear_wide_bb == 2 && p.batch > 128) { pl.bblocks = 2; pl.br = 128; }
+    if ((pl.nw != 64 && pl.nw != 128) || p.n % pl.nw) return none;
     const int64_t chunks = p.k / 64;
-    splits = (int)std::min<int64_t>(std::min<int64_t>(splits, WIDE_MAX_MERGE), std::max<int64_t>(chunks / 4, 1));
-    splits = (int)cdiv(chunks, cdiv(chunks, splits));
-    if (splits > 1 && p.n / nw > 4096) return;                    // one arrival counter per tile
-    *nw_out = nw;
-    *splits_out = splits;
+    int splits = (int)std::min<int64_t>(std::min<int64_t>(pl.splits, WIDE_MAX_MERGE), std::max<int64_t>(chunks / 4, 1));
+    pl.splits = (int)cdiv(chunks, cdiv(chunks, splits));
+    if (pl.splits > 1 && p.n / pl.nw * pl.bblocks > 8192) return none;
+    return pl;
 }
 
 // the RoPE epilogue can ride on this product: served, and a tile holds both halves of a head
 bool linear_wide_can_rope(const LinearParams &p, int head_dim) {
-    int nw, splits;
-    wide_route(p, &nw, &splits);
+    const int nw = wide_route(p).nw;
     return nw != 0 && head_dim % 32 == 0 && nw / 2 <= head_dim / 2 && (head_dim / 2) % (nw / 2) == 0;
 }
 
@@ -400,8 +411,9 @@ template <typename T, int NW, int BR, int MODE> static constexpr size_t wide_lds
 }
 
 template <typename T> static int launch_linear_wide_t(LinearParams &p, hipStream_t stream, const WideRope *rope) {
-    int nw, splits;
-    wide_route(p, &nw, &splits);
+    const WidePlan pl = wide_route(p);
+    const int nw = pl.nw;
+    int splits = pl.splits;
     if (nw == 0) return 1;
     const int64_t chunks = p.k / 64;
     WideParams tp{};
@@ -410,10 +422,10 @@ template <typename T> static int launch_linear_wide_t(LinearParams &p, hipStream
     tp.splits = splits;
     p.splits = splits;
     p.partial = nullptr;
-    const int br = wide_batch_rows(p.batch);
+    const int br = pl.br;
     const int64_t tiles = p.n / nw;
     if (splits > 1) {
-        tp.slabs = static_cast<float *>(workspace(stream, (size_t)tiles * splits * nw * br * sizeof(float)));
+        tp.slabs = static_cast<float *>(workspace(stream, (size_t)tiles * pl.bblocks * splits * nw * br * sizeof(float)));
         tp.counters = sync_counters(stream);
         if (!tp.slabs || !tp.counters) return -1;
     }
@@ -424,7 +436,7 @@ template <typename T> static int launch_linear_wide_t(LinearParams &p, hipStream
     const int mode = rope ? WIDE_ROPE : (p.epilogue == 2 ? WIDE_GATE_UP : WIDE_PLAIN);
     // xcd_map: groups of 8 workgroups cover 8 / S tiles: round the tile count up to a whole group (surplus workgroups leave at once)
     const int64_t wgs = tp.xcd_map ? cdiv(tiles, 8 / splits) * 8 : tiles * splits;
-    const dim3 grid((unsigned)wgs), block(512);
+    const dim3 grid((unsigned)wgs, (unsigned)pl.bblocks), block(512);
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev < 0 || dev >= 64 ? 0 : dev;
