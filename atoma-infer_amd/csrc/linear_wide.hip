@@ -328,6 +328,109 @@ __global__ void __launch_bounds__(512, 1) linear_wide_kernel(const WideParams tp
     }
 }
 
+// ---- gate/up + SiLU.up with 112-row tiles: every CU of the chip gets a workgroup ------------------------------------------------------------------------
+// The stacked gate / up matrix of the Llama MLPs has 2 x 14336 (8B) or 2 x 28672 (70B) rows: 128-row tiles give 224 / 448 workgroups -- 224 leave 32 of the
+// 256 CUs idle, and on this kernel's memory-path bound a workgroup's time is its own bytes, so the launch takes as long with 224 as it would with 256.
+// 112-row tiles (56 gate + 56 up rows) give 256 workgroups of 7/8 the weight bytes each (model: 72.8 -> 67 us at 256 batch rows).  56 is not a multiple of
+// the 16-row MFMA group, so the tile INTERLEAVES: group g (of 7) holds gate rows 8g..8g+7 in its first eight rows and their up partners in its last eight;
+// a DMA piece (8 rows x 128 B) is still eight consecutive rows of one of the two blocks.  In the 16 x 16 output a lane holds rows 4.(lane >> 4) + i: gate
+// for lanes 0..31, up for lanes 32..63 of the SAME batch column -- one cross-half exchange per group pairs them (the low half finishes batch tile 0 of the
+// wavefront, the high half batch tile 1: no idle lanes).  K is never split here (one round of workgroups): every output is the same chain of MFMA
+// accumulations as in the 128-row kernel, so the result is bit-identical to the plain projection + atoma_silu_mul whatever tile either used.
+template <typename T>
+__global__ void __launch_bounds__(512, 1) linear_wide_gu112_kernel(const WideParams tp) {
+    const LinearParams &p = tp.p;
+    constexpr int NW = 112, BR = 256, G = 7, NSLOT = 3;
+    constexpr int WT = NW * 128, XT = BR * 128, SLOT = WT + XT;
+    static_assert(NSLOT * SLOT <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = lane >> 4, col = lane & 15;
+    const int out_n = p.n / 2, tile = blockIdx.x, n0 = tile * (NW / 2);
+    const int chunks = p.k >> 6;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    // W: 14 pieces per chunk (piece q = tile rows 8q..8q+7: even q = gate rows n0 + 4q.., odd q = up rows out_n + n0 + 4(q - 1)..): wavefronts 0..5 move
+    // two each, 6 and 7 one; x: 32 pieces, four per wavefront.  The lane fills (row, slot) = (8q + (lane >> 3), lane & 7) from source piece (lane & 7) ^ (row & 7).
+    const int nwp = wave < 6 ? 2 : 1, q0 = wave < 6 ? 2 * wave : 12 + (wave - 6);
+    uint32_t woff[2], wdst[2], xoff[4], xdst[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = min(q0 + i, 13), row = 8 * q + (lane >> 3);
+        const int64_t src_row = (q & 1 ? (int64_t)out_n : 0) + 8 * (q >> 1) + (lane >> 3);
+        woff[i] = (uint32_t)(src_row * p.w_row_stride * 2 + ((lane & 7) ^ (row & 7)) * 16);
+        wdst[i] = 8 * q * 128;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = 4 * wave + i, row = 8 * q + (lane >> 3);
+        xoff[i] = (uint32_t)((int64_t)min(row, p.batch - 1) * p.x_row_stride * 2 + ((lane & 7) ^ (row & 7)) * 16);
+        xdst[i] = WT + 8 * q * 128;
+    }
+    const uint64_t wb = wide_uniform64((uint64_t)(p.w + (int64_t)n0 * p.w_row_stride));
+    const uint64_t xb = wide_uniform64((uint64_t)p.x);
+    auto issue = [&](int chunk, int slot) {
+        const uint32_t sl = lds0 + slot * SLOT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wide_dma(xb + (uint64_t)chunk * 128, xoff[i], sl + xdst[i]);
+        wide_dma_nt(wb + (uint64_t)chunk * 128, woff[0], sl + wdst[0]);
+        if (nwp == 2) wide_dma_nt(wb + (uint64_t)chunk * 128, woff[1], sl + wdst[1]);
+    };
+    lf32x4 acc[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc[g][0] = lf32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = lf32x4{0.f, 0.f, 0.f, 0.f}; }
+    const bool live = 32 * wave < p.batch;
+    auto compute = [&](int slot) {
+        const char *base = smem + slot * SLOT;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int sw = ((4 * s + grp) ^ (col & 7)) * 16;
+            lu32x4 bf[2], af[G];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const lu32x4 *>(base + WT + (16 * (2 * wave + b) + col) * 128 + sw);
+#pragma unroll
+            for (int g = 0; g < G; ++g) af[g] = *reinterpret_cast<const lu32x4 *>(base + (16 * g + col) * 128 + sw);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g][b] = lin_mfma<T>(af[g], bf[b], acc[g][b]);
+        }
+    };
+    for (int s = 0; s < NSLOT - 1; ++s)
+        if (s < chunks) issue(s, s);
+    int slot = 0;
+    for (int c = 0; c < chunks; ++c) {
+        // this wavefront's pieces of chunk c have landed (5 or 6 per chunk: the count is the wavefront's own), then everybody's
+        if (c + NSLOT - 2 < chunks) { if (nwp == 2) wide_vm_wait<6 * (NSLOT - 2)>(); else wide_vm_wait<5 * (NSLOT - 2)>(); } else wide_vm_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        const int pslot = slot == 0 ? NSLOT - 1 : slot - 1;
+        if (c + NSLOT - 1 < chunks) issue(c + NSLOT - 1, pslot);
+        if (live) compute(slot);
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+    }
+    // lanes 0..31 hold gate rows 8g + 4.(grp & 1) + i, lanes 32..63 the matching up rows, of batch columns 16.(2 wave + b) + col.  The halves swap one
+    // accumulator per group: the low half gets the up values of batch tile 0, the high half the gate values of batch tile 1 -- each finishes one tile.
+    const bool hi = lane >= 32;
+    const int brow = 16 * (2 * wave + (hi ? 1 : 0)) + col;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const lf32x4 give = hi ? acc[g][0] : acc[g][1];
+        lf32x4 got;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) got[i] = __shfl_xor(give[i], 32, 64);
+        if (brow >= p.batch) continue;
+        const lf32x4 gate = hi ? got : acc[g][0], up = hi ? acc[g][1] : got;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                  // rounding points as in linear_reduce_kernel / the 128-row kernel
+            const float x = round_through<T>(gate[i]);
+            v[i] = round_through<T>(x / (1.f + __expf(-x))) * round_through<T>(up[i]);
+        }
+        uint2 o;
+        o.x = pack2<T>(v[0], v[1]);
+        o.y = pack2<T>(v[2], v[3]);
+        *reinterpret_cast<uint2 *>(p.y + (int64_t)brow * p.y_row_stride + n0 + 8 * g + 4 * (grp & 1)) = o;
+    }
+}
+
 static int wide_env_or(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
 // knobs: environment at load time, atoma_set_option("linear_wide*") at run time (A/B runs inside one process)
 static std::atomic<int> linear_wide_on{wide_env_or("ATOMA_LINEAR_WIDE", 1)};           // 0: linear_big_kernel serves 65..256 rows
@@ -335,6 +438,7 @@ static std::atomic<int> linear_wide_nw{wide_env_or("ATOMA_LINEAR_WIDE_NW", 0)}; 
 static std::atomic<int> linear_wide_splits{wide_env_or("ATOMA_LINEAR_WIDE_SPLITS", 0)};   // K splits: 0 = by shape
 static std::atomic<int> linear_wide_var{wide_env_or("ATOMA_LINEAR_WIDE_VAR", 0)};      // probe bits, see WideParams::var
 static std::atomic<int> linear_wide_bb{wide_env_or("ATOMA_LINEAR_WIDE_BB", 0)};        // batch blocks: 0 = by shape, 1 = one tile over the batch, 2 = blocks of 128 rows
+static std::atomic<int> linear_wide_gu112{wide_env_or("ATOMA_LINEAR_WIDE_GU112", 1)};  // 0: gate/up + SiLU.up always on the 128-row tiles
 static std::atomic<int> linear_wide_xcd{wide_env_or("ATOMA_LINEAR_WIDE_XCD", 0)};      // 1: a K range per XCD (splits 2 / 4 / 8) -- measured slower (o 25.2 vs 23.7 us, down 53.4 vs 52.0): off
 bool set_linear_wide_option(const std::string &name, int value) {
     if (name == "linear_wide") linear_wide_on = value;
@@ -343,6 +447,7 @@ bool set_linear_wide_option(const std::string &name, int value) {
     else if (name == "linear_wide_xcd") linear_wide_xcd = value;
     else if (name == "linear_wide_var") linear_wide_var = value;
     else if (name == "linear_wide_bb") linear_wide_bb = value;
+    else if (name == "linear_wide_gu112") linear_wide_gu112 = value;
     else return false;
     return true;
 }
@@ -434,6 +539,24 @@ template <typename T> static int launch_linear_wide_t(LinearParams &p, hipStream
     tp.var = linear_wide_var;
     if (rope) tp.rope = *rope;
     const int mode = rope ? WIDE_ROPE : (p.epilogue == 2 ? WIDE_GATE_UP : WIDE_PLAIN);
+    // gate/up + SiLU.up, unsplit, one 256-row batch tile: 112-row tiles when they fill more CUs in the same number of rounds (8B / 70B: 256 workgroups
+    // instead of 224) -- bit-identical to any other unsplit tiling (linear_wide_gu112_kernel's header)
+    if (mode == WIDE_GATE_UP && splits == 1 && pl.bblocks == 1 && br == 256 && linear_wide_gu112 && (p.n / 2) % 56 == 0) {
+        const int64_t t112 = p.n / 112, t128 = p.n / 128, cus = device_num_cus();
+        if (cdiv(t112, cus) <= cdiv(t128, cus)) {
+            tp.p = p;
+            tp.var = linear_wide_var;
+            tp.splits = 1;
+            int dev112 = 0;
+            (void)hipGetDevice(&dev112);
+            dev112 = dev112 < 0 || dev112 >= 64 ? 0 : dev112;
+            constexpr size_t lds112 = 3 * (112 + 256) * 128;
+            static std::atomic<bool> once112[64];
+            if (!once112[dev112].load()) { if (!check_hip(hipFuncSetAttribute((const void *)linear_wide_gu112_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds112), "linear_wide_gu112 LDS")) return -1; once112[dev112] = true; }
+            hipLaunchKernelGGL((linear_wide_gu112_kernel<T>), dim3((unsigned)t112), dim3(512), lds112, stream, tp);
+            return ATOMA_CHECK_LAUNCH("linear_wide_gu112_kernel") ? 0 : -1;
+        }
+    }
     // xcd_map: groups of 8 workgroups cover 8 / S tiles: round the tile count up to a whole group (surplus workgroups leave at once)
     const int64_t wgs = tp.xcd_map ? cdiv(tiles, 8 / splits) * 8 : tiles * splits;
     const dim3 grid((unsigned)wgs, (unsigned)pl.bblocks), block(512);
@@ -463,7 +586,12 @@ template <typename T, int MODE> static bool wide_prepare_m() {
 }
 template <typename T> static bool wide_prepare_t() { return wide_prepare_m<T, WIDE_PLAIN>() && wide_prepare_m<T, WIDE_GATE_UP>() && wide_prepare_m<T, WIDE_ROPE>(); }
 // atoma_warmup: raise the LDS limit of every variant on the current device (a hipGraph capture can then be the first call)
-bool linear_wide_prepare() { return wide_prepare_t<bf16_t>() && wide_prepare_t<f16_t>(); }
+bool linear_wide_prepare() {
+    constexpr int lds112 = 3 * (112 + 256) * 128;
+    return wide_prepare_t<bf16_t>() && wide_prepare_t<f16_t>() &&
+           check_hip(hipFuncSetAttribute((const void *)linear_wide_gu112_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds112), "linear_wide_gu112 LDS") &&
+           check_hip(hipFuncSetAttribute((const void *)linear_wide_gu112_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds112), "linear_wide_gu112 LDS");
+}
 
 // 0 = launched, 1 = shape not served (the caller falls back to linear_big_kernel), -1 = error
 int launch_linear_wide(LinearParams &p, int dtype, hipStream_t stream) {

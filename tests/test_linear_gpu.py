@@ -250,7 +250,9 @@ def test_linear_decode_big_exact_cases(gpu):
                                      # path, exactly one unrolled iteration), 16- and 32-row workgroups, row counts that are not a multiple of 32
                                      (64, 8192, 1280, 3584), (64, 1024, 8192, 256), (48, 3584, 8192, 512), (17, 256, 32, 16), (31, 2304, 48, 80),
                                      (64, 2048, 6144, 1024), (50, 4352, 4112, 48), (20, 1280, 128, 64),   # K = 1280: not a multiple of 256 -> linear_mid_kernel
-                                     (65, 1024, 256, 128), (130, 4096, 1024, 1024), (256, 2048, 4096, 14336), (256, 14336, 512, 256)])
+                                     (65, 1024, 256, 128), (130, 4096, 1024, 1024), (256, 2048, 4096, 14336), (256, 14336, 512, 256),
+                                     # 193..256 rows, unsplit gate/up with 56 | intermediate: linear_wide_gu112_kernel (112-row interleaved tiles, the halves of a wavefront swap accumulators)
+                                     (256, 4096, 128, 14336), (200, 512, 128, 28672), (193, 1024, 64, 14336)])
 def test_linear_mid_batch_epilogues_match_the_separate_ops(gpu, B, K, N, I):
     """17..64 rows (linear_mid_kernel: one workgroup per 64 features) and 65..256 rows (linear_big_kernel), with and without K
     splitting: the fused epilogues keep the rounding points of projection + atoma_add / atoma_silu_mul -- bit for bit -- and the

@@ -26,10 +26,11 @@ VARIANTS = [("wide", {}), ("wide nw64", {"linear_wide_nw": 64}), ("wide nw128", 
             ("wide bb2 nw64 s2", {"linear_wide_bb": 2, "linear_wide_nw": 64, "linear_wide_splits": 2}), ("wide bb2 nw64 s4", {"linear_wide_bb": 2, "linear_wide_nw": 64, "linear_wide_splits": 4}),
             ("wide bb2 nw128 s2", {"linear_wide_bb": 2, "linear_wide_nw": 128, "linear_wide_splits": 2}), ("wide bb2 nw128 s4", {"linear_wide_bb": 2, "linear_wide_nw": 128, "linear_wide_splits": 4}),
             ("wide bb2 nw128 s1", {"linear_wide_bb": 2, "linear_wide_nw": 128, "linear_wide_splits": 1}),
+            ("wide 128-row tiles", {"linear_wide_gu112": 0}),
             ("wide xcd map", {"linear_wide_xcd": 1}), ("wide W first", {"linear_wide_var": 1}), ("wide W plain", {"linear_wide_var": 2}), ("wide x nt", {"linear_wide_var": 4}),
             ("wide W first W plain", {"linear_wide_var": 3}),
             ("big kernel", {"linear_wide": 0}), ("vendor", {"vendor": 1}), ("vendor + epilogue", {"vendor": 2})]
-DEFAULTS = {"linear_wide": 1, "linear_wide_nw": 0, "linear_wide_splits": 0, "linear_wide_xcd": 0, "linear_wide_var": 0, "linear_wide_bb": 0}
+DEFAULTS = {"linear_wide": 1, "linear_wide_nw": 0, "linear_wide_splits": 0, "linear_wide_xcd": 0, "linear_wide_var": 0, "linear_wide_bb": 0, "linear_wide_gu112": 1}
 ROUNDS, ITERS = 7, 12
 
 
