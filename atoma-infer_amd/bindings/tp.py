@@ -179,13 +179,19 @@ def preflight(ah, dist, rank, world, comm=None, xgmi=None, sizes=(16, 1 << 20, 6
             th = threading.Thread(target=attempt, daemon=True)
             th.start()
             th.join(timeout_s)
-            if th.is_alive():
+            hung_here = th.is_alive()
+            if hung_here:
                 out["note"] = "hung: no return within %.0f s" % timeout_s
-                state["hung"] = "%s %s" % (name, key)
-            t = torch.tensor([out["ok"], -out["us"]], dtype=torch.float64)
-            if not state["hung"]:
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)                # ok on every rank; the slowest rank's time
-            res[name][key] = {"ok": bool(t[0].item() >= 1.0), "us": round(-t[1].item(), 1) if out["us"] else None}
+                out["ok"] = 0.0
+            # the agreement is ALWAYS taken, by every rank, once per pair (CPU tensors over the rendezvous: a hung device call does not block it):
+            # a rank that skipped it would leave the others waiting in it and desynchronise every later collective of the run
+            t = torch.tensor([out["ok"], -out["us"], 0.0 if hung_here else 1.0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)                    # ok on every rank; the slowest rank's time; nobody hung
+            if t[2].item() < 1.0:
+                state["hung"] = "%s %s" % (name, key)                   # on EVERY rank alike: the remaining pairs are skipped consistently
+                if not hung_here:
+                    out["note"] = ((out["note"] + "; ") if out["note"] else "") + "another rank hung in this pair"
+            res[name][key] = {"ok": bool(t[0].item() >= 1.0), "us": round(-t[1].item(), 1) if (out["us"] and t[0].item() >= 1.0) else None}
             if out["note"]:
                 res[name][key]["note"] = out["note"]
             if log is not None and rank == 0:
