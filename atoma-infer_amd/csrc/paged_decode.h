@@ -92,6 +92,7 @@ __device__ __forceinline__ int decode_seq_len(const DecodeParams &p, int b) {
 // owns.  The split index is slowest: the dispatcher places workgroups on CUs round-robin by index, so
 // wavefronts that exit at once must not be interleaved with the working ones -- measured 2.5x slower with the
 // split index in the middle (only every 4th CU of an XCD got work).
+constexpr int DECODE_PAIR_MAX_B = 512;   // paged_decode_pair_kernel ranks the batch's lengths in LDS
 struct DecodeWork {
     int b, hk, gc, split;
     int L, n_tiles, t0, t1;

@@ -756,6 +756,106 @@ __global__ void __launch_bounds__(64 * NWG, 2) paged_decode_wg_kernel(const Deco
     }
 }
 
+// ---- narrow ragged batches: two sequences per workgroup (round 6 probe, option decode_pair) ----------------------------------------------------------
+// BASELINE configs[2] mid-trace: 256 sequences of U[2048, 2560) tokens x 8 kv heads = 2048 (sequence, kv head) units for 2048 resident wavefronts --
+// one unit each, so the launch lasts as long as its LONGEST sequence (0.383 ms against 0.356 for a uniform batch of the same bytes) and cutting
+// sequences between wavefronts costs more than it returns below ~15 % idle share.  Here a workgroup of 8 wavefronts takes a PAIR of sequences --
+// the i-th shortest with the i-th longest (each workgroup ranks the batch's lengths itself: 256 compares per thread) -- and 4 kv heads: wavefront
+// (head j, half k) streams half k of sequence A's tiles, the two halves of a head merge in LDS (paged_decode_wg_kernel's arithmetic), then the same
+// for sequence B.  Every wavefront of the launch then streams (len_A + len_B) / 2 tokens: balanced to the pairing's residue, no partial ever leaves the CU.
+template <typename T, int G, int P, bool NT>
+__global__ void __launch_bounds__(512, 2) paged_decode_pair_kernel(const DecodeParams p) {
+    constexpr int D = 128, NW = 8;
+    __shared__ __attribute__((aligned(16))) float s_o[NW][G][D];
+    __shared__ float s_lse[NW][G];
+    __shared__ int s_len[DECODE_PAIR_MAX_B];
+    __shared__ short s_order[DECODE_PAIR_MAX_B];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ int s_lo[NW], s_hi[NW];
+    const int hk_chunks = p.h_k * p.gchunks, hgroups = hk_chunks / 4;
+    int lo = 0x7fffffff, hi = -1;
+    for (int b = tid; b < p.b; b += 64 * NW) { const int l = decode_seq_len(p, b); s_len[b] = l; lo = min(lo, l); hi = max(hi, l); }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+    if ((tid & 63) == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
+    // A batch of EQUAL lengths has nothing to pair: there the workgroup is the 8 (kv head, q chunk) units of one sequence or of two, one
+    // wavefront each, written straight to the output -- the kv-head-major order of the balanced line by construction (same grid: B . units / 8
+    // workgroups) -- and nothing is ranked.
+    if (lo == hi && (p.b * hk_chunks) % 8 == 0) {
+        const int unit = blockIdx.x * 8 + wave;            // sequence-major: the 8 wavefronts of a workgroup = consecutive kv heads of one sequence
+        DecodeWork wk;
+        wk.b = unit / hk_chunks;
+        if (wk.b >= p.b) return;                           // (an odd batch: the grid is rounded up to whole pairs)
+        const int c = unit - wk.b * hk_chunks;
+        wk.hk = c / p.gchunks;
+        wk.gc = c % p.gchunks;
+        wk.split = 0;
+        wk.L = lo;
+        wk.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + wk.b) : 0;
+        wk.n_tiles = (wk.L + 15) >> 4;
+        wk.t0 = 0;
+        wk.t1 = wk.n_tiles;
+        wk.partial = false;
+        wk.balanced = false;
+        wk.prow = 0;
+        wk.sink_o = nullptr;
+        wk.sink_lse = nullptr;
+        paged_decode_mqk_item<T, G, P, NT, false>(p, wk);
+        return;
+    }
+    for (int b = tid; b < p.b; b += 64 * NW) {
+        const int lb = s_len[b];
+        int rank = 0;
+        for (int j = 0; j < p.b; ++j) { const int lj = s_len[j]; rank += (lj < lb || (lj == lb && j < b)) ? 1 : 0; }
+        s_order[rank] = (short)b;
+    }
+    __syncthreads();
+    const int pair = blockIdx.x / hgroups, hg = blockIdx.x - pair * hgroups;
+    const int seq[2] = {s_order[pair], s_order[p.b - 1 - pair]};
+    const int nseq = seq[0] == seq[1] ? 1 : 2;
+    const int hkc = hg * 4 + (wave >> 1), half = wave & 1;
+    for (int s = 0; s < nseq; ++s) {
+        DecodeWork wk;
+        wk.b = seq[s];
+        wk.hk = hkc / p.gchunks;
+        wk.gc = hkc % p.gchunks;
+        wk.split = half;
+        wk.L = s_len[wk.b];
+        wk.kv_row0 = (p.cu_seqlens_k && p.is_seqlens_k_cumulative) ? load_ro(p.cu_seqlens_k + wk.b) : 0;
+        wk.n_tiles = (wk.L + 15) >> 4;
+        const int per = (wk.n_tiles + 1) >> 1;
+        wk.t0 = half * per;
+        wk.t1 = min(wk.t0 + per, wk.n_tiles);
+        wk.partial = true;
+        wk.balanced = false;
+        wk.prow = 0;
+        wk.sink_o = &s_o[wave][0][0];
+        wk.sink_lse = &s_lse[wave][0];
+        paged_decode_mqk_item<T, G, P, NT, true>(p, wk);
+        __syncthreads();
+        // the two halves of every (kv head, q head): decode_combine_kernel's arithmetic, pieces in order
+        for (int idx = tid; idx < 4 * G * (D / 2); idx += 64 * NW) {
+            const int u = idx / (G * (D / 2)), r = idx - u * (G * (D / 2)), h = r / (D / 2), d2 = r - h * (D / 2);
+            const int c = hg * 4 + u, hk = c / p.gchunks, gc = c % p.gchunks;
+            if (h >= min(G, p.g - gc * G)) continue;
+            const float l0 = s_lse[2 * u][h], l1 = s_lse[2 * u + 1][h];
+            const float mx = fmaxf(l0, l1), ms = mx == -INFINITY ? 0.f : mx;
+            const float tot = __expf(l0 - ms) + __expf(l1 - ms);
+            const bool empty = !(tot > 0.f);
+            const float lse = empty ? INFINITY : __logf(tot) + ms;
+            const float w0 = empty ? 0.f : __expf(l0 - lse), w1 = empty ? 0.f : __expf(l1 - lse);
+            const float2 a = *reinterpret_cast<const float2 *>(&s_o[2 * u][h][2 * d2]), b2 = *reinterpret_cast<const float2 *>(&s_o[2 * u + 1][h][2 * d2]);
+            const int hq = hk * p.g + gc * G + h;
+            *reinterpret_cast<uint32_t *>(p.o + (int64_t)wk.b * p.o_batch_stride + (int64_t)hq * p.o_head_stride + 2 * d2) = pack2<T>(w0 * a.x + w1 * b2.x, w0 * a.y + w1 * b2.y);
+            if (p.lse && d2 == 0) p.lse[(int64_t)wk.b * p.h + hq] = lse;
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T, int D>
 __global__ void __launch_bounds__(64) decode_combine_kernel(const DecodeParams p) {
     const int lane = threadIdx.x;
@@ -896,6 +996,7 @@ struct DecodeOptions {
     opt_int min_tiles{env_int("ATOMA_DECODE_MIN_TILES", 8)};
     opt_int fp8_wg{env_int("ATOMA_DECODE_FP8_WG", 0)};     // fp8 KV cache: 8 wavefronts (the kv heads of a sequence) per workgroup: 0 never (default since the kv-head-major order does the same for free), 1 split-KV launches, 2 always
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
+    opt_int pair{env_int("ATOMA_DECODE_PAIR", 0)};         // two sequences per workgroup (paged_decode_pair_kernel): 0 never, 1 for narrow ragged batches that give every resident wavefront one unit, 2 whenever applicable
     opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
     opt_int pair64{env_int("ATOMA_DECODE_PAIR64", 1)};   // head_dim 64 with an even number of kv heads and groups of 1 / 2 / 4 q heads: two kv heads per wavefront on the matrix-core kernel (1) or the dot2 kernel (0)
     opt_int line_merge{env_int("ATOMA_DECODE_LINE_MERGE", 1)};   // balanced line: cut sequences merged by the last wavefront to arrive (1) or by decode_combine_kernel (0)
@@ -924,6 +1025,7 @@ bool set_decode_option(const std::string &name, int value) {
     else if (name == "decode_min_tiles") o.min_tiles = value;
     else if (name == "decode_mqk") o.mqk = value;
     else if (name == "decode_wg_merge") o.wg_merge = value;
+    else if (name == "decode_pair") o.pair = value;
     else if (name == "decode_line_merge") o.line_merge = value;
     else if (name == "decode_pair64") o.pair64 = value;
     else if (name == "decode_fp8_mqk") o.fp8_mqk = value;
@@ -1035,6 +1137,21 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
         if (decode_wg_applicable(p)) {
             if (nt) { if (p3) launch_decode_wg<T, 128, G, 3, true, true>(p, stream); else launch_decode_wg<T, 128, G, 2, true, true>(p, stream); }
             else { if (p3) launch_decode_wg<T, 128, G, 3, false, true>(p, stream); else launch_decode_wg<T, 128, G, 2, false, true>(p, stream); }
+            return;
+        }
+    }
+    if constexpr (!PAIR64) {
+        // two sequences per workgroup: lengths on the device, no KV split, groups of 4 (kv head, q chunk) units, at least one unit per resident wavefront
+        const int pair_opt = decode_options().pair;
+        const int64_t units = (int64_t)p.b * p.h_k * p.gchunks;
+        if (pair_opt != 0 && p.stream_waves > 0 && p.num_splits == 1 && !p.k_scale && (p.h_k * p.gchunks) % 4 == 0 && p.b >= 2 && p.b <= DECODE_PAIR_MAX_B &&
+            (pair_opt == 2 || (units >= (int64_t)device_num_cus() * 6 && units <= (int64_t)device_num_cus() * 8))) {
+            p.stream_waves = 0;
+            const dim3 grid((unsigned)(((int64_t)p.b + 1) / 2 * (p.h_k * p.gchunks / 4)));
+            note_decode_kernel("paged_decode_pair_kernel", decode_tname<T>(), 128, G, p3 ? 3 : 2, nt, "two sequences per workgroup, halves merged in LDS");
+            if (nt) { if (p3) hipLaunchKernelGGL((paged_decode_pair_kernel<T, G, 3, true>), grid, dim3(512), 0, stream, p); else hipLaunchKernelGGL((paged_decode_pair_kernel<T, G, 2, true>), grid, dim3(512), 0, stream, p); }
+            else { if (p3) hipLaunchKernelGGL((paged_decode_pair_kernel<T, G, 3, false>), grid, dim3(512), 0, stream, p); else hipLaunchKernelGGL((paged_decode_pair_kernel<T, G, 2, false>), grid, dim3(512), 0, stream, p); }
+            ATOMA_CHECK_LAUNCH("paged_decode_pair_kernel");
             return;
         }
     }

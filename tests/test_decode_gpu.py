@@ -233,6 +233,44 @@ def test_decode_small_groups_on_the_balanced_line(gpu, dtype, h, hk, mqk, unifor
         assert_close(out3[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"decode_stream=3 seq {i} (L={L})")
 
 
+@pytest.mark.parametrize("dtype,B,h,hk", [(BF16, 141, 32, 8), (F16, 400, 16, 4), (BF16, 257, 32, 8)])
+def test_decode_two_sequences_per_workgroup_option(gpu, dtype, B, h, hk):
+    """decode_pair (round 6, opt-in): a workgroup of 8 wavefronts takes the i-th shortest and the i-th longest sequence (ranked on the device) and
+    4 kv heads, every (sequence, kv head) in two halves merged in LDS -- against the oracle on a ragged batch with empty sequences, equal lengths
+    (the rank's tie-break), an odd batch (the middle sequence pairs with itself) and the lengths' extremes."""
+    rng = np.random.default_rng(B + h)
+    d, page = 128, 16
+    lens = rng.integers(1, 700, B).astype(np.int32)
+    lens[0] = 0
+    lens[B // 2] = 2100
+    if B > 10:
+        lens[3:7] = 333
+    nb = int(sum((int(x) + page - 1) // page for x in lens)) + 1
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+    q = rand_half(rng, (B, 1, h, d), dtype)
+    ref = _oracle_decode(q, kc, vc, bt, lens, dtype)
+    with _options(gpu, decode_pair=2):
+        out, lse = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+        name = gpu.lib.atoma_last_decode_kernel().decode()
+    assert "paged_decode_pair_kernel" in name, name
+    for i, L in enumerate(lens):
+        assert_close(out[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"seq {i} (L={L})")
+    assert not out[0].any() and np.isposinf(lse[0]).all()
+    # a batch of EQUAL lengths through the same option: one unit per wavefront, written directly (no halves, no merge)
+    lens_u = np.full(B, 333, np.int32)
+    kcu, vcu, btu = make_paged_cache(rng, B * 21 + 1, page, hk, d, dtype, lens_u)
+    ref_u = _oracle_decode(q, kcu, vcu, btu, lens_u, dtype)
+    with _options(gpu, decode_pair=2):
+        out_u, _ = gpu_decode(gpu, q, kcu, vcu, btu, lens_u, d ** -0.5, dtype)
+        assert "paged_decode_pair_kernel" in gpu.lib.atoma_last_decode_kernel().decode()
+    for i in range(B):
+        assert_close(out_u[i], ref_u[i], dtype, atol=attn_atol(dtype, 333), what=f"uniform batch, seq {i}")
+    out_d, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)          # default: off
+    assert "pair" not in gpu.lib.atoma_last_decode_kernel().decode()
+    for i, L in enumerate(lens):
+        assert_close(out[i], out_d[i], dtype, atol=attn_atol(dtype, L), what=f"pair vs line, seq {i}")
+
+
 @pytest.mark.parametrize("B,L,h,hk,d", [(16, 3000, 32, 8, 128), (3, 5000, 16, 2, 128), (40, 900, 8, 8, 64), (7, 2000, 64, 8, 128)])
 def test_decode_workgroup_order_does_not_change_the_bits(gpu, B, L, h, hk, d):
     """Split-KV and small resident launches: kv head slowest (default: the wavefronts that share a CU are the kv heads of one piece)
@@ -494,7 +532,7 @@ def test_decode_full_size_70b_shape_properties(gpu):
 
 class _options:
     """atoma_set_option for the duration of a test (defaults restored afterwards)."""
-    DEFAULTS = {"decode_mqk": 29, "decode_min_tiles": 8, "decode_stream": 1, "decode_head_major": 1, "decode_pair64": 1}
+    DEFAULTS = {"decode_mqk": 29, "decode_min_tiles": 8, "decode_stream": 1, "decode_head_major": 1, "decode_pair64": 1, "decode_pair": 0}
 
     def __init__(self, gpu, **kw):
         self.gpu, self.kw = gpu, kw

@@ -91,6 +91,29 @@ def c5_phi3_mini_decode_step(iters=10):
     return c3_decode_step(iters=iters, batch=64, cfg=PHI_3_MINI, name="Phi-3-mini-shaped decode step (32 layers, hidden 3072, 32 MHA heads of 96)")
 
 
+def _with_option(name, value, fn):
+    """run fn() with a library option set (what an engine would set once at start-up), restored afterwards; the result says so"""
+    assert ah.lib.atoma_set_option(name.encode(), value) == 0, ah.last_error()
+    try:
+        out = fn()
+    finally:
+        ah.lib.atoma_set_option(name.encode(), 0)
+    out["library_option"] = f"{name} = {value} (default 0)"
+    return out
+
+
+def c3_decode_step_paired(iters=10):
+    """VARIANT of c3_decode_step, not the default dispatch: `decode_pair = 1` -- the engine-level option for decode batches that are ragged (continuous
+    batching): two sequences per workgroup, the i-th shortest with the i-th longest (paged_decode_pair_kernel).  +3..5.6 % on ragged batches that give every
+    resident wavefront one unit, -1.8 % on exactly uniform ones, which is why it is not the default (the host cannot see the lengths)."""
+    return _with_option("decode_pair", 1, lambda: c3_decode_step(iters=iters, name="Llama-3.1-8B decode step (BASELINE configs[2] mid-trace), decode_pair = 1"))
+
+
+def c2c_ragged_paired(iters=20):
+    """VARIANT of c2c_ragged with `decode_pair = 1` (see c3_decode_step_paired)."""
+    return _with_option("decode_pair", 1, lambda: c2c_ragged(iters=iters))
+
+
 def c3_decode_step_fp8_kv(iters=10):
     """The same step over an fp8 (e4m3fn) KV cache: the attention bytes halve; a VARIANT, not the headline --
     the reference's cache is 16-bit."""
@@ -354,7 +377,7 @@ def c4_rank_step(iters=10):
     return rank_step.run(iters=iters)
 
 
-ALL = ("c3_decode_step", "c3_trace", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "p1_prefill_4096", "p2_prefill_d96", "p2_prefill_d256", "c2b_mha", "c2c_ragged", "c2c_identity",
+ALL = ("c3_decode_step", "c3_decode_step_paired", "c3_trace", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "p1_prefill_4096", "p2_prefill_d96", "p2_prefill_d256", "c2b_mha", "c2c_ragged", "c2c_ragged_paired", "c2c_identity",
        "c2a_seeds", "k4_reshape_and_cache", "k4_sizes", "k5_copy_blocks", "k5_sizes", "n1_norm_rope", "n1_norm_rope_t256", "swap", "c5_swap_sizes")
 
 
