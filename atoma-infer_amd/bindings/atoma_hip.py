@@ -114,6 +114,7 @@ _opt("atoma_allreduce_add_rms_norm", [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, 
 _opt("atoma_warmup_prefill", [_vp, _i64, _i64, _i64])
 _opt("atoma_debug_sync_words", [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)])
 _opt("atoma_debug_workspace", [_vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)])
+_opt("atoma_hint_decode_lengths", [_i64, _i64, _i64])
 _opt("atoma_debug_launch_epoch", [_vp, _vp])
 _opt("atoma_rms_norm", [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _int, _vp])
 _opt("atoma_add_rms_norm", [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _int, _vp])

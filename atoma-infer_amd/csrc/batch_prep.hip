@@ -18,6 +18,8 @@ static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace atoma
 
+namespace atoma { void note_decode_lengths(int64_t min_len, int64_t max_len, int64_t count); }   // paged_decode.hip
+
 extern "C" int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequences, int64_t block_size, int64_t sliding_window,
                                     int enable_chunked_prefill, void *host_staging, int64_t host_capacity, void *device_buffer,
                                     int64_t device_capacity, atoma_batch_layout *layout, void *stream) {
@@ -34,6 +36,7 @@ extern "C" int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequ
     atoma_batch_layout L;
     memset(&L, 0, sizeof L);
     L.num_sequences = num_sequences;
+    int64_t min_decode_seq_len = INT64_MAX;
     for (int64_t i = 0; i < num_sequences; ++i) {
         const atoma_seq_desc &s = seqs[i];
         Seq &q = info[(size_t)i];
@@ -84,6 +87,7 @@ extern "C" int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequ
         } else {
             L.num_decode_tokens += 1;
             L.max_decode_seq_len = std::max(L.max_decode_seq_len, q.sliding_seq_len);
+            min_decode_seq_len = std::min(min_decode_seq_len, q.sliding_seq_len);
         }
     }
     // ---- layout: every tensor 256-byte aligned inside the one buffer ----
@@ -145,6 +149,8 @@ extern "C" int atoma_prepare_inputs(const atoma_seq_desc *seqs, int64_t num_sequ
         sl += q.slots;
     }
     if (!device_buffer) return 0;
+    // what the decode dispatcher cannot see on its own: whether this batch's decode sequences all have ONE length (paged_decode.hip, decode_pair)
+    if (L.num_decode_tokens > 0) note_decode_lengths(min_decode_seq_len, L.max_decode_seq_len, L.num_decode_tokens);
     return check_hip(hipMemcpyAsync(device_buffer, host_staging, (size_t)L.total_bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)),
                      "prepare_inputs: hipMemcpyAsync") ? 0 : -1;
 }

@@ -996,7 +996,7 @@ struct DecodeOptions {
     opt_int min_tiles{env_int("ATOMA_DECODE_MIN_TILES", 8)};
     opt_int fp8_wg{env_int("ATOMA_DECODE_FP8_WG", 0)};     // fp8 KV cache: 8 wavefronts (the kv heads of a sequence) per workgroup: 0 never (default since the kv-head-major order does the same for free), 1 split-KV launches, 2 always
     opt_int fp8_mqk{env_int("ATOMA_DECODE_FP8_MQK", 1)};   // fp8 KV cache: q.K^T of the converted K on the matrix cores (1) or v_dot2c (0)
-    opt_int pair{env_int("ATOMA_DECODE_PAIR", 0)};         // two sequences per workgroup (paged_decode_pair_kernel): 0 never, 1 for narrow ragged batches that give every resident wavefront one unit, 2 whenever applicable
+    opt_int pair{env_int("ATOMA_DECODE_PAIR", 0)};         // two sequences per workgroup (paged_decode_pair_kernel): 0 = when atoma_prepare_inputs packed a RAGGED batch of this size last (the hint above) and the launch gives every resident wavefront about one unit, 1 = for every such launch, 2 = whenever applicable, -1 = never
     opt_int wg_merge{env_int("ATOMA_DECODE_WG_MERGE", 1)};   // split-KV merged inside the launch (paged_decode_wg_kernel) instead of split kernel + combine kernel
     opt_int pair64{env_int("ATOMA_DECODE_PAIR64", 1)};   // head_dim 64 with an even number of kv heads and groups of 1 / 2 / 4 q heads: two kv heads per wavefront on the matrix-core kernel (1) or the dot2 kernel (0)
     opt_int line_merge{env_int("ATOMA_DECODE_LINE_MERGE", 1)};   // balanced line: cut sequences merged by the last wavefront to arrive (1) or by decode_combine_kernel (0)
@@ -1004,6 +1004,34 @@ struct DecodeOptions {
     opt_int head_major{env_int("ATOMA_DECODE_HEAD_MAJOR", 1)};   // workgroup order of the non-balanced launches: kv head slowest (1) or fastest (0)
     opt_int mqk{env_int("ATOMA_DECODE_MQK", 29)};   // q.K^T on the matrix cores at d = 128: bit 0 = groups of more than 4 q heads, bit 1 = all smaller groups, bit 2 = groups of 2..4 at tiny batches, bit 3 = groups of 2..4 on the balanced line, bit 4 = groups of 2..4 on split-KV launches
 };
+// Lengths of the decode sequences of the batch atoma_prepare_inputs last packed on this device (one host thread per GPU: model_executor.rs:428) -- the
+// one thing the dispatcher cannot see for itself (the lengths live on the device) and the paired kernel's choice depends on: exactly uniform batches lose on
+// it, ragged ones win.  A HINT: it changes which kernel runs, never a result; a caller that does not prepare its batches through the library never sets it.
+struct DecodeLengthHint { std::atomic<int64_t> min_len{0}, max_len{0}, count{0}; };
+static DecodeLengthHint *decode_length_hints() { static DecodeLengthHint h[64]; return h; }
+void note_decode_lengths(int64_t min_len, int64_t max_len, int64_t count) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return; }
+    DecodeLengthHint &h = decode_length_hints()[dev];
+    h.min_len = min_len; h.max_len = max_len; h.count = count;
+}
+}  // namespace atoma
+// The same hint from a caller that packs its batches itself: the shortest / longest decode sequence of the batch about to be decoded and their number on
+// the current device (0, 0, 0 forgets it).
+extern "C" int atoma_hint_decode_lengths(int64_t min_len, int64_t max_len, int64_t count) {
+    atoma::clear_error();
+    if (min_len < 0 || max_len < min_len || count < 0) { atoma::set_error("atoma_hint_decode_lengths: need 0 <= min_len <= max_len and count >= 0"); return -1; }
+    atoma::note_decode_lengths(min_len, max_len, count);
+    return 0;
+}
+namespace atoma {
+// 1: the batch packed last on this device was ragged and had `b` decode sequences
+static bool decode_hint_says_ragged(int b) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
+    const DecodeLengthHint &h = decode_length_hints()[dev];
+    return h.count.load() == b && h.max_len.load() > h.min_len.load();
+}
 static DecodeOptions &decode_options() {
     static DecodeOptions o;
     return o;
@@ -1144,8 +1172,8 @@ static void launch_decode_mqk(DecodeParams &p, hipStream_t stream) {
         // two sequences per workgroup: lengths on the device, no KV split, groups of 4 (kv head, q chunk) units, at least one unit per resident wavefront
         const int pair_opt = decode_options().pair;
         const int64_t units = (int64_t)p.b * p.h_k * p.gchunks;
-        if (pair_opt != 0 && p.stream_waves > 0 && p.num_splits == 1 && !p.k_scale && (p.h_k * p.gchunks) % 4 == 0 && p.b >= 2 && p.b <= DECODE_PAIR_MAX_B &&
-            (pair_opt == 2 || (units >= (int64_t)device_num_cus() * 6 && units <= (int64_t)device_num_cus() * 8))) {
+        if (pair_opt >= 0 && p.stream_waves > 0 && p.num_splits == 1 && !p.k_scale && (p.h_k * p.gchunks) % 4 == 0 && p.b >= 2 && p.b <= DECODE_PAIR_MAX_B &&
+            (pair_opt == 2 || (units >= (int64_t)device_num_cus() * 6 && units <= (int64_t)device_num_cus() * 8 && (pair_opt == 1 || decode_hint_says_ragged(p.b))))) {
             p.stream_waves = 0;
             const dim3 grid((unsigned)(((int64_t)p.b + 1) / 2 * (p.h_k * p.gchunks / 4)));
             note_decode_kernel("paged_decode_pair_kernel", decode_tname<T>(), 128, G, p3 ? 3 : 2, nt, "two sequences per workgroup, halves merged in LDS");

@@ -472,6 +472,13 @@ int atoma_reserve_workspace(void *stream, int64_t bytes);
 int atoma_release_workspaces(void);
 int atoma_reset_sync_counters(void *stream);
 int atoma_warmup_prefill(void *stream, int64_t max_seqlen_q, int64_t max_seqs, int64_t num_heads);
+/* Decode dispatch hint (round 6).  The lengths of a decode batch live on the device, so the dispatcher cannot see whether they are all equal; it matters for ONE
+ * choice: a launch that gives every resident wavefront about one (sequence, kv head) unit runs 3-5.6 % faster on paged_decode_pair_kernel (two sequences per
+ * workgroup, the i-th shortest with the i-th longest) when the batch is ragged and 1.8 % slower when its lengths are all equal.  atoma_prepare_inputs records the
+ * shortest / longest decode sequence and their number for the current device whenever it packs a batch (worker.rs:224-460 has them on the host); a caller that
+ * packs its own batches can say the same here (0, 0, 0 forgets it).  A hint changes which kernel runs, never a result; option "decode_pair": 0 (default) follows
+ * the hint, 1 = every such launch is treated as ragged, 2 = whenever the kernel applies, -1 = never. */
+int atoma_hint_decode_lengths(int64_t min_len, int64_t max_len, int64_t count);
 int atoma_debug_sync_words(void *stream, void **words_out, int64_t *count_out);
 /* tests: the stream's current scratch block (null / 0 when it has none yet): filled with poison between launches by the merge stress tests */
 int atoma_debug_workspace(void *stream, void **ptr_out, int64_t *bytes_out);

@@ -233,7 +233,7 @@ def test_decode_small_groups_on_the_balanced_line(gpu, dtype, h, hk, mqk, unifor
         assert_close(out3[i], ref[i], dtype, atol=attn_atol(dtype, L), what=f"decode_stream=3 seq {i} (L={L})")
 
 
-@pytest.mark.parametrize("dtype,B,h,hk", [(BF16, 141, 32, 8), (F16, 400, 16, 4), (BF16, 257, 32, 8)])
+@pytest.mark.parametrize("dtype,B,h,hk", [(BF16, 141, 32, 8), (F16, 400, 16, 4), (BF16, 257, 32, 8), (BF16, 250, 16, 8)])
 def test_decode_two_sequences_per_workgroup_option(gpu, dtype, B, h, hk):
     """decode_pair (round 6, opt-in): a workgroup of 8 wavefronts takes the i-th shortest and the i-th longest sequence (ranked on the device) and
     4 kv heads, every (sequence, kv head) in two halves merged in LDS -- against the oracle on a ragged batch with empty sequences, equal lengths
@@ -265,8 +265,16 @@ def test_decode_two_sequences_per_workgroup_option(gpu, dtype, B, h, hk):
         assert "paged_decode_pair_kernel" in gpu.lib.atoma_last_decode_kernel().decode()
     for i in range(B):
         assert_close(out_u[i], ref_u[i], dtype, atol=attn_atol(dtype, 333), what=f"uniform batch, seq {i}")
-    out_d, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)          # default: off
+    out_d, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)          # default: only on the hint of a batch packed by atoma_prepare_inputs
     assert "pair" not in gpu.lib.atoma_last_decode_kernel().decode()
+    if B * hk >= 256 * 6 and B * hk <= 256 * 8:                                # one unit per resident wavefront: the hint decides
+        assert gpu.lib.atoma_hint_decode_lengths(int(lens.min()), int(lens.max()), B) == 0
+        out_h, _ = gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+        assert "pair" in gpu.lib.atoma_last_decode_kernel().decode() and np.array_equal(out_h, out)
+        assert gpu.lib.atoma_hint_decode_lengths(333, 333, B) == 0             # "all equal": the line kernel
+        gpu_decode(gpu, q, kc, vc, bt, lens, d ** -0.5, dtype)
+        assert "pair" not in gpu.lib.atoma_last_decode_kernel().decode()
+        assert gpu.lib.atoma_hint_decode_lengths(5, 3, B) == -1 and "min_len" in gpu.last_error()
     for i, L in enumerate(lens):
         assert_close(out[i], out_d[i], dtype, atol=attn_atol(dtype, L), what=f"pair vs line, seq {i}")
 

@@ -103,9 +103,9 @@ def _with_option(name, value, fn):
 
 
 def c3_decode_step_paired(iters=10):
-    """VARIANT of c3_decode_step, not the default dispatch: `decode_pair = 1` -- the engine-level option for decode batches that are ragged (continuous
-    batching): two sequences per workgroup, the i-th shortest with the i-th longest (paged_decode_pair_kernel).  +3..5.6 % on ragged batches that give every
-    resident wavefront one unit, -1.8 % on exactly uniform ones, which is why it is not the default (the host cannot see the lengths)."""
+    """VARIANT of c3_decode_step, not the default dispatch: `decode_pair = 1` -- what the dispatcher does BY DEFAULT for a batch atoma_prepare_inputs packed (it records that the lengths
+    differ; this micro-step sets its metadata directly, so it says it through the option): two sequences per workgroup, the i-th shortest with the i-th longest
+    (paged_decode_pair_kernel).  +3..5.6 % on ragged batches that give every resident wavefront one unit, -1.8 % on exactly uniform ones, hence hint-driven."""
     return _with_option("decode_pair", 1, lambda: c3_decode_step(iters=iters, name="Llama-3.1-8B decode step (BASELINE configs[2] mid-trace), decode_pair = 1"))
 
 
@@ -335,7 +335,7 @@ def c3_trace():
     prefill phase beside it, and a sample of the LAST step's last-layer attention for the oracle."""
     import engine_trace
     r = engine_trace.run()
-    keep = ("workload", "prefill_s", "prefill_tokens_per_s", "decode_s", "decode_ms_per_step", "decode_tokens_per_s_per_gpu", "decode_roofline_tokens_per_s",
+    keep = ("workload", "prefill_s", "prefill_tokens_per_s", "decode_s", "decode_ms_per_step", "decode_tokens_per_s_per_gpu", "decode_roofline_tokens_per_s", "decode_attention_kernel",
             "decode_frac_of_roofline", "host_metadata_ms_per_step", "trace_s", "generated_tokens_per_s_over_trace", "data", "sample")
     return {k: r[k] for k in keep}
 

@@ -159,6 +159,8 @@ def run(requests=256, prompt=2048, decode_steps=512, layers=0, model="8b", promp
            "generated_tokens_per_s_over_trace": round(B * (N + 1) / (t_prefill + t_decode)),
            "decode_roofline_tokens_per_s": round(B / ((weight_bytes + B * (P + N / 2) * kv_bytes_per_token) / 8e12)),
            "data": "synthetic weights and prompts; greedy sampling on the device", "sample": sample}
+    out["decode_attention_kernel"] = (ah.lib.atoma_last_decode_kernel() or b"").decode()     # (ragged batches packed by atoma_prepare_inputs: the paired kernel by default)
+    ah.lib.atoma_hint_decode_lengths(0, 0, 0)                              # the trace's batches are gone: later decode calls of this process must not inherit their hint
     out["decode_tokens_per_s_per_gpu"] = out["decode_tokens_per_s"]
     out["decode_frac_of_roofline"] = round(out["decode_tokens_per_s"] / out["decode_roofline_tokens_per_s"], 4)
     for b_ in step.kc + step.vc:
