@@ -1,0 +1,275 @@
+"""Differential fuzzing of run_mha against the oracle (test infrastructure: the oracle is the checker, the C-ABI library the thing checked).
+
+One case = one call of the reference's `run_mha` boundary (csrc/src/ffi.rs:3-102 -> include/atoma_hip.h) with a randomly drawn shape from the
+space the reference's three entry families span (csrc/src/lib.rs:392-2105):
+
+  prefill        flash_attn_varlen: ragged q / k lengths (empty sequences, Lq > Lk, a cached prefix in front of the queries), causal or not, ALiBi
+  paged_prefill  flash_attn_varlen_with_block_table: the same over a paged cache (pages of 16 .. 256 tokens, a shuffled block table)
+  kv_cache       flash_attn_kv_cache: 1 .. 6 query rows per sequence over a paged or contiguous cache with per-sequence lengths, ALiBi
+
+head sizes 8 .. 256 (weighted towards 64 / 128), 1 .. 8 kv heads x groups of 1 .. 8 q heads, bf16 / f16.  Every row is held to the f32 definition
+(oracle/attn_oracle.py attend_rows) with the tolerance of tests/util.py (1e-3 + 1 ulp from 512 visible keys on, the P-rounding bound below), rows
+without a visible key must be exact zeros with LSE = +inf, all other LSE values must match to 1e-4, and nothing may be left unwritten.
+
+    python tests/fuzz_parity.py --seconds 600 [--seed 0] [--kinds prefill,paged_prefill,kv_cache]      (prints one JSON line; failures carry their seed)
+    tests/test_fuzz_parity_gpu.py runs a fixed set of seeds in the GPU suite.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT, os.path.join(ROOT, "atoma-infer_amd", "bindings")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from oracle import attn_oracle as A  # noqa: E402
+from oracle.halfs import F16, BF16, to_f32, from_f32  # noqa: E402
+from util import rand_half, make_paged_cache, ulp_tol, attn_atol  # noqa: E402
+
+KINDS = ("prefill", "paged_prefill", "kv_cache")
+HEAD_SIZES = [8, 32, 64, 64, 64, 96, 128, 128, 128, 128, 160, 192, 224, 256]
+
+
+def draw(seed, kinds=KINDS):
+    """the case of `seed`: a dict of plain ints / lists (what a failure report prints)"""
+    rng = np.random.default_rng(seed)
+    kind = kinds[int(rng.integers(len(kinds)))]
+    d = int(rng.choice(HEAD_SIZES))
+    hk = int(rng.choice([1, 1, 2, 3, 4, 8]))
+    g = int(rng.choice([1, 1, 2, 3, 4, 5, 8]))
+    c = dict(seed=int(seed), kind=kind, d=d, hk=hk, h=hk * g, dtype=int(rng.choice([BF16, BF16, F16])), causal=bool(rng.integers(2)),
+             alibi=bool(rng.integers(5) == 0), scale=float(d ** -0.5 * rng.choice([1.0, 1.0, 0.5, 1.7])))
+    budget = 1 << 22                                    # ~ score elements per head the oracle computes per case (keeps a case under a second or two)
+    if kind == "kv_cache":
+        B = int(rng.choice([1, 2, 5, 16, 33, 70]))
+        top = int(rng.choice([30, 200, 900, 2500]))
+        top = max(16, min(top, budget // (B * c["h"])))
+        lens = rng.integers(0, top + 1, B)
+        lens[rng.integers(0, B)] = top
+        if rng.integers(4) == 0:
+            lens[:] = top
+        c.update(B=B, sq=int(rng.choice([1, 1, 1, 2, 3, 6])), lens_k=[int(x) for x in lens], page=int(rng.choice([0, 16, 16, 32, 64, 128, 256])))
+        return c
+    B = int(rng.choice([1, 2, 3, 6, 11]))
+    top = int(rng.choice([20, 130, 300, 700, 1500]))
+    top = max(8, min(top, int((budget / (B * c["h"])) ** 0.5)))
+    lq = rng.integers(0, top + 1, B)
+    lq[rng.integers(0, B)] = top
+    mode = int(rng.integers(4))                          # 0/1: keys = queries; 2: a cached prefix in front; 3: unrelated key lengths (Lq > Lk, no keys)
+    if mode <= 1:
+        lk = lq.copy()
+    elif mode == 2:
+        lk = lq + rng.integers(0, top + 1, B) * rng.integers(0, 2, B)
+    else:
+        lk = rng.integers(0, top + 1, B)
+    c.update(B=B, lens_q=[int(x) for x in lq], lens_k=[int(x) for x in lk])
+    if kind == "paged_prefill":
+        c["page"] = int(rng.choice([16, 16, 32, 64, 128, 256]))
+    return c
+
+
+# Rounding the kernels do and the f32 definition does not (the reference's CUDA kernel does the first too): P goes to the storage type before P.V
+# (softmax.h + the bf16 MMA: up to 2^-8 relative per term, bf16), and the hand-scheduled prefill kernel's "fast" blocks round Q.scale.log2(e) once
+# (another ~2^-8 on a probability).  With the softmax mass spread over hundreds of keys both vanish in the sum and BASELINE.json's
+# 1e-3 holds -- tests/util.py draws that line at 512 visible keys, which is right for N(0,1) scores at scale d^-1/2 but not for a sharper scale or
+# ALiBi (a few recent keys carry the mass whatever the length).  So a row that misses the simple line gets the bound its OWN probabilities give:
+#   |got - ref| <= 1e-3 + 1 ulp + min(E_MAX . sum_i p_i |v_i|,  6 . E_SIG . sqrt(sum_i p_i^2 v_i^2))       (worst case, 6 sigma of independent roundings)
+E_MAX = {BF16: 2.0 ** -7, F16: 2.0 ** -10}
+E_SIG = {BF16: 2.5e-3, F16: 3.2e-4}
+LSE_ATOL_FAST = 2.5e-3      # LSE of the fast blocks (d = 128 prefill kernels, rows with >= 512 keys): off by ~1e-3 at scale d^-1/2, documented in DESIGN.md 4.2 (nobody
+                            # reads it: SURVEY Q4); a scale f times sharper moves it f^2 times further (larger scores, fewer keys to average over): 3.5e-3 .. 6e-3 at f = 1.7
+
+
+def p_bounds(qf, kf, vf, scale, causal, alibi):
+    """per (row, head, dim): sum_i p_i |v_i| and sqrt(sum_i p_i^2 v_i^2) of the f32 definition (attend_rows' masks and ALiBi)"""
+    Lq, h, d = qf.shape
+    Lk, hk, _ = kf.shape
+    g = h // hk
+    rows, cols, shift = np.arange(Lq)[:, None], np.arange(Lk)[None, :], Lk - Lq
+    ab, sq = np.zeros((Lq, h, d), np.float32), np.zeros((Lq, h, d), np.float32)
+    for head in range(h):
+        s = (qf[:, head] @ kf[:, head // g].T) * np.float32(scale)
+        if alibi is not None:
+            s = s - np.float32(alibi[head]) * np.abs(rows + shift - cols).astype(np.float32)
+        if causal:
+            s = np.where(cols <= rows + shift, s, -np.inf)
+        m = s.max(axis=1, keepdims=True)
+        p = np.exp(s - np.where(np.isfinite(m), m, 0)).astype(np.float32)
+        p /= np.maximum(p.sum(axis=1, keepdims=True), np.float32(1e-30))
+        v = vf[:, head // g]
+        ab[:, head], sq[:, head] = p @ np.abs(v), np.sqrt((p * p) @ (v * v))
+    return ab, sq
+
+
+def _check(out, lse_rows, ref, ref_lse, visible, dtype, what, bounds=None, fast_lse=0.0):
+    """out / ref: uint16 [rows, h, d]; lse_rows / ref_lse: f32 [h, rows]; visible: keys each row sees, [rows]; bounds() -> p_bounds of the sequence
+    (called only when a row misses the simple line).  Returns (finding or None, rows that needed their own bound)."""
+    got, want = to_f32(out, dtype), to_f32(ref, dtype)
+    if not np.isfinite(got).all():
+        return f"{what}: non-finite output ({(~np.isfinite(got)).sum()} elements; unwritten rows read as NaN)", 0
+    dead = visible <= 0
+    if dead.any() and (out[dead].any() or not np.isposinf(lse_rows[:, dead]).all()):
+        return f"{what}: rows without a visible key must be zeros with LSE = +inf", 0
+    live = ~dead
+    if not live.any():
+        return None, 0
+    err = np.abs(got - want)
+    simple = ulp_tol(want, dtype, 1e-3)
+    simple[visible < 512] = ulp_tol(want[visible < 512], dtype, attn_atol(dtype, 1))
+    bad = (err > simple) & live[:, None, None]
+    soft = 0
+    if bad.any():
+        ab, sq = bounds()
+        own = ulp_tol(want, dtype, 1e-3) + np.minimum(E_MAX[dtype] * ab, 6 * E_SIG[dtype] * sq)
+        soft = int(bad.any(axis=(1, 2)).sum())
+        bad &= err > own
+        if bad.any():
+            i = np.unravel_index(np.where(bad, err - own, -1).argmax(), err.shape)
+            return (f"{what}: {bad.sum()} of {bad.size} elements beyond the bound of their own probabilities; worst at (row, head, dim) = {tuple(int(x) for x in i)}: "
+                    f"got {got[i]:.6f}, ref {want[i]:.6f}, bound {own[i]:.2e}, visible keys {int(visible[i[0]])}"), soft
+    lse_atol = np.where(visible[live] >= 512, LSE_ATOL_FAST * max(1.0, fast_lse) ** 2, 1e-4) if fast_lse else 1e-4    # fast_lse: scale / d^-1/2 where the fast blocks run, else 0
+    dl = np.abs(lse_rows[:, live] - ref_lse[:, live])
+    if (dl > lse_atol + 1e-4 * np.abs(ref_lse[:, live])).any():
+        return f"{what}: LSE differs by up to {dl.max():.3e}", soft
+    return None, soft
+
+
+def run_case(gpu, c):
+    """(None when the library's answer is the oracle's, else a one-line description; the number of rows that were held to the bound of their own probabilities)"""
+    rng = np.random.default_rng(c["seed"] + (1 << 40))
+    soft = 0
+    d, h, hk, dtype, scale = c["d"], c["h"], c["hk"], c["dtype"], c["scale"]
+    alibi = (rng.uniform(0.02, 0.5, h).astype(np.float32) if c["alibi"] else None)
+    D = gpu.DeviceBuffer
+    da = D.from_numpy(alibi) if alibi is not None else None
+    if c["kind"] == "kv_cache":
+        B, sq, page, lens = c["B"], c["sq"], c["page"], np.asarray(c["lens_k"], np.int32)
+        causal = c["causal"] or sq == 1
+        q = rand_half(rng, (B, sq, h, d), dtype)
+        if page:
+            nb = int(sum((int(x) + page - 1) // page for x in lens)) + 2
+            kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lens)
+        else:
+            S = max(1, int(lens.max()))
+            kc, vc, bt = rand_half(rng, (B, S, hk, d), dtype), rand_half(rng, (B, S, hk, d), dtype), None
+        dq, dk, dv, do = D.from_numpy(q), D.from_numpy(kc), D.from_numpy(vc), D(q.nbytes)
+        do.fill_bytes(0xFF)
+        dlse = D.zeros((B, h, sq), np.float32)
+        dbt = D.from_numpy(np.ascontiguousarray(bt, np.int32)) if bt is not None else None
+        dl = D.from_numpy(lens)
+        seqlen_k = bt.shape[1] * page if bt is not None else kc.shape[1]
+        gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=sq, seqlen_k=seqlen_k, softmax_scale=scale, is_bf16=dtype,
+                    q_strides=(sq * h * d, h * d, d), o_strides=(sq * h * d, h * d, d), k_strides=(kc.shape[1] * hk * d, hk * d, d),
+                    v_strides=(vc.shape[1] * hk * d, hk * d, d), is_causal=int(causal if (sq > 1 or alibi is not None) else 0),      # lib.rs:1629-1631
+                    cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt, block_table_batch_stride=0 if bt is None else bt.shape[1],
+                    page_block_size=page, alibi_slopes=da, softmax_lse=dlse, force_split_kernel=bt is not None, unpadded_lse=False)
+        gpu.synchronize()
+        out, lse = do.numpy(np.uint16, q.shape), dlse.numpy()
+        qf, kf, vf = to_f32(q, dtype), to_f32(kc, dtype), to_f32(vc, dtype)
+        for b in range(B):
+            L = int(lens[b])
+            kb, vb = (A.gather_paged(kf, bt[b], L, page), A.gather_paged(vf, bt[b], L, page)) if page else (kf[b, :L], vf[b, :L])
+            o, l = A.attend_rows(qf[b], kb, vb, scale, causal=bool(causal and (sq > 1 or alibi is not None)), alibi_slopes=alibi, dtype=dtype)
+            visible = np.minimum(L, np.arange(sq) + L - sq + 1) if (causal and (sq > 1 or alibi is not None)) else np.full(sq, L)
+            cz = bool(causal and (sq > 1 or alibi is not None))
+            msg, n = _check(out[b], lse[b], from_f32(o, dtype), l, visible, dtype, f"seq {b} (L={L})", lambda: p_bounds(qf[b], kb, vb, scale, cz, alibi), fast_lse=scale * d ** 0.5 if (d == 128 and sq > 1) else 0.0)
+            soft += n
+            if msg:
+                return msg, soft
+        return None, soft
+    lq, lk = np.asarray(c["lens_q"], np.int64), np.asarray(c["lens_k"], np.int64)
+    cu_q = np.concatenate([[0], np.cumsum(lq)]).astype(np.int32)
+    cu_k = np.concatenate([[0], np.cumsum(lk)]).astype(np.int32)
+    Tq = int(cu_q[-1])
+    q = rand_half(rng, (max(Tq, 1), h, d), dtype)[:Tq]
+    bt, page = None, 0
+    if c["kind"] == "paged_prefill":
+        page = c["page"]
+        nb = int(sum((int(x) + page - 1) // page for x in lk)) + 2
+        k, v, bt = make_paged_cache(rng, nb, page, hk, d, dtype, lk)
+    else:
+        Tk = max(1, int(cu_k[-1]))
+        k, v = rand_half(rng, (Tk, hk, d), dtype), rand_half(rng, (Tk, hk, d), dtype)
+    if Tq == 0:
+        return None, 0
+    dq, dk, dv, do = D.from_numpy(q), D.from_numpy(k), D.from_numpy(v), D(q.nbytes)
+    do.fill_bytes(0xFF)
+    dcq, dck = D.from_numpy(cu_q), D.from_numpy(cu_k)
+    dbt = D.from_numpy(np.ascontiguousarray(bt, np.int32)) if bt is not None else None
+    dlse = D.zeros((h, Tq), np.float32)
+    kstr = (page * hk * d, hk * d, d) if bt is not None else (0, hk * d, d)
+    gpu.run_mha(dq, dk, dv, do, b=c["B"], h=h, h_k=hk, d=d, seqlen_q=int(lq.max()), seqlen_k=int(max(1, lk.max())), softmax_scale=scale, is_bf16=dtype,
+                q_strides=(0, h * d, d), o_strides=(0, h * d, d), k_strides=kstr, v_strides=kstr, is_causal=int(c["causal"]), cu_seqlens_q=dcq,
+                cu_seqlens_k=dck, block_table=dbt, block_table_batch_stride=0 if bt is None else bt.shape[1], page_block_size=page, alibi_slopes=da,
+                softmax_lse=dlse, force_split_kernel=bt is not None)
+    gpu.synchronize()
+    out, lse = do.numpy(np.uint16, q.shape), dlse.numpy()
+    ref, ref_lse = A.flash_attn_varlen(q, k, v, cu_q, cu_k, scale, c["causal"], dtype, block_table=bt, alibi_slopes=alibi, return_lse=True)
+    for b in range(c["B"]):
+        q0, q1, Lq, Lk = int(cu_q[b]), int(cu_q[b + 1]), int(lq[b]), int(lk[b])
+        if Lq == 0:
+            continue
+        visible = np.minimum(Lk, np.arange(Lq) + Lk - Lq + 1) if c["causal"] else np.full(Lq, Lk)
+        k0, k1 = int(cu_k[b]), int(cu_k[b + 1])
+
+        def bounds():
+            kb, vb = ((A.gather_paged(to_f32(k, dtype), bt[b], Lk, page), A.gather_paged(to_f32(v, dtype), bt[b], Lk, page)) if bt is not None
+                      else (to_f32(k[k0:k1], dtype), to_f32(v[k0:k1], dtype)))
+            return p_bounds(to_f32(q[q0:q1], dtype), kb, vb, scale, c["causal"], alibi)
+        msg, n = _check(out[q0:q1], lse[:, q0:q1], ref[q0:q1], ref_lse[b], visible, dtype, f"seq {b} (Lq={Lq}, Lk={Lk})", bounds, fast_lse=scale * d ** 0.5 if d == 128 else 0.0)
+        soft += n
+        if msg:
+            return msg, soft
+    return None, soft
+
+
+def try_case(gpu, c):
+    """run_case with library errors turned into findings (a shape the reference serves must not be refused)"""
+    try:
+        return run_case(gpu, c)[0]
+    except (RuntimeError, AssertionError) as e:
+        return f"raised {type(e).__name__}: {str(e)[:300]}"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--count", type=int, default=0, help="stop after this many cases (0 = by time)")
+    ap.add_argument("--kinds", default=",".join(KINDS))
+    ap.add_argument("--seeds", default="", help="comma-separated seeds to run instead of a range (re-running findings)")
+    a = ap.parse_args()
+    import atoma_hip as gpu
+    gpu.set_device(0)
+    kinds = tuple(a.kinds.split(","))
+    t0, n, fails, per_kind, soft_rows, soft_cases = time.time(), 0, [], {}, 0, 0
+    seed = a.seed
+    todo = [int(x) for x in a.seeds.split(",") if x]
+    while (todo or not a.seeds) and (time.time() - t0 < a.seconds) and (not a.count or n < a.count):
+        if a.seeds:
+            seed = todo.pop(0)
+        c = draw(seed, kinds)
+        try:
+            msg, soft = run_case(gpu, c)
+        except (RuntimeError, AssertionError) as e:
+            msg, soft = f"raised {type(e).__name__}: {str(e)[:300]}", 0
+        soft_rows, soft_cases = soft_rows + soft, soft_cases + (soft > 0)
+        per_kind[c["kind"]] = per_kind.get(c["kind"], 0) + 1
+        if msg:
+            fails.append(dict(case=c, finding=msg))
+            print(json.dumps(fails[-1]), file=sys.stderr, flush=True)
+        n += 1
+        seed += 1
+    print(json.dumps(dict(cases=n, seeds=[a.seed, seed - 1], per_kind=per_kind, seconds=round(time.time() - t0, 1), failures=len(fails),
+                          cases_with_rows_held_to_their_own_bound=soft_cases, rows_held_to_their_own_bound=soft_rows, findings=fails[:40])), flush=True)
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

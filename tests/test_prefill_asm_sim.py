@@ -90,6 +90,16 @@ def test_f16_and_more_queries_than_keys_and_empty():
     run_case([100, 40], 1, 1, False, lens_k=[400, 10], exact=True)
 
 
+def test_block_without_keys_between_two_blocks():
+    """A block that sees no key at all FOLLOWED by a normal block of the same persistent workgroup (round 6, found by tests/fuzz_parity.py on the
+    GPU: until then the tile-less block left the ring's read state half rewound and the next block read its K fragments from the wrong slot):
+    the kv_cache shape that found it (3 query rows per sequence, a sequence without keys in the middle), empty sequences between prompts
+    walked by two workgroups, and a causal sequence with more queries than keys (its first 256 rows see nothing) in front of another one."""
+    run_case([3, 3, 3], 1, 1, False, lens_k=[4, 0, 30], exact=True)
+    run_case([100, 40, 70, 300], 2, 1, True, lens_k=[400, 0, 0, 310], auto=True, g=2)
+    run_case([64, 600, 64], 1, 1, True, lens_k=[64, 100, 64], auto=True)
+
+
 def test_forced_late_raise_of_the_reference():
     """a key far above the others in the 4th tile of the last row (cdna guide T13 / rule 26): the rescale block with alpha != 1"""
     for exact in (False, True):

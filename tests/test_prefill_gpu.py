@@ -163,6 +163,31 @@ def test_prefill_more_queries_than_keys_and_empty_sequences(gpu):
         assert np.isposinf(lse[:, 40:47]).all()
 
 
+@pytest.mark.parametrize("causal", [True, False])
+def test_prefill_sequences_without_keys_between_others_contiguous(gpu, causal):
+    """Contiguous K/V with more query blocks than CUs, so that every persistent workgroup walks several blocks: sequences WITHOUT keys in the
+    middle of the batch and a causal sequence with more queries than keys (whole 256-row blocks that see nothing).  Round 6: a tile-less block
+    left the K/V ring's read state half rewound and the block after it came out wrong (tests/fuzz_parity.py seed 6614; the simulator's
+    test_block_without_keys_between_two_blocks is the same on the CPU)."""
+    rng = np.random.default_rng(66 + causal)
+    d, h, hk = 128, 32, 8
+    lens_q = np.array([3, 40, 3, 3, 700, 3, 17, 3, 3, 90, 3, 3, 300, 3, 3, 3, 64, 3, 3, 3], np.int32)
+    lens_k = np.array([30, 40, 0, 4, 100, 0, 17, 30, 0, 90, 25, 0, 300, 1, 0, 22, 0, 30, 0, 16], np.int32)
+    cu_q = np.concatenate([[0], np.cumsum(lens_q)]).astype(np.int32)
+    cu_k = np.concatenate([[0], np.cumsum(lens_k)]).astype(np.int32)
+    q = rand_half(rng, (int(cu_q[-1]), h, d), BF16)
+    k, v = rand_half(rng, (int(cu_k[-1]), hk, d), BF16), rand_half(rng, (int(cu_k[-1]), hk, d), BF16)
+    out, lse = gpu_varlen(gpu, q, k, v, cu_q, cu_k, d ** -0.5, causal, BF16)
+    ref, want = A.flash_attn_varlen(q, k, v, cu_q, cu_k, d ** -0.5, causal, BF16, return_lse=True)
+    assert_close(out, ref, BF16, atol=ATOL_VS_F32[BF16], what=f"sequences without keys between others, causal={causal}")
+    for b in range(len(lens_q)):
+        rows = slice(int(cu_q[b]), int(cu_q[b + 1]))
+        dead = ~np.isfinite(want[b])
+        assert np.isposinf(lse[:, rows][dead]).all() and np.allclose(lse[:, rows][~dead], want[b][~dead], rtol=1e-4, atol=1e-4)
+        if lens_k[b] == 0:
+            assert not out[rows].any()
+
+
 @pytest.mark.parametrize("dtype", [BF16, F16])
 def test_prefill_d64_paged_llama_1b_shape(gpu, dtype):
     """Llama-3.2-1B head shape (d = 64, 32 q / 8 kv heads) through the paged path, causal."""

@@ -1237,6 +1237,14 @@ class Builder:
         # fragment registers and the NEXT entry's fetch goes out BEFORE the drain wait and the barrier: its round trip to memory (1.2k
         # cycles after the barrier, `profiles/r04_prefill_block_regions.txt`) rides under them.
         P.label("BLOCK_DRAIN")             # no K/V tile at all: every request in flight must land
+        # The ring state a block leaves behind is "reads at slot 2" (K read addresses = slot 0 + S_RBASE, V = slot 2 + S_RBASE - 2 slots: new_block
+        # rewinds both by S_RBASE).  A block without tiles never reaches PRO_K1 / PRO_ENTRY_STATE, which establish it: until round 6 it left the
+        # PREVIOUS block's S_RBASE next to read addresses that new_block had already rewound, so the block AFTER it rewound them a second time
+        # and read its K fragments from somewhere else in LDS (found by tests/fuzz_parity.py: kv_cache call, 3 query rows, a sequence without keys
+        # in the middle of the batch; the simulator reproduces it: test_block_without_keys_between_two_blocks).
+        for j in range(8):
+            e("v_add_u32", KAD[j], 2 * SLOT, KAD[j])
+        e("s_mov_b32", S_RBASE, 2 * SLOT)
         e("s_mov_b32", S_T, 0)
         e("s_branch", "BLOCK_END_COMMON")
         P.label("BLOCK_END_Q")

@@ -17,7 +17,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench_kernels as bk  # noqa: E402
 
 ah = bk.ah
-SHAPES = {"qkv": (6144, 4096, 0), "o": (4096, 4096, 1), "gate_up": (28672, 4096, 2), "down": (4096, 14336, 1), "qkv_rope": (6144, 4096, 3), "lm_head": (128256, 4096, 0)}
+SHAPES = {"qkv": (6144, 4096, 0), "o": (4096, 4096, 1), "gate_up": (28672, 4096, 2), "down": (4096, 14336, 1), "qkv_rope": (6144, 4096, 3), "lm_head": (128256, 4096, 0),
+          # what ONE rank of the 70B TP=8 step multiplies (BASELINE configs[3]; run with L256_BATCH=64)
+          "r_qkv": (1280, 8192, 0), "r_o": (8192, 1024, 1), "r_gate_up": (7168, 8192, 2), "r_down": (8192, 3584, 1)}
 VARIANTS = [("wide", {}), ("wide nw64", {"linear_wide_nw": 64}), ("wide nw128", {"linear_wide_nw": 128}),
             ("wide s1", {"linear_wide_splits": 1}), ("wide s2", {"linear_wide_splits": 2}), ("wide s4", {"linear_wide_splits": 4}), ("wide s8", {"linear_wide_splits": 8}),
             ("wide nw128 s4", {"linear_wide_nw": 128, "linear_wide_splits": 4}), ("wide nw128 s8", {"linear_wide_nw": 128, "linear_wide_splits": 8}),
@@ -42,7 +44,7 @@ def main():
     variants = [v for v in VARIANTS if not only or v[0] in only]
     for name in (sys.argv[1:] or list(SHAPES)):
         N, K, ep = SHAPES[name]
-        nbuf = max(2, int(600e6 // (N * K * 2)))
+        nbuf = int(os.environ.get("L256_NBUF", "0")) or max(2, int(600e6 // (N * K * 2)))       # L256_NBUF=1: every launch finds its matrix where the last one left it (256 MB cache)
         ws = [bk.rand_dev(rng, N * K * 2) for _ in range(nbuf)]
         x, r = bk.rand_dev(rng, B * K * 2), bk.rand_dev(rng, B * N * 2)
         y, y2 = ah.DeviceBuffer(B * N * 2), ah.DeviceBuffer(B * N * 2)
@@ -94,7 +96,7 @@ def main():
         for vname, _ in variants:
             t = times[vname]
             if t:
-                print(json.dumps({"shape": f"{name} [{N} x {K}] batch {B}", "variant": vname, "median_us": round(float(np.median(t)), 2), "min_us": round(min(t), 2),
+                print(json.dumps({"shape": f"{name} [{N} x {K}] batch {B}", "weight_copies": nbuf, "variant": vname, "median_us": round(float(np.median(t)), 2), "min_us": round(min(t), 2),
                                   "GBps_W": round(N * K * 2 / np.median(t) / 1e3), "TFLOPs": round(2 * B * N * K / np.median(t) / 1e6)}), flush=True)
         for w in ws:
             w.free()
