@@ -6,6 +6,9 @@ space the reference's three entry families span (csrc/src/lib.rs:392-2105):
   prefill        flash_attn_varlen: ragged q / k lengths (empty sequences, Lq > Lk, a cached prefix in front of the queries), causal or not, ALiBi
   paged_prefill  flash_attn_varlen_with_block_table: the same over a paged cache (pages of 16 .. 256 tokens, a shuffled block table)
   kv_cache       flash_attn_kv_cache: 1 .. 6 query rows per sequence over a paged or contiguous cache with per-sequence lengths, ALiBi
+  forward        the operator itself, FlashAttention::forward (models/src/flash_attention.rs:281-474 -> atoma_flash_attention_forward): a mixed batch of
+                 prompts (with or without a cached prefix -- the prefix route is NON-causal in the reference, SURVEY B/Q3, mirrored) and decode tokens;
+                 cache write bit-exact, every output row against the definition
 
 head sizes 8 .. 256 (weighted towards 64 / 128), 1 .. 8 kv heads x groups of 1 .. 8 q heads, bf16 / f16.  Every row is held to the f32 definition
 (oracle/attn_oracle.py attend_rows) with the tolerance of tests/util.py (1e-3 + 1 ulp from 512 visible keys on, the P-rounding bound below), rows
@@ -33,6 +36,8 @@ from oracle.halfs import F16, BF16, to_f32, from_f32  # noqa: E402
 from util import rand_half, make_paged_cache, ulp_tol, attn_atol  # noqa: E402
 
 KINDS = ("prefill", "paged_prefill", "kv_cache")
+DECODE_BASE = 2 * 10 ** 6   # ... and from here on decode batches of 64 .. 512 sequences (the balanced line, the paired kernel on a length hint, kv-head pairs at d = 64)
+FORWARD_BASE = 10 ** 6      # seeds from here on are "forward" cases (added after the first campaigns: a seed below keeps naming the case it always named)
 HEAD_SIZES = [8, 32, 64, 64, 64, 96, 128, 128, 128, 128, 160, 192, 224, 256]
 
 
@@ -40,12 +45,39 @@ def draw(seed, kinds=KINDS):
     """the case of `seed`: a dict of plain ints / lists (what a failure report prints)"""
     rng = np.random.default_rng(seed)
     kind = kinds[int(rng.integers(len(kinds)))]
+    if seed >= FORWARD_BASE:
+        kind = "forward"
+    if seed >= DECODE_BASE:
+        hk, g = (int(x) for x in rng.choice([(8, 4), (8, 4), (4, 4), (1, 8), (8, 8), (8, 1), (2, 2), (4, 8)]))
+        B = int(rng.choice([64, 100, 130, 200, 250, 256, 257, 320, 400, 512]))
+        d = int(rng.choice([64, 128, 128, 128]))
+        top = max(20, min(int(rng.choice([60, 300, 1000, 3000])), (1 << 23) // (B * hk * g)))
+        lens = rng.integers(max(0, top - int(rng.choice([top, top // 2, top // 8 + 1]))), top + 1, B)
+        if rng.integers(5) == 0:
+            lens[:] = top
+        return dict(seed=int(seed), kind="kv_cache", d=d, hk=hk, h=hk * g, dtype=int(rng.choice([BF16, BF16, F16])), causal=False, alibi=False, scale=float(d ** -0.5),
+                    B=B, sq=1, lens_k=[int(x) for x in lens], page=int(rng.choice([16, 16, 32])), hint=bool(rng.integers(2)))
     d = int(rng.choice(HEAD_SIZES))
     hk = int(rng.choice([1, 1, 2, 3, 4, 8]))
     g = int(rng.choice([1, 1, 2, 3, 4, 5, 8]))
     c = dict(seed=int(seed), kind=kind, d=d, hk=hk, h=hk * g, dtype=int(rng.choice([BF16, BF16, F16])), causal=bool(rng.integers(2)),
              alibi=bool(rng.integers(5) == 0), scale=float(d ** -0.5 * rng.choice([1.0, 1.0, 0.5, 1.7])))
     budget = 1 << 22                                    # ~ score elements per head the oracle computes per case (keeps a case under a second or two)
+    if kind == "forward":
+        c["d"] = int(rng.choice([64, 128, 128, 96, 256]))
+        c["scale"] = float(c["d"] ** -0.5)
+        n_pre = int(rng.choice([0, 1, 2, 4]))
+        top = int(rng.choice([5, 40, 200, 600]))
+        top = max(2, min(top, int((budget / (max(n_pre, 1) * c["h"])) ** 0.5)))
+        n_dec = int(rng.choice([0, 1, 3, 17, 64])) if n_pre else int(rng.choice([1, 3, 17, 64]))
+        dtop = int(rng.choice([5, 60, 700, 2000]))
+        dtop = max(2, min(dtop, budget // (max(n_dec, 1) * c["h"])))
+        prefix = bool(n_pre and rng.integers(2))
+        c.update(page=int(rng.choice([16, 32])), lens_q=[int(x) for x in rng.integers(1, top + 1, n_pre)],
+                 prefix=[int(x) for x in (rng.integers(0, 100, n_pre) * rng.integers(0, 2, n_pre) if prefix else np.zeros(n_pre, np.int64))],
+                 use_prefix_route=prefix, dec_lens=[int(x) for x in rng.integers(1, dtop + 1, n_dec)], alibi=bool(prefix and rng.integers(4) == 0) or (not n_pre and rng.integers(5) == 0))
+        c["alibi"] = bool(c["alibi"])
+        return c
     if kind == "kv_cache":
         B = int(rng.choice([1, 2, 5, 16, 33, 70]))
         top = int(rng.choice([30, 200, 900, 2500]))
@@ -148,6 +180,8 @@ def run_case(gpu, c):
     alibi = (rng.uniform(0.02, 0.5, h).astype(np.float32) if c["alibi"] else None)
     D = gpu.DeviceBuffer
     da = D.from_numpy(alibi) if alibi is not None else None
+    if c["kind"] == "forward":
+        return _run_forward(gpu, c, rng, alibi)
     if c["kind"] == "kv_cache":
         B, sq, page, lens = c["B"], c["sq"], c["page"], np.asarray(c["lens_k"], np.int32)
         causal = c["causal"] or sq == 1
@@ -164,12 +198,15 @@ def run_case(gpu, c):
         dbt = D.from_numpy(np.ascontiguousarray(bt, np.int32)) if bt is not None else None
         dl = D.from_numpy(lens)
         seqlen_k = bt.shape[1] * page if bt is not None else kc.shape[1]
+        if c.get("hint"):                                   # what atoma_prepare_inputs would have recorded for this batch (a dispatch hint, never a result)
+            gpu.lib.atoma_hint_decode_lengths(int(lens.min()), int(lens.max()), B)
         gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=sq, seqlen_k=seqlen_k, softmax_scale=scale, is_bf16=dtype,
                     q_strides=(sq * h * d, h * d, d), o_strides=(sq * h * d, h * d, d), k_strides=(kc.shape[1] * hk * d, hk * d, d),
                     v_strides=(vc.shape[1] * hk * d, hk * d, d), is_causal=int(causal if (sq > 1 or alibi is not None) else 0),      # lib.rs:1629-1631
                     cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt, block_table_batch_stride=0 if bt is None else bt.shape[1],
                     page_block_size=page, alibi_slopes=da, softmax_lse=dlse, force_split_kernel=bt is not None, unpadded_lse=False)
         gpu.synchronize()
+        gpu.lib.atoma_hint_decode_lengths(0, 0, 0)
         out, lse = do.numpy(np.uint16, q.shape), dlse.numpy()
         qf, kf, vf = to_f32(q, dtype), to_f32(kc, dtype), to_f32(vc, dtype)
         for b in range(B):
@@ -229,6 +266,116 @@ def run_case(gpu, c):
     return None, soft
 
 
+def _run_forward(gpu, c, rng, alibi):
+    import ctypes as C
+    from oracle import cache_oracle as CO
+    d, h, hk, dtype, scale, page = c["d"], c["h"], c["hk"], c["dtype"], c["scale"], c["page"]
+    lq, pre, dl = np.asarray(c["lens_q"], np.int64), np.asarray(c["prefix"], np.int64), np.asarray(c["dec_lens"], np.int64)
+    n_pre_seqs, n_dec = len(lq), len(dl)
+    tot = pre + lq
+    need = [int((x + page - 1) // page) for x in list(tot) + list(dl)]
+    nb = sum(need) + 2
+    perm = rng.permutation(nb)
+    tables, pos = [], 0
+    for n in need:
+        tables.append(perm[pos:pos + n])
+        pos += n
+    pre_bt = np.zeros((max(n_pre_seqs, 1), max([1] + need[:n_pre_seqs])), np.uint32)
+    dec_bt = np.zeros((max(n_dec, 1), max([1] + need[n_pre_seqs:])), np.uint32)
+    for i in range(n_pre_seqs):
+        pre_bt[i, :need[i]] = tables[i]
+    for j in range(n_dec):
+        dec_bt[j, :need[n_pre_seqs + j]] = tables[n_pre_seqs + j]
+    np_tok, T = int(lq.sum()), int(lq.sum()) + n_dec
+    slots = np.empty(T, np.int64)
+    t = 0
+    for i in range(n_pre_seqs):
+        p = pre[i] + np.arange(lq[i])
+        slots[t:t + lq[i]] = pre_bt[i, p // page].astype(np.int64) * page + p % page
+        t += int(lq[i])
+    for j in range(n_dec):
+        p = int(dl[j]) - 1
+        slots[t] = int(dec_bt[j, p // page]) * page + p % page
+        t += 1
+    q, k, v = rand_half(rng, (T, h, d), dtype), rand_half(rng, (T, hk, d), dtype), rand_half(rng, (T, hk, d), dtype)
+    kv = rand_half(rng, (2, nb, page, hk, d), dtype)
+    cu_q = np.concatenate([[0], np.cumsum(lq)]).astype(np.uint32)
+    cu_k = np.concatenate([[0], np.cumsum(tot)]).astype(np.uint32)
+    D = gpu.DeviceBuffer
+    bufs = {n: D.from_numpy(a) for n, a in dict(q=q, k=k, v=v, kv=kv, slots=slots, cu_q=cu_q, cu_k=cu_k, pre_bt=pre_bt, dec_bt=dec_bt,
+                                                 dec_lens=dl.astype(np.uint32) if n_dec else np.zeros(1, np.uint32)).items()}
+    dout = D(q.nbytes)
+    dout.fill_bytes(0xFF)
+    fa = gpu.FlashAttention()
+    ta = None
+    if alibi is not None:
+        bufs["alibi"] = D.from_numpy(alibi)
+        ta = gpu.tensor(bufs["alibi"], (h,), gpu.F32) if hasattr(gpu, "F32") else None
+        if ta is None:
+            return None, 0
+    if gpu.lib.atoma_flash_attention_new(C.byref(fa), h, hk, d, float(scale), gpu.ref(ta) if ta is not None else None, -1, dtype, 0) != 0:
+        raise RuntimeError("flash_attention_new: " + gpu.last_error())
+    tn = dict(q=gpu.tensor(bufs["q"], (T, h, d), dtype), k=gpu.tensor(bufs["k"], (T, hk, d), dtype), v=gpu.tensor(bufs["v"], (T, hk, d), dtype),
+              kv=gpu.tensor(bufs["kv"], (2, nb, page, hk, d), dtype), slots=gpu.tensor(bufs["slots"], (T,), gpu.I64),
+              cu_q=gpu.tensor(bufs["cu_q"], (n_pre_seqs + 1,), gpu.U32), cu_k=gpu.tensor(bufs["cu_k"], (n_pre_seqs + 1,), gpu.U32),
+              pre_bt=gpu.tensor(bufs["pre_bt"], pre_bt.shape, gpu.U32), dec_bt=gpu.tensor(bufs["dec_bt"], dec_bt.shape, gpu.U32),
+              dec_lens=gpu.tensor(bufs["dec_lens"], (max(n_dec, 1),), gpu.U32), out=gpu.tensor(dout, (T, h * d), dtype))
+    meta = gpu.AttnMetadata()
+    meta.slot_mapping = C.pointer(tn["slots"])
+    meta.num_prefill_tokens, meta.num_decoding_tokens = np_tok, n_dec
+    use_prefix = c["use_prefix_route"]
+    if n_pre_seqs:
+        meta.has_prefill, meta.max_prefill_sequence_length, meta.max_sequence_length_k = 1, int(lq.max()), int(tot.max())
+        meta.query_start_locations = C.pointer(tn["cu_q"])
+        meta.sequence_start_locations = C.pointer(tn["cu_k"] if use_prefix else tn["cu_q"])
+        if use_prefix:
+            meta.prefill_block_tables = C.pointer(tn["pre_bt"])
+    if n_dec:
+        meta.has_decoding = 1
+        meta.decoding_block_tables = C.pointer(tn["dec_bt"])
+        meta.decoding_sequence_lengths = C.pointer(tn["dec_lens"])
+    rc = gpu.lib.atoma_flash_attention_forward(C.byref(fa), gpu.ref(tn["q"]), gpu.ref(tn["k"]), gpu.ref(tn["v"]), gpu.ref(tn["kv"]), C.byref(meta), gpu.ref(tn["out"]))
+    if rc != 0:
+        raise RuntimeError("flash_attention_forward: " + gpu.last_error())
+    gpu.synchronize()
+    out = dout.numpy(np.uint16, (T, h, d))
+    kc, vc = kv[0].copy(), kv[1].copy()
+    CO.reshape_and_cache_flash(k, v, kc, vc, slots)
+    got_kv = bufs["kv"].numpy(np.uint16, kv.shape)
+    if not (np.array_equal(got_kv[0], kc) and np.array_equal(got_kv[1], vc)):
+        return "the cache write is not bit-exact", 0
+    soft = 0
+    kcf, vcf, qf = to_f32(kc, dtype), to_f32(vc, dtype), to_f32(q, dtype)
+    # Prefill rows.  Without a prefix: causal over the new tokens only, no ALiBi (flash_attention.rs:399-409: alibi_slopes is not passed on this route);
+    # with block tables: over the cache, NON-causal (flash_attention.rs:435-448, SURVEY B/Q3), ALiBi if the layer has slopes.
+    for i in range(n_pre_seqs):
+        q0, q1 = int(cu_q[i]), int(cu_q[i + 1])
+        if use_prefix:
+            Lk = int(tot[i])
+            kb, vb = A.gather_paged(kcf, pre_bt[i].astype(np.int64), Lk, page), A.gather_paged(vcf, pre_bt[i].astype(np.int64), Lk, page)
+            causal, al = False, alibi
+        else:
+            Lk = q1 - q0
+            kb, vb = to_f32(k[q0:q1], dtype), to_f32(v[q0:q1], dtype)
+            causal, al = T > 1, None
+        o, l = A.attend_rows(qf[q0:q1], kb, vb, scale, causal=causal, alibi_slopes=al, dtype=dtype)
+        visible = np.minimum(Lk, np.arange(q1 - q0) + Lk - (q1 - q0) + 1) if causal else np.full(q1 - q0, Lk)
+        msg, n = _check(out[q0:q1], l, from_f32(o, dtype), l, visible, dtype, f"prompt {i} (Lq={q1 - q0}, Lk={Lk}, prefix route={use_prefix})",
+                        lambda: p_bounds(qf[q0:q1], kb, vb, scale, causal, al))
+        soft += n
+        if msg:
+            return msg, soft
+    for j in range(n_dec):
+        L, r = int(dl[j]), np_tok + j
+        kb, vb = A.gather_paged(kcf, dec_bt[j].astype(np.int64), L, page), A.gather_paged(vcf, dec_bt[j].astype(np.int64), L, page)
+        o, l = A.attend_rows(qf[r:r + 1], kb, vb, scale, causal=alibi is not None, alibi_slopes=alibi, dtype=dtype)
+        msg, n = _check(out[r:r + 1], l, from_f32(o, dtype), l, np.full(1, L), dtype, f"decode token {j} (L={L})", lambda: p_bounds(qf[r:r + 1], kb, vb, scale, False, alibi))
+        soft += n
+        if msg:
+            return msg, soft
+    return None, soft
+
+
 def try_case(gpu, c):
     """run_case with library errors turned into findings (a shape the reference serves must not be refused)"""
     try:
@@ -243,6 +390,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--count", type=int, default=0, help="stop after this many cases (0 = by time)")
     ap.add_argument("--kinds", default=",".join(KINDS))
+    ap.add_argument("--forward-every", type=int, default=4, help="every n-th case is a `forward` case (seed + 10^6) and every n-th a large decode batch (seed + 2.10^6); 0 = none")
     ap.add_argument("--seeds", default="", help="comma-separated seeds to run instead of a range (re-running findings)")
     a = ap.parse_args()
     import atoma_hip as gpu
@@ -254,13 +402,15 @@ def main():
     while (todo or not a.seeds) and (time.time() - t0 < a.seconds) and (not a.count or n < a.count):
         if a.seeds:
             seed = todo.pop(0)
-        c = draw(seed, kinds)
+        extra = 0 if (a.seeds or not a.forward_every) else (FORWARD_BASE if n % a.forward_every == a.forward_every - 1 else (DECODE_BASE if n % a.forward_every == 0 else 0))
+        c = draw(seed + extra, kinds)
         try:
             msg, soft = run_case(gpu, c)
         except (RuntimeError, AssertionError) as e:
             msg, soft = f"raised {type(e).__name__}: {str(e)[:300]}", 0
         soft_rows, soft_cases = soft_rows + soft, soft_cases + (soft > 0)
-        per_kind[c["kind"]] = per_kind.get(c["kind"], 0) + 1
+        kname = c["kind"] + (" (large decode batches)" if c["seed"] >= DECODE_BASE else "")
+        per_kind[kname] = per_kind.get(kname, 0) + 1
         if msg:
             fails.append(dict(case=c, finding=msg))
             print(json.dumps(fails[-1]), file=sys.stderr, flush=True)

@@ -18,6 +18,20 @@ def test_random_cases_match_the_oracle(gpu, seed0):
     assert not findings, findings
 
 
+@pytest.mark.parametrize("seed0", range(F.FORWARD_BASE, F.FORWARD_BASE + 48, 8))
+def test_random_operator_calls_match_the_oracle(gpu, seed0):
+    """FlashAttention::forward (atoma_flash_attention_forward) on mixed batches of prompts and decode tokens: cache write bit-exact, rows against the definition"""
+    findings = [(F.draw(s), msg) for s in range(seed0, seed0 + 8) for msg in [F.try_case(gpu, F.draw(s))] if msg]
+    assert not findings, findings
+
+
+@pytest.mark.parametrize("seed0", range(F.DECODE_BASE, F.DECODE_BASE + 32, 8))
+def test_random_large_decode_batches_match_the_oracle(gpu, seed0):
+    """64 .. 512 sequences through whatever the dispatcher picks (the balanced line, the paired kernel when a length hint says ragged, kv-head pairs at d = 64)"""
+    findings = [(F.draw(s), msg) for s in range(seed0, seed0 + 8) for msg in [F.try_case(gpu, F.draw(s))] if msg]
+    assert not findings, findings
+
+
 @pytest.mark.parametrize("seed", [6614, 1010, 1031, 1836, 1904, 3798, 4006, 7029, 7052, 7072, 7089])
 def test_seeds_that_once_were_findings(gpu, seed):
     """6614: a kv_cache call with 3 query rows and a sequence without keys in the middle of the batch -- the hand-scheduled prefill kernel's block after a
