@@ -6,6 +6,8 @@ fallback), random in / out features and padded strides.  Test infrastructure: or
              (a K-split merged by its last arriver must not depend on who came last);
              _residual / _silu_mul / _rmsnorm / _rmsnorm_silu_mul against projection + separate op, bit for bit (the rounding points are part of the contract)
   qkv_rope   atoma_linear_decode_qkv_rope_cache against atoma_linear_decode + atoma_rope_qk_cache, bit for bit (q/k/v output and both caches)
+  swap       atoma_swap_blocks_multi (cache_manager.rs:196-402 / worker.rs:602-632 loop): 1 .. 16 tensors, pages of 16 B .. 17 MiB (odd sizes too), gpu -> gpu,
+             cpu -> gpu and gpu -> cpu with pageable host memory at odd byte offsets (the pinned bounce ring and its copy threads) or pinned, byte for byte
   norm_rope  atoma_rms_norm (<= 1 ulp vs oracle), atoma_add_rms_norm == atoma_add + atoma_rms_norm bit for bit, atoma_rope per-op mode bit-exact vs oracle
 
     python tests/fuzz_ops.py --seconds 300 [--seed 0] [--kinds linear,qkv_rope,norm_rope]
@@ -29,6 +31,7 @@ from oracle.halfs import F16, BF16, to_f32, from_f32  # noqa: E402
 from util import rand_half  # noqa: E402
 
 KINDS = ("linear", "linear", "qkv_rope", "norm_rope")
+SWAP_BASE = 10 ** 6       # seeds from here on: swap_blocks / swap_blocks_multi (added after the first campaign; earlier seeds keep their cases)
 BATCHES = [1, 2, 3, 4, 5, 8, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 66, 96, 127, 128, 129, 160, 191, 192, 193, 224, 255, 256]
 K_UNITS = [1, 2, 3, 4, 8, 12, 16, 24, 32, 40, 56, 64, 112, 128]                       # x 128
 N_UNITS = [1, 2, 3, 4, 7, 8, 9, 16, 24, 32, 48, 64, 80, 96, 128, 256, 257, 384, 512, 896, 1792]      # x 16
@@ -38,6 +41,12 @@ MAX_WEIGHTS = 24 << 20
 def draw(seed, kinds=KINDS):
     rng = np.random.default_rng(seed)
     kind = kinds[int(rng.integers(len(kinds)))]
+    if seed >= SWAP_BASE:
+        block = int(rng.choice([16, 48, 2048, 4104, 32768, 32768, 131072, 1 << 20, (17 << 20) + 16]))
+        nt = int(rng.choice([1, 2, 5, 16]))
+        nb = int(max(2, min(int(rng.choice([4, 17, 60])), (192 << 20) // (block * nt))))
+        return dict(seed=int(seed), kind="swap", block=block, nt=nt, nb=nb, pairs=int(rng.integers(1, nb + 1)), dir=int(rng.choice([0, 1, 1, 2, 2])),
+                    pinned=bool(rng.integers(3) == 0), offset=int(rng.choice([0, 0, 8, 2])))
     c = dict(seed=int(seed), kind=kind, dtype=int(rng.choice([BF16, BF16, F16])), B=int(rng.choice(BATCHES)) if rng.integers(3) else int(rng.integers(1, 257)))
     if kind == "linear":
         K = 128 * int(rng.choice(K_UNITS))
@@ -73,11 +82,71 @@ def _ulp_check(got, ref, dtype, what):
 
 def run_case(gpu, c):
     rng = np.random.default_rng(c["seed"] + (1 << 41))
-    L, D, dtype, B = gpu.lib, gpu.DeviceBuffer, c["dtype"], c["B"]
+    L, D, dtype, B = gpu.lib, gpu.DeviceBuffer, c.get("dtype"), c.get("B")
 
     def ok(rc, what):
         if rc != 0:
             raise RuntimeError(f"{what}: {gpu.last_error()}")
+    if c["kind"] == "swap":
+        import ctypes as C
+        block, nt, nb, kind = c["block"], c["nt"], c["nb"], c["dir"]
+        src_pages, dst_pages = rng.permutation(nb)[:c["pairs"]], rng.permutation(nb)[:c["pairs"]]
+        m = np.stack([src_pages, dst_pages], 1).astype(np.int64)
+        off = 0 if c["pinned"] else c["offset"]
+        keep, host_ptrs = [], []
+
+        def host_tensor():
+            if c["pinned"]:
+                p = L.atoma_host_alloc(nb * block)
+                if not p:
+                    raise RuntimeError("atoma_host_alloc failed")
+                a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nb * block,)).reshape(nb, block)
+                host_ptrs.append(p)
+            else:
+                raw = np.empty(nb * block + 64, np.uint8)
+                keep.append(raw)
+                a = raw[off:off + nb * block].reshape(nb, block)
+            a[...] = rng.integers(0, 256, (nb, 1), dtype=np.uint8) ^ np.arange(block, dtype=np.uint8)[None, :]
+            return a
+        dev_np = [(rng.integers(0, 256, (nb, 1), dtype=np.uint8) + np.arange(block, dtype=np.uint8)[None, :] * 3).astype(np.uint8) for _ in range(nt)]
+        devs = [D.from_numpy(a) for a in dev_np]
+        try:
+            if kind == 0:
+                dst_np = [np.full((nb, block), 7 + i, np.uint8) for i in range(nt)]
+                dsts = [D.from_numpy(a) for a in dst_np]
+                sp, dp = (C.c_void_p * nt)(*[b.ptr for b in devs]), (C.c_void_p * nt)(*[b.ptr for b in dsts])
+                ok(L.atoma_swap_blocks_multi(sp, dp, nt, m.ctypes.data, len(m), block, 0, None), "swap_blocks_multi gpu -> gpu")
+                gpu.synchronize()
+                got = [b.numpy(np.uint8, (nb, block)) for b in dsts]
+                want = [a.copy() for a in dst_np]
+                for t in range(nt):
+                    want[t][dst_pages] = dev_np[t][src_pages]
+            else:
+                hosts = [host_tensor() for _ in range(nt)]
+                hp = (C.c_void_p * nt)(*[h.ctypes.data for h in hosts])
+                gp = (C.c_void_p * nt)(*[b.ptr for b in devs])
+                if kind == 1:                                                   # cpu -> gpu
+                    ok(L.atoma_swap_blocks_multi(hp, gp, nt, m.ctypes.data, len(m), block, 1, None), "swap_blocks_multi cpu -> gpu")
+                    gpu.synchronize()
+                    got = [b.numpy(np.uint8, (nb, block)) for b in devs]
+                    want = [a.copy() for a in dev_np]
+                    for t in range(nt):
+                        want[t][dst_pages] = hosts[t][src_pages]
+                else:
+                    want = [h.copy() for h in hosts]
+                    ok(L.atoma_swap_blocks_multi(gp, hp, nt, m.ctypes.data, len(m), block, 2, None), "swap_blocks_multi gpu -> cpu")
+                    gpu.synchronize()
+                    got = [h.copy() for h in hosts]
+                    for t in range(nt):
+                        want[t][dst_pages] = dev_np[t][src_pages]
+            for t in range(nt):
+                if not np.array_equal(got[t], want[t]):
+                    bad = np.argwhere((got[t] != want[t]).any(axis=1))[:, 0]
+                    return f"tensor {t}: pages {bad[:8].tolist()} differ ({len(bad)} pages)"
+            return None
+        finally:
+            for p in host_ptrs:
+                L.atoma_host_free(p)
     if c["kind"] == "linear":
         K, N, ep = c["K"], c["N"], c["ep"]
         xs, ws = K + c["xpad"], K + c["wpad"]
@@ -221,7 +290,7 @@ def main():
     kinds = tuple(a.kinds.split(","))
     t0, n, fails, per_kind, seed = time.time(), 0, [], {}, a.seed
     while time.time() - t0 < a.seconds:
-        c = draw(seed, kinds)
+        c = draw(seed + (SWAP_BASE if n % 8 == 7 else 0), kinds)
         msg = try_case(gpu, c)
         per_kind[c["kind"]] = per_kind.get(c["kind"], 0) + 1
         if msg:
