@@ -36,6 +36,8 @@ from oracle.halfs import F16, BF16, to_f32, from_f32  # noqa: E402
 from util import rand_half, make_paged_cache, ulp_tol, attn_atol  # noqa: E402
 
 KINDS = ("prefill", "paged_prefill", "kv_cache")
+STRIDE_BASE = 3 * 10 ** 6   # ... and from here on the ordinary kinds with padded row strides of q / k / v / o (slices of a fused q/k/v projection, llama.rs:269-303) and
+                            # seqlen_q / seqlen_k arguments larger than any sequence (an engine passes its configured maximum)
 DECODE_BASE = 2 * 10 ** 6   # ... and from here on decode batches of 64 .. 512 sequences (the balanced line, the paired kernel on a length hint, kv-head pairs at d = 64)
 FORWARD_BASE = 10 ** 6      # seeds from here on are "forward" cases (added after the first campaigns: a seed below keeps naming the case it always named)
 HEAD_SIZES = [8, 32, 64, 64, 64, 96, 128, 128, 128, 128, 160, 192, 224, 256]
@@ -43,6 +45,12 @@ HEAD_SIZES = [8, 32, 64, 64, 64, 96, 128, 128, 128, 128, 160, 192, 224, 256]
 
 def draw(seed, kinds=KINDS):
     """the case of `seed`: a dict of plain ints / lists (what a failure report prints)"""
+    if seed >= STRIDE_BASE:
+        c = draw(seed - STRIDE_BASE + 500_000, KINDS)
+        r2 = np.random.default_rng(seed)
+        c.update(seed=int(seed), qpad=int(r2.choice([0, 8, 64, 2 * c["hk"] * c["d"]])), opad=int(r2.choice([0, 8, 64])), kpad=int(r2.choice([0, 8, 64, c["h"] * c["d"]])),
+                 max_extra=int(r2.choice([0, 1, 37, 300])))
+        return c
     rng = np.random.default_rng(seed)
     kind = kinds[int(rng.integers(len(kinds)))]
     if seed >= FORWARD_BASE:
@@ -172,6 +180,24 @@ def _check(out, lse_rows, ref, ref_lse, visible, dtype, what, bounds=None, fast_
     return None, soft
 
 
+def _widen(rng, a, pad, dtype):
+    """a [..., heads, d] -> ([..., heads * d + pad] with random padding, row width): rows as slices of a wider buffer"""
+    flat = a.reshape(a.shape[:-2] + (a.shape[-2] * a.shape[-1],))
+    if not pad:
+        return np.ascontiguousarray(flat), flat.shape[-1]
+    w = rand_half(rng, flat.shape[:-1] + (flat.shape[-1] + pad,), dtype)
+    w[..., :flat.shape[-1]] = flat
+    return w, flat.shape[-1] + pad
+
+
+def _read_out(do, rows_shape, h, d, orow):
+    """the output buffer [rows..., orow] -> [rows..., h, d]; the padding between rows must still hold the poison"""
+    a = do.numpy(np.uint16, rows_shape + (orow,))
+    if orow > h * d and not (a[..., h * d:] == 0xFFFF).all():
+        raise RuntimeError("padding between output rows was written")
+    return np.ascontiguousarray(a[..., :h * d]).reshape(rows_shape + (h, d))
+
+
 def run_case(gpu, c):
     """(None when the library's answer is the oracle's, else a one-line description; the number of rows that were held to the bound of their own probabilities)"""
     rng = np.random.default_rng(c["seed"] + (1 << 40))
@@ -192,22 +218,27 @@ def run_case(gpu, c):
         else:
             S = max(1, int(lens.max()))
             kc, vc, bt = rand_half(rng, (B, S, hk, d), dtype), rand_half(rng, (B, S, hk, d), dtype), None
-        dq, dk, dv, do = D.from_numpy(q), D.from_numpy(kc), D.from_numpy(vc), D(q.nbytes)
+        qpad, opad, kpad, extra = c.get("qpad", 0), c.get("opad", 0), (c.get("kpad", 0) if not page else 0), c.get("max_extra", 0)
+        qw, qrow = _widen(rng, q, qpad, dtype)
+        kw, krow = _widen(rng, kc, kpad, dtype)
+        vw, _ = _widen(rng, vc, kpad, dtype)
+        orow = h * d + opad
+        dq, dk, dv, do = D.from_numpy(qw), D.from_numpy(kw), D.from_numpy(vw), D(B * sq * orow * 2)
         do.fill_bytes(0xFF)
         dlse = D.zeros((B, h, sq), np.float32)
         dbt = D.from_numpy(np.ascontiguousarray(bt, np.int32)) if bt is not None else None
         dl = D.from_numpy(lens)
-        seqlen_k = bt.shape[1] * page if bt is not None else kc.shape[1]
+        seqlen_k = (bt.shape[1] * page if bt is not None else kc.shape[1]) + (extra if bt is not None else 0)
         if c.get("hint"):                                   # what atoma_prepare_inputs would have recorded for this batch (a dispatch hint, never a result)
             gpu.lib.atoma_hint_decode_lengths(int(lens.min()), int(lens.max()), B)
         gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=sq, seqlen_k=seqlen_k, softmax_scale=scale, is_bf16=dtype,
-                    q_strides=(sq * h * d, h * d, d), o_strides=(sq * h * d, h * d, d), k_strides=(kc.shape[1] * hk * d, hk * d, d),
-                    v_strides=(vc.shape[1] * hk * d, hk * d, d), is_causal=int(causal if (sq > 1 or alibi is not None) else 0),      # lib.rs:1629-1631
+                    q_strides=(sq * qrow, qrow, d), o_strides=(sq * orow, orow, d), k_strides=(kc.shape[1] * krow, krow, d),
+                    v_strides=(vc.shape[1] * krow, krow, d), is_causal=int(causal if (sq > 1 or alibi is not None) else 0),      # lib.rs:1629-1631
                     cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt, block_table_batch_stride=0 if bt is None else bt.shape[1],
                     page_block_size=page, alibi_slopes=da, softmax_lse=dlse, force_split_kernel=bt is not None, unpadded_lse=False)
         gpu.synchronize()
         gpu.lib.atoma_hint_decode_lengths(0, 0, 0)
-        out, lse = do.numpy(np.uint16, q.shape), dlse.numpy()
+        out, lse = _read_out(do, (B, sq), h, d, orow), dlse.numpy()
         qf, kf, vf = to_f32(q, dtype), to_f32(kc, dtype), to_f32(vc, dtype)
         for b in range(B):
             L = int(lens[b])
@@ -235,18 +266,23 @@ def run_case(gpu, c):
         k, v = rand_half(rng, (Tk, hk, d), dtype), rand_half(rng, (Tk, hk, d), dtype)
     if Tq == 0:
         return None, 0
-    dq, dk, dv, do = D.from_numpy(q), D.from_numpy(k), D.from_numpy(v), D(q.nbytes)
+    qpad, opad, kpad, extra = c.get("qpad", 0), c.get("opad", 0), (c.get("kpad", 0) if bt is None else 0), c.get("max_extra", 0)
+    qw, qrow = _widen(rng, q, qpad, dtype)
+    kw, krow = _widen(rng, k, kpad, dtype)
+    vw, _ = _widen(rng, v, kpad, dtype)
+    orow = h * d + opad
+    dq, dk, dv, do = D.from_numpy(qw), D.from_numpy(kw), D.from_numpy(vw), D(Tq * orow * 2)
     do.fill_bytes(0xFF)
     dcq, dck = D.from_numpy(cu_q), D.from_numpy(cu_k)
     dbt = D.from_numpy(np.ascontiguousarray(bt, np.int32)) if bt is not None else None
     dlse = D.zeros((h, Tq), np.float32)
-    kstr = (page * hk * d, hk * d, d) if bt is not None else (0, hk * d, d)
-    gpu.run_mha(dq, dk, dv, do, b=c["B"], h=h, h_k=hk, d=d, seqlen_q=int(lq.max()), seqlen_k=int(max(1, lk.max())), softmax_scale=scale, is_bf16=dtype,
-                q_strides=(0, h * d, d), o_strides=(0, h * d, d), k_strides=kstr, v_strides=kstr, is_causal=int(c["causal"]), cu_seqlens_q=dcq,
+    kstr = (page * hk * d, hk * d, d) if bt is not None else (0, krow, d)
+    gpu.run_mha(dq, dk, dv, do, b=c["B"], h=h, h_k=hk, d=d, seqlen_q=int(lq.max()) + extra, seqlen_k=int(max(1, lk.max())) + extra, softmax_scale=scale, is_bf16=dtype,
+                q_strides=(0, qrow, d), o_strides=(0, orow, d), k_strides=kstr, v_strides=kstr, is_causal=int(c["causal"]), cu_seqlens_q=dcq,
                 cu_seqlens_k=dck, block_table=dbt, block_table_batch_stride=0 if bt is None else bt.shape[1], page_block_size=page, alibi_slopes=da,
                 softmax_lse=dlse, force_split_kernel=bt is not None)
     gpu.synchronize()
-    out, lse = do.numpy(np.uint16, q.shape), dlse.numpy()
+    out, lse = _read_out(do, (Tq,), h, d, orow), dlse.numpy()
     ref, ref_lse = A.flash_attn_varlen(q, k, v, cu_q, cu_k, scale, c["causal"], dtype, block_table=bt, alibi_slopes=alibi, return_lse=True)
     for b in range(c["B"]):
         q0, q1, Lq, Lk = int(cu_q[b]), int(cu_q[b + 1]), int(lq[b]), int(lk[b])
@@ -391,6 +427,7 @@ def main():
     ap.add_argument("--count", type=int, default=0, help="stop after this many cases (0 = by time)")
     ap.add_argument("--kinds", default=",".join(KINDS))
     ap.add_argument("--forward-every", type=int, default=4, help="every n-th case is a `forward` case (seed + 10^6) and every n-th a large decode batch (seed + 2.10^6); 0 = none")
+    ap.add_argument("--strides", type=int, default=1, help="1: every other ordinary case with padded strides / oversized seqlen arguments (seed + 3.10^6)")
     ap.add_argument("--seeds", default="", help="comma-separated seeds to run instead of a range (re-running findings)")
     a = ap.parse_args()
     import atoma_hip as gpu
@@ -402,14 +439,15 @@ def main():
     while (todo or not a.seeds) and (time.time() - t0 < a.seconds) and (not a.count or n < a.count):
         if a.seeds:
             seed = todo.pop(0)
-        extra = 0 if (a.seeds or not a.forward_every) else (FORWARD_BASE if n % a.forward_every == a.forward_every - 1 else (DECODE_BASE if n % a.forward_every == 0 else 0))
+        fe = a.forward_every
+        extra = 0 if a.seeds else (FORWARD_BASE if fe and n % fe == fe - 1 else DECODE_BASE if fe and n % fe == 0 else STRIDE_BASE if a.strides and n % 2 else 0)
         c = draw(seed + extra, kinds)
         try:
             msg, soft = run_case(gpu, c)
         except (RuntimeError, AssertionError) as e:
             msg, soft = f"raised {type(e).__name__}: {str(e)[:300]}", 0
         soft_rows, soft_cases = soft_rows + soft, soft_cases + (soft > 0)
-        kname = c["kind"] + (" (large decode batches)" if c["seed"] >= DECODE_BASE else "")
+        kname = c["kind"] + (" (padded strides)" if c["seed"] >= STRIDE_BASE else " (large decode batches)" if c["seed"] >= DECODE_BASE else "")
         per_kind[kname] = per_kind.get(kname, 0) + 1
         if msg:
             fails.append(dict(case=c, finding=msg))

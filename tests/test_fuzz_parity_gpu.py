@@ -25,6 +25,13 @@ def test_random_operator_calls_match_the_oracle(gpu, seed0):
     assert not findings, findings
 
 
+@pytest.mark.parametrize("seed0", range(F.STRIDE_BASE, F.STRIDE_BASE + 64, 8))
+def test_random_cases_with_padded_strides_match_the_oracle(gpu, seed0):
+    """q / k / v / o rows as slices of wider buffers, seqlen_q / seqlen_k arguments larger than any sequence; the padding between output rows stays untouched"""
+    findings = [(F.draw(s), msg) for s in range(seed0, seed0 + 8) for msg in [F.try_case(gpu, F.draw(s))] if msg]
+    assert not findings, findings
+
+
 @pytest.mark.parametrize("seed0", range(F.DECODE_BASE, F.DECODE_BASE + 32, 8))
 def test_random_large_decode_batches_match_the_oracle(gpu, seed0):
     """64 .. 512 sequences through whatever the dispatcher picks (the balanced line, the paired kernel when a length hint says ragged, kv-head pairs at d = 64)"""
