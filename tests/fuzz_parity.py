@@ -199,6 +199,46 @@ def _read_out(do, rows_shape, h, d, orow):
 
 
 def run_case(gpu, c):
+    """(finding or None, rows held to the bound of their own probabilities)"""
+    g = case_steps(gpu, c)
+    try:
+        next(g)
+        next(g)
+    except StopIteration as e:
+        return e.value
+    raise AssertionError("case_steps yields once")
+
+
+def run_burst(gpu, cases):
+    """All cases LAUNCHED back to back on the stream -- no synchronisation, no host read in between: the library's grow-only scratch block, its plan tables
+    and arrival counters are handed from one launch to the next while the earlier ones still run -- then every result checked.  Returns [(case, finding)]."""
+    gens = []
+    for c in cases:
+        g = case_steps(gpu, c)
+        try:
+            next(g)
+            gens.append((c, g, None))
+        except StopIteration as e:                      # a case that launches nothing (no query rows)
+            gens.append((c, None, e.value))
+        except (RuntimeError, AssertionError) as e:
+            gens.append((c, None, (f"raised {type(e).__name__}: {str(e)[:300]}", 0)))
+    out = []
+    for c, g, res in gens:
+        if g is not None:
+            try:
+                next(g)
+                res = ("case_steps yields once", 0)
+            except StopIteration as e:
+                res = e.value
+            except (RuntimeError, AssertionError) as e:
+                res = (f"raised {type(e).__name__}: {str(e)[:300]}", 0)
+        if res[0]:
+            out.append((c, res[0]))
+    return out
+
+
+def case_steps(gpu, c):
+    """generator: builds the inputs and launches, yields, then synchronises, reads and checks (its return value = run_case's)"""
     """(None when the library's answer is the oracle's, else a one-line description; the number of rows that were held to the bound of their own probabilities)"""
     rng = np.random.default_rng(c["seed"] + (1 << 40))
     soft = 0
@@ -207,7 +247,7 @@ def run_case(gpu, c):
     D = gpu.DeviceBuffer
     da = D.from_numpy(alibi) if alibi is not None else None
     if c["kind"] == "forward":
-        return _run_forward(gpu, c, rng, alibi)
+        return (yield from _run_forward(gpu, c, rng, alibi))
     if c["kind"] == "kv_cache":
         B, sq, page, lens = c["B"], c["sq"], c["page"], np.asarray(c["lens_k"], np.int32)
         causal = c["causal"] or sq == 1
@@ -236,8 +276,9 @@ def run_case(gpu, c):
                     v_strides=(vc.shape[1] * krow, krow, d), is_causal=int(causal if (sq > 1 or alibi is not None) else 0),      # lib.rs:1629-1631
                     cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt, block_table_batch_stride=0 if bt is None else bt.shape[1],
                     page_block_size=page, alibi_slopes=da, softmax_lse=dlse, force_split_kernel=bt is not None, unpadded_lse=False)
-        gpu.synchronize()
         gpu.lib.atoma_hint_decode_lengths(0, 0, 0)
+        yield
+        gpu.synchronize()
         out, lse = _read_out(do, (B, sq), h, d, orow), dlse.numpy()
         qf, kf, vf = to_f32(q, dtype), to_f32(kc, dtype), to_f32(vc, dtype)
         for b in range(B):
@@ -281,6 +322,7 @@ def run_case(gpu, c):
                 q_strides=(0, qrow, d), o_strides=(0, orow, d), k_strides=kstr, v_strides=kstr, is_causal=int(c["causal"]), cu_seqlens_q=dcq,
                 cu_seqlens_k=dck, block_table=dbt, block_table_batch_stride=0 if bt is None else bt.shape[1], page_block_size=page, alibi_slopes=da,
                 softmax_lse=dlse, force_split_kernel=bt is not None)
+    yield
     gpu.synchronize()
     out, lse = _read_out(do, (Tq,), h, d, orow), dlse.numpy()
     ref, ref_lse = A.flash_attn_varlen(q, k, v, cu_q, cu_k, scale, c["causal"], dtype, block_table=bt, alibi_slopes=alibi, return_lse=True)
@@ -373,6 +415,7 @@ def _run_forward(gpu, c, rng, alibi):
     rc = gpu.lib.atoma_flash_attention_forward(C.byref(fa), gpu.ref(tn["q"]), gpu.ref(tn["k"]), gpu.ref(tn["v"]), gpu.ref(tn["kv"]), C.byref(meta), gpu.ref(tn["out"]))
     if rc != 0:
         raise RuntimeError("flash_attention_forward: " + gpu.last_error())
+    yield
     gpu.synchronize()
     out = dout.numpy(np.uint16, (T, h, d))
     kc, vc = kv[0].copy(), kv[1].copy()
@@ -427,13 +470,14 @@ def main():
     ap.add_argument("--count", type=int, default=0, help="stop after this many cases (0 = by time)")
     ap.add_argument("--kinds", default=",".join(KINDS))
     ap.add_argument("--forward-every", type=int, default=4, help="every n-th case is a `forward` case (seed + 10^6) and every n-th a large decode batch (seed + 2.10^6); 0 = none")
+    ap.add_argument("--burst", type=int, default=0, help="launch this many cases back to back before the first synchronisation (run_burst)")
     ap.add_argument("--strides", type=int, default=1, help="1: every other ordinary case with padded strides / oversized seqlen arguments (seed + 3.10^6)")
     ap.add_argument("--seeds", default="", help="comma-separated seeds to run instead of a range (re-running findings)")
     a = ap.parse_args()
     import atoma_hip as gpu
     gpu.set_device(0)
     kinds = tuple(a.kinds.split(","))
-    t0, n, fails, per_kind, soft_rows, soft_cases = time.time(), 0, [], {}, 0, 0
+    t0, n, fails, per_kind, soft_rows, soft_cases, pending = time.time(), 0, [], {}, 0, 0, []
     seed = a.seed
     todo = [int(x) for x in a.seeds.split(",") if x]
     while (todo or not a.seeds) and (time.time() - t0 < a.seconds) and (not a.count or n < a.count):
@@ -442,19 +486,27 @@ def main():
         fe = a.forward_every
         extra = 0 if a.seeds else (FORWARD_BASE if fe and n % fe == fe - 1 else DECODE_BASE if fe and n % fe == 0 else STRIDE_BASE if a.strides and n % 2 else 0)
         c = draw(seed + extra, kinds)
-        try:
-            msg, soft = run_case(gpu, c)
-        except (RuntimeError, AssertionError) as e:
-            msg, soft = f"raised {type(e).__name__}: {str(e)[:300]}", 0
-        soft_rows, soft_cases = soft_rows + soft, soft_cases + (soft > 0)
         kname = c["kind"] + (" (padded strides)" if c["seed"] >= STRIDE_BASE else " (large decode batches)" if c["seed"] >= DECODE_BASE else "")
         per_kind[kname] = per_kind.get(kname, 0) + 1
-        if msg:
-            fails.append(dict(case=c, finding=msg))
-            print(json.dumps(fails[-1]), file=sys.stderr, flush=True)
+        if a.burst:
+            pending.append(c)
+            if len(pending) == a.burst:
+                for cc, msg in run_burst(gpu, pending):
+                    fails.append(dict(case=cc, finding=msg, burst=[x["seed"] for x in pending]))
+                    print(json.dumps(fails[-1]), file=sys.stderr, flush=True)
+                pending = []
+        else:
+            try:
+                msg, soft = run_case(gpu, c)
+            except (RuntimeError, AssertionError) as e:
+                msg, soft = f"raised {type(e).__name__}: {str(e)[:300]}", 0
+            soft_rows, soft_cases = soft_rows + soft, soft_cases + (soft > 0)
+            if msg:
+                fails.append(dict(case=c, finding=msg))
+                print(json.dumps(fails[-1]), file=sys.stderr, flush=True)
         n += 1
         seed += 1
-    print(json.dumps(dict(cases=n, seeds=[a.seed, seed - 1], per_kind=per_kind, seconds=round(time.time() - t0, 1), failures=len(fails),
+    print(json.dumps(dict(cases=n - len(pending), burst=a.burst, seeds=[a.seed, seed - 1], per_kind=per_kind, seconds=round(time.time() - t0, 1), failures=len(fails),
                           cases_with_rows_held_to_their_own_bound=soft_cases, rows_held_to_their_own_bound=soft_rows, findings=fails[:40])), flush=True)
     return 1 if fails else 0
 

@@ -32,6 +32,13 @@ def test_random_cases_with_padded_strides_match_the_oracle(gpu, seed0):
     assert not findings, findings
 
 
+@pytest.mark.parametrize("seed0", [100, 112, F.DECODE_BASE + 100, F.FORWARD_BASE + 100])
+def test_bursts_of_calls_without_a_synchronisation_in_between(gpu, seed0):
+    """12 cases launched back to back: the library's scratch block (grown by a later call while an earlier kernel may still run), plan tables and
+    arrival counters pass from launch to launch in stream order only"""
+    assert not F.run_burst(gpu, [F.draw(s) for s in range(seed0, seed0 + 12)])
+
+
 @pytest.mark.parametrize("seed0", range(F.DECODE_BASE, F.DECODE_BASE + 32, 8))
 def test_random_large_decode_batches_match_the_oracle(gpu, seed0):
     """64 .. 512 sequences through whatever the dispatcher picks (the balanced line, the paired kernel when a length hint says ragged, kv-head pairs at d = 64)"""
