@@ -237,8 +237,37 @@ def run_burst(gpu, cases):
     return out
 
 
+def run_threads(gpu, cases, threads=3):
+    """The cases dealt to `threads` host threads, each with its own stream, running concurrently (ctypes releases the GIL inside the library): scratch blocks,
+    plan tables and arrival counters are per (device, stream); the option table, the length hint and the kernel registry are shared.  Returns [(case, finding)]."""
+    import threading
+    out, lock = [], threading.Lock()
+
+    def worker(mine):
+        gpu.set_device(0)
+        stream = gpu.Stream()
+        for c in mine:
+            c = dict(c, _stream=stream.s)
+            try:
+                msg = run_case(gpu, c)[0]
+            except (RuntimeError, AssertionError) as e:
+                msg = f"raised {type(e).__name__}: {str(e)[:300]}"
+            if msg:
+                with lock:
+                    out.append(({k: v for k, v in c.items() if k != "_stream"}, msg))
+        stream.synchronize()
+    ts = [threading.Thread(target=worker, args=([c for i, c in enumerate(cases) if i % threads == t and c["kind"] != "forward"],)) for t in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    return out
+
+
 def case_steps(gpu, c):
-    """generator: builds the inputs and launches, yields, then synchronises, reads and checks (its return value = run_case's)"""
+    """generator: builds the inputs and launches, yields, then synchronises, reads and checks (its return value = run_case's).
+    c["_stream"]: a hipStream_t to launch on (run_threads: one stream per host thread), default the null stream."""
+    st = c.get("_stream")
     """(None when the library's answer is the oracle's, else a one-line description; the number of rows that were held to the bound of their own probabilities)"""
     rng = np.random.default_rng(c["seed"] + (1 << 40))
     soft = 0
@@ -275,10 +304,10 @@ def case_steps(gpu, c):
                     q_strides=(sq * qrow, qrow, d), o_strides=(sq * orow, orow, d), k_strides=(kc.shape[1] * krow, krow, d),
                     v_strides=(vc.shape[1] * krow, krow, d), is_causal=int(causal if (sq > 1 or alibi is not None) else 0),      # lib.rs:1629-1631
                     cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt, block_table_batch_stride=0 if bt is None else bt.shape[1],
-                    page_block_size=page, alibi_slopes=da, softmax_lse=dlse, force_split_kernel=bt is not None, unpadded_lse=False)
+                    page_block_size=page, alibi_slopes=da, softmax_lse=dlse, force_split_kernel=bt is not None, unpadded_lse=False, stream=st)
         gpu.lib.atoma_hint_decode_lengths(0, 0, 0)
         yield
-        gpu.synchronize()
+        gpu.synchronize() if st is None else gpu.hip_check(gpu.hip.hipStreamSynchronize(st), "hipStreamSynchronize")
         out, lse = _read_out(do, (B, sq), h, d, orow), dlse.numpy()
         qf, kf, vf = to_f32(q, dtype), to_f32(kc, dtype), to_f32(vc, dtype)
         for b in range(B):
@@ -321,9 +350,9 @@ def case_steps(gpu, c):
     gpu.run_mha(dq, dk, dv, do, b=c["B"], h=h, h_k=hk, d=d, seqlen_q=int(lq.max()) + extra, seqlen_k=int(max(1, lk.max())) + extra, softmax_scale=scale, is_bf16=dtype,
                 q_strides=(0, qrow, d), o_strides=(0, orow, d), k_strides=kstr, v_strides=kstr, is_causal=int(c["causal"]), cu_seqlens_q=dcq,
                 cu_seqlens_k=dck, block_table=dbt, block_table_batch_stride=0 if bt is None else bt.shape[1], page_block_size=page, alibi_slopes=da,
-                softmax_lse=dlse, force_split_kernel=bt is not None)
+                softmax_lse=dlse, force_split_kernel=bt is not None, stream=st)
     yield
-    gpu.synchronize()
+    gpu.synchronize() if st is None else gpu.hip_check(gpu.hip.hipStreamSynchronize(st), "hipStreamSynchronize")
     out, lse = _read_out(do, (Tq,), h, d, orow), dlse.numpy()
     ref, ref_lse = A.flash_attn_varlen(q, k, v, cu_q, cu_k, scale, c["causal"], dtype, block_table=bt, alibi_slopes=alibi, return_lse=True)
     for b in range(c["B"]):
@@ -470,6 +499,7 @@ def main():
     ap.add_argument("--count", type=int, default=0, help="stop after this many cases (0 = by time)")
     ap.add_argument("--kinds", default=",".join(KINDS))
     ap.add_argument("--forward-every", type=int, default=4, help="every n-th case is a `forward` case (seed + 10^6) and every n-th a large decode batch (seed + 2.10^6); 0 = none")
+    ap.add_argument("--threads", type=int, default=0, help="with --burst N: each group of N cases is dealt to this many host threads with a stream each (run_threads)")
     ap.add_argument("--burst", type=int, default=0, help="launch this many cases back to back before the first synchronisation (run_burst)")
     ap.add_argument("--strides", type=int, default=1, help="1: every other ordinary case with padded strides / oversized seqlen arguments (seed + 3.10^6)")
     ap.add_argument("--seeds", default="", help="comma-separated seeds to run instead of a range (re-running findings)")
@@ -491,7 +521,7 @@ def main():
         if a.burst:
             pending.append(c)
             if len(pending) == a.burst:
-                for cc, msg in run_burst(gpu, pending):
+                for cc, msg in (run_threads(gpu, pending, a.threads) if a.threads else run_burst(gpu, pending)):
                     fails.append(dict(case=cc, finding=msg, burst=[x["seed"] for x in pending]))
                     print(json.dumps(fails[-1]), file=sys.stderr, flush=True)
                 pending = []

@@ -39,6 +39,13 @@ def test_bursts_of_calls_without_a_synchronisation_in_between(gpu, seed0):
     assert not F.run_burst(gpu, [F.draw(s) for s in range(seed0, seed0 + 12)])
 
 
+@pytest.mark.parametrize("seed0", [200, F.DECODE_BASE + 200, F.STRIDE_BASE + 200])
+def test_three_host_threads_with_a_stream_each(gpu, seed0):
+    """24 cases dealt to 3 threads that call the library concurrently, each on its own stream (the reference runs one thread per GPU; a server with several
+    engines in one process does this): per-stream scratch and counters, shared options / registries"""
+    assert not F.run_threads(gpu, [F.draw(s) for s in range(seed0, seed0 + 24)], threads=3)
+
+
 @pytest.mark.parametrize("seed0", range(F.DECODE_BASE, F.DECODE_BASE + 32, 8))
 def test_random_large_decode_batches_match_the_oracle(gpu, seed0):
     """64 .. 512 sequences through whatever the dispatcher picks (the balanced line, the paired kernel when a length hint says ragged, kv-head pairs at d = 64)"""
