@@ -264,6 +264,57 @@ def run_threads(gpu, cases, threads=3):
     return out
 
 
+def graph_case(gpu, c):
+    """A decode call (one query row, paged cache) CAPTURED into a hipGraph after one eager call, then replayed three times with OTHER lengths in the same block
+    tables (what a serving loop does every step: model_executor / worker rebuild the metadata, the graph stays): shorter, longer, ragged where the capture was
+    uniform, empty sequences.  Every replay against the definition.  What the host decided at capture time (kernel, KV splits, scratch layout) must be right for
+    any lengths the tables can hold.  Returns a finding or None."""
+    rng = np.random.default_rng(c["seed"] + (1 << 42))
+    d, h, hk, dtype, scale, B, page = c["d"], c["h"], c["hk"], c["dtype"], c["scale"], c["B"], c["page"] or 16
+    lens0 = np.asarray(c["lens_k"], np.int32)
+    cap = np.maximum(lens0, 1) + rng.integers(0, 3 * page, B)                      # what each sequence's block-table row can hold
+    pages = (cap + page - 1) // page
+    cap = (pages * page).astype(np.int32)
+    nb = int(pages.sum()) + 2
+    kc, vc, bt = make_paged_cache(rng, nb, page, hk, d, dtype, cap)
+    q = rand_half(rng, (B, 1, h, d), dtype)
+    D = gpu.DeviceBuffer
+    st = gpu.Stream()
+    dq, dk, dv, do = D.from_numpy(q), D.from_numpy(kc), D.from_numpy(vc), D(q.nbytes)
+    dlse, dbt, dl = D.zeros((B, h, 1), np.float32), D.from_numpy(np.ascontiguousarray(bt, np.int32)), D.from_numpy(lens0)
+
+    def call():
+        gpu.run_mha(dq, dk, dv, do, b=B, h=h, h_k=hk, d=d, seqlen_q=1, seqlen_k=bt.shape[1] * page, softmax_scale=scale, is_bf16=dtype,
+                    q_strides=(h * d, h * d, d), o_strides=(h * d, h * d, d), k_strides=(page * hk * d, hk * d, d), v_strides=(page * hk * d, hk * d, d), is_causal=0,
+                    cu_seqlens_k=dl, is_seqlens_k_cumulative=False, block_table=dbt, block_table_batch_stride=bt.shape[1], page_block_size=page, softmax_lse=dlse,
+                    force_split_kernel=True, unpadded_lse=False, stream=st.s)
+    if c.get("hint"):
+        gpu.lib.atoma_hint_decode_lengths(int(lens0.min()), int(lens0.max()), B)
+    call()                                                                          # eager: sizes the stream's scratch (or atoma_warmup would)
+    st.synchronize()
+    with gpu.Graph.capture(st) as g:
+        call()
+    gpu.lib.atoma_hint_decode_lengths(0, 0, 0)
+    kernel = (gpu.lib.atoma_last_decode_kernel() or b"").decode()
+    qf, kf, vf = to_f32(q, dtype), to_f32(kc, dtype), to_f32(vc, dtype)
+    variants = [lens0, (cap * rng.random(B)).astype(np.int32), cap.copy(), np.where(rng.random(B) < 0.3, 0, np.minimum(cap, 1 + rng.integers(0, 40, B))).astype(np.int32)]
+    for r, lens in enumerate(variants):
+        gpu.hip_check(gpu.hip.hipMemcpy(dl.ptr, np.ascontiguousarray(lens, np.int32).ctypes.data, 4 * B, gpu.H2D), "lengths")
+        do.fill_bytes(0xFF)
+        g.launch()
+        st.synchronize()
+        out, lse = do.numpy(np.uint16, (B, 1, h, d)), dlse.numpy()
+        for b in range(B):
+            L = int(lens[b])
+            kb, vb = A.gather_paged(kf, bt[b], L, page), A.gather_paged(vf, bt[b], L, page)
+            o, l = A.attend_rows(qf[b], kb, vb, scale, dtype=dtype)
+            msg, _ = _check(out[b], lse[b], from_f32(o, dtype), l, np.full(1, L), dtype, f"replay {r} ({kernel}) seq {b} (L={L}, captured at {int(lens0[b])})",
+                            lambda: p_bounds(qf[b], kb, vb, scale, False, None))
+            if msg:
+                return msg
+    return None
+
+
 def case_steps(gpu, c):
     """generator: builds the inputs and launches, yields, then synchronises, reads and checks (its return value = run_case's).
     c["_stream"]: a hipStream_t to launch on (run_threads: one stream per host thread), default the null stream."""
@@ -499,6 +550,7 @@ def main():
     ap.add_argument("--count", type=int, default=0, help="stop after this many cases (0 = by time)")
     ap.add_argument("--kinds", default=",".join(KINDS))
     ap.add_argument("--forward-every", type=int, default=4, help="every n-th case is a `forward` case (seed + 10^6) and every n-th a large decode batch (seed + 2.10^6); 0 = none")
+    ap.add_argument("--graphs", type=int, default=0, help="1: only captured-and-replayed decode calls (graph_case) on the large-batch and the ordinary kv_cache cases")
     ap.add_argument("--threads", type=int, default=0, help="with --burst N: each group of N cases is dealt to this many host threads with a stream each (run_threads)")
     ap.add_argument("--burst", type=int, default=0, help="launch this many cases back to back before the first synchronisation (run_burst)")
     ap.add_argument("--strides", type=int, default=1, help="1: every other ordinary case with padded strides / oversized seqlen arguments (seed + 3.10^6)")
@@ -516,6 +568,22 @@ def main():
         fe = a.forward_every
         extra = 0 if a.seeds else (FORWARD_BASE if fe and n % fe == fe - 1 else DECODE_BASE if fe and n % fe == 0 else STRIDE_BASE if a.strides and n % 2 else 0)
         c = draw(seed + extra, kinds)
+        if a.graphs:
+            c = draw((DECODE_BASE if n % 2 else 0) + seed, ("kv_cache",))
+            if c["d"] not in (64, 128) and n % 4 != 2:            # mostly the head sizes the streaming kernels serve; the others now and then
+                c["d"], c["scale"] = 128, 128 ** -0.5
+            c.update(sq=1, alibi=False)
+            try:
+                msg = graph_case(gpu, c)
+            except (RuntimeError, AssertionError) as e:
+                msg = f"raised {type(e).__name__}: {str(e)[:300]}"
+            per_kind["graph replay"] = per_kind.get("graph replay", 0) + 1
+            if msg:
+                fails.append(dict(case=c, finding=msg))
+                print(json.dumps(fails[-1]), file=sys.stderr, flush=True)
+            n += 1
+            seed += 1
+            continue
         kname = c["kind"] + (" (padded strides)" if c["seed"] >= STRIDE_BASE else " (large decode batches)" if c["seed"] >= DECODE_BASE else "")
         per_kind[kname] = per_kind.get(kname, 0) + 1
         if a.burst:

@@ -39,6 +39,13 @@ def test_bursts_of_calls_without_a_synchronisation_in_between(gpu, seed0):
     assert not F.run_burst(gpu, [F.draw(s) for s in range(seed0, seed0 + 12)])
 
 
+@pytest.mark.parametrize("seed", [F.DECODE_BASE + 300, F.DECODE_BASE + 301, F.DECODE_BASE + 302, F.DECODE_BASE + 303, F.DECODE_BASE + 304, F.DECODE_BASE + 305])
+def test_captured_decode_call_replayed_with_other_lengths(gpu, seed):
+    """graph_case: eager call, capture, then four replays with other lengths in the same block tables (the captured host decisions must hold for any of them)"""
+    c = F.draw(seed)
+    assert F.graph_case(gpu, c) is None
+
+
 @pytest.mark.parametrize("seed0", [200, F.DECODE_BASE + 200, F.STRIDE_BASE + 200])
 def test_three_host_threads_with_a_stream_each(gpu, seed0):
     """24 cases dealt to 3 threads that call the library concurrently, each on its own stream (the reference runs one thread per GPU; a server with several
