@@ -31,6 +31,7 @@ from oracle.halfs import F16, BF16, to_f32, from_f32  # noqa: E402
 from util import rand_half  # noqa: E402
 
 KINDS = ("linear", "linear", "qkv_rope", "norm_rope")
+FP8_BASE = 2 * 10 ** 6    # ... decode over the fp8 (e4m3fn) KV cache: atoma_paged_decode_fp8 against the definition over the dequantised cache
 SWAP_BASE = 10 ** 6       # seeds from here on: swap_blocks / swap_blocks_multi (added after the first campaign; earlier seeds keep their cases)
 BATCHES = [1, 2, 3, 4, 5, 8, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 66, 96, 127, 128, 129, 160, 191, 192, 193, 224, 255, 256]
 K_UNITS = [1, 2, 3, 4, 8, 12, 16, 24, 32, 40, 56, 64, 112, 128]                       # x 128
@@ -41,6 +42,16 @@ MAX_WEIGHTS = 24 << 20
 def draw(seed, kinds=KINDS):
     rng = np.random.default_rng(seed)
     kind = kinds[int(rng.integers(len(kinds)))]
+    if seed >= FP8_BASE:
+        hk, g = (int(x) for x in rng.choice([(8, 4), (8, 1), (2, 3), (1, 8), (1, 13), (2, 20), (4, 16), (8, 2), (1, 5)]))
+        B = int(rng.choice([1, 2, 7, 16, 40, 64, 130, 256, 320]))
+        top = max(20, min(int(rng.choice([40, 300, 1200, 4000])), (1 << 22) // (B * hk * g)))
+        lens = rng.integers(0, top + 1, B)
+        lens[rng.integers(0, B)] = top
+        if rng.integers(4) == 0:
+            lens[:] = top
+        return dict(seed=int(seed), kind="fp8_decode", dtype=int(rng.choice([BF16, BF16, F16])), B=B, hk=hk, h=hk * g, page=int(rng.choice([16, 16, 32, 64])),
+                    lens=[int(x) for x in lens], mqk=int(rng.integers(4) != 0))
     if seed >= SWAP_BASE:
         block = int(rng.choice([16, 48, 2048, 4104, 32768, 32768, 131072, 1 << 20, (17 << 20) + 16]))
         nt = int(rng.choice([1, 2, 5, 16]))
@@ -87,6 +98,42 @@ def run_case(gpu, c):
     def ok(rc, what):
         if rc != 0:
             raise RuntimeError(f"{what}: {gpu.last_error()}")
+    if c["kind"] == "fp8_decode":
+        import test_kv_fp8_gpu as T8
+        import fuzz_parity as FP
+        from util import ulp_tol, attn_atol
+        from oracle import fp8_oracle as F8, attn_oracle as A
+        d, h, hk, page, lens = 128, c["h"], c["hk"], c["page"], np.asarray(c["lens"], np.int32)
+        nb = int(sum((int(x) + page - 1) // page for x in lens)) + 3
+        kc8, vc8, ks, vs, bt = T8.make_fp8_cache(rng, nb, page, hk, d, lens)
+        q = rand_half(rng, (B, h, d), dtype)
+        scale = np.float32(d ** -0.5)
+        ok(L.atoma_set_option(b"decode_fp8_mqk", c["mqk"]), "set_option")
+        try:
+            out = T8.gpu_decode_fp8(gpu, q, kc8, vc8, ks, vs, bt, lens, scale, dtype)
+        finally:
+            L.atoma_set_option(b"decode_fp8_mqk", 1)
+        ref = T8.oracle_decode(q, kc8, vc8, ks, vs, bt, lens, scale, dtype)
+        g, r = to_f32(out, dtype), to_f32(ref, dtype)
+        if not np.isfinite(g).all():
+            return "non-finite output"
+        kf = vf = None
+        for b in range(B):
+            n = int(lens[b])
+            if n == 0:
+                if out[b].any():
+                    return f"seq {b}: an empty sequence must give exact zeros"
+                continue
+            err = np.abs(g[b] - r[b])
+            if (err > ulp_tol(r[b], dtype, attn_atol(dtype, n))).any():
+                if kf is None:
+                    kf, vf = F8.dequantize(kc8, ks), F8.dequantize(vc8, vs)
+                kb, vb = A.gather_paged(kf, bt[b], n, page), A.gather_paged(vf, bt[b], n, page)
+                ab, sq = FP.p_bounds(to_f32(q[b][None], dtype), kb, vb, scale, False, None)
+                own = ulp_tol(r[b], dtype, 1e-3) + np.minimum(FP.E_MAX[dtype] * ab[0], 6 * FP.E_SIG[dtype] * sq[0])
+                if (err > own).any():
+                    return f"seq {b} (L={n}): max err {err.max():.3e} beyond the bound of its own probabilities"
+        return None
     if c["kind"] == "swap":
         import ctypes as C
         block, nt, nb, kind = c["block"], c["nt"], c["nb"], c["dir"]
@@ -290,7 +337,7 @@ def main():
     kinds = tuple(a.kinds.split(","))
     t0, n, fails, per_kind, seed = time.time(), 0, [], {}, a.seed
     while time.time() - t0 < a.seconds:
-        c = draw(seed + (SWAP_BASE if n % 8 == 7 else 0), kinds)
+        c = draw(seed + (SWAP_BASE if n % 8 == 7 else FP8_BASE if n % 8 == 3 else 0), kinds)
         msg = try_case(gpu, c)
         per_kind[c["kind"]] = per_kind.get(c["kind"], 0) + 1
         if msg:
