@@ -36,6 +36,7 @@ from oracle.halfs import F16, BF16, to_f32, from_f32  # noqa: E402
 from util import rand_half, make_paged_cache, ulp_tol, attn_atol  # noqa: E402
 
 KINDS = ("prefill", "paged_prefill", "kv_cache")
+LONG_BASE = 4 * 10 ** 6     # ... and from here on prompts of 500 .. 5000 tokens (a persistent prefill workgroup walks many blocks; sampled rows against the definition)
 STRIDE_BASE = 3 * 10 ** 6   # ... and from here on the ordinary kinds with padded row strides of q / k / v / o (slices of a fused q/k/v projection, llama.rs:269-303) and
                             # seqlen_q / seqlen_k arguments larger than any sequence (an engine passes its configured maximum)
 DECODE_BASE = 2 * 10 ** 6   # ... and from here on decode batches of 64 .. 512 sequences (the balanced line, the paired kernel on a length hint, kv-head pairs at d = 64)
@@ -45,6 +46,22 @@ HEAD_SIZES = [8, 32, 64, 64, 64, 96, 128, 128, 128, 128, 160, 192, 224, 256]
 
 def draw(seed, kinds=KINDS):
     """the case of `seed`: a dict of plain ints / lists (what a failure report prints)"""
+    if seed >= LONG_BASE:
+        rng = np.random.default_rng(seed)
+        hk, g = int(rng.choice([1, 2, 8])), int(rng.choice([1, 4]))
+        d = int(rng.choice([128, 128, 128, 64, 96]))
+        B = int(rng.choice([1, 2, 3, 5]))
+        top = int(rng.choice([1800, 3000, 5000]))
+        top = min(top, (96 << 20) // (B * hk * g * d * 2))
+        lq = rng.integers(top // 8, top + 1, B)
+        lq[rng.integers(0, B)] = top
+        mode = int(rng.integers(4))
+        lk = lq.copy() if mode <= 1 else (lq + rng.integers(0, top // 2, B) * rng.integers(0, 2, B) if mode == 2 else rng.integers(0, top + 1, B))
+        c = dict(seed=int(seed), kind=("prefill", "paged_prefill")[int(rng.integers(2))], d=d, hk=hk, h=hk * g, dtype=int(rng.choice([BF16, BF16, F16])),
+                 causal=bool(rng.integers(4) != 0), alibi=False, scale=float(d ** -0.5), B=B, lens_q=[int(x) for x in lq], lens_k=[int(x) for x in lk], sample=True)
+        if c["kind"] == "paged_prefill":
+            c["page"] = int(rng.choice([16, 16, 32, 256]))
+        return c
     if seed >= STRIDE_BASE:
         c = draw(seed - STRIDE_BASE + 500_000, KINDS)
         r2 = np.random.default_rng(seed)
@@ -405,6 +422,26 @@ def case_steps(gpu, c):
     yield
     gpu.synchronize() if st is None else gpu.hip_check(gpu.hip.hipStreamSynchronize(st), "hipStreamSynchronize")
     out, lse = _read_out(do, (Tq,), h, d, orow), dlse.numpy()
+    if c.get("sample"):                                   # long prompts: nothing unwritten anywhere, and ~40 rows per sequence against the definition
+        if not np.isfinite(to_f32(out, dtype)).all():
+            return "non-finite output (unwritten rows read as NaN)", soft
+        kf_all, vf_all = to_f32(k, dtype), to_f32(v, dtype)
+        for b in range(c["B"]):
+            q0, Lq, Lk, k0 = int(cu_q[b]), int(lq[b]), int(lk[b]), int(cu_k[b])
+            if Lq == 0:
+                continue
+            kb, vb = (A.gather_paged(kf_all, bt[b], Lk, page), A.gather_paged(vf_all, bt[b], Lk, page)) if bt is not None else (kf_all[k0:k0 + Lk], vf_all[k0:k0 + Lk])
+            rows = sorted({0, 1, Lq - 1, Lq // 2} | {r for m in range(256, Lq, 256) for r in (m - 1, m) if rng.integers(3) == 0} | {int(x) for x in rng.integers(0, Lq, 24)})
+            for r in rows:
+                vis = min(Lk, r + Lk - Lq + 1) if c["causal"] else Lk
+                qr = to_f32(q[q0 + r:q0 + r + 1], dtype)
+                o, l = A.attend_rows(qr, kb[:max(vis, 0)], vb[:max(vis, 0)], scale, dtype=dtype)
+                msg, n = _check(out[q0 + r:q0 + r + 1], lse[:, q0 + r:q0 + r + 1], from_f32(o, dtype), l, np.full(1, vis), dtype, f"seq {b} (Lq={Lq}, Lk={Lk}) row {r}",
+                                lambda: p_bounds(qr, kb[:vis], vb[:vis], scale, False, None), fast_lse=scale * d ** 0.5 if d == 128 else 0.0)
+                soft += n
+                if msg:
+                    return msg, soft
+        return None, soft
     ref, ref_lse = A.flash_attn_varlen(q, k, v, cu_q, cu_k, scale, c["causal"], dtype, block_table=bt, alibi_slopes=alibi, return_lse=True)
     for b in range(c["B"]):
         q0, q1, Lq, Lk = int(cu_q[b]), int(cu_q[b + 1]), int(lq[b]), int(lk[b])
@@ -550,6 +587,7 @@ def main():
     ap.add_argument("--count", type=int, default=0, help="stop after this many cases (0 = by time)")
     ap.add_argument("--kinds", default=",".join(KINDS))
     ap.add_argument("--forward-every", type=int, default=4, help="every n-th case is a `forward` case (seed + 10^6) and every n-th a large decode batch (seed + 2.10^6); 0 = none")
+    ap.add_argument("--long", type=int, default=0, help="1: only prompts of 500 .. 5000 tokens (seed + 4.10^6), sampled rows")
     ap.add_argument("--graphs", type=int, default=0, help="1: only captured-and-replayed decode calls (graph_case) on the large-batch and the ordinary kv_cache cases")
     ap.add_argument("--threads", type=int, default=0, help="with --burst N: each group of N cases is dealt to this many host threads with a stream each (run_threads)")
     ap.add_argument("--burst", type=int, default=0, help="launch this many cases back to back before the first synchronisation (run_burst)")
@@ -567,7 +605,7 @@ def main():
             seed = todo.pop(0)
         fe = a.forward_every
         extra = 0 if a.seeds else (FORWARD_BASE if fe and n % fe == fe - 1 else DECODE_BASE if fe and n % fe == 0 else STRIDE_BASE if a.strides and n % 2 else 0)
-        c = draw(seed + extra, kinds)
+        c = draw(seed + (LONG_BASE if a.long else extra), kinds)
         if a.graphs:
             c = draw((DECODE_BASE if n % 2 else 0) + seed, ("kv_cache",))
             if c["d"] not in (64, 128) and n % 4 != 2:            # mostly the head sizes the streaming kernels serve; the others now and then
@@ -584,7 +622,7 @@ def main():
             n += 1
             seed += 1
             continue
-        kname = c["kind"] + (" (padded strides)" if c["seed"] >= STRIDE_BASE else " (large decode batches)" if c["seed"] >= DECODE_BASE else "")
+        kname = c["kind"] + (" (long prompts)" if c["seed"] >= LONG_BASE else " (padded strides)" if c["seed"] >= STRIDE_BASE else " (large decode batches)" if c["seed"] >= DECODE_BASE else "")
         per_kind[kname] = per_kind.get(kname, 0) + 1
         if a.burst:
             pending.append(c)

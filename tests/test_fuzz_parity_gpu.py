@@ -25,6 +25,13 @@ def test_random_operator_calls_match_the_oracle(gpu, seed0):
     assert not findings, findings
 
 
+@pytest.mark.parametrize("seed0", range(F.LONG_BASE, F.LONG_BASE + 16, 4))
+def test_random_long_prompts_match_the_oracle(gpu, seed0):
+    """prompts of 500 .. 5000 tokens (a persistent prefill workgroup walks many blocks): nothing unwritten, ~40 sampled rows per sequence against the definition"""
+    findings = [(F.draw(s), msg) for s in range(seed0, seed0 + 4) for msg in [F.try_case(gpu, F.draw(s))] if msg]
+    assert not findings, findings
+
+
 @pytest.mark.parametrize("seed0", range(F.STRIDE_BASE, F.STRIDE_BASE + 64, 8))
 def test_random_cases_with_padded_strides_match_the_oracle(gpu, seed0):
     """q / k / v / o rows as slices of wider buffers, seqlen_q / seqlen_k arguments larger than any sequence; the padding between output rows stays untouched"""
