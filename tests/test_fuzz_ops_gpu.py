@@ -7,7 +7,7 @@ import fuzz_ops as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed0", list(range(0, 96, 12)) + list(range(F.SWAP_BASE, F.SWAP_BASE + 24, 12)) + list(range(F.FP8_BASE, F.FP8_BASE + 24, 12)))
+@pytest.mark.parametrize("seed0", list(range(0, 48, 12)) + [F.SWAP_BASE, F.FP8_BASE])
 def test_random_cases_match_the_oracle(gpu, seed0):
     findings = [(F.draw(s), msg) for s in range(seed0, seed0 + 12) for msg in [F.try_case(gpu, F.draw(s))] if msg]
     assert not findings, findings
