@@ -7,6 +7,10 @@ libamdhip64.  Importing this module fails loudly if the HIP extension is not bui
 import ctypes as C
 import os
 
+# The host driver of the MI355X pool only supports dmabuf IPC: without this hipIpcGetMemHandle (the direct all-reduce's handle exchange, RCCL's own
+# peer set-up) fails with "invalid argument".  It must be in the environment before the HIP runtime initialises; a value the caller set is kept.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

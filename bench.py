@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (hipIpcGetMemHandle / RCCL across processes on this pool): before any HIP library loads
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
