@@ -32,7 +32,7 @@ for step in "$@"; do
           f=$(find "$O/prof_rank" -name "*kernel_trace.csv" | head -1); python tools/step_breakdown.py "$f" "one rank of the 70B TP=8 step, 8 layers, $TAG" > "$O/rank_step_breakdown.json"; rm -rf "$O/prof_rank" ;;
     lin256) timeout 600 python tools/probes/linear256_ab.py ${arg//,/ } > "$O/linear256_ab.jsonl" 2>&1; cut -c1-160 "$O/linear256_ab.jsonl" ;;
     c3ab) timeout 600 python tools/probes/c3_own_vs_vendor.py 3 2>&1 | tail -1 | tee "$O/c3_own_vs_vendor.json" ;;
-    prefill_pmc) bash tools/prefill_pmc.sh "$O" ;;
+    prefill_pmc) bash tools/prefill_pmc.sh "$TAG" ;;
     *) echo "unknown step $step" ;;
   esac
 done
