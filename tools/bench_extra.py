@@ -340,6 +340,17 @@ def c3_trace():
     return {k: r[k] for k in keep}
 
 
+def c3_trace_ragged():
+    """VARIANT of c3_trace (not BASELINE configs[2], which has equal prompts): the requests' prompts are 2048 - U[0, 512) tokens long, so every decode batch is
+    ragged (contexts spread over 512 tokens, as in a serving loop) and the DEFAULT dispatch -- atoma_prepare_inputs has seen that the lengths differ -- takes
+    paged_decode_pair_kernel (`decode_attention_kernel`).  The same checks: a sample of the last step's last-layer attention against the oracle."""
+    import engine_trace
+    r = engine_trace.run(ragged_spread=512)
+    keep = ("workload", "decode_s", "decode_ms_per_step", "decode_tokens_per_s_per_gpu", "decode_roofline_tokens_per_s", "decode_attention_kernel", "decode_frac_of_roofline",
+            "host_metadata_ms_per_step", "data", "sample")
+    return {k: r[k] for k in keep}
+
+
 def c5_swap_sizes(iters=3):
     """BASELINE.md C5's other map sizes: swap-out / swap-in of n = 16 and n = 4096 random distinct pages (n = 256 is extra.swap)."""
     return {"n16": swap(iters=iters, pages=16, nb=512), "n4096": swap(iters=iters, pages=4096, nb=8192, tensors=16)}
@@ -377,7 +388,7 @@ def c4_rank_step(iters=10):
     return rank_step.run(iters=iters)
 
 
-ALL = ("c3_decode_step", "c3_decode_step_paired", "c3_trace", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "p1_prefill_4096", "p2_prefill_d96", "p2_prefill_d256", "c2b_mha", "c2c_ragged", "c2c_ragged_paired", "c2c_identity",
+ALL = ("c3_decode_step", "c3_decode_step_paired", "c3_trace", "c3_trace_ragged", "c3_decode_step_fp8_kv", "c4_rank_step", "prefill", "p1_prefill_4096", "p2_prefill_d96", "p2_prefill_d256", "c2b_mha", "c2c_ragged", "c2c_ragged_paired", "c2c_identity",
        "c2a_seeds", "k4_reshape_and_cache", "k4_sizes", "k5_copy_blocks", "k5_sizes", "n1_norm_rope", "n1_norm_rope_t256", "swap", "c5_swap_sizes")
 
 

@@ -56,10 +56,13 @@ def main():
     print(json.dumps(out), flush=True)
 
 
-def run(requests=256, prompt=2048, decode_steps=512, layers=0, model="8b", prompts_per_launch=2, sample_seqs=(0, 131)):
+def run(requests=256, prompt=2048, decode_steps=512, layers=0, model="8b", prompts_per_launch=2, sample_seqs=(0, 131), ragged_spread=0):
     """The trace; returns the result dict.  "sample" = host copies of what the LAST decode step's LAST layer attended over for `sample_seqs`
     (its rotated q, the attention output the timed graph wrote, the sequence's K / V gathered from that layer's cache through the trace's
-    block table): bench.py checks them against the oracle -- every cache write, slot mapping and block table of the whole trace is behind them."""
+    block table): bench.py checks them against the oracle -- every cache write, slot mapping and block table of the whole trace is behind them.
+    ragged_spread > 0 (a VARIANT, not BASELINE configs[2]): request i's prompt is its first prompt - U[0, ragged_spread) tokens -- the prefill phase still
+    computes `prompt` positions per request (its graph has one shape), the decode phase starts at the shorter lengths and overwrites the rest of the cache
+    rows as it goes, so the decode batches are ragged as in a serving loop and atoma_prepare_inputs' length hint picks the dispatch."""
     rng = np.random.default_rng(3)
     c = DS.LLAMA_3_1_8B if model == "8b" else DS.Config(80, 8192, 8, 1, 128, 28672 // 8, 128256 // 8)
     if layers:
@@ -77,6 +80,7 @@ def run(requests=256, prompt=2048, decode_steps=512, layers=0, model="8b", promp
     tokens = np.zeros((B, P + N + 1), np.uint32)
     tokens[:, :P] = rng.integers(0, c.vocab, (B, P))
     lengths = np.full(B, P, np.int64)
+    rows_all = np.arange(B)
 
     # ---- phase 1: prefill, one prompt per graph replay ----
     slots_of = lambda r: (tables[r, np.arange(P) // c.page].astype(np.int64) * c.page + np.arange(P) % c.page)
@@ -93,7 +97,9 @@ def run(requests=256, prompt=2048, decode_steps=512, layers=0, model="8b", promp
         st.synchronize()
         first[r:r + G] = pre.next_id.numpy(np.int32, (G,))
     t_prefill = time.perf_counter() - t0
-    tokens[:, P] = first
+    if ragged_spread:
+        lengths -= rng.integers(0, ragged_spread, B)
+    tokens[rows_all, lengths] = first                                    # (ragged: a synthetic first token -- the one sampled at position prompt - 1)
     lengths += 1
 
     # ---- phase 2: decode at batch B, metadata through atoma_prepare_inputs ----
@@ -152,12 +158,12 @@ def run(requests=256, prompt=2048, decode_steps=512, layers=0, model="8b", promp
         sample.append({"kind": "decode", "q": qkv_h[b_, :hd].reshape(c.h, c.d).copy(), "o": att_h[b_].copy(), "k": ks.reshape(npg * c.page, c.hk, c.d)[:L].copy(),
                        "v": vs.reshape(npg * c.page, c.hk, c.d)[:L].copy(), "scale": c.d ** -0.5, "L": L})
     name = "C3-lite trace: Llama-3.1-8B shapes" if model == "8b" else "C4-lite trace: one rank of Llama-3.1-70B TP=8 (no all-reduce)"
-    out = {"workload": f"{name} ({c.layers} layers), {B} requests, prompt {P}, {N} decode steps, block {c.page}",
+    out = {"workload": f"{name} ({c.layers} layers), {B} requests, prompt {P}" + (f" - U[0,{ragged_spread}) (ragged decode batches)" if ragged_spread else "") + f", {N} decode steps, block {c.page}",
            "prefill_s": round(t_prefill, 3), "prefill_tokens_per_s": round(B * P / t_prefill), "prefill_ms_per_prompt": round(t_prefill / B * 1e3, 2),
            "decode_s": round(t_decode, 3), "decode_ms_per_step": round(t_decode / N * 1e3, 3), "decode_tokens_per_s": round(B * N / t_decode),
            "host_metadata_ms_per_step": round(host_s / N * 1e3, 4), "trace_s": round(t_prefill + t_decode, 3),
            "generated_tokens_per_s_over_trace": round(B * (N + 1) / (t_prefill + t_decode)),
-           "decode_roofline_tokens_per_s": round(B / ((weight_bytes + B * (P + N / 2) * kv_bytes_per_token) / 8e12)),
+           "decode_roofline_tokens_per_s": round(B / ((weight_bytes + (float(lengths.sum()) - B * (N / 2 + 1)) * kv_bytes_per_token) / 8e12)),   # mean context over the decode phase
            "data": "synthetic weights and prompts; greedy sampling on the device", "sample": sample}
     out["decode_attention_kernel"] = (ah.lib.atoma_last_decode_kernel() or b"").decode()     # (ragged batches packed by atoma_prepare_inputs: the paired kernel by default)
     ah.lib.atoma_hint_decode_lengths(0, 0, 0)                              # the trace's batches are gone: later decode calls of this process must not inherit their hint
